@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py — aggregated edges/sec, forward+backward, 3-layer GraphSAGE on a synthetic
+ogbn-products-shaped graph (BASELINE.json `metric`, `configs[1]`), 1..N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = zero grads, full-batch forward of GraphSAGE(100, 256, 3 layers, 47 classes),
+cross-entropy on random labels, backward, (N > 1: ONE flat-bucket gradient all-reduce over RCCL),
+Adam update.  Inputs are resident in HBM before the timed region.  N > 1 is plain data parallelism
+over graph replicas: each rank owns its own synthetic graph of the same shape (seed + rank), so
+per-GPU work is fixed ("weak").  value = L * E * N / t_step.
+
+Prints ONE JSON line on rank 0, including `roofline` (dominant kernel = the F=256 CSR SpMM,
+HIP-event timed inside the timed region) and `cpu_baseline` (the oracle's CPU scatter path on a
+bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def spmm_algorithmic_bytes(info) -> float:
+    """E*(4F + b) + (N_rows + 1)*b + N_rows*4F  (+ N*4 for the mean's degree
+    vector when it is read as a per-source scale)."""
+    b, Fw = info['idx_bytes'], info['F']
+    total = info['nnz'] * (4 * Fw + b) + (info['n_rows'] + 1) * b + info['n_rows'] * 4 * Fw
+    if info['src_scale']:
+        total += info['n_src'] * 4
+    if info['weighted']:
+        total += info['nnz'] * 4
+    return float(total)
+
+
+def cpu_baseline(scale: float, steps: int = 2):
+    """The reference's CPU scatter path (index_select -> scatter_add_ -> divide; oracle port,
+    torch ATen CPU kernels on all host cores) on a `scale` x products-shaped sample."""
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd.datasets import products_like
+    from pytorch_geometric_amd.nn import GraphSAGE
+    x, y, ei, c = products_like(seed=1, scale=scale)
+    torch.manual_seed(0)
+    model = GraphSAGE(100, 256, num_layers=3, out_channels=c)
+    params = [(cv.lin_l.weight, cv.lin_l.bias, cv.lin_r.weight) for cv in model.convs]
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        for p in model.parameters():
+            p.grad = None
+        out = O.graphsage(x, ei, params)
+        loss = F.cross_entropy(out, y)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {
+        'value': 3 * ei.size(1) / t, 'unit': 'edges/s', 'cores': torch.get_num_threads(),
+        'kind': 'port',
+        'sample': (f'oracle/pyg_oracle.py graphsage fwd+bwd (index_select + scatter_add_ mean), '
+                   f'{scale:g} x ogbn-products shape: N={x.size(0)}, E={ei.size(1)}, '
+                   f'median of {steps} steps after 1 warm-up, {t * 1e3:.0f} ms/step'),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--scale', type=float, default=1.0, help='fraction of the products shape')
+    ap.add_argument('--index-dtype', choices=['int64', 'int32'], default='int64')
+    ap.add_argument('--uniform', action='store_true', help='uniform instead of power-law graph')
+    ap.add_argument('--cpu-scale', type=float, default=1 / 64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd.data_parallel import FlatGradBucket, broadcast_parameters
+    from pytorch_geometric_amd.datasets import products_like
+    from pytorch_geometric_amd.nn import GraphSAGE
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    pga.load_library()  # fail loudly if the HIP library is missing
+
+    idx_dtype = torch.int64 if args.index_dtype == 'int64' else torch.int32
+    t_gen = time.perf_counter()
+    x, y, ei, num_classes = products_like(seed=1 + rank, scale=args.scale,
+                                          skewed=not args.uniform, dtype=idx_dtype)
+    N, E = x.size(0), ei.size(1)
+    x, y, ei = x.to(dev), y.to(dev), ei.to(dev)
+    t_gen = time.perf_counter() - t_gen
+
+    torch.manual_seed(0)
+    model = GraphSAGE(100, 256, num_layers=3, out_channels=num_classes).to(dev)
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def step():
+        bucket.zero_()
+        out = model(x, ei)
+        loss = F.cross_entropy(out, y)
+        loss.backward()
+        bucket.all_reduce_mean()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    sink = []
+    _native.timing_sink = sink
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    _native.timing_sink = None
+    assert bucket.check_views(), 'gradient views were replaced: the all-reduce saw stale data'
+    assert torch.isfinite(loss).item(), 'loss is not finite'
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = 3.0 * E * world / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel: CSR SpMM at F = 256 (4 of the 5 launches per step) ----
+    groups = {}
+    for info, ev0, ev1 in sink:
+        groups.setdefault(info['F'], []).append((info, ev0.elapsed_time(ev1)))
+    dom_F = 256 if 256 in groups else max(groups)
+    dom = groups[dom_F]
+    avg_ms = sum(ms for _, ms in dom) / len(dom)
+    alg_bytes = sum(spmm_algorithmic_bytes(i) for i, _ in dom) / len(dom)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    spmm_ms_per_step = sum(ms for g in groups.values() for _, ms in g) / args.steps
+    roofline = {
+        'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+        'kernel': f'spmm_sum_rows<F={dom_F}> (pygamd_spmm_csr, fwd mean + transposed bwd)',
+        'launches_timed': len(dom), 'avg_launch_ms': round(avg_ms, 4),
+        'algorithmic_bytes_per_launch': alg_bytes,
+        'all_spmm_ms_per_step': round(spmm_ms_per_step, 3),
+        'per_width_avg_ms': {str(k): round(sum(ms for _, ms in v) / len(v), 4)
+                             for k, v in sorted(groups.items())},
+    }
+
+    if rank == 0:
+        result = {
+            'metric': 'edges/sec (fwd+bwd) 3-layer SAGE, ogbn-products shape',
+            'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': (f'GraphSAGE(100->256->256->{num_classes}, mean aggr) full-batch '
+                             f'fwd+bwd+Adam on a synthetic ogbn-products-shaped graph per GPU '
+                             f'(N={N}, E={E}, {"uniform" if args.uniform else "power-law"} '
+                             f'degrees, {args.index_dtype} edge_index, fp32 features)'),
+                'edges_per_step_per_gpu': 3 * E, 'scale': args.scale,
+                'parallelism': f'dp{world} (graph replicas, one flat-bucket all-reduce/step)',
+                'graph_gen_s': round(t_gen, 1),
+            },
+            'roofline': roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result['cpu_baseline'] = cpu_baseline(args.cpu_scale)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

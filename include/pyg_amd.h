@@ -1,0 +1,257 @@
+/*
+ * pyg_amd.h — C ABI of the MI355X (gfx950) message-passing / aggregation backend.
+ *
+ * This header is the drop-in boundary.  The reference (PyG 2.9, pure Python) has no C ABI of its
+ * own; its native seam is the set of `torch.ops.torch_sparse.*`, `torch_scatter.*` and
+ * `pyg_lib.ops.*` symbols it *expects to exist* (SURVEY.md §2.3, §8(b) S2).  Every entry point
+ * below names the reference call site (file:line under the reference root) it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream); every call is
+ *     asynchronous on that stream unless marked [sync];
+ *   - index tensors are int32 or int64, selected by `idx_dtype` (PYGAMD_IDX_I32 / _I64) — the
+ *     reference accepts both (torch_geometric/typing.py:32-36);
+ *   - features are fp32, row-major, with an explicit leading dimension in ELEMENTS
+ *     (`ldx`, `ldo` ≥ F) so callers can aggregate in/out of wider buffers without copies;
+ *   - every function returns a pygamd_status (0 = ok).  No function allocates device memory:
+ *     workspaces are passed in, their size comes from the matching `*_workspace_bytes` query;
+ *   - outputs never alias inputs.
+ */
+#ifndef PYG_AMD_H
+#define PYG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYGAMD_API __attribute__((visibility("default")))
+
+#define PYGAMD_ABI_VERSION 1
+
+typedef enum {
+  PYGAMD_OK = 0,
+  PYGAMD_ERR_INVALID_ARG = 1,   /* bad size / dtype / NULL pointer                     */
+  PYGAMD_ERR_UNSUPPORTED = 2,   /* valid in the reference but not implemented natively */
+  PYGAMD_ERR_WORKSPACE = 3,     /* workspace too small                                 */
+  PYGAMD_ERR_HIP = 4            /* a HIP runtime call failed (see pygamd_last_hip_error) */
+} pygamd_status;
+
+typedef enum { PYGAMD_IDX_I32 = 0, PYGAMD_IDX_I64 = 1 } pygamd_idx_dtype;
+
+/* reduce ids follow torch_geometric/utils/_scatter.py:14-138 */
+typedef enum {
+  PYGAMD_SUM = 0,
+  PYGAMD_MEAN = 1,
+  PYGAMD_MIN = 2,
+  PYGAMD_MAX = 3,
+  PYGAMD_MUL = 4,
+  PYGAMD_ANY = 5
+} pygamd_reduce;
+
+/* ---- library info ------------------------------------------------------------------------- */
+PYGAMD_API int pygamd_abi_version(void);
+PYGAMD_API const char* pygamd_status_string(int status);
+PYGAMD_API int pygamd_last_hip_error(void);          /* hipError_t of the last failing call */
+PYGAMD_API const char* pygamd_build_arch(void);      /* "gfx950" */
+
+/* ---- a12: index_sort ------------------------------------------------------------------------
+ * Replaces `pyg_lib.ops.index_sort(inputs, max_value)` / `inputs.sort(stable=True)`
+ * (torch_geometric/utils/_index_sort.py:10-32).  Stable LSD radix sort of non-negative integer
+ * keys; `perm_out` (always int64, like torch.sort's indices) satisfies
+ * keys_out[i] == keys_in[perm_out[i]] and is bit-identical to a stable sort.
+ * `max_value` (>= every key, or <0 = unknown) bounds the radix passes.                        */
+PYGAMD_API int pygamd_index_sort_workspace_bytes(int idx_dtype, int64_t n, size_t* bytes /*[host]*/);
+PYGAMD_API int pygamd_index_sort(const void* keys_in, int idx_dtype, int64_t n, int64_t max_value,
+                                 void* keys_out, int64_t* perm_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
+/* ---- a11: index2ptr / ptr2index -------------------------------------------------------------
+ * `torch._convert_indices_from_coo_to_csr(index, size)` and
+ * `arange(n).repeat_interleave(ptr.diff())` (torch_geometric/index.py:27-37).
+ * `index` must be sorted ascending with values in [0, size).  ptr has size+1 entries.          */
+PYGAMD_API int pygamd_index2ptr(const void* index, int idx_dtype, int64_t n, int64_t size,
+                                void* ptr_out, void* stream);
+PYGAMD_API int pygamd_ptr2index(const void* ptr, int idx_dtype, int64_t size, int64_t n,
+                                void* index_out, void* stream);
+
+/* Range check used by maybe_num_nodes / _index_select_safe
+ * (torch_geometric/utils/num_nodes.py, nn/conv/message_passing.py:269-290).
+ * Writes {min, max} (int64) to `minmax_out` (device, 2 entries); n == 0 gives {INT64_MAX, -1}. */
+PYGAMD_API int pygamd_index_minmax(const void* index, int idx_dtype, int64_t n,
+                                   int64_t* minmax_out, void* stream);
+
+/* out[i] = src[perm[i]] for integer payloads (COO -> CSR column permutation,
+ * torch_geometric/edge_index.py:605-623).  perm is int64.                                      */
+PYGAMD_API int pygamd_permute_index(const void* src, int idx_dtype, const int64_t* perm,
+                                    int64_t n, void* out, void* stream);
+/* out[i] = (idx_dtype) perm[i]; narrows an int64 permutation to the graph's index dtype.      */
+PYGAMD_API int pygamd_cast_index(const int64_t* src, int64_t n, int idx_dtype, void* out,
+                                 void* stream);
+
+/* ---- a10: hub plan for a CSR handle ---------------------------------------------------------
+ * Rows with more than `threshold` stored entries ("hubs", power-law graphs) are split into
+ * chunks of `chunk` entries so no single wavefront walks an unbounded row.  Produces, in
+ * ascending row order, hub_rows[n_hub] and hub_chunk_ptr[n_hub+1] (exclusive scan of the chunk
+ * counts).  Capacity of both outputs is `cap` (+1).  [sync]: n_hub / n_chunks are returned to
+ * the host.  No reference equivalent (the reference never splits rows); internal to a10's cache
+ * (torch_geometric/edge_index.py:677-696).                                                     */
+PYGAMD_API int pygamd_hub_plan_workspace_bytes(int idx_dtype, int64_t n_rows, size_t* bytes);
+PYGAMD_API int pygamd_hub_plan(const void* rowptr, int idx_dtype, int64_t n_rows,
+                               int64_t threshold, int64_t chunk, void* hub_rows,
+                               void* hub_chunk_ptr, int64_t cap, int64_t* n_hub_out /*[host]*/,
+                               int64_t* n_chunks_out /*[host]*/, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+/* ---- a9/a13/a14: CSR SpMM (fused gather -> message -> segmented reduce) ---------------------
+ * Replaces torch.ops.torch_sparse.spmm_{sum,mean,min,max}
+ * (torch_geometric/edge_index.py:1798-1810) and the unfused
+ * index_select -> message -> scatter chain of MessagePassing.propagate
+ * (nn/conv/message_passing.py:421-563, utils/_scatter.py:68-80):
+ *
+ *   out[i, f] = post(i) * REDUCE_{k in [rowptr[i], rowptr[i+1])}
+ *                   m(k, f) * x[col[k], f]
+ *   m(k, f)  = (w ? w[e(k) * w_heads + f / head_dim] : 1) * (src_scale ? src_scale[col[k]] : 1)
+ *   e(k)     = eid ? eid[k] : k
+ *   post(i)  = reduce == MEAN ? 1 / max(deg(i), 1) : 1
+ *
+ * `col == NULL` means col[k] = k (segment reduce over contiguous rows: torch_scatter.segment_csr,
+ * torch_geometric/utils/_segment.py:11-50).  Empty rows give 0 for every reduce.
+ * For MIN/MAX `arg_out` (optional, same idx dtype, [n_rows, ldo]) receives the winning slot k
+ * (first on ties) or -1 for an empty row; w/src_scale must be NULL.
+ * The hub_* arrays come from pygamd_hub_plan (n_hub == 0: no splitting); `workspace` must hold
+ * n_chunks * F floats (pygamd_spmm_csr_workspace_bytes).  Per-row accumulation order is the
+ * slot order (deterministic; no atomics).                                                      */
+typedef struct {
+  const void* rowptr;        /* [n_rows + 1]                         */
+  const void* col;           /* [nnz] or NULL                        */
+  const void* eid;           /* [nnz] or NULL                        */
+  const float* w;            /* [n_edges, w_heads] or NULL           */
+  const float* src_scale;    /* [n_src] or NULL                      */
+  const float* x;            /* [n_src, ldx]                         */
+  float* out;                /* [n_rows, ldo]                        */
+  void* arg_out;             /* [n_rows, ldo] or NULL (MIN/MAX only) */
+  int64_t n_rows;
+  int64_t n_src;
+  int64_t F;
+  int64_t ldx;
+  int64_t ldo;
+  int32_t idx_dtype;
+  int32_t reduce;            /* PYGAMD_SUM | MEAN | MIN | MAX        */
+  int32_t w_heads;           /* >= 1                                 */
+  int32_t head_dim;          /* F / w_heads when w_heads > 1         */
+  const void* hub_rows;      /* [n_hub] or NULL                      */
+  const void* hub_chunk_ptr; /* [n_hub + 1] or NULL                  */
+  int64_t n_hub;
+  int64_t n_chunks;
+  int64_t hub_threshold;
+  int64_t hub_chunk;
+} pygamd_spmm_args;
+
+PYGAMD_API int pygamd_spmm_csr_workspace_bytes(const pygamd_spmm_args* args, size_t* bytes);
+PYGAMD_API int pygamd_spmm_csr(const pygamd_spmm_args* args, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+/* Tie statistics for the backward of MIN/MAX, following the reference's CPU path
+ * (zeros.scatter_reduce_(amax/amin, include_self=False), utils/_scatter.py:84-100): the
+ * incoming gradient of out[i,f] is split evenly over all k with x[col[k],f] == out[i,f], and the
+ * zero-initialised self entry counts as one more tie when out[i,f] == 0.
+ * ntie_out[i,f] = (count_self ? [out[i,f] == 0] : 0) + #{k in row i : x[col[k],f] == out[i,f]}.
+ * count_self = 0 gives the rule of torch._segment_reduce's backward (utils/_segment.py:37-50),
+ * which has no self entry.                                                                      */
+PYGAMD_API int pygamd_spmm_csr_tie_count(const void* rowptr, const void* col, int idx_dtype,
+                                         const float* x, int64_t ldx, const float* out,
+                                         int64_t ldo, int64_t n_rows, int64_t F, int count_self,
+                                         float* ntie_out, void* stream);
+/* grad_x[j,f] = sum over slots k of the TRANSPOSED handle (rowptr_t over sources, col_t = dst)
+ *   [x[j,f] == out[col_t[k],f]] * grad_out[col_t[k],f] / ntie[col_t[k],f]                       */
+PYGAMD_API int pygamd_spmm_csr_minmax_backward(const void* rowptr_t, const void* col_t,
+                                               int idx_dtype, const float* x, int64_t ldx,
+                                               const float* out, const float* grad_out,
+                                               const float* ntie, int64_t ldo, int64_t n_src,
+                                               int64_t F, float* grad_x, int64_t ldg,
+                                               void* stream);
+
+/* ---- SDDMM: gradient w.r.t. edge weights ----------------------------------------------------
+ * grad_w[e(k), h] = sum_{f in head h} grad_out[i, f] * x[col[k], f] * (src_scale? ...)  for k in
+ * row i — the `value.requires_grad` branch of EdgeIndex._spmm (edge_index.py:1950-1953,
+ * 1903-1922) and GATConv.message's alpha gradient (nn/conv/gat_conv.py:408-409).              */
+PYGAMD_API int pygamd_sddmm_csr(const void* rowptr, const void* col, const void* eid,
+                                int idx_dtype, const float* grad_out, int64_t ldg,
+                                const float* x, int64_t ldx, int64_t n_rows, int64_t F,
+                                int32_t w_heads, int32_t head_dim, float* grad_w, void* stream);
+
+/* ---- a2: gather (index_select along dim 0) --------------------------------------------------
+ * out[e, :] = x[index[e], :]  (nn/conv/message_passing.py:263-290, collect.jinja:118-127).
+ * Out-of-range indices set *err_flag (device int32, optional) to 1 and read row 0.             */
+PYGAMD_API int pygamd_gather_rows(const float* x, int64_t ldx, int64_t n_src, const void* index,
+                                  int idx_dtype, int64_t n, int64_t F, float* out, int64_t ldo,
+                                  int32_t* err_flag, void* stream);
+
+/* ---- a5: scatter (unsorted COO, atomics) ----------------------------------------------------
+ * out[index[e], :] (reduce)= src[e, :]   (utils/_scatter.py:14-138).  `out` must be
+ * pre-initialised by pygamd_scatter_init; MEAN/MIN/MAX need `count` ([dim_size] float, zeroed)
+ * and a pygamd_scatter_finalize call (mean: divide by clamp(count,1); min/max: untouched -> 0). */
+PYGAMD_API int pygamd_scatter_init(float* out, int64_t ldo, int64_t dim_size, int64_t F,
+                                   int reduce, float* count, void* stream);
+PYGAMD_API int pygamd_scatter_rows(const float* src, int64_t lds, const void* index,
+                                   int idx_dtype, int64_t n, int64_t F, float* out, int64_t ldo,
+                                   int64_t dim_size, int reduce, float* count,
+                                   int32_t* err_flag, void* stream);
+PYGAMD_API int pygamd_scatter_finalize(float* out, int64_t ldo, int64_t dim_size, int64_t F,
+                                       int reduce, const float* count, void* stream);
+/* backward of MIN/MAX/MUL-free scatter: see utils/_scatter.py:84-100 (same tie rule as above).
+ * ntie[g,f] = [out[g,f]==0] + #{e: index[e]==g, src[e,f]==out[g,f]}  (initialised internally);
+ * grad_src[e,f] = [src[e,f]==out[g,f]] * grad_out[g,f] / ntie[g,f].                             */
+PYGAMD_API int pygamd_scatter_minmax_tie_count(const float* src, int64_t lds, const void* index,
+                                               int idx_dtype, int64_t n, int64_t F,
+                                               const float* out, int64_t ldo, int64_t dim_size,
+                                               float* ntie, void* stream);
+PYGAMD_API int pygamd_scatter_minmax_backward(const float* src, int64_t lds, const void* index,
+                                              int idx_dtype, int64_t n, int64_t F,
+                                              const float* out, const float* grad_out,
+                                              const float* ntie, int64_t ldo, float* grad_src,
+                                              int64_t ldg, void* stream);
+
+/* ---- a6: scatter_argmax (1-D) ---------------------------------------------------------------
+ * utils/_scatter.py:147-184: out[g] = the LAST e (largest e) with src[e] == max of group g,
+ * dim_size-1 for empty groups.  `gmax` is a [dim_size] float scratch.                          */
+PYGAMD_API int pygamd_scatter_argmax(const float* src, const void* index, int idx_dtype,
+                                     int64_t n, int64_t dim_size, float* gmax, void* arg_out,
+                                     void* stream);
+
+/* ---- a8: segment softmax (edge softmax) -----------------------------------------------------
+ * utils/_softmax.py:12-92, ptr branch :60-81 (also pyg_lib.ops.softmax_csr): for each segment
+ * s and column h:  out[k,h] = exp(src[k,h] - max_s) / (sum_s exp(src - max_s) + 1e-16).
+ * src/out are [n, H] contiguous.  Backward: grad_src = out * (grad_out - sum_s(out*grad_out)).  */
+PYGAMD_API int pygamd_segment_softmax_forward(const float* src, const void* ptr, int idx_dtype,
+                                              int64_t n_seg, int64_t H, float* out,
+                                              void* stream);
+PYGAMD_API int pygamd_segment_softmax_backward(const float* out, const float* grad_out,
+                                               const void* ptr, int idx_dtype, int64_t n_seg,
+                                               int64_t H, float* grad_src, void* stream);
+
+/* ---- a15: fused GAT edge logits ------------------------------------------------------------
+ * nn/conv/gat_conv.py:387-406 on a dst-sorted handle: for slot k in row i,
+ *   logit = leaky_relu(alpha_src[col[k],h] + alpha_dst[i,h], slope); softmax over the row.
+ * alpha_out is [nnz, H] in SLOT order.  Backward returns grad_alpha_src / grad_alpha_dst
+ * accumulated with atomics (grad buffers must be zeroed).                                      */
+PYGAMD_API int pygamd_gat_edge_softmax_forward(const void* rowptr, const void* col,
+                                               int idx_dtype, const float* alpha_src,
+                                               const float* alpha_dst, int64_t n_rows,
+                                               int64_t H, float slope, float* alpha_out,
+                                               void* stream);
+PYGAMD_API int pygamd_gat_edge_softmax_backward(const void* rowptr, const void* col,
+                                                int idx_dtype, const float* alpha_src,
+                                                const float* alpha_dst, const float* alpha_out,
+                                                const float* grad_alpha, int64_t n_rows,
+                                                int64_t H, float slope, float* grad_alpha_src,
+                                                float* grad_alpha_dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYG_AMD_H */

@@ -1,0 +1,28 @@
+"""pytorch_geometric_amd — MI355X (gfx950) native message-passing / aggregation backend.
+
+The hot path of PyG's ``MessagePassing.propagate`` (gather on ``edge_index[0]``, edge-wise message,
+scatter-{add, mean, max} onto ``edge_index[1]``) and the CSR SpMM path of SAGEConv / GCNConv /
+GATConv, as hand-written HIP kernels behind a C ABI (``include/pyg_amd.h`` ->
+``lib/libpyg_amd.so``).  The Python layer mirrors the reference's operator interface
+(``utils.scatter / segment / softmax / spmm / index_sort``, ``nn.SAGEConv`` ...) and
+``backend.install()`` rebinds the same names inside an importable ``torch_geometric``.
+
+There is no CPU fallback: every op needs HIP device tensors and the built library.
+"""
+from . import _build
+from ._lib import PygAmdError, lib_path, load as load_library
+from .edge_index import EdgeIndex, as_edge_index, clear_cache, set_cache_enabled
+from .index import index2ptr, ptr2index
+from . import utils
+from . import nn
+
+__version__ = '0.1.0'
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into ``lib/libpyg_amd.so`` (in-tree)."""
+    return _build.build_library(force=force)
+
+
+__all__ = ['EdgeIndex', 'as_edge_index', 'clear_cache', 'set_cache_enabled', 'index2ptr',
+           'ptr2index', 'utils', 'nn', 'build', 'load_library', 'lib_path', 'PygAmdError']

@@ -1,0 +1,217 @@
+"""Autograd glue: each ``torch.autograd.Function`` pairs one forward HIP kernel with the HIP kernels
+of its backward.  Formulas follow the reference's CPU path (see the docstrings for file:line)."""
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _native
+from .edge_index import CSR, EdgeIndex
+
+
+class SpmmFunction(Function):
+    r"""``out[i] = reduce_{(j -> i)} w_e * x[j]`` on an :class:`EdgeIndex` handle.
+
+    Forward = fused gather/message/reduce of ``MessagePassing.propagate``
+    (nn/conv/message_passing.py:421-563; utils/_spmm.py:12-136).  Backward w.r.t. ``x`` = the same
+    kernel on the transposed handle (edge_index.py:1849-1900); w.r.t. ``w`` = SDDMM
+    (edge_index.py:1903-1922).  ``w_order``: 'coo' (``w[e]`` follows ``edge_index`` order) or
+    'slot' (``w`` follows the by-destination slot order, e.g. GAT's alpha).
+    """
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Optional[Tensor], graph: EdgeIndex, reduce: str,
+                w_order: str):
+        fwd = graph.by_dst()
+        if x.size(0) != graph.num_src_nodes:
+            raise ValueError(f"'x' has {x.size(0)} rows but the graph has "
+                             f"{graph.num_src_nodes} source nodes")
+        ctx.graph, ctx.reduce, ctx.w_order = graph, reduce, w_order
+        ctx.x_shape = x.shape
+        x2 = x.reshape(x.size(0), -1)
+        if reduce in ('min', 'max'):
+            if w is not None:
+                raise NotImplementedError("edge weights are not supported for min/max")
+            out = _native.spmm_csr(fwd.ptr, fwd.idx, x2, reduce, n_rows=fwd.n_rows)
+            ctx.save_for_backward(x2, out)
+        else:
+            eid = fwd.perm if (w is not None and w_order == 'coo') else None
+            out = _native.spmm_csr(fwd.ptr, fwd.idx, x2, reduce, n_rows=fwd.n_rows, eid=eid, w=w,
+                                   hub=fwd.hub)
+            need_x = w is not None and ctx.needs_input_grad[1]
+            ctx.save_for_backward(x2 if need_x else None, w)
+        return out.view(fwd.n_rows, *x.shape[1:])
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        graph, reduce = ctx.graph, ctx.reduce
+        g2 = grad_out.reshape(grad_out.size(0), -1)
+        grad_x = grad_w = None
+        if reduce in ('min', 'max'):
+            x2, out = ctx.saved_tensors
+            if ctx.needs_input_grad[0]:
+                fwd, bwd = graph.by_dst(), graph.by_src()
+                ntie = _native.spmm_tie_count(fwd.ptr, fwd.idx, x2, out, count_self=True)
+                grad_x = _native.spmm_minmax_backward(bwd.ptr, bwd.idx, x2, out, g2, ntie)
+                grad_x = grad_x.view(ctx.x_shape)
+            return grad_x, None, None, None, None
+        x2, w = ctx.saved_tensors
+        fwd = graph.by_dst()
+        if reduce == 'mean' and w is not None:
+            g2 = g2 * fwd.inv_degree().view(-1, 1)
+        if ctx.needs_input_grad[0]:
+            bwd = graph.by_src()
+            eid = None
+            if w is not None:
+                eid = bwd.perm if ctx.w_order == 'coo' else graph.src_slot_to_dst_slot()
+            scale = fwd.inv_degree() if (reduce == 'mean' and w is None) else None
+            grad_x = _native.spmm_csr(bwd.ptr, bwd.idx, g2, 'sum', n_rows=bwd.n_rows, eid=eid,
+                                      w=w, src_scale=scale, hub=bwd.hub)
+            grad_x = grad_x.view(ctx.x_shape)
+        if w is not None and ctx.needs_input_grad[1]:
+            eid = fwd.perm if ctx.w_order == 'coo' else None
+            heads = 1 if w.dim() == 1 else w.size(1)
+            grad_w = _native.sddmm_csr(fwd.ptr, fwd.idx, eid, g2, x2, fwd.nnz, heads)
+            grad_w = grad_w.view(w.shape)
+        return grad_x, grad_w, None, None, None
+
+
+class GatherFunction(Function):
+    """``x.index_select(0, index)`` (message_passing.py:263-290); backward = scatter-add."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, index: Tensor, check_bounds: bool):
+        ctx.save_for_backward(index)
+        ctx.x_shape = x.shape
+        out = _native.gather_rows(x.reshape(x.size(0), -1), index, check_bounds)
+        return out.view(index.numel(), *x.shape[1:])
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        (index,) = ctx.saved_tensors
+        g = _native.scatter_rows(grad_out.reshape(grad_out.size(0), -1), index, ctx.x_shape[0],
+                                 'sum')
+        return g.view(ctx.x_shape), None, None
+
+
+class ScatterFunction(Function):
+    """``scatter(src, index, 0, dim_size, reduce)`` on an unsorted index (utils/_scatter.py)."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, index: Tensor, dim_size: int, reduce: str):
+        s2 = src.reshape(src.size(0), -1)
+        ctx.reduce, ctx.src_shape = reduce, src.shape
+        if reduce == 'mean':
+            out, count = _native.scatter_rows(s2, index, dim_size, reduce, return_count=True)
+            ctx.save_for_backward(index, count)
+        elif reduce in ('min', 'max'):
+            out = _native.scatter_rows(s2, index, dim_size, reduce)
+            ctx.save_for_backward(index, s2, out)
+        elif reduce == 'mul':
+            out = _native.scatter_rows(s2, index, dim_size, reduce)
+            ctx.save_for_backward(index, s2, out)
+        else:
+            out = _native.scatter_rows(s2, index, dim_size, reduce)
+            ctx.save_for_backward(index)
+        return out.view(dim_size, *src.shape[1:])
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        reduce = ctx.reduce
+        g2 = grad_out.reshape(grad_out.size(0), -1)
+        if reduce in ('sum', 'add'):
+            (index,) = ctx.saved_tensors
+            grad = _native.gather_rows(g2, index)
+        elif reduce == 'mean':
+            index, count = ctx.saved_tensors
+            grad = _native.gather_rows(g2 / count.clamp(min=1).view(-1, 1), index)
+        elif reduce in ('min', 'max'):
+            index, s2, out = ctx.saved_tensors
+            grad = _native.scatter_minmax_backward(s2, index, out, g2)
+        elif reduce == 'mul':
+            # d(prod)/d(src_e) = prod / src_e (the reference's scatter_reduce 'prod' backward for
+            # non-zero inputs)
+            index, s2, out = ctx.saved_tensors
+            grad = _native.gather_rows(g2 * out, index) / s2
+        else:
+            raise NotImplementedError(f"backward of scatter(reduce='{reduce}') is undefined")
+        return grad.view(ctx.src_shape), None, None, None
+
+
+class SegmentFunction(Function):
+    """``segment(src, ptr, reduce)`` over contiguous row ranges (utils/_segment.py:11-50)."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, ptr: Tensor, reduce: str):
+        s2 = src.reshape(src.size(0), -1)
+        n_seg = ptr.numel() - 1
+        out = _native.spmm_csr(ptr, None, s2, reduce, n_rows=n_seg)
+        ctx.reduce, ctx.src_shape = reduce, src.shape
+        if reduce in ('min', 'max'):
+            ctx.save_for_backward(ptr, s2, out)
+        else:
+            ctx.save_for_backward(ptr)
+        return out.view(n_seg, *src.shape[1:])
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        reduce = ctx.reduce
+        g2 = grad_out.reshape(grad_out.size(0), -1)
+        n = ctx.src_shape[0]
+        if reduce in ('min', 'max'):
+            ptr, s2, out = ctx.saved_tensors
+            ntie = _native.spmm_tie_count(ptr, None, s2, out, count_self=False)
+            index = _native.ptr2index(ptr, n)
+            # each row belongs to exactly one segment: grad = [src == out[seg]] * g[seg] / ntie[seg]
+            o_e = _native.gather_rows(out, index)
+            g_e = _native.gather_rows(g2 / ntie.clamp(min=1), index)
+            grad = torch.where(s2 == o_e, g_e, torch.zeros_like(g_e))
+        else:
+            (ptr,) = ctx.saved_tensors
+            index = _native.ptr2index(ptr, n)
+            if reduce == 'mean':
+                cnt = (ptr[1:] - ptr[:-1]).clamp(min=1).to(torch.float32)
+                g2 = g2 / cnt.view(-1, 1)
+            grad = _native.gather_rows(g2, index)
+        return grad.view(ctx.src_shape), None, None
+
+
+class SegmentSoftmaxFunction(Function):
+    """Softmax within ``ptr`` segments (utils/_softmax.py:60-81); the max is taken on the detached
+    input, so the backward is the plain softmax Jacobian."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, ptr: Tensor):
+        s2 = src.reshape(src.size(0), -1)
+        out = _native.segment_softmax_forward(s2, ptr)
+        ctx.save_for_backward(out, ptr)
+        ctx.src_shape = src.shape
+        return out.view(src.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        out, ptr = ctx.saved_tensors
+        g = _native.segment_softmax_backward(out, grad_out.reshape(out.shape), ptr)
+        return g.view(ctx.src_shape), None
+
+
+class GatEdgeSoftmaxFunction(Function):
+    """alpha[k,h] = softmax_row(leaky_relu(alpha_src[col[k],h] + alpha_dst[i,h])) in by-destination
+    slot order (nn/conv/gat_conv.py:387-406)."""
+
+    @staticmethod
+    def forward(ctx, alpha_src: Tensor, alpha_dst: Tensor, graph: EdgeIndex, slope: float):
+        fwd = graph.by_dst()
+        alpha = _native.gat_edge_softmax_forward(fwd.ptr, fwd.idx, alpha_src, alpha_dst, slope)
+        ctx.save_for_backward(alpha_src, alpha_dst, alpha)
+        ctx.graph, ctx.slope = graph, slope
+        return alpha
+
+    @staticmethod
+    def backward(ctx, grad_alpha: Tensor):
+        alpha_src, alpha_dst, alpha = ctx.saved_tensors
+        fwd = ctx.graph.by_dst()
+        g_src, g_dst = _native.gat_edge_softmax_backward(fwd.ptr, fwd.idx, alpha_src, alpha_dst,
+                                                         alpha, grad_alpha, ctx.slope)
+        return g_src, g_dst, None, None

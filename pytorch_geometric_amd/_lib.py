@@ -1,0 +1,117 @@
+"""ctypes binding of ``libpyg_amd.so`` — the C ABI declared in ``include/pyg_amd.h``.
+
+This module is the only place that touches the shared object.  There is deliberately no CPU
+fallback: if the library is missing (and cannot be built) or a call fails, we raise.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
+                    c_void_p)
+
+from . import _build
+
+IDX_I32, IDX_I64 = 0, 1
+SUM, MEAN, MIN, MAX, MUL, ANY = 0, 1, 2, 3, 4, 5
+REDUCE_IDS = {'sum': SUM, 'add': SUM, 'mean': MEAN, 'min': MIN, 'amin': MIN, 'max': MAX,
+              'amax': MAX, 'mul': MUL, 'any': ANY}
+
+
+class PygAmdError(RuntimeError):
+    pass
+
+
+class SpmmArgs(Structure):
+    """Mirror of ``pygamd_spmm_args`` (include/pyg_amd.h)."""
+    _fields_ = [
+        ('rowptr', c_void_p), ('col', c_void_p), ('eid', c_void_p), ('w', c_void_p),
+        ('src_scale', c_void_p), ('x', c_void_p), ('out', c_void_p), ('arg_out', c_void_p),
+        ('n_rows', c_int64), ('n_src', c_int64), ('F', c_int64), ('ldx', c_int64),
+        ('ldo', c_int64), ('idx_dtype', c_int32), ('reduce', c_int32), ('w_heads', c_int32),
+        ('head_dim', c_int32), ('hub_rows', c_void_p), ('hub_chunk_ptr', c_void_p),
+        ('n_hub', c_int64), ('n_chunks', c_int64), ('hub_threshold', c_int64),
+        ('hub_chunk', c_int64),
+    ]
+
+
+# name -> (restype, argtypes); must list every PYGAMD_API symbol of include/pyg_amd.h
+_P = c_void_p
+SIGNATURES = {
+    'pygamd_abi_version': (c_int, []),
+    'pygamd_status_string': (c_char_p, [c_int]),
+    'pygamd_last_hip_error': (c_int, []),
+    'pygamd_build_arch': (c_char_p, []),
+    'pygamd_index_sort_workspace_bytes': (c_int, [c_int, c_int64, POINTER(c_size_t)]),
+    'pygamd_index_sort': (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
+    'pygamd_index2ptr': (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),
+    'pygamd_ptr2index': (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),
+    'pygamd_index_minmax': (c_int, [_P, c_int, c_int64, _P, _P]),
+    'pygamd_permute_index': (c_int, [_P, c_int, _P, c_int64, _P, _P]),
+    'pygamd_cast_index': (c_int, [_P, c_int64, c_int, _P, _P]),
+    'pygamd_hub_plan_workspace_bytes': (c_int, [c_int, c_int64, POINTER(c_size_t)]),
+    'pygamd_hub_plan': (c_int, [_P, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64,
+                                POINTER(c_int64), POINTER(c_int64), _P, c_size_t, _P]),
+    'pygamd_spmm_csr_workspace_bytes': (c_int, [POINTER(SpmmArgs), POINTER(c_size_t)]),
+    'pygamd_spmm_csr': (c_int, [POINTER(SpmmArgs), _P, c_size_t, _P]),
+    'pygamd_spmm_csr_tie_count': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, c_int64,
+                                          c_int64, c_int, _P, _P]),
+    'pygamd_spmm_csr_minmax_backward': (c_int, [_P, _P, c_int, _P, c_int64, _P, _P, _P, c_int64,
+                                                c_int64, c_int64, _P, c_int64, _P]),
+    'pygamd_sddmm_csr': (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int64, c_int64, c_int64,
+                                 c_int32, c_int32, _P, _P]),
+    'pygamd_gather_rows': (c_int, [_P, c_int64, c_int64, _P, c_int, c_int64, c_int64, _P,
+                                   c_int64, _P, _P]),
+    'pygamd_scatter_init': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
+    'pygamd_scatter_rows': (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P, c_int64,
+                                    c_int64, c_int, _P, _P, _P]),
+    'pygamd_scatter_finalize': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
+    'pygamd_scatter_minmax_tie_count': (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P,
+                                                c_int64, c_int64, _P, _P]),
+    'pygamd_scatter_minmax_backward': (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P, _P,
+                                               _P, c_int64, _P, c_int64, _P]),
+    'pygamd_scatter_argmax': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P, _P]),
+    'pygamd_segment_softmax_forward': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P]),
+    'pygamd_segment_softmax_backward': (c_int, [_P, _P, _P, c_int, c_int64, c_int64, _P, _P]),
+    'pygamd_gat_edge_softmax_forward': (c_int, [_P, _P, c_int, _P, _P, c_int64, c_int64,
+                                                c_float, _P, _P]),
+    'pygamd_gat_edge_softmax_backward': (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int64,
+                                                 c_int64, c_float, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the in-tree .so is missing/stale and hipcc exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if _build.is_stale():
+        if _build.find_hipcc() is not None and os.environ.get('PYG_AMD_NO_BUILD') != '1':
+            _build.build_library(verbose=False)
+        elif not os.path.exists(path):
+            raise PygAmdError(
+                f"{path} is missing and hipcc is unavailable: run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` on a machine with ROCm. "
+                f"There is no CPU fallback for the pytorch_geometric_amd kernels.")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.pygamd_abi_version() != 1:
+        raise PygAmdError(f'ABI mismatch: library reports {lib.pygamd_abi_version()}')
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        lib = load()
+        msg = lib.pygamd_status_string(rc).decode()
+        extra = f' (hipError {lib.pygamd_last_hip_error()})' if rc == 4 else ''
+        raise PygAmdError(f'{what or "pygamd call"} failed: {msg}{extra}')

@@ -1,0 +1,404 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs with the torch caching
+allocator, pass raw device pointers + the current HIP stream.  No arithmetic happens here.
+
+PyTorch is plumbing only (device memory, streams).  Every function requires HIP device tensors
+and raises otherwise — there is no CPU fallback.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import REDUCE_IDS, PygAmdError, SpmmArgs, check
+
+# rows with more stored entries than this are split into chunks (see csrc/spmm.hip)
+HUB_THRESHOLD = 1024
+HUB_CHUNK = 1024
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PygAmdError(
+                'pytorch_geometric_amd kernels need HIP device tensors (got a '
+                f'{t.device} tensor); there is no CPU fallback on this path')
+
+
+def _idx_dtype(t: Tensor) -> int:
+    if t.dtype == torch.int64:
+        return _lib.IDX_I64
+    if t.dtype == torch.int32:
+        return _lib.IDX_I32
+    raise ValueError(f"index tensors must be int32 or int64 (got {t.dtype})")
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(ref: Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+
+
+def _f32_rows(t: Tensor, name: str) -> Tensor:
+    """2-D fp32 view with unit inner stride (row stride may exceed the width)."""
+    if t.dtype != torch.float32:
+        raise ValueError(f"'{name}' must be float32 (got {t.dtype})")
+    if t.dim() != 2:
+        raise ValueError(f"'{name}' must be two-dimensional (got {t.dim()} dimensions)")
+    if t.size(1) > 0 and t.size(0) > 0 and (t.stride(1) != 1 or t.stride(0) < t.size(1)):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: Tensor) -> int:
+    return t.stride(0) if (t.size(0) > 1 and t.size(1) > 0) else max(t.size(1), 1)
+
+
+# ---- integer side --------------------------------------------------------------------------------
+def index_sort(keys: Tensor, max_value: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    _require_device(keys)
+    if keys.dim() != 1:
+        raise ValueError("'inputs' must be one-dimensional")
+    keys = keys.contiguous()
+    lib = _lib.load()
+    n = keys.numel()
+    out = torch.empty_like(keys)
+    perm = torch.empty(n, dtype=torch.int64, device=keys.device)
+    if n == 0:
+        return out, perm
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_index_sort_workspace_bytes(_idx_dtype(keys), n, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=keys.device)
+    check(lib.pygamd_index_sort(_p(keys), _idx_dtype(keys), n,
+                                -1 if max_value is None else int(max_value), _p(out), _p(perm),
+                                _p(ws), nbytes.value, _stream(keys)), 'index_sort')
+    return out, perm
+
+
+def index2ptr(index: Tensor, size: int) -> Tensor:
+    _require_device(index)
+    index = index.contiguous()
+    lib = _lib.load()
+    ptr = torch.empty(size + 1, dtype=index.dtype, device=index.device)
+    check(lib.pygamd_index2ptr(_p(index), _idx_dtype(index), index.numel(), size, _p(ptr),
+                               _stream(index)), 'index2ptr')
+    return ptr
+
+
+def ptr2index(ptr: Tensor, n: int) -> Tensor:
+    _require_device(ptr)
+    ptr = ptr.contiguous()
+    lib = _lib.load()
+    out = torch.empty(n, dtype=ptr.dtype, device=ptr.device)
+    check(lib.pygamd_ptr2index(_p(ptr), _idx_dtype(ptr), ptr.numel() - 1, n, _p(out),
+                               _stream(ptr)), 'ptr2index')
+    return out
+
+
+def index_minmax(index: Tensor) -> Tuple[int, int]:
+    """(min, max) of an index tensor; one host sync (the reference syncs here too)."""
+    _require_device(index)
+    index = index.contiguous()
+    lib = _lib.load()
+    mm = torch.empty(2, dtype=torch.int64, device=index.device)
+    check(lib.pygamd_index_minmax(_p(index), _idx_dtype(index), index.numel(), _p(mm),
+                                  _stream(index)), 'index_minmax')
+    lo, hi = mm.tolist()
+    return lo, hi
+
+
+def permute_index(src: Tensor, perm: Tensor) -> Tensor:
+    _require_device(src, perm)
+    src = src.contiguous()
+    lib = _lib.load()
+    out = torch.empty(perm.numel(), dtype=src.dtype, device=src.device)
+    check(lib.pygamd_permute_index(_p(src), _idx_dtype(src), _p(perm), perm.numel(), _p(out),
+                                   _stream(src)), 'permute_index')
+    return out
+
+
+def cast_index(src: Tensor, dtype: torch.dtype) -> Tensor:
+    _require_device(src)
+    if src.dtype == dtype:
+        return src
+    assert src.dtype == torch.int64
+    lib = _lib.load()
+    out = torch.empty(src.numel(), dtype=dtype, device=src.device)
+    check(lib.pygamd_cast_index(_p(src), src.numel(), _idx_dtype(out), _p(out), _stream(src)),
+          'cast_index')
+    return out
+
+
+def hub_plan(rowptr: Tensor, threshold: int = None, chunk: int = None):
+    """Returns (hub_rows, hub_chunk_ptr, n_hub, n_chunks); tensors are None when n_hub == 0."""
+    _require_device(rowptr)
+    threshold = HUB_THRESHOLD if threshold is None else threshold
+    chunk = HUB_CHUNK if chunk is None else chunk
+    lib = _lib.load()
+    n_rows = rowptr.numel() - 1
+    if n_rows <= 0:
+        return None, None, 0, 0
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_hub_plan_workspace_bytes(_idx_dtype(rowptr), n_rows, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=rowptr.device)
+    rows = torch.empty(n_rows, dtype=rowptr.dtype, device=rowptr.device)
+    cptr = torch.empty(n_rows + 1, dtype=rowptr.dtype, device=rowptr.device)
+    n_hub, n_chunks = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.pygamd_hub_plan(_p(rowptr), _idx_dtype(rowptr), n_rows, threshold, chunk, _p(rows),
+                              _p(cptr), n_rows, ctypes.byref(n_hub), ctypes.byref(n_chunks),
+                              _p(ws), nbytes.value, _stream(rowptr)), 'hub_plan')
+    if n_hub.value == 0:
+        return None, None, 0, 0
+    return (rows[:n_hub.value].clone(), cptr[:n_hub.value + 1].clone(), n_hub.value,
+            n_chunks.value)
+
+
+# ---- CSR SpMM --------------------------------------------------------------------------------------
+# Optional launch timing (bench.py): when a list is installed here, every spmm_csr call appends
+# (info, start_event, end_event) recorded on the launch stream around the kernel(s).
+timing_sink = None
+
+
+def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
+             n_rows: Optional[int] = None, eid: Optional[Tensor] = None,
+             w: Optional[Tensor] = None, src_scale: Optional[Tensor] = None,
+             hub=None, out: Optional[Tensor] = None, return_arg: bool = False):
+    """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h."""
+    _require_device(rowptr, col, x, eid, w, src_scale)
+    lib = _lib.load()
+    x2 = _f32_rows(x, 'x')
+    n_rows = rowptr.numel() - 1 if n_rows is None else n_rows
+    F = x2.size(1)
+    if out is None:
+        out = torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
+    red = REDUCE_IDS[reduce]
+    a = SpmmArgs()
+    a.rowptr = rowptr.data_ptr()
+    a.col = 0 if col is None else col.data_ptr()
+    a.eid = 0 if eid is None else eid.data_ptr()
+    w_heads, head_dim = 1, F
+    if w is not None:
+        if w.dtype != torch.float32:
+            raise ValueError("edge weights must be float32")
+        w = w.contiguous()
+        w_heads = 1 if w.dim() == 1 else w.size(1)
+        if w_heads > 1:
+            if F % w_heads != 0:
+                raise ValueError('feature width must be divisible by the number of heads')
+            head_dim = F // w_heads
+        a.w = w.data_ptr()
+    if src_scale is not None:
+        src_scale = src_scale.contiguous()
+        a.src_scale = src_scale.data_ptr()
+    a.x = x2.data_ptr()
+    a.out = out.data_ptr()
+    arg = None
+    if return_arg:
+        arg = torch.empty(n_rows, F, dtype=rowptr.dtype, device=x.device)
+        a.arg_out = arg.data_ptr()
+    a.n_rows, a.n_src, a.F = n_rows, x2.size(0), F
+    a.ldx, a.ldo = _ld(x2), _ld(out)
+    a.idx_dtype, a.reduce = _idx_dtype(rowptr), red
+    a.w_heads, a.head_dim = w_heads, head_dim
+    ws, ws_bytes = None, 0
+    if hub is not None and hub[2] > 0 and red in (_lib.SUM, _lib.MEAN):
+        hub_rows, hub_cptr, n_hub, n_chunks = hub
+        a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), hub_cptr.data_ptr()
+        a.n_hub, a.n_chunks = n_hub, n_chunks
+        a.hub_threshold, a.hub_chunk = HUB_THRESHOLD, HUB_CHUNK
+        ws_bytes = n_chunks * F * 4
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    sink = timing_sink
+    if sink is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(x.device))
+    check(lib.pygamd_spmm_csr(ctypes.byref(a), _p(ws), ws_bytes, _stream(x)), 'spmm_csr')
+    if sink is not None:
+        ev1.record(torch.cuda.current_stream(x.device))
+        nnz = (col.numel() if col is not None else x2.size(0))
+        sink.append(({'n_rows': n_rows, 'n_src': x2.size(0), 'nnz': nnz, 'F': F,
+                      'reduce': reduce, 'idx_bytes': rowptr.element_size(),
+                      'weighted': w is not None, 'src_scale': src_scale is not None,
+                      'n_hub': a.n_hub}, ev0, ev1))
+    return (out, arg) if return_arg else out
+
+
+def spmm_tie_count(rowptr, col, x, out, count_self: bool) -> Tensor:
+    _require_device(rowptr, col, x, out)
+    lib = _lib.load()
+    x2, o2 = _f32_rows(x, 'x'), _f32_rows(out, 'out')
+    ntie = torch.empty_like(o2, memory_format=torch.contiguous_format)
+    o2 = o2.contiguous()
+    check(lib.pygamd_spmm_csr_tie_count(_p(rowptr), _p(col), _idx_dtype(rowptr), _p(x2), _ld(x2),
+                                        _p(o2), _ld(o2), o2.size(0), o2.size(1),
+                                        1 if count_self else 0, _p(ntie), _stream(x)),
+          'spmm_tie_count')
+    return ntie
+
+
+def spmm_minmax_backward(rowptr_t, col_t, x, out, grad_out, ntie) -> Tensor:
+    _require_device(rowptr_t, col_t, x, out, grad_out, ntie)
+    lib = _lib.load()
+    x2 = _f32_rows(x, 'x')
+    o2, g2, n2 = out.contiguous(), grad_out.contiguous(), ntie.contiguous()
+    grad_x = torch.empty(x2.size(0), x2.size(1), dtype=torch.float32, device=x.device)
+    check(lib.pygamd_spmm_csr_minmax_backward(_p(rowptr_t), _p(col_t), _idx_dtype(rowptr_t),
+                                              _p(x2), _ld(x2), _p(o2), _p(g2), _p(n2), _ld(o2),
+                                              x2.size(0), x2.size(1), _p(grad_x), _ld(grad_x),
+                                              _stream(x)), 'spmm_minmax_backward')
+    return grad_x
+
+
+def sddmm_csr(rowptr, col, eid, grad_out, x, n_edges: int, w_heads: int) -> Tensor:
+    _require_device(rowptr, col, eid, grad_out, x)
+    lib = _lib.load()
+    g2, x2 = _f32_rows(grad_out, 'grad_out'), _f32_rows(x, 'x')
+    F = x2.size(1)
+    grad_w = torch.zeros(n_edges, w_heads, dtype=torch.float32, device=x.device)
+    check(lib.pygamd_sddmm_csr(_p(rowptr), _p(col), _p(eid), _idx_dtype(rowptr), _p(g2), _ld(g2),
+                               _p(x2), _ld(x2), rowptr.numel() - 1, F, w_heads,
+                               F // max(w_heads, 1), _p(grad_w), _stream(x)), 'sddmm_csr')
+    return grad_w
+
+
+# ---- unsorted gather / scatter ----------------------------------------------------------------
+_pending_err = []  # device flags set by kernels that met an out-of-range index
+
+
+def _err_flag(device):
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    del _pending_err[:-7]  # bounded history
+    _pending_err.append(flag)
+    return flag
+
+
+def consume_index_error() -> bool:
+    """True if any scatter/gather since the last call met an out-of-range index (host sync)."""
+    bad = any(int(f.item()) != 0 for f in _pending_err)
+    _pending_err.clear()
+    return bad
+
+
+def gather_rows(x: Tensor, index: Tensor, check_bounds: bool = False) -> Tensor:
+    _require_device(x, index)
+    lib = _lib.load()
+    x2 = _f32_rows(x, 'x')
+    index = index.contiguous()
+    n, F = index.numel(), x2.size(1)
+    out = torch.empty(n, F, dtype=torch.float32, device=x.device)
+    err = torch.zeros(1, dtype=torch.int32, device=x.device) if check_bounds else None
+    check(lib.pygamd_gather_rows(_p(x2), _ld(x2), x2.size(0), _p(index), _idx_dtype(index), n, F,
+                                 _p(out), _ld(out), _p(err), _stream(x)), 'gather_rows')
+    if check_bounds and int(err.item()) != 0:
+        lo, hi = index_minmax(index)
+        raise IndexError(
+            f"Found indices in 'edge_index' outside the valid range [0, {x2.size(0) - 1}] "
+            f"(got interval [{lo}, {hi}])")
+    return out
+
+
+def scatter_rows(src: Tensor, index: Tensor, dim_size: int, reduce: str,
+                 return_count: bool = False):
+    _require_device(src, index)
+    lib = _lib.load()
+    s2 = _f32_rows(src, 'src')
+    index = index.contiguous()
+    n, F = index.numel(), s2.size(1)
+    red = REDUCE_IDS[reduce]
+    out = torch.empty(dim_size, F, dtype=torch.float32, device=src.device)
+    need_count = red in (_lib.MEAN, _lib.MIN, _lib.MAX)
+    count = torch.empty(dim_size, dtype=torch.float32, device=src.device) if need_count else None
+    st = _stream(src)
+    check(lib.pygamd_scatter_init(_p(out), _ld(out), dim_size, F, red, _p(count), st),
+          'scatter_init')
+    err = _err_flag(src.device)
+    check(lib.pygamd_scatter_rows(_p(s2), _ld(s2), _p(index), _idx_dtype(index), n, F, _p(out),
+                                  _ld(out), dim_size, red, _p(count), _p(err), st), 'scatter_rows')
+    check(lib.pygamd_scatter_finalize(_p(out), _ld(out), dim_size, F, red, _p(count), st),
+          'scatter_finalize')
+    return (out, count) if return_count else out
+
+
+def scatter_minmax_backward(src, index, out, grad_out) -> Tensor:
+    _require_device(src, index, out, grad_out)
+    lib = _lib.load()
+    s2 = _f32_rows(src, 'src')
+    o2, g2 = out.contiguous(), grad_out.contiguous()
+    index = index.contiguous()
+    n, F, dim_size = index.numel(), s2.size(1), o2.size(0)
+    ntie = torch.empty_like(o2)
+    st = _stream(src)
+    check(lib.pygamd_scatter_minmax_tie_count(_p(s2), _ld(s2), _p(index), _idx_dtype(index), n, F,
+                                              _p(o2), _ld(o2), dim_size, _p(ntie), st),
+          'scatter_minmax_tie_count')
+    grad_src = torch.empty(n, F, dtype=torch.float32, device=src.device)
+    check(lib.pygamd_scatter_minmax_backward(_p(s2), _ld(s2), _p(index), _idx_dtype(index), n, F,
+                                             _p(o2), _p(g2), _p(ntie), _ld(o2), _p(grad_src),
+                                             _ld(grad_src), st), 'scatter_minmax_backward')
+    return grad_src
+
+
+def scatter_argmax(src: Tensor, index: Tensor, dim_size: int) -> Tensor:
+    _require_device(src, index)
+    lib = _lib.load()
+    src = src.contiguous()
+    index = index.contiguous()
+    gmax = torch.empty(dim_size, dtype=torch.float32, device=src.device)
+    arg = torch.empty(dim_size, dtype=index.dtype, device=src.device)
+    check(lib.pygamd_scatter_argmax(_p(src), _p(index), _idx_dtype(index), index.numel(),
+                                    dim_size, _p(gmax), _p(arg), _stream(src)), 'scatter_argmax')
+    return arg
+
+
+# ---- softmax ---------------------------------------------------------------------------------
+def segment_softmax_forward(src: Tensor, ptr: Tensor) -> Tensor:
+    _require_device(src, ptr)
+    lib = _lib.load()
+    s2 = src.contiguous()
+    out = torch.empty_like(s2)
+    check(lib.pygamd_segment_softmax_forward(_p(s2), _p(ptr), _idx_dtype(ptr), ptr.numel() - 1,
+                                             s2.size(1), _p(out), _stream(src)),
+          'segment_softmax_forward')
+    return out
+
+
+def segment_softmax_backward(out: Tensor, grad_out: Tensor, ptr: Tensor) -> Tensor:
+    _require_device(out, grad_out, ptr)
+    lib = _lib.load()
+    o2, g2 = out.contiguous(), grad_out.contiguous()
+    grad_src = torch.empty_like(o2)
+    check(lib.pygamd_segment_softmax_backward(_p(o2), _p(g2), _p(ptr), _idx_dtype(ptr),
+                                              ptr.numel() - 1, o2.size(1), _p(grad_src),
+                                              _stream(out)), 'segment_softmax_backward')
+    return grad_src
+
+
+def gat_edge_softmax_forward(rowptr, col, alpha_src, alpha_dst, slope: float) -> Tensor:
+    _require_device(rowptr, col, alpha_src, alpha_dst)
+    lib = _lib.load()
+    a_s, a_d = alpha_src.contiguous(), alpha_dst.contiguous()
+    H = a_s.size(1)
+    out = torch.empty(col.numel(), H, dtype=torch.float32, device=a_s.device)
+    check(lib.pygamd_gat_edge_softmax_forward(_p(rowptr), _p(col), _idx_dtype(rowptr), _p(a_s),
+                                              _p(a_d), rowptr.numel() - 1, H, float(slope),
+                                              _p(out), _stream(a_s)), 'gat_edge_softmax_forward')
+    return out
+
+
+def gat_edge_softmax_backward(rowptr, col, alpha_src, alpha_dst, alpha, grad_alpha, slope: float):
+    _require_device(rowptr, col, alpha_src, alpha_dst, alpha, grad_alpha)
+    lib = _lib.load()
+    a_s, a_d = alpha_src.contiguous(), alpha_dst.contiguous()
+    al, g = alpha.contiguous(), grad_alpha.contiguous()
+    H = a_s.size(1)
+    g_src = torch.zeros_like(a_s)
+    g_dst = torch.zeros_like(a_d)
+    check(lib.pygamd_gat_edge_softmax_backward(_p(rowptr), _p(col), _idx_dtype(rowptr), _p(a_s),
+                                               _p(a_d), _p(al), _p(g), rowptr.numel() - 1, H,
+                                               float(slope), _p(g_src), _p(g_dst),
+                                               _stream(a_s)), 'gat_edge_softmax_backward')
+    return g_src, g_dst

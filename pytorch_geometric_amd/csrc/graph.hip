@@ -1,0 +1,364 @@
+// graph.hip — integer side of the path: index_sort, index2ptr/ptr2index, range checks and the hub
+// plan of a CSR handle.  Everything here is bit-exact by construction (stable LSD radix sort,
+// boundary-detection for the pointer array).  See include/pyg_amd.h for the reference call sites.
+#include <cstring>
+#include <limits>
+#include <type_traits>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace pygamd {
+
+static int bits_for(int64_t max_value, int key_bits) {
+  if (max_value < 0) return key_bits;
+  int b = 1;
+  while (b < key_bits - 1 && (static_cast<int64_t>(1) << b) <= max_value) ++b;
+  return b;
+}
+
+template <typename IdxT>
+static int index_sort_impl(const void* keys_in, int64_t n, int64_t max_value, void* keys_out,
+                           int64_t* perm_out, void* ws, size_t* ws_bytes, hipStream_t st) {
+  // Keys are non-negative, so they sort identically as unsigned; radix passes only cover the
+  // bits max_value can set.
+  using KeyT = typename std::make_unsigned<IdxT>::type;
+  const KeyT* kin = static_cast<const KeyT*>(keys_in);
+  KeyT* kout = static_cast<KeyT*>(keys_out);
+  rocprim::counting_iterator<int64_t> iota(0);
+  const unsigned end_bit = static_cast<unsigned>(bits_for(max_value, sizeof(IdxT) * 8));
+  PYGAMD_HIP_CHECK(rocprim::radix_sort_pairs(ws, *ws_bytes, kin, kout, iota, perm_out,
+                                             static_cast<size_t>(n), 0u, end_bit, st));
+  return PYGAMD_OK;
+}
+
+// ptr[v] = number of entries < v  (index sorted ascending).  One thread per entry i fills
+// ptr[index[i-1]+1 .. index[i]] = i; the last thread also fills the tail with n.
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    index2ptr_kernel(const IdxT* __restrict__ index, int64_t n, int64_t size,
+                     IdxT* __restrict__ ptr) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i > n) return;
+  int64_t lo = (i == 0) ? 0 : static_cast<int64_t>(index[i - 1]) + 1;
+  int64_t hi = (i == n) ? size : static_cast<int64_t>(index[i]);
+  if (lo < 0) lo = 0;        // out-of-range values never write outside ptr[0..size]
+  if (hi > size) hi = size;  // (callers validate the range; this only keeps memory safe)
+  for (int64_t v = lo; v <= hi; ++v) ptr[v] = static_cast<IdxT>(i);
+}
+
+// index[k] = the row r with ptr[r] <= k < ptr[r+1]  (upper_bound - 1 per output element).
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    ptr2index_kernel(const IdxT* __restrict__ ptr, int64_t size, int64_t n,
+                     IdxT* __restrict__ index) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= n) return;
+  int64_t lo = 0, hi = size;  // ptr[lo] <= k < ptr[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (static_cast<int64_t>(ptr[mid]) <= k) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  index[k] = static_cast<IdxT>(lo);
+}
+
+__global__ void minmax_init_kernel(int64_t* mm) {
+  mm[0] = std::numeric_limits<int64_t>::max();
+  mm[1] = -1;
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    index_minmax_kernel(const IdxT* __restrict__ index, int64_t n, int64_t* __restrict__ mm) {
+  int64_t lo = std::numeric_limits<int64_t>::max();
+  int64_t hi = std::numeric_limits<int64_t>::min();
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t v = index[i];
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const int64_t olo = bcast_lane(lo, lane_id() ^ off);
+    const int64_t ohi = bcast_lane(hi, lane_id() ^ off);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  if (lane_id() == 0 && hi >= lo) {
+    atomicMin(reinterpret_cast<long long*>(&mm[0]), static_cast<long long>(lo));
+    atomicMax(reinterpret_cast<long long*>(&mm[1]), static_cast<long long>(hi));
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    permute_index_kernel(const IdxT* __restrict__ src, const int64_t* __restrict__ perm,
+                         int64_t n, IdxT* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) out[i] = src[perm[i]];
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    cast_index_kernel(const int64_t* __restrict__ src, int64_t n, IdxT* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) out[i] = static_cast<IdxT>(src[i]);
+}
+
+// ---- hub plan -------------------------------------------------------------------------------
+template <typename IdxT>
+struct IsHub {
+  const IdxT* rowptr;
+  int64_t threshold;
+  __device__ bool operator()(int64_t r) const {
+    return static_cast<int64_t>(rowptr[r + 1]) - static_cast<int64_t>(rowptr[r]) > threshold;
+  }
+};
+
+// single-block exclusive scan of the chunk counts of the (few) hub rows
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    hub_chunk_scan_kernel(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ hub_rows,
+                          const int64_t* __restrict__ n_hub_dev, int64_t cap, int64_t chunk,
+                          IdxT* __restrict__ hub_chunk_ptr, int64_t* __restrict__ n_chunks_dev) {
+  __shared__ int64_t carry;
+  __shared__ int64_t wave_tot[kWavesPerBlock];
+  int64_t n_hub = *n_hub_dev;
+  if (n_hub > cap) n_hub = cap;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n_hub; base += kBlock) {
+    const int64_t h = base + threadIdx.x;
+    int64_t c = 0;
+    if (h < n_hub) {
+      const int64_t r = hub_rows[h];
+      const int64_t deg = static_cast<int64_t>(rowptr[r + 1]) - static_cast<int64_t>(rowptr[r]);
+      c = (deg + chunk - 1) / chunk;
+    }
+    // inclusive scan inside the wave
+    int64_t s = c;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int64_t o = bcast_lane(s, (lane_id() - off) & (kWave - 1));
+      if (lane_id() >= off) s += o;
+    }
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == kWave - 1) wave_tot[w] = s;
+    __syncthreads();
+    int64_t wave_off = 0;
+    for (int i = 0; i < w; ++i) wave_off += wave_tot[i];
+    const int64_t excl = carry + wave_off + s - c;
+    if (h < n_hub) hub_chunk_ptr[h] = static_cast<IdxT>(excl);
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry = excl + c;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    hub_chunk_ptr[n_hub] = static_cast<IdxT>(carry);
+    *n_chunks_dev = carry;
+  }
+}
+
+template <typename IdxT>
+static int hub_plan_impl(const void* rowptr_v, int64_t n_rows, int64_t threshold, int64_t chunk,
+                         void* hub_rows_v, void* hub_chunk_ptr_v, int64_t cap,
+                         int64_t* n_hub_out, int64_t* n_chunks_out, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+  const IdxT* rowptr = static_cast<const IdxT*>(rowptr_v);
+  IdxT* hub_rows = static_cast<IdxT*>(hub_rows_v);
+  IdxT* hub_chunk_ptr = static_cast<IdxT*>(hub_chunk_ptr_v);
+  // workspace layout: [n_hub (int64)] [n_chunks (int64)] [rocprim temp ...]
+  int64_t* counters = static_cast<int64_t*>(ws);
+  void* temp = static_cast<char*>(ws) + 16;
+  size_t temp_bytes = ws_bytes - 16;
+  rocprim::counting_iterator<int64_t> rows(0);
+  IsHub<IdxT> pred{rowptr, threshold};
+  // select() writes the selected row ids (ascending) and their count
+  size_t need = 0;
+  PYGAMD_HIP_CHECK(rocprim::select(nullptr, need, rows, hub_rows,
+                                   reinterpret_cast<size_t*>(counters),
+                                   static_cast<size_t>(n_rows), pred, st));
+  if (need > temp_bytes) return PYGAMD_ERR_WORKSPACE;
+  (void)cap;
+  PYGAMD_HIP_CHECK(rocprim::select(temp, need, rows, hub_rows,
+                                   reinterpret_cast<size_t*>(counters),
+                                   static_cast<size_t>(n_rows), pred, st));
+  hipLaunchKernelGGL((hub_chunk_scan_kernel<IdxT>), dim3(1), dim3(kBlock), 0, st, rowptr,
+                     hub_rows, counters, cap, chunk, hub_chunk_ptr, counters + 1);
+  PYGAMD_LAUNCH_CHECK();
+  int64_t host[2] = {0, 0};
+  PYGAMD_HIP_CHECK(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, st));
+  PYGAMD_HIP_CHECK(hipStreamSynchronize(st));
+  *n_hub_out = host[0];
+  *n_chunks_out = host[1];
+  return PYGAMD_OK;
+}
+
+}  // namespace pygamd
+
+using namespace pygamd;
+
+extern "C" {
+
+int pygamd_index_sort_workspace_bytes(int idx_dtype, int64_t n, size_t* bytes) {
+  if (!bytes || n < 0) return PYGAMD_ERR_INVALID_ARG;
+  size_t need = 0;
+  rocprim::counting_iterator<int64_t> iota(0);
+  hipError_t e;
+  if (idx_dtype == PYGAMD_IDX_I64) {
+    e = rocprim::radix_sort_pairs(nullptr, need, static_cast<const uint64_t*>(nullptr),
+                                  static_cast<uint64_t*>(nullptr), iota,
+                                  static_cast<int64_t*>(nullptr), static_cast<size_t>(n), 0u, 64u,
+                                  static_cast<hipStream_t>(nullptr));
+  } else if (idx_dtype == PYGAMD_IDX_I32) {
+    e = rocprim::radix_sort_pairs(nullptr, need, static_cast<const uint32_t*>(nullptr),
+                                  static_cast<uint32_t*>(nullptr), iota,
+                                  static_cast<int64_t*>(nullptr), static_cast<size_t>(n), 0u, 32u,
+                                  static_cast<hipStream_t>(nullptr));
+  } else {
+    return PYGAMD_ERR_INVALID_ARG;
+  }
+  if (e != hipSuccess) return hip_fail(e);
+  *bytes = need < 16 ? 16 : need;
+  return PYGAMD_OK;
+}
+
+int pygamd_index_sort(const void* keys_in, int idx_dtype, int64_t n, int64_t max_value,
+                      void* keys_out, int64_t* perm_out, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (n < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0) return PYGAMD_OK;
+  if (!keys_in || !keys_out || !perm_out || !workspace) return PYGAMD_ERR_INVALID_ARG;
+  size_t need = 0;
+  int rc = pygamd_index_sort_workspace_bytes(idx_dtype, n, &need);
+  if (rc != PYGAMD_OK) return rc;
+  if (workspace_bytes < need) return PYGAMD_ERR_WORKSPACE;
+  size_t ws_bytes = workspace_bytes;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    return index_sort_impl<IdxT>(keys_in, n, max_value, keys_out, perm_out, workspace, &ws_bytes,
+                                 as_stream(stream));
+  });
+}
+
+int pygamd_index2ptr(const void* index, int idx_dtype, int64_t n, int64_t size, void* ptr_out,
+                     void* stream) {
+  if (n < 0 || size < 0 || !ptr_out) return PYGAMD_ERR_INVALID_ARG;
+  if (n > 0 && !index) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const unsigned grid = static_cast<unsigned>(ceil_div(n + 1, kBlock));
+    hipLaunchKernelGGL((index2ptr_kernel<IdxT>), dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       static_cast<const IdxT*>(index), n, size, static_cast<IdxT*>(ptr_out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_ptr2index(const void* ptr, int idx_dtype, int64_t size, int64_t n, void* index_out,
+                     void* stream) {
+  if (n < 0 || size < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0) return PYGAMD_OK;
+  if (!ptr || !index_out || size == 0) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const unsigned grid = static_cast<unsigned>(ceil_div(n, kBlock));
+    hipLaunchKernelGGL((ptr2index_kernel<IdxT>), dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       static_cast<const IdxT*>(ptr), size, n, static_cast<IdxT*>(index_out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_index_minmax(const void* index, int idx_dtype, int64_t n, int64_t* minmax_out,
+                        void* stream) {
+  if (n < 0 || !minmax_out) return PYGAMD_ERR_INVALID_ARG;
+  if (n > 0 && !index) return PYGAMD_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, as_stream(stream), minmax_out);
+  PYGAMD_LAUNCH_CHECK();
+  if (n == 0) return PYGAMD_OK;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    int64_t blocks = ceil_div(n, kBlock);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((index_minmax_kernel<IdxT>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(kBlock), 0, as_stream(stream), static_cast<const IdxT*>(index), n,
+                       minmax_out);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_permute_index(const void* src, int idx_dtype, const int64_t* perm, int64_t n,
+                         void* out, void* stream) {
+  if (n < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0) return PYGAMD_OK;
+  if (!src || !perm || !out) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const unsigned grid = static_cast<unsigned>(ceil_div(n, kBlock));
+    hipLaunchKernelGGL((permute_index_kernel<IdxT>), dim3(grid), dim3(kBlock), 0,
+                       as_stream(stream), static_cast<const IdxT*>(src), perm, n,
+                       static_cast<IdxT*>(out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_cast_index(const int64_t* src, int64_t n, int idx_dtype, void* out, void* stream) {
+  if (n < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0) return PYGAMD_OK;
+  if (!src || !out) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const unsigned grid = static_cast<unsigned>(ceil_div(n, kBlock));
+    hipLaunchKernelGGL((cast_index_kernel<IdxT>), dim3(grid), dim3(kBlock), 0, as_stream(stream),
+                       src, n, static_cast<IdxT*>(out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_hub_plan_workspace_bytes(int idx_dtype, int64_t n_rows, size_t* bytes) {
+  if (!bytes || n_rows < 0) return PYGAMD_ERR_INVALID_ARG;
+  size_t need = 0;
+  rocprim::counting_iterator<int64_t> rows(0);
+  hipError_t e;
+  if (idx_dtype == PYGAMD_IDX_I64) {
+    IsHub<int64_t> pred{nullptr, 0};
+    e = rocprim::select(nullptr, need, rows, static_cast<int64_t*>(nullptr),
+                        static_cast<size_t*>(nullptr), static_cast<size_t>(n_rows), pred,
+                        static_cast<hipStream_t>(nullptr));
+  } else if (idx_dtype == PYGAMD_IDX_I32) {
+    IsHub<int32_t> pred{nullptr, 0};
+    e = rocprim::select(nullptr, need, rows, static_cast<int32_t*>(nullptr),
+                        static_cast<size_t*>(nullptr), static_cast<size_t>(n_rows), pred,
+                        static_cast<hipStream_t>(nullptr));
+  } else {
+    return PYGAMD_ERR_INVALID_ARG;
+  }
+  if (e != hipSuccess) return hip_fail(e);
+  *bytes = need + 16;
+  return PYGAMD_OK;
+}
+
+int pygamd_hub_plan(const void* rowptr, int idx_dtype, int64_t n_rows, int64_t threshold,
+                    int64_t chunk, void* hub_rows, void* hub_chunk_ptr, int64_t cap,
+                    int64_t* n_hub_out, int64_t* n_chunks_out, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  if (n_rows < 0 || threshold < 1 || chunk < 1 || !n_hub_out || !n_chunks_out)
+    return PYGAMD_ERR_INVALID_ARG;
+  *n_hub_out = 0;
+  *n_chunks_out = 0;
+  if (n_rows == 0) return PYGAMD_OK;
+  if (!rowptr || !hub_rows || !hub_chunk_ptr || !workspace || workspace_bytes < 32 ||
+      cap < n_rows)
+    return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    return hub_plan_impl<IdxT>(rowptr, n_rows, threshold, chunk, hub_rows, hub_chunk_ptr, cap,
+                               n_hub_out, n_chunks_out, workspace, workspace_bytes,
+                               as_stream(stream));
+  });
+}
+
+}  // extern "C"

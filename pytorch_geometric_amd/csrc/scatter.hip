@@ -1,0 +1,364 @@
+// scatter.hip — the unfused halves of MessagePassing.propagate on an UNSORTED index:
+// gather (a2: index_select), scatter-{sum,mean,min,max,mul,any} (a5) and scatter_argmax (a6).
+// These exist for callers that hold a raw, unsorted `index` and no graph handle
+// (torch_geometric/utils/_scatter.py:14-184).  Work items are flat (row, 16-byte chunk) pairs so
+// every global access is a full-width coalesced vector; reductions use device-scope atomics
+// (fp32 add is native on CDNA; min/max go through the integer trick in common.h).
+#include "common.h"
+
+namespace pygamd {
+
+template <typename IdxT, int VW>
+__global__ void __launch_bounds__(kBlock)
+    gather_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_src,
+                       const IdxT* __restrict__ index, int64_t n, int64_t units, int64_t F,
+                       float* __restrict__ out, int64_t ldo, int32_t* __restrict__ err) {
+  const int64_t total = n * units;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t e = t / units;
+    const int64_t f = (t - e * units) * VW;
+    int64_t r = index[e];
+    if (r < 0 || r >= n_src) {
+      if (err) *err = 1;
+      r = 0;
+    }
+    if (f < F) store_vec<VW>(out + e * ldo + f, load_vec<VW>(x + r * ldx + f));
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    fill_rows_kernel(float* __restrict__ out, int64_t ldo, int64_t rows, int64_t F, float v) {
+  const int64_t total = rows * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t r = t / F;
+    out[r * ldo + (t - r * F)] = v;
+  }
+}
+
+template <typename IdxT, int REDUCE>
+__global__ void __launch_bounds__(kBlock)
+    scatter_rows_kernel(const float* __restrict__ src, int64_t lds,
+                        const IdxT* __restrict__ index, int64_t n, int64_t F,
+                        float* __restrict__ out, int64_t ldo, int64_t dim_size,
+                        float* __restrict__ count, int32_t* __restrict__ err) {
+  const int64_t total = n * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t e = t / F;
+    const int64_t f = t - e * F;
+    const int64_t g = index[e];
+    if (g < 0 || g >= dim_size) {
+      if (err) *err = 1;
+      continue;
+    }
+    const float v = src[e * lds + f];
+    float* dst = out + g * ldo + f;
+    if (REDUCE == PYGAMD_SUM || REDUCE == PYGAMD_MEAN) {
+      atomicAdd(dst, v);
+    } else if (REDUCE == PYGAMD_MAX) {
+      atomic_max_f32(dst, v);
+    } else if (REDUCE == PYGAMD_MIN) {
+      atomic_min_f32(dst, v);
+    } else if (REDUCE == PYGAMD_MUL) {
+      atomic_mul_f32(dst, v);
+    } else {
+      *dst = v;  // 'any': some contributing row wins
+    }
+    if (count && f == 0) atomicAdd(count + g, 1.f);
+  }
+}
+
+template <int REDUCE>
+__global__ void __launch_bounds__(kBlock)
+    scatter_finalize_kernel(float* __restrict__ out, int64_t ldo, int64_t rows, int64_t F,
+                            const float* __restrict__ count) {
+  const int64_t total = rows * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t r = t / F;
+    float* p = out + r * ldo + (t - r * F);
+    const float c = count[r];
+    if (REDUCE == PYGAMD_MEAN) {
+      *p = *p / (c < 1.f ? 1.f : c);
+    } else {
+      if (c == 0.f) *p = 0.f;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    tie_init_kernel(const float* __restrict__ out, int64_t ldo, int64_t rows, int64_t F,
+                    float* __restrict__ ntie) {
+  const int64_t total = rows * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t r = t / F;
+    const int64_t o = r * ldo + (t - r * F);
+    ntie[o] = (out[o] == 0.f) ? 1.f : 0.f;
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    scatter_tie_count_kernel(const float* __restrict__ src, int64_t lds,
+                             const IdxT* __restrict__ index, int64_t n, int64_t F,
+                             const float* __restrict__ out, int64_t ldo, int64_t dim_size,
+                             float* __restrict__ ntie) {
+  const int64_t total = n * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t e = t / F;
+    const int64_t f = t - e * F;
+    const int64_t g = index[e];
+    if (g < 0 || g >= dim_size) continue;
+    if (src[e * lds + f] == out[g * ldo + f]) atomicAdd(ntie + g * ldo + f, 1.f);
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    scatter_minmax_bwd_kernel(const float* __restrict__ src, int64_t lds,
+                              const IdxT* __restrict__ index, int64_t n, int64_t F,
+                              const float* __restrict__ out, const float* __restrict__ grad_out,
+                              const float* __restrict__ ntie, int64_t ldo,
+                              float* __restrict__ grad_src, int64_t ldg) {
+  const int64_t total = n * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t e = t / F;
+    const int64_t f = t - e * F;
+    const int64_t o = static_cast<int64_t>(index[e]) * ldo + f;
+    grad_src[e * ldg + f] = (src[e * lds + f] == out[o]) ? grad_out[o] / ntie[o] : 0.f;
+  }
+}
+
+// ---- scatter_argmax (1-D) -------------------------------------------------------------------
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    argmax_init_kernel(float* __restrict__ gmax, IdxT* __restrict__ arg, int64_t dim_size) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (g < dim_size) {
+    gmax[g] = -INFINITY;
+    arg[g] = -1;
+  }
+}
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    argmax_max_kernel(const float* __restrict__ src, const IdxT* __restrict__ index, int64_t n,
+                      int64_t dim_size, float* __restrict__ gmax) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= n) return;
+  const int64_t g = index[e];
+  if (g >= 0 && g < dim_size) atomic_max_f32(gmax + g, src[e]);
+}
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    argmax_pick_kernel(const float* __restrict__ src, const IdxT* __restrict__ index, int64_t n,
+                       int64_t dim_size, const float* __restrict__ gmax,
+                       IdxT* __restrict__ arg) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= n) return;
+  const int64_t g = index[e];
+  if (g >= 0 && g < dim_size && src[e] == gmax[g]) {
+    if (sizeof(IdxT) == 8) {
+      atomicMax(reinterpret_cast<long long*>(arg + g), static_cast<long long>(e));
+    } else {
+      atomicMax(reinterpret_cast<int*>(arg + g), static_cast<int>(e));
+    }
+  }
+}
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    argmax_fix_kernel(IdxT* __restrict__ arg, int64_t dim_size) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (g < dim_size && arg[g] < 0) arg[g] = static_cast<IdxT>(dim_size - 1);
+}
+
+static unsigned flat_grid(int64_t total) {
+  int64_t blocks = ceil_div(total, kBlock);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
+  return static_cast<unsigned>(blocks);
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename IdxT>
+static int launch_scatter(const float* src, int64_t lds, const IdxT* idx, int64_t n, int64_t F,
+                          float* out, int64_t ldo, int64_t dim_size, int reduce, float* count,
+                          int32_t* err_flag, dim3 grid, hipStream_t st) {
+#define PYGAMD_SCATTER_CASE(R)                                                              \
+  case R:                                                                                   \
+    hipLaunchKernelGGL((scatter_rows_kernel<IdxT, R>), grid, dim3(kBlock), 0, st, src, lds, \
+                       idx, n, F, out, ldo, dim_size, count, err_flag);                     \
+    break;
+  switch (reduce) {
+    PYGAMD_SCATTER_CASE(PYGAMD_SUM)
+    PYGAMD_SCATTER_CASE(PYGAMD_MEAN)
+    PYGAMD_SCATTER_CASE(PYGAMD_MIN)
+    PYGAMD_SCATTER_CASE(PYGAMD_MAX)
+    PYGAMD_SCATTER_CASE(PYGAMD_MUL)
+    PYGAMD_SCATTER_CASE(PYGAMD_ANY)
+    default:
+      return PYGAMD_ERR_INVALID_ARG;
+  }
+#undef PYGAMD_SCATTER_CASE
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+}  // namespace pygamd
+
+using namespace pygamd;
+
+extern "C" {
+
+int pygamd_gather_rows(const float* x, int64_t ldx, int64_t n_src, const void* index,
+                       int idx_dtype, int64_t n, int64_t F, float* out, int64_t ldo,
+                       int32_t* err_flag, void* stream) {
+  if (n < 0 || F < 0 || n_src < 0 || ldx < F || ldo < F) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0 || F == 0) return PYGAMD_OK;
+  if (!x || !index || !out) return PYGAMD_ERR_INVALID_ARG;
+  const bool v4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) &&
+                  aligned16(out);
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    if (v4) {
+      const int64_t units = F / 4;
+      hipLaunchKernelGGL((gather_rows_kernel<IdxT, 4>), dim3(flat_grid(n * units)), dim3(kBlock),
+                         0, as_stream(stream), x, ldx, n_src, static_cast<const IdxT*>(index), n,
+                         units, F, out, ldo, err_flag);
+    } else {
+      hipLaunchKernelGGL((gather_rows_kernel<IdxT, 1>), dim3(flat_grid(n * F)), dim3(kBlock), 0,
+                         as_stream(stream), x, ldx, n_src, static_cast<const IdxT*>(index), n, F,
+                         F, out, ldo, err_flag);
+    }
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_scatter_init(float* out, int64_t ldo, int64_t dim_size, int64_t F, int reduce,
+                        float* count, void* stream) {
+  if (dim_size < 0 || F < 0 || ldo < F) return PYGAMD_ERR_INVALID_ARG;
+  if (reduce < PYGAMD_SUM || reduce > PYGAMD_ANY) return PYGAMD_ERR_INVALID_ARG;
+  if (dim_size == 0) return PYGAMD_OK;
+  hipStream_t st = as_stream(stream);
+  if (count) PYGAMD_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(float) * dim_size, st));
+  if (F == 0) return PYGAMD_OK;
+  if (!out) return PYGAMD_ERR_INVALID_ARG;
+  float v = 0.f;
+  if (reduce == PYGAMD_MAX) v = -INFINITY;
+  if (reduce == PYGAMD_MIN) v = INFINITY;
+  if (reduce == PYGAMD_MUL) v = 1.f;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3(flat_grid(dim_size * F)), dim3(kBlock), 0, st, out,
+                     ldo, dim_size, F, v);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+int pygamd_scatter_rows(const float* src, int64_t lds, const void* index, int idx_dtype,
+                        int64_t n, int64_t F, float* out, int64_t ldo, int64_t dim_size,
+                        int reduce, float* count, int32_t* err_flag, void* stream) {
+  if (n < 0 || F < 0 || dim_size < 0 || lds < F || ldo < F) return PYGAMD_ERR_INVALID_ARG;
+  if (reduce < PYGAMD_SUM || reduce > PYGAMD_ANY) return PYGAMD_ERR_INVALID_ARG;
+  if ((reduce == PYGAMD_MEAN || reduce == PYGAMD_MIN || reduce == PYGAMD_MAX) && !count &&
+      dim_size > 0)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0 || F == 0) return PYGAMD_OK;
+  if (!src || !index || !out) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(flat_grid(n * F));
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    return launch_scatter<IdxT>(src, lds, static_cast<const IdxT*>(index), n, F, out, ldo,
+                                dim_size, reduce, count, err_flag, grid, st);
+  });
+}
+
+int pygamd_scatter_finalize(float* out, int64_t ldo, int64_t dim_size, int64_t F, int reduce,
+                            const float* count, void* stream) {
+  if (dim_size < 0 || F < 0 || ldo < F) return PYGAMD_ERR_INVALID_ARG;
+  if (dim_size == 0 || F == 0) return PYGAMD_OK;
+  if (reduce != PYGAMD_MEAN && reduce != PYGAMD_MIN && reduce != PYGAMD_MAX) return PYGAMD_OK;
+  if (!out || !count) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(flat_grid(dim_size * F));
+  if (reduce == PYGAMD_MEAN) {
+    hipLaunchKernelGGL((scatter_finalize_kernel<PYGAMD_MEAN>), grid, dim3(kBlock), 0, st, out,
+                       ldo, dim_size, F, count);
+  } else {
+    hipLaunchKernelGGL((scatter_finalize_kernel<PYGAMD_MAX>), grid, dim3(kBlock), 0, st, out,
+                       ldo, dim_size, F, count);
+  }
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+int pygamd_scatter_minmax_tie_count(const float* src, int64_t lds, const void* index,
+                                    int idx_dtype, int64_t n, int64_t F, const float* out,
+                                    int64_t ldo, int64_t dim_size, float* ntie, void* stream) {
+  if (n < 0 || F < 0 || dim_size < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (dim_size == 0 || F == 0) return PYGAMD_OK;
+  if (!out || !ntie) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(tie_init_kernel, dim3(flat_grid(dim_size * F)), dim3(kBlock), 0, st, out,
+                     ldo, dim_size, F, ntie);
+  PYGAMD_LAUNCH_CHECK();
+  if (n == 0) return PYGAMD_OK;
+  if (!src || !index) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((scatter_tie_count_kernel<IdxT>), dim3(flat_grid(n * F)), dim3(kBlock), 0,
+                       st, src, lds, static_cast<const IdxT*>(index), n, F, out, ldo, dim_size,
+                       ntie);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_scatter_minmax_backward(const float* src, int64_t lds, const void* index,
+                                   int idx_dtype, int64_t n, int64_t F, const float* out,
+                                   const float* grad_out, const float* ntie, int64_t ldo,
+                                   float* grad_src, int64_t ldg, void* stream) {
+  if (n < 0 || F < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0 || F == 0) return PYGAMD_OK;
+  if (!src || !index || !out || !grad_out || !ntie || !grad_src) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((scatter_minmax_bwd_kernel<IdxT>), dim3(flat_grid(n * F)), dim3(kBlock),
+                       0, as_stream(stream), src, lds, static_cast<const IdxT*>(index), n, F, out,
+                       grad_out, ntie, ldo, grad_src, ldg);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_scatter_argmax(const float* src, const void* index, int idx_dtype, int64_t n,
+                          int64_t dim_size, float* gmax, void* arg_out, void* stream) {
+  if (n < 0 || dim_size < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (dim_size == 0) return PYGAMD_OK;
+  if (!gmax || !arg_out) return PYGAMD_ERR_INVALID_ARG;
+  if (n > 0 && (!src || !index)) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const IdxT* idx = static_cast<const IdxT*>(index);
+    IdxT* arg = static_cast<IdxT*>(arg_out);
+    const dim3 ggrid(static_cast<unsigned>(ceil_div(dim_size, kBlock)));
+    hipLaunchKernelGGL((argmax_init_kernel<IdxT>), ggrid, dim3(kBlock), 0, st, gmax, arg,
+                       dim_size);
+    PYGAMD_LAUNCH_CHECK();
+    if (n > 0) {
+      const dim3 egrid(static_cast<unsigned>(ceil_div(n, kBlock)));
+      hipLaunchKernelGGL((argmax_max_kernel<IdxT>), egrid, dim3(kBlock), 0, st, src, idx, n,
+                         dim_size, gmax);
+      PYGAMD_LAUNCH_CHECK();
+      hipLaunchKernelGGL((argmax_pick_kernel<IdxT>), egrid, dim3(kBlock), 0, st, src, idx, n,
+                         dim_size, gmax, arg);
+      PYGAMD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((argmax_fix_kernel<IdxT>), ggrid, dim3(kBlock), 0, st, arg, dim_size);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+}  // extern "C"

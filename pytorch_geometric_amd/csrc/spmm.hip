@@ -1,0 +1,735 @@
+// spmm.hip — CSR segmented-reduce SpMM for gfx950 (MI355X).
+//
+// The fused form of MessagePassing.propagate (gather on edge_index[j] -> message -> reduce on
+// edge_index[i]); see include/pyg_amd.h for the reference call sites.  HBM-bound: every stored
+// entry reads one full source row (4F bytes) exactly once; nothing of size [E, F] is ever
+// materialised.
+//
+// Mapping (wave64):
+//   * one wavefront owns one destination row (4 rows per 256-thread workgroup, workgroups
+//     XCD-remapped so each XCD walks a contiguous eighth of the rows);
+//   * a row's column indices are fetched 64 at a time with one coalesced load (lane l holds
+//     slot base+l) and handed out through v_readlane (when a whole wave serves one source row)
+//     or ds_bpermute (when a wave serves 64/LPR source rows at once);
+//   * LPR lanes cover one source row with VW-wide (16-byte when F % 4 == 0) loads, so a
+//     256-float row is ONE global_load_dwordx4 per wave = 1 KiB contiguous;
+//   * U independent row loads are issued before the first add (8 x 1 KiB in flight per wave,
+//     <= 64 VGPRs -> 8 waves/SIMD) — latency is hidden by memory-level parallelism, not LDS;
+//   * accumulation is in registers in slot order, one non-atomic store per output row;
+//   * rows longer than hub_threshold are skipped here and processed as fixed-size chunks by
+//     spmm_hub_chunks + spmm_hub_combine (deterministic two-stage sum).
+#include "common.h"
+
+namespace pygamd {
+
+template <typename IdxT>
+struct SpmmDev {
+  const IdxT* __restrict__ rowptr;
+  const IdxT* __restrict__ col;
+  const IdxT* __restrict__ eid;
+  const float* __restrict__ w;
+  const float* __restrict__ src_scale;
+  const float* __restrict__ x;
+  float* __restrict__ out;
+  IdxT* __restrict__ arg_out;
+  int64_t n_rows, F, ldx, ldo;
+  int w_heads, head_dim;
+  int mean;
+  int64_t hub_threshold;
+};
+
+// Independent row loads issued per lane before the first add.  A staged index chunk holds 64
+// slots, so EPI * U never needs to exceed 64 (U <= LPR).
+template <int LPR, int CH>
+constexpr int spmm_unroll() {
+  return CH == 1 ? (LPR < 8 ? LPR : 8) : 4;
+}
+
+// WMODE: 0 = plain sum; 1 = one staged multiplier per slot (w with one head and/or src_scale);
+//        2 = per-head weights fetched per slot (+ optional staged src_scale).
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, bool FULL>
+__device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cnt, int sub,
+                                           IdxT myc, IdxT mye, float mym, const int (&fo)[CH],
+                                           const bool (&fv)[CH], const int (&head)[CH],
+                                           float (&acc)[CH][VW]) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = spmm_unroll<LPR, CH>();
+  Vec<VW> v[U][CH];
+  float m[U];
+  float wv[U][CH];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = j + u * EPI + sub;
+    const bool valid = FULL || (k < cnt);
+    const int kk = FULL ? k : (k < cnt ? k : cnt - 1);
+    IdxT c;
+    if constexpr (EPI == 1) {
+      c = bcast_uniform(myc, kk);
+    } else {
+      c = bcast_lane(myc, kk);
+    }
+    if constexpr (WMODE != 0) {
+      float mm;
+      if constexpr (EPI == 1) {
+        mm = bcast_uniform(mym, kk);
+      } else {
+        mm = bcast_lane(mym, kk);
+      }
+      m[u] = valid ? mm : 0.f;
+    } else {
+      m[u] = 1.f;
+    }
+    const float* __restrict__ xr = a.x + static_cast<int64_t>(c) * a.ldx;
+    if constexpr (WMODE == 2) {
+      IdxT e;
+      if constexpr (EPI == 1) {
+        e = bcast_uniform(mye, kk);
+      } else {
+        e = bcast_lane(mye, kk);
+      }
+      const float* __restrict__ wr = a.w + static_cast<int64_t>(e) * a.w_heads;
+#pragma unroll
+      for (int c2 = 0; c2 < CH; ++c2) wv[u][c2] = fv[c2] ? wr[head[c2]] : 0.f;
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < CH; ++c2) {
+      if (fv[c2] && valid) {
+        v[u][c2] = load_vec<VW>(xr + fo[c2]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VW; ++i) v[u][c2].v[i] = 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int c2 = 0; c2 < CH; ++c2) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) {
+        if constexpr (WMODE == 0) {
+          acc[c2][i] += v[u][c2].v[i];
+        } else if constexpr (WMODE == 1) {
+          acc[c2][i] = fmaf(v[u][c2].v[i], m[u], acc[c2][i]);
+        } else {
+          acc[c2][i] = fmaf(v[u][c2].v[i], m[u] * wv[u][c2], acc[c2][i]);
+        }
+      }
+    }
+  }
+}
+
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
+__device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT start, IdxT end,
+                                                int lane, const int (&fo)[CH],
+                                                const bool (&fv)[CH], const int (&head)[CH],
+                                                float (&acc)[CH][VW]) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = spmm_unroll<LPR, CH>();
+  constexpr int STEP = EPI * U;
+  const int sub = lane / LPR;
+  for (IdxT base = start; base < end; base += kWave) {
+    const IdxT rem = end - base;
+    const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+    IdxT myc = 0, mye = 0;
+    float mym = 1.f;
+    if (lane < cnt) {
+      const IdxT k = base + lane;
+      if constexpr (IDENT) {
+        myc = k;
+      } else {
+        myc = a.col[k];
+      }
+      if constexpr (WMODE != 0) {
+        mye = a.eid ? a.eid[k] : k;
+        if (a.src_scale) mym = a.src_scale[myc];
+        if constexpr (WMODE == 1) {
+          if (a.w) mym *= a.w[mye];
+        }
+      }
+    }
+    int j = 0;
+    for (; j + STEP <= cnt; j += STEP) {
+      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, true>(a, j, cnt, sub, myc, mye, mym, fo, fv,
+                                                        head, acc);
+    }
+    if (j < cnt) {
+      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, false>(a, j, cnt, sub, myc, mye, mym, fo, fv,
+                                                         head, acc);
+    }
+  }
+}
+
+template <int VW, int LPR, int CH>
+__device__ __forceinline__ void feature_slots(int lane, int64_t F, int head_dim, int (&fo)[CH],
+                                              bool (&fv)[CH], int (&head)[CH]) {
+  const int lir = lane % LPR;
+  const int f0 = blockIdx.y * (LPR * CH * VW);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    fo[c] = f0 + (lir + LPR * c) * VW;
+    fv[c] = fo[c] < F;
+    head[c] = fv[c] ? fo[c] / head_dim : 0;
+  }
+}
+
+template <int VW, int LPR, int CH>
+__device__ __forceinline__ void combine_subgroups(float (&acc)[CH][VW]) {
+#pragma unroll
+  for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) acc[c][i] += __shfl_xor(acc[c][i], off, kWave);
+    }
+  }
+}
+
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
+__global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
+  const int lane = lane_id();
+  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (row >= a.n_rows) return;
+  const IdxT start = a.rowptr[row];
+  const IdxT end = a.rowptr[row + 1];
+  const IdxT deg = end - start;
+  if (a.hub_threshold > 0 && deg > a.hub_threshold) return;  // owned by the hub path
+  int fo[CH], head[CH];
+  bool fv[CH];
+  feature_slots<VW, LPR, CH>(lane, a.F, a.head_dim, fo, fv, head);
+  float acc[CH][VW];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) acc[c][i] = 0.f;
+  }
+  spmm_accumulate<IdxT, VW, LPR, CH, WMODE, IDENT>(a, start, end, lane, fo, fv, head, acc);
+  combine_subgroups<VW, LPR, CH>(acc);
+  if (lane < LPR) {
+    const float cntf = static_cast<float>(deg > 0 ? deg : 1);
+    float* __restrict__ orow = a.out + row * a.ldo;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (fv[c]) {
+        Vec<VW> o;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = a.mean ? acc[c][i] / cntf : acc[c][i];
+        store_vec<VW>(orow + fo[c], o);
+      }
+    }
+  }
+}
+
+// One wave per hub chunk: partial[ck, :] = sum over the chunk's slots (no post-scale).
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
+__global__ void __launch_bounds__(kBlock)
+    spmm_hub_chunks(SpmmDev<IdxT> a, const IdxT* __restrict__ hub_rows,
+                    const IdxT* __restrict__ hub_chunk_ptr, int64_t n_hub, int64_t n_chunks,
+                    int64_t chunk, float* __restrict__ partial) {
+  const int lane = lane_id();
+  const int64_t ck = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (ck >= n_chunks) return;
+  int64_t lo = 0, hi = n_hub;  // hub_chunk_ptr[lo] <= ck < hub_chunk_ptr[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (static_cast<int64_t>(hub_chunk_ptr[mid]) <= ck) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const int64_t row = hub_rows[lo];
+  const int64_t ci = ck - static_cast<int64_t>(hub_chunk_ptr[lo]);
+  const IdxT rs = a.rowptr[row];
+  const IdxT re = a.rowptr[row + 1];
+  const IdxT start = rs + static_cast<IdxT>(ci * chunk);
+  IdxT end = start + static_cast<IdxT>(chunk);
+  if (end > re) end = re;
+  int fo[CH], head[CH];
+  bool fv[CH];
+  feature_slots<VW, LPR, CH>(lane, a.F, a.head_dim, fo, fv, head);
+  float acc[CH][VW];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) acc[c][i] = 0.f;
+  }
+  spmm_accumulate<IdxT, VW, LPR, CH, WMODE, IDENT>(a, start, end, lane, fo, fv, head, acc);
+  combine_subgroups<VW, LPR, CH>(acc);
+  if (lane < LPR) {
+    float* __restrict__ prow = partial + ck * a.F;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (fv[c]) {
+        Vec<VW> o;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = acc[c][i];
+        store_vec<VW>(prow + fo[c], o);
+      }
+    }
+  }
+}
+
+// One wave per hub row: out[row, :] = post * (partial chunks summed in chunk order).
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    spmm_hub_combine(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ hub_rows,
+                     const IdxT* __restrict__ hub_chunk_ptr, int64_t n_hub,
+                     const float* __restrict__ partial, float* __restrict__ out, int64_t F,
+                     int64_t ldo, int mean) {
+  const int lane = lane_id();
+  const int64_t h = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  if (h >= n_hub) return;
+  const int64_t row = hub_rows[h];
+  const int64_t c0 = hub_chunk_ptr[h];
+  const int64_t c1 = hub_chunk_ptr[h + 1];
+  const IdxT deg = rowptr[row + 1] - rowptr[row];
+  const float cntf = static_cast<float>(deg > 0 ? deg : 1);
+  for (int64_t f = lane; f < F; f += kWave) {
+    float s = 0.f;
+    for (int64_t c = c0; c < c1; ++c) s += partial[c * F + f];
+    out[row * ldo + f] = mean ? s / cntf : s;
+  }
+}
+
+// ---- min / max with first-on-tie arg ------------------------------------------------------
+template <bool IS_MAX>
+__device__ __forceinline__ bool better_val(float v, float best) {
+  // NaN propagates (torch amax/amin semantics): a NaN beats any non-NaN.
+  const bool vn = (v != v), bn = (best != best);
+  if (bn) return false;
+  if (vn) return true;
+  return IS_MAX ? (v > best) : (v < best);
+}
+
+template <typename IdxT, int VW, int LPR, int CH, bool IS_MAX, bool IDENT>
+__global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = 4;
+  constexpr int STEP = EPI * U;
+  const int lane = lane_id();
+  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (row >= a.n_rows) return;
+  const IdxT start = a.rowptr[row];
+  const IdxT end = a.rowptr[row + 1];
+  int fo[CH], head[CH];
+  bool fv[CH];
+  feature_slots<VW, LPR, CH>(lane, a.F, 1, fo, fv, head);
+  const int sub = lane / LPR;
+  const float init = IS_MAX ? -INFINITY : INFINITY;
+  float best[CH][VW];
+  IdxT barg[CH][VW];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      best[c][i] = init;
+      barg[c][i] = -1;
+    }
+  }
+  for (IdxT base = start; base < end; base += kWave) {
+    const IdxT rem = end - base;
+    const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+    IdxT myc = 0;
+    if (lane < cnt) {
+      if constexpr (IDENT) {
+        myc = base + lane;
+      } else {
+        myc = a.col[base + lane];
+      }
+    }
+    for (int j = 0; j < cnt; j += STEP) {
+      Vec<VW> v[U][CH];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = j + u * EPI + sub;
+        ok[u] = k < cnt;
+        const int kk = ok[u] ? k : cnt - 1;
+        IdxT c;
+        if constexpr (EPI == 1) {
+          c = bcast_uniform(myc, kk);
+        } else {
+          c = bcast_lane(myc, kk);
+        }
+        const float* __restrict__ xr = a.x + static_cast<int64_t>(c) * a.ldx;
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+          if (fv[c2] && ok[u]) {
+            v[u][c2] = load_vec<VW>(xr + fo[c2]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < VW; ++i) v[u][c2].v[i] = init;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const IdxT slot = base + static_cast<IdxT>(j + u * EPI + sub);
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+#pragma unroll
+          for (int i = 0; i < VW; ++i) {
+            const float val = v[u][c2].v[i];
+            // the first valid slot always wins over the (arg == -1) initial state
+            if (ok[u] && (barg[c2][i] < 0 || better_val<IS_MAX>(val, best[c2][i]))) {
+              best[c2][i] = val;
+              barg[c2][i] = slot;
+            }
+          }
+        }
+      }
+    }
+  }
+  // merge the EPI sub-groups: better value wins, equal values keep the smaller slot
+#pragma unroll
+  for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) {
+        const float ov = bcast_lane(best[c][i], lane ^ off);
+        const IdxT oa = bcast_lane(barg[c][i], lane ^ off);
+        bool take = false;
+        if (oa >= 0) {
+          if (barg[c][i] < 0) {
+            take = true;
+          } else if (better_val<IS_MAX>(ov, best[c][i])) {
+            take = true;
+          } else if (!better_val<IS_MAX>(best[c][i], ov) && oa < barg[c][i]) {
+            take = true;
+          }
+        }
+        if (take) {
+          best[c][i] = ov;
+          barg[c][i] = oa;
+        }
+      }
+    }
+  }
+  if (lane < LPR) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (fv[c]) {
+        Vec<VW> o;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = barg[c][i] < 0 ? 0.f : best[c][i];
+        store_vec<VW>(a.out + row * a.ldo + fo[c], o);
+        if (a.arg_out) {
+#pragma unroll
+          for (int i = 0; i < VW; ++i) a.arg_out[row * a.ldo + fo[c] + i] = barg[c][i];
+        }
+      }
+    }
+  }
+}
+
+// ---- min/max backward helpers (reference tie rule, see pyg_amd.h) --------------------------
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    spmm_tie_count_rows(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ col,
+                        const float* __restrict__ x, int64_t ldx, const float* __restrict__ out,
+                        int64_t ldo, int64_t n_rows, int64_t F, int count_self,
+                        float* __restrict__ ntie) {
+  const int lane = lane_id();
+  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (row >= n_rows) return;
+  const IdxT start = rowptr[row];
+  const IdxT end = rowptr[row + 1];
+  for (int64_t f = lane; f < F; f += kWave) {
+    const float o = out[row * ldo + f];
+    float n = (count_self && o == 0.f) ? 1.f : 0.f;
+    for (IdxT k = start; k < end; ++k) {
+      const int64_t c = col ? static_cast<int64_t>(col[k]) : static_cast<int64_t>(k);
+      n += (x[c * ldx + f] == o) ? 1.f : 0.f;
+    }
+    ntie[row * ldo + f] = n;
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    spmm_minmax_bwd_rows(const IdxT* __restrict__ rowptr_t, const IdxT* __restrict__ col_t,
+                         const float* __restrict__ x, int64_t ldx, const float* __restrict__ out,
+                         const float* __restrict__ grad_out, const float* __restrict__ ntie,
+                         int64_t ldo, int64_t n_src, int64_t F, float* __restrict__ grad_x,
+                         int64_t ldg) {
+  const int lane = lane_id();
+  const int64_t j = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (j >= n_src) return;
+  const IdxT start = rowptr_t[j];
+  const IdxT end = rowptr_t[j + 1];
+  for (int64_t f = lane; f < F; f += kWave) {
+    const float xv = x[j * ldx + f];
+    float g = 0.f;
+    for (IdxT k = start; k < end; ++k) {
+      const int64_t i = col_t[k];
+      if (xv == out[i * ldo + f]) g += grad_out[i * ldo + f] / ntie[i * ldo + f];
+    }
+    grad_x[j * ldg + f] = g;
+  }
+}
+
+// ---- SDDMM ----------------------------------------------------------------------------------
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    sddmm_rows(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ col,
+               const IdxT* __restrict__ eid, const float* __restrict__ grad_out, int64_t ldg,
+               const float* __restrict__ x, int64_t ldx, int64_t n_rows, int64_t F, int w_heads,
+               int head_dim, float* __restrict__ grad_w) {
+  const int lane = lane_id();
+  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (row >= n_rows) return;
+  const IdxT start = rowptr[row];
+  const IdxT end = rowptr[row + 1];
+  const float* __restrict__ g = grad_out + row * ldg;
+  for (IdxT k = start; k < end; ++k) {
+    const int64_t c = col ? static_cast<int64_t>(col[k]) : static_cast<int64_t>(k);
+    const int64_t e = eid ? static_cast<int64_t>(eid[k]) : static_cast<int64_t>(k);
+    const float* __restrict__ xr = x + c * ldx;
+    for (int h = 0; h < w_heads; ++h) {
+      const int64_t f0 = static_cast<int64_t>(h) * head_dim;
+      float p = 0.f;
+      for (int64_t f = lane; f < head_dim; f += kWave) p = fmaf(g[f0 + f], xr[f0 + f], p);
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) p += __shfl_xor(p, off, kWave);
+      if (lane == 0) grad_w[e * w_heads + h] = p;
+    }
+  }
+}
+
+// ---- host dispatch --------------------------------------------------------------------------
+template <typename IdxT>
+static SpmmDev<IdxT> make_dev(const pygamd_spmm_args* p) {
+  SpmmDev<IdxT> a;
+  a.rowptr = static_cast<const IdxT*>(p->rowptr);
+  a.col = static_cast<const IdxT*>(p->col);
+  a.eid = static_cast<const IdxT*>(p->eid);
+  a.w = p->w;
+  a.src_scale = p->src_scale;
+  a.x = p->x;
+  a.out = p->out;
+  a.arg_out = static_cast<IdxT*>(p->arg_out);
+  a.n_rows = p->n_rows;
+  a.F = p->F;
+  a.ldx = p->ldx;
+  a.ldo = p->ldo;
+  a.w_heads = p->w_heads < 1 ? 1 : p->w_heads;
+  a.head_dim = (p->w_heads > 1) ? p->head_dim : static_cast<int>(p->F > 0 ? p->F : 1);
+  a.mean = (p->reduce == PYGAMD_MEAN);
+  a.hub_threshold = (p->n_hub > 0) ? p->hub_threshold : 0;
+  return a;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct Shape {
+  int vw, lpr, ch;
+  unsigned tiles;
+};
+
+static Shape pick_shape(const pygamd_spmm_args* p) {
+  Shape s;
+  const bool v4 = (p->F % 4 == 0) && (p->ldx % 4 == 0) && (p->ldo % 4 == 0) &&
+                  aligned16(p->x) && aligned16(p->out) &&
+                  (p->w_heads <= 1 || p->head_dim % 4 == 0);
+  s.vw = v4 ? 4 : 1;
+  const int64_t units = ceil_div(p->F, s.vw);  // lanes needed to cover a row once
+  int lpr = 4;
+  while (lpr < 64 && lpr < units) lpr <<= 1;
+  s.lpr = lpr;
+  s.ch = (lpr == 64 && units > 64) ? 2 : 1;
+  s.tiles = static_cast<unsigned>(ceil_div(units, static_cast<int64_t>(s.lpr) * s.ch));
+  return s;
+}
+
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
+static int launch_sum(const pygamd_spmm_args* p, const Shape& s, float* partial,
+                      hipStream_t st) {
+  SpmmDev<IdxT> a = make_dev<IdxT>(p);
+  dim3 grid(wave_grid(p->n_rows), s.tiles);
+  hipLaunchKernelGGL((spmm_sum_rows<IdxT, VW, LPR, CH, WMODE, IDENT>), grid, dim3(kBlock), 0, st,
+                     a);
+  PYGAMD_LAUNCH_CHECK();
+  if (p->n_hub > 0) {
+    dim3 hgrid(wave_grid(p->n_chunks), s.tiles);
+    hipLaunchKernelGGL((spmm_hub_chunks<IdxT, VW, LPR, CH, WMODE, IDENT>), hgrid, dim3(kBlock),
+                       0, st, a, static_cast<const IdxT*>(p->hub_rows),
+                       static_cast<const IdxT*>(p->hub_chunk_ptr), p->n_hub, p->n_chunks,
+                       p->hub_chunk, partial);
+    PYGAMD_LAUNCH_CHECK();
+    dim3 cgrid(static_cast<unsigned>(ceil_div(p->n_hub, kWavesPerBlock)));
+    hipLaunchKernelGGL((spmm_hub_combine<IdxT>), cgrid, dim3(kBlock), 0, st, a.rowptr,
+                       static_cast<const IdxT*>(p->hub_rows),
+                       static_cast<const IdxT*>(p->hub_chunk_ptr), p->n_hub, partial, a.out,
+                       a.F, a.ldo, a.mean);
+    PYGAMD_LAUNCH_CHECK();
+  }
+  return PYGAMD_OK;
+}
+
+template <typename IdxT, int VW, int LPR, int CH, bool IDENT>
+static int launch_sum_w(const pygamd_spmm_args* p, const Shape& s, float* partial,
+                        hipStream_t st) {
+  const bool has_w = p->w != nullptr;
+  const bool has_scale = p->src_scale != nullptr;
+  if (has_w && p->w_heads > 1)
+    return launch_sum<IdxT, VW, LPR, CH, 2, IDENT>(p, s, partial, st);
+  if (has_w || has_scale) return launch_sum<IdxT, VW, LPR, CH, 1, IDENT>(p, s, partial, st);
+  return launch_sum<IdxT, VW, LPR, CH, 0, IDENT>(p, s, partial, st);
+}
+
+template <typename IdxT, int VW, int LPR, int CH, bool IDENT>
+static int launch_minmax(const pygamd_spmm_args* p, const Shape& s, hipStream_t st) {
+  SpmmDev<IdxT> a = make_dev<IdxT>(p);
+  a.hub_threshold = 0;
+  dim3 grid(wave_grid(p->n_rows), s.tiles);
+  if (p->reduce == PYGAMD_MAX) {
+    hipLaunchKernelGGL((spmm_minmax_rows<IdxT, VW, LPR, CH, true, IDENT>), grid, dim3(kBlock), 0,
+                       st, a);
+  } else {
+    hipLaunchKernelGGL((spmm_minmax_rows<IdxT, VW, LPR, CH, false, IDENT>), grid, dim3(kBlock),
+                       0, st, a);
+  }
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+template <typename IdxT, int VW, int LPR, int CH>
+static int launch_shape(const pygamd_spmm_args* p, const Shape& s, float* partial,
+                        hipStream_t st) {
+  const bool ident = (p->col == nullptr);
+  const bool mm = (p->reduce == PYGAMD_MIN || p->reduce == PYGAMD_MAX);
+  if (mm) {
+    return ident ? launch_minmax<IdxT, VW, LPR, CH, true>(p, s, st)
+                 : launch_minmax<IdxT, VW, LPR, CH, false>(p, s, st);
+  }
+  return ident ? launch_sum_w<IdxT, VW, LPR, CH, true>(p, s, partial, st)
+               : launch_sum_w<IdxT, VW, LPR, CH, false>(p, s, partial, st);
+}
+
+template <typename IdxT, int VW>
+static int launch_vw(const pygamd_spmm_args* p, const Shape& s, float* partial, hipStream_t st) {
+  switch (s.lpr) {
+    case 4:
+      return launch_shape<IdxT, VW, 4, 1>(p, s, partial, st);
+    case 8:
+      return launch_shape<IdxT, VW, 8, 1>(p, s, partial, st);
+    case 16:
+      return launch_shape<IdxT, VW, 16, 1>(p, s, partial, st);
+    case 32:
+      return launch_shape<IdxT, VW, 32, 1>(p, s, partial, st);
+    default:
+      return s.ch == 2 ? launch_shape<IdxT, VW, 64, 2>(p, s, partial, st)
+                       : launch_shape<IdxT, VW, 64, 1>(p, s, partial, st);
+  }
+}
+
+static int validate(const pygamd_spmm_args* p) {
+  if (!p) return PYGAMD_ERR_INVALID_ARG;
+  if (p->n_rows < 0 || p->F < 0 || p->ldx < p->F || p->ldo < p->F) return PYGAMD_ERR_INVALID_ARG;
+  if (p->idx_dtype != PYGAMD_IDX_I32 && p->idx_dtype != PYGAMD_IDX_I64)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (p->reduce != PYGAMD_SUM && p->reduce != PYGAMD_MEAN && p->reduce != PYGAMD_MIN &&
+      p->reduce != PYGAMD_MAX)
+    return PYGAMD_ERR_UNSUPPORTED;
+  if (p->n_rows > 0 && p->F > 0 && (!p->rowptr || !p->x || !p->out)) return PYGAMD_ERR_INVALID_ARG;
+  const bool mm = (p->reduce == PYGAMD_MIN || p->reduce == PYGAMD_MAX);
+  if (mm && (p->w || p->src_scale)) return PYGAMD_ERR_UNSUPPORTED;
+  if (p->w && p->w_heads > 1) {
+    if (p->head_dim < 1 || static_cast<int64_t>(p->head_dim) * p->w_heads != p->F)
+      return PYGAMD_ERR_INVALID_ARG;
+  }
+  if (p->n_hub > 0 && (!p->hub_rows || !p->hub_chunk_ptr || p->hub_chunk < 1 ||
+                       p->hub_threshold < 1 || p->n_chunks < p->n_hub))
+    return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_OK;
+}
+
+}  // namespace pygamd
+
+using namespace pygamd;
+
+extern "C" {
+
+int pygamd_spmm_csr_workspace_bytes(const pygamd_spmm_args* args, size_t* bytes) {
+  if (!args || !bytes) return PYGAMD_ERR_INVALID_ARG;
+  const bool mm = (args->reduce == PYGAMD_MIN || args->reduce == PYGAMD_MAX);
+  *bytes = (args->n_hub > 0 && !mm)
+               ? static_cast<size_t>(args->n_chunks) * static_cast<size_t>(args->F) * sizeof(float)
+               : 0;
+  return PYGAMD_OK;
+}
+
+int pygamd_spmm_csr(const pygamd_spmm_args* args, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  int rc = validate(args);
+  if (rc != PYGAMD_OK) return rc;
+  if (args->n_rows == 0 || args->F == 0) return PYGAMD_OK;
+  size_t need = 0;
+  pygamd_spmm_csr_workspace_bytes(args, &need);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return PYGAMD_ERR_WORKSPACE;
+  const Shape s = pick_shape(args);
+  hipStream_t st = as_stream(stream);
+  float* partial = static_cast<float*>(workspace);
+  return PYGAMD_DISPATCH_IDX(args->idx_dtype, [&]() -> int {
+    return s.vw == 4 ? launch_vw<IdxT, 4>(args, s, partial, st)
+                     : launch_vw<IdxT, 1>(args, s, partial, st);
+  });
+}
+
+int pygamd_spmm_csr_tie_count(const void* rowptr, const void* col, int idx_dtype, const float* x,
+                              int64_t ldx, const float* out, int64_t ldo, int64_t n_rows,
+                              int64_t F, int count_self, float* ntie_out, void* stream) {
+  if (n_rows < 0 || F < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows == 0 || F == 0) return PYGAMD_OK;
+  if (!rowptr || !x || !out || !ntie_out) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((spmm_tie_count_rows<IdxT>), dim3(wave_grid(n_rows)), dim3(kBlock), 0,
+                       as_stream(stream), static_cast<const IdxT*>(rowptr),
+                       static_cast<const IdxT*>(col), x, ldx, out, ldo, n_rows, F, count_self,
+                       ntie_out);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_spmm_csr_minmax_backward(const void* rowptr_t, const void* col_t, int idx_dtype,
+                                    const float* x, int64_t ldx, const float* out,
+                                    const float* grad_out, const float* ntie, int64_t ldo,
+                                    int64_t n_src, int64_t F, float* grad_x, int64_t ldg,
+                                    void* stream) {
+  if (n_src < 0 || F < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n_src == 0 || F == 0) return PYGAMD_OK;
+  if (!rowptr_t || !col_t || !x || !out || !grad_out || !ntie || !grad_x)
+    return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((spmm_minmax_bwd_rows<IdxT>), dim3(wave_grid(n_src)), dim3(kBlock), 0,
+                       as_stream(stream), static_cast<const IdxT*>(rowptr_t),
+                       static_cast<const IdxT*>(col_t), x, ldx, out, grad_out, ntie, ldo, n_src,
+                       F, grad_x, ldg);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_sddmm_csr(const void* rowptr, const void* col, const void* eid, int idx_dtype,
+                     const float* grad_out, int64_t ldg, const float* x, int64_t ldx,
+                     int64_t n_rows, int64_t F, int32_t w_heads, int32_t head_dim, float* grad_w,
+                     void* stream) {
+  if (n_rows < 0 || F < 0 || w_heads < 1) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows == 0) return PYGAMD_OK;
+  if (!rowptr || !grad_out || !x || !grad_w) return PYGAMD_ERR_INVALID_ARG;
+  const int hd = (w_heads > 1) ? head_dim : static_cast<int>(F);
+  if (static_cast<int64_t>(hd) * w_heads != F) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((sddmm_rows<IdxT>), dim3(wave_grid(n_rows)), dim3(kBlock), 0,
+                       as_stream(stream), static_cast<const IdxT*>(rowptr),
+                       static_cast<const IdxT*>(col), static_cast<const IdxT*>(eid), grad_out,
+                       ldg, x, ldx, n_rows, F, w_heads, hd, grad_w);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+"""Graph handle: COO ``edge_index`` plus cached CSR (sorted by destination), CSC (sorted by
+source), the two stable permutations and the hub plans the SpMM kernels need.
+
+Mirrors the cache of the reference's ``EdgeIndex`` (torch_geometric/edge_index.py:589-696:
+``get_indptr`` / ``_sort_by_transpose`` / ``get_csr`` / ``get_csc`` / ``fill_cache_``) but is a plain
+object, not a Tensor subclass.  Message flow is ``source_to_target``: ``edge_index[0]`` = source j,
+``edge_index[1]`` = destination i (collect.jinja:31,67-68).
+
+All integer outputs are bit-exact with ``torch.sort(stable=True)`` +
+``torch._convert_indices_from_coo_to_csr`` (tests/test_gpu_graph.py).
+"""
+import weakref
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _native
+
+
+class CSR:
+    """One sorted orientation: ``ptr`` over the sorted rows, ``idx`` = the other endpoint per slot,
+    ``perm`` = slot -> position in the COO edge list (stable), ``hub`` = split plan for long rows."""
+
+    def __init__(self, ptr: Tensor, idx: Tensor, perm: Tensor, n_rows: int, n_cols: int):
+        self.ptr, self.idx, self.perm = ptr, idx, perm
+        self.n_rows, self.n_cols = n_rows, n_cols
+        self._hub = None
+        self._inv_deg = None
+
+    @property
+    def hub(self):
+        if self._hub is None:
+            self._hub = _native.hub_plan(self.ptr)
+        return self._hub
+
+    @property
+    def nnz(self) -> int:
+        return self.idx.numel()
+
+    def degree(self) -> Tensor:
+        return self.ptr[1:] - self.ptr[:-1]
+
+    def inv_degree(self) -> Tensor:
+        """1 / clamp(deg, 1) as fp32 — the mean normaliser (utils/_scatter.py:72-80)."""
+        if self._inv_deg is None:
+            self._inv_deg = 1.0 / self.degree().clamp(min=1).to(torch.float32)
+        return self._inv_deg
+
+
+def build_csr(key: Tensor, other: Tensor, n_rows: int, n_cols: int,
+              is_sorted: bool = False) -> CSR:
+    """Stable sort of the COO list by ``key`` (edge_index.py:605-623 ``_sort_by_transpose``)."""
+    if is_sorted:
+        perm = torch.arange(key.numel(), dtype=key.dtype, device=key.device)
+        ptr = _native.index2ptr(key, n_rows)
+        return CSR(ptr, other.contiguous(), perm, n_rows, n_cols)
+    sorted_key, perm64 = _native.index_sort(key, max_value=max(n_rows - 1, 0))
+    idx = _native.permute_index(other, perm64)
+    ptr = _native.index2ptr(sorted_key, n_rows)
+    perm = _native.cast_index(perm64, key.dtype)
+    return CSR(ptr, idx, perm, n_rows, n_cols)
+
+
+class EdgeIndex:
+    r"""COO edge list of a (bipartite) graph with lazily built, cached sorted forms.
+
+    Args:
+        edge_index: ``[2, E]`` int32/int64 device tensor (row 0 = source, row 1 = destination).
+        sparse_size: ``(num_src_nodes, num_dst_nodes)``; inferred (one host sync) when ``None``,
+            like ``maybe_num_nodes`` in the reference.
+        sort_order: ``'row'`` if ``edge_index[0]`` is already sorted, ``'col'`` if ``edge_index[1]``
+            is, else ``None`` (same vocabulary as the reference's ``EdgeIndex``).
+        validate: range-check the indices against ``sparse_size`` once (two host syncs).
+    """
+
+    def __init__(self, edge_index: Tensor, sparse_size: Optional[Tuple[int, int]] = None,
+                 sort_order: Optional[str] = None, validate: bool = True):
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError(f"'edge_index' needs to be of shape [2, num_edges] "
+                             f"(got {list(edge_index.shape)})")
+        if edge_index.dtype not in (torch.int32, torch.int64):
+            raise ValueError(f"'edge_index' holds an unsupported data type "
+                             f"(got '{edge_index.dtype}', expected int32 or int64)")
+        if sort_order not in (None, 'row', 'col'):
+            raise ValueError(f"invalid sort_order '{sort_order}'")
+        self.edge_index = edge_index
+        if sparse_size is None or sparse_size[0] is None or sparse_size[1] is None:
+            n = 0
+            if edge_index.numel() > 0:
+                n = _native.index_minmax(edge_index.reshape(-1))[1] + 1
+            given = sparse_size or (None, None)
+            sparse_size = (n if given[0] is None else given[0],
+                           n if given[1] is None else given[1])
+        self.sparse_size = (int(sparse_size[0]), int(sparse_size[1]))
+        if validate and edge_index.numel() > 0:
+            # the reference raises IndexError from index_select (message_passing.py:269-290);
+            # the fused kernels never bounds-check, so the handle does it once, up front
+            for row, n in ((0, self.sparse_size[0]), (1, self.sparse_size[1])):
+                lo, hi = _native.index_minmax(edge_index[row])
+                if lo < 0:
+                    raise IndexError(
+                        f"Found negative indices in 'edge_index' (got {lo}). Please ensure that "
+                        f"all indices in 'edge_index' point to valid indices in the interval "
+                        f"[0, {n}) in your node feature matrix and try again.")
+                if hi >= n:
+                    raise IndexError(
+                        f"Found indices in 'edge_index' that are larger than {n - 1} (got "
+                        f"{hi}). Please ensure that all indices in 'edge_index' point to valid "
+                        f"indices in the interval [0, {n}) in your node feature matrix and try "
+                        f"again.")
+        self.sort_order = sort_order
+        self._csr: Optional[CSR] = None   # sorted by destination (aggregation / forward)
+        self._csc: Optional[CSR] = None   # sorted by source (transposed / backward)
+        self._slot_map = None
+
+    # -- accessors -------------------------------------------------------------------------------
+    @property
+    def num_edges(self) -> int:
+        return self.edge_index.size(1)
+
+    @property
+    def num_src_nodes(self) -> int:
+        return self.sparse_size[0]
+
+    @property
+    def num_dst_nodes(self) -> int:
+        return self.sparse_size[1]
+
+    @property
+    def device(self):
+        return self.edge_index.device
+
+    def by_dst(self) -> CSR:
+        """ptr over destinations, idx = sources (``get_csc`` in the reference's row/col naming:
+        the form ``message_and_aggregate`` consumes, edge_index.py:646-663)."""
+        if self._csr is None:
+            src, dst = self.edge_index[0], self.edge_index[1]
+            self._csr = build_csr(dst, src, self.num_dst_nodes, self.num_src_nodes,
+                                  is_sorted=self.sort_order == 'col')
+        return self._csr
+
+    def by_src(self) -> CSR:
+        """ptr over sources, idx = destinations (the transposed handle for the backward,
+        edge_index.py:1849-1900)."""
+        if self._csc is None:
+            src, dst = self.edge_index[0], self.edge_index[1]
+            self._csc = build_csr(src, dst, self.num_src_nodes, self.num_dst_nodes,
+                                  is_sorted=self.sort_order == 'row')
+        return self._csc
+
+    def fill_cache_(self) -> 'EdgeIndex':
+        self.by_dst().hub
+        self.by_src().hub
+        return self
+
+    def src_slot_to_dst_slot(self) -> Tensor:
+        """For every slot of the by-source form, the slot of the same edge in the by-destination
+        form (needed when per-edge values live in by-destination slot order, e.g. GAT's alpha)."""
+        if self._slot_map is None:
+            fwd, bwd = self.by_dst(), self.by_src()
+            inv = torch.empty_like(fwd.perm)
+            inv[fwd.perm.long()] = torch.arange(fwd.perm.numel(), dtype=fwd.perm.dtype,
+                                                device=fwd.perm.device)
+            self._slot_map = inv[bwd.perm.long()].contiguous()
+        return self._slot_map
+
+    def __repr__(self) -> str:
+        return (f'EdgeIndex(num_edges={self.num_edges}, sparse_size={self.sparse_size}, '
+                f'sort_order={self.sort_order})')
+
+
+# ---- cache for raw ``edge_index`` tensors ------------------------------------------------------
+# nn.conv layers receive a plain tensor every call; sorting it once per (tensor, version, size)
+# turns 3 layers x N epochs of scatter into CSR SpMM.
+_cache = {}
+_cache_enabled = True
+MAX_CACHE_ENTRIES = 8
+
+
+def set_cache_enabled(flag: bool):
+    global _cache_enabled
+    _cache_enabled = bool(flag)
+    if not flag:
+        _cache.clear()
+
+
+def clear_cache():
+    _cache.clear()
+
+
+def as_edge_index(edge_index, num_src: Optional[int] = None, num_dst: Optional[int] = None,
+                  flip: bool = False) -> EdgeIndex:
+    """Handle for a raw ``[2, E]`` tensor, cached per (tensor identity, version, sizes, flip).
+    ``flip=True`` swaps the two rows first (``flow='target_to_source'``)."""
+    if isinstance(edge_index, EdgeIndex):
+        if flip:
+            raise ValueError("an EdgeIndex handle is always 'source_to_target'; pass a raw "
+                             "tensor to use flow='target_to_source'")
+        return edge_index
+    if not isinstance(edge_index, Tensor):
+        raise ValueError(f"'edge_index' must be a Tensor or EdgeIndex (got {type(edge_index)})")
+
+    def make():
+        ei = edge_index.flip(0).contiguous() if flip else edge_index
+        return EdgeIndex(ei, (num_src, num_dst))
+
+    if not _cache_enabled:
+        return make()
+    key = (id(edge_index), flip)
+    hit = _cache.get(key)
+    if hit is not None:
+        ref, version, size, handle = hit
+        if (ref() is edge_index and version == edge_index._version
+                and size == (num_src, num_dst)):
+            return handle
+    handle = make()
+    if len(_cache) >= MAX_CACHE_ENTRIES:
+        _cache.pop(next(iter(_cache)))
+
+    def _drop(_, key=key):
+        _cache.pop(key, None)
+
+    _cache[key] = (weakref.ref(edge_index, _drop), edge_index._version, (num_src, num_dst), handle)
+    return handle

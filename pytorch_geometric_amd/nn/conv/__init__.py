@@ -1,0 +1,6 @@
+from .message_passing import MessagePassing
+from .sage_conv import SAGEConv
+from .gcn_conv import GCNConv, gcn_norm
+from .gat_conv import GATConv
+
+__all__ = ['MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv']

@@ -1,0 +1,134 @@
+from typing import Callable, List, Optional, Union
+
+import torch
+from torch import Tensor
+from torch.nn import ModuleList
+
+from ...utils import trim_to_layer
+from ..conv import GATConv, GCNConv, MessagePassing, SAGEConv
+
+_ACTS = {'relu': torch.nn.ReLU, 'elu': torch.nn.ELU, 'leaky_relu': torch.nn.LeakyReLU,
+         'gelu': torch.nn.GELU, 'tanh': torch.nn.Tanh, 'sigmoid': torch.nn.Sigmoid}
+
+
+def activation_resolver(act, **kwargs):
+    if act is None or callable(act):
+        return act
+    if isinstance(act, str) and act.lower() in _ACTS:
+        return _ACTS[act.lower()](**kwargs)
+    raise ValueError(f"Could not resolve activation '{act}'")
+
+
+class BasicGNN(torch.nn.Module):
+    r"""Stack of ``num_layers`` message-passing layers with activation / dropout between them —
+    the layer loop of ``torch_geometric.nn.models.BasicGNN``
+    (torch_geometric/nn/models/basic_gnn.py:69-274), restricted to ``norm=None`` and ``jk=None``:
+    ``in -> hidden -> ... -> hidden -> (out_channels or hidden)``; the last layer has no
+    activation; ``num_sampled_*_per_hop`` enables ``trim_to_layer``."""
+    supports_edge_weight: bool = False
+    supports_edge_attr: bool = False
+
+    def __init__(self, in_channels: int, hidden_channels: int, num_layers: int,
+                 out_channels: Optional[int] = None, dropout: float = 0.0,
+                 act: Union[str, Callable, None] = 'relu', act_first: bool = False,
+                 act_kwargs=None, norm=None, jk: Optional[str] = None, **kwargs):
+        super().__init__()
+        if norm is not None or jk is not None:
+            raise NotImplementedError("only norm=None and jk=None are supported")
+        self.in_channels = in_channels
+        self.hidden_channels = hidden_channels
+        self.num_layers = num_layers
+        self.dropout = torch.nn.Dropout(p=dropout)
+        self.act = activation_resolver(act, **(act_kwargs or {}))
+        self.act_first = act_first
+        self.out_channels = out_channels if out_channels is not None else hidden_channels
+        self.convs = ModuleList()
+        if num_layers > 1:
+            self.convs.append(self.init_conv(in_channels, hidden_channels, **kwargs))
+            in_channels = hidden_channels
+        for _ in range(num_layers - 2):
+            self.convs.append(self.init_conv(in_channels, hidden_channels, **kwargs))
+            in_channels = hidden_channels
+        if out_channels is not None:
+            self._is_conv_to_out = True
+            self.convs.append(self.init_conv(in_channels, out_channels, **kwargs))
+        else:
+            self.convs.append(self.init_conv(in_channels, hidden_channels, **kwargs))
+
+    def init_conv(self, in_channels: int, out_channels: int, **kwargs) -> MessagePassing:
+        raise NotImplementedError
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+
+    def forward(self, x: Tensor, edge_index, edge_weight: Optional[Tensor] = None,
+                edge_attr: Optional[Tensor] = None,
+                num_sampled_nodes_per_hop: Optional[List[int]] = None,
+                num_sampled_edges_per_hop: Optional[List[int]] = None) -> Tensor:
+        if (num_sampled_nodes_per_hop is not None and isinstance(edge_weight, Tensor)
+                and isinstance(edge_attr, Tensor)):
+            raise NotImplementedError("'trim_to_layer' functionality does not yet support "
+                                      "trimming of both 'edge_weight' and 'edge_attr'")
+        for i, conv in enumerate(self.convs):
+            if num_sampled_nodes_per_hop is not None:
+                x, edge_index, value = trim_to_layer(
+                    i, num_sampled_nodes_per_hop, num_sampled_edges_per_hop, x, edge_index,
+                    edge_weight if edge_weight is not None else edge_attr)
+                if edge_weight is not None:
+                    edge_weight = value
+                else:
+                    edge_attr = value
+            if self.supports_edge_weight and self.supports_edge_attr:
+                x = conv(x, edge_index, edge_weight=edge_weight, edge_attr=edge_attr)
+            elif self.supports_edge_weight:
+                x = conv(x, edge_index, edge_weight=edge_weight)
+            elif self.supports_edge_attr:
+                x = conv(x, edge_index, edge_attr=edge_attr)
+            else:
+                x = conv(x, edge_index)
+            if i < self.num_layers - 1:
+                if self.act is not None:
+                    x = self.act(x)
+                x = self.dropout(x)
+        return x
+
+    def __repr__(self) -> str:
+        return (f'{self.__class__.__name__}({self.in_channels}, '
+                f'{self.out_channels}, num_layers={self.num_layers})')
+
+
+class GCN(BasicGNN):
+    """:class:`GCNConv` stack (basic_gnn.py:389-432)."""
+    supports_edge_weight = True
+
+    def init_conv(self, in_channels: int, out_channels: int, **kwargs) -> MessagePassing:
+        return GCNConv(in_channels, out_channels, **kwargs)
+
+
+class GraphSAGE(BasicGNN):
+    """:class:`SAGEConv` stack (basic_gnn.py:434-476)."""
+
+    def init_conv(self, in_channels, out_channels: int, **kwargs) -> MessagePassing:
+        return SAGEConv(in_channels, out_channels, **kwargs)
+
+
+class GAT(BasicGNN):
+    """:class:`GATConv` stack (basic_gnn.py:528-597): hidden layers concatenate ``heads`` of
+    width ``hidden // heads``; an explicit output layer averages its heads."""
+    supports_edge_attr = True
+
+    def init_conv(self, in_channels, out_channels: int, **kwargs) -> MessagePassing:
+        heads = kwargs.pop('heads', 1)
+        concat = kwargs.pop('concat', True)
+        # do not use concatenation in the last layer when out_channels was given explicitly
+        if getattr(self, '_is_conv_to_out', False):
+            concat = False
+        if concat and out_channels % heads != 0:
+            raise ValueError(f"Ensure that the number of output channels of 'GATConv' (got "
+                             f"'{out_channels}') is divisible by the number of heads "
+                             f"(got '{heads}')")
+        if concat:
+            out_channels = out_channels // heads
+        return GATConv(in_channels, out_channels, heads=heads, concat=concat,
+                       dropout=self.dropout.p, **kwargs)

@@ -1,0 +1,16 @@
+from ._scatter import scatter, scatter_argmax
+from ._segment import segment
+from ._softmax import softmax
+from ._spmm import spmm
+from ._index_sort import index_sort
+from ._degree import degree
+from .num_nodes import maybe_num_nodes
+from ._trim_to_layer import trim_to_layer
+from .loop import (add_remaining_self_loops, add_self_loops, contains_self_loops,
+                   remove_self_loops)
+
+__all__ = [
+    'scatter', 'scatter_argmax', 'segment', 'softmax', 'spmm', 'index_sort', 'degree',
+    'maybe_num_nodes', 'trim_to_layer', 'add_remaining_self_loops', 'add_self_loops', 'contains_self_loops',
+    'remove_self_loops',
+]

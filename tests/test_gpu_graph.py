@@ -1,0 +1,110 @@
+"""Integer side: bit-exact parity with the oracle (= torch.sort(stable) /
+_convert_indices_from_coo_to_csr) and the reference's golden vectors."""
+import pytest
+import torch
+
+from oracle import pyg_oracle as O
+from tests._util import assert_close, gen, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+@pytest.mark.parametrize('n,hi', [(0, 5), (1, 1), (500, 37), (100_000, 1000), (300_000, 3)])
+def test_index_sort_bit_exact(dev, dtype, n, hi):
+    import pytorch_geometric_amd as pga
+    keys = torch.randint(0, hi, (n, ), generator=gen(n + hi)).to(dtype)
+    s, p = pga.utils.index_sort(keys.to(dev), max_value=hi)
+    rs, rp = O.index_sort(keys, stable=True)
+    assert_close(s, rs)
+    assert_close(p, rp)
+    assert p.dtype == torch.int64
+    s2, p2 = pga.utils.index_sort(keys.to(dev))  # unknown max_value: full-width radix
+    assert_close(s2, rs)
+    assert_close(p2, rp)
+
+
+def test_index_sort_golden(dev, golden):
+    import pytorch_geometric_amd as pga
+    ix = golden['index']
+    s, p = pga.utils.index_sort(ix['keys'].to(dev), max_value=37, stable=True)
+    assert_close(s, ix['sorted'])
+    assert_close(p, ix['perm'])
+    assert_close(pga.index2ptr(s, 40), ix['ptr'])
+    assert_close(pga.ptr2index(pga.index2ptr(s, 40)), ix['ptr2index'])
+    p32 = pga.index2ptr(s.int(), 40)
+    assert p32.dtype == torch.int32
+    assert_close(p32, ix['keys32_ptr'])
+    k = ix['known_index2ptr']
+    assert pga.index2ptr(k['index'].to(dev), 3).tolist() == [0, 1, 3, 4]
+    assert pga.index2ptr(k['index'].to(dev)).tolist() == [0, 1, 3, 4]  # size inferred
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_index2ptr_ptr2index_edge_cases(dev, dtype):
+    import pytorch_geometric_amd as pga
+    for idx, size in [([], 0), ([], 4), ([3, 3, 3], 6), ([0, 5], 6), ([2], 3)]:
+        t = torch.tensor(idx, dtype=dtype)
+        ref = O.index2ptr(t, size)
+        got = pga.index2ptr(t.to(dev), size)
+        assert_close(got, ref)
+        assert got.dtype == dtype
+        assert_close(pga.ptr2index(got, len(idx)), O.ptr2index(ref, len(idx)))
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_edge_index_handles(dev, dtype, golden):
+    import pytorch_geometric_amd as pga
+    e = golden['index']['known_edge_index']  # test/test_edge_index.py:196-233
+    h = pga.EdgeIndex(e['edge_index'].to(dtype).to(dev), (3, 3)).fill_cache_()
+    assert h.by_src().ptr.tolist() == [0, 1, 3, 4]
+    assert h.by_dst().ptr.tolist() == [0, 1, 3, 4]
+    assert h.by_dst().perm.tolist() == [1, 0, 3, 2]  # the stable one of the two accepted perms
+    ei = random_graph(700, 900, 20_000, seed=5, dtype=dtype, skew=True)
+    h = pga.EdgeIndex(ei.to(dev), (700, 900))
+    for csr, key, other, n in [(h.by_dst(), ei[1], ei[0], 900), (h.by_src(), ei[0], ei[1], 700)]:
+        ptr, idx, perm = O.csr_from_coo(key, other, n)
+        assert_close(csr.ptr, ptr)
+        assert_close(csr.idx, idx)
+        assert_close(csr.perm.long(), perm)
+        assert csr.ptr.dtype == dtype and csr.idx.dtype == dtype
+    # sizes inferred from the data (maybe_num_nodes)
+    h2 = pga.EdgeIndex(ei.to(dev))
+    assert h2.sparse_size == (int(ei.max()) + 1, ) * 2
+    m = h.src_slot_to_dst_slot()
+    fwd, bwd = h.by_dst(), h.by_src()
+    assert torch.equal(fwd.perm[m.long()], bwd.perm)
+
+
+def test_presorted_edge_index(dev):
+    import pytorch_geometric_amd as pga
+    ei = random_graph(50, 60, 1000, seed=7)
+    order = ei[1].sort(stable=True).indices
+    ei_c = ei[:, order].contiguous()
+    h = pga.EdgeIndex(ei_c.to(dev), (50, 60), sort_order='col')
+    ptr, idx, _ = O.csr_from_coo(ei_c[1], ei_c[0], 60)
+    assert_close(h.by_dst().ptr, ptr)
+    assert_close(h.by_dst().idx, idx)
+
+
+def test_hub_plan(dev):
+    from pytorch_geometric_amd import _native
+    deg = torch.tensor([0, 5, 2049, 1024, 1025, 0, 7000, 3])
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)]).to(dev)
+    rows, cptr, n_hub, n_chunks = _native.hub_plan(ptr, threshold=1024, chunk=1024)
+    assert n_hub == 3 and rows.tolist() == [2, 4, 6]
+    assert cptr.tolist() == [0, 3, 5, 12] and n_chunks == 12
+    assert _native.hub_plan(ptr, threshold=10_000, chunk=1024)[2] == 0
+    big = torch.full((3000, ), 40, dtype=torch.int32)  # more hubs than one scan tile
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int32), big.cumsum(0).int()]).to(dev)
+    rows, cptr, n_hub, n_chunks = _native.hub_plan(ptr, threshold=16, chunk=16)
+    assert n_hub == 3000 and n_chunks == 9000
+    assert cptr.tolist() == list(range(0, 9001, 3))
+
+
+def test_index_minmax(dev):
+    from pytorch_geometric_amd import _native
+    t = torch.randint(3, 100_000, (1_000_003, ), generator=gen(3))
+    assert _native.index_minmax(t.to(dev)) == (int(t.min()), int(t.max()))
+    assert _native.index_minmax(t.int().to(dev)) == (int(t.min()), int(t.max()))
+    assert _native.index_minmax(torch.empty(0, dtype=torch.long, device=dev))[1] == -1

@@ -1,0 +1,193 @@
+"""SAGEConv / GCNConv / GATConv and the BasicGNN models on the HIP path vs the reference's golden
+outputs and gradients (tests/golden/make_golden.py), plus the reference's own self-consistency
+checks (fused vs unfused, edge permutation invariance, flow reversal)."""
+import pytest
+import torch
+
+from tests._util import assert_close, gen
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_layer(conv, case, x, dev, *args, **kwargs):
+    conv.load_state_dict(case['state'])
+    conv = conv.to(dev).eval()
+    xx = x.to(dev).requires_grad_(True)
+    out = conv(xx, *[a.to(dev) if torch.is_tensor(a) else a for a in args], **kwargs)
+    params = list(conv.parameters())
+    grads = torch.autograd.grad(out, [xx] + params, case['grad_out'].to(dev), allow_unused=True)
+    assert_close(out, case['out'], what='out')
+    assert_close(grads[0], case['grad_x'], what='grad_x')
+    for (n, _), g in zip(conv.named_parameters(), grads[1:]):
+        ref = case['grad_params'][n]
+        if ref is not None:
+            assert_close(g, ref, atol=5e-5, rtol=5e-5, what=f'grad {n}')
+    return conv
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_sage_conv_golden(dev, golden, fuse):
+    from pytorch_geometric_amd.nn import SAGEConv
+    gr, L = golden['graph'], golden['layers']
+    for name, kw in [('sage_mean', dict(aggr='mean')), ('sage_max', dict(aggr='max')),
+                     ('sage_sum_noroot', dict(aggr='sum', root_weight=False, bias=False))]:
+        conv = SAGEConv(16, 24, **kw)
+        conv.fuse = fuse
+        _run_layer(conv, L[name], gr['x'], dev, gr['edge_index'])
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_gcn_conv_golden(dev, golden, fuse):
+    from pytorch_geometric_amd.nn import GCNConv
+    gr, L = golden['graph'], golden['layers']
+    for name, kw, args in [('gcn', {}, (gr['edge_index'], )),
+                           ('gcn_weighted', {}, (gr['edge_index'], gr['edge_weight'])),
+                           ('gcn_nonorm', dict(normalize=False),
+                            (gr['edge_index'], gr['edge_weight']))]:
+        conv = GCNConv(16, 12, **kw)
+        conv.fuse = fuse
+        _run_layer(conv, L[name], gr['x'], dev, *args)
+
+
+def test_gcn_norm_golden(dev, golden):
+    from pytorch_geometric_amd.nn import gcn_norm
+    gr, lp = golden['graph'], golden['loops']
+    ei, ew = gcn_norm(gr['edge_index'].to(dev), gr['edge_weight'].to(dev), gr['N'])
+    assert_close(ei, lp['norm_ei'])
+    assert_close(ew, lp['norm_ew'])
+    ei, ew = gcn_norm(gr['edge_index'].to(dev), None, gr['N'])
+    assert_close(ei, lp['norm0_ei'])
+    assert_close(ew, lp['norm0_ew'])
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_gat_conv_golden(dev, golden, fuse):
+    from pytorch_geometric_amd.nn import GATConv
+    gr, L = golden['graph'], golden['layers']
+    for name, kw in [('gat', dict(heads=4)), ('gat_mean_heads', dict(heads=4, concat=False)),
+                     ('gat_noloops', dict(heads=2, add_self_loops=False))]:
+        conv = GATConv(16, 6, **kw)
+        conv.fuse = fuse
+        _run_layer(conv, L[name], gr['x'], dev, gr['edge_index'])
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_gat_attention_weights(dev, golden, fuse):
+    from pytorch_geometric_amd.nn import GATConv
+    gr, ga = golden['graph'], golden['gat_attention']
+    conv = GATConv(16, 6, heads=4)
+    conv.load_state_dict(ga['state'])
+    conv = conv.to(dev).eval()
+    conv.fuse = fuse
+    out, (ei, alpha) = conv(gr['x'].to(dev), gr['edge_index'].to(dev),
+                            return_attention_weights=True)
+    assert_close(out, ga['out'])
+    assert_close(ei, ga['edge_index'])
+    assert_close(alpha, ga['alpha'])
+
+
+def _run_model(model, case, golden, dev):
+    gr = golden['graph']
+    model.load_state_dict(case['state'])
+    model = model.to(dev).eval()
+    xx = gr['x'].to(dev).requires_grad_(True)
+    out = model(xx, gr['edge_index'].to(dev))
+    params = list(model.parameters())
+    grads = torch.autograd.grad(out, [xx] + params, case['grad_out'].to(dev))
+    assert_close(out, case['out'], atol=2e-5, what='model out')
+    assert_close(grads[0], case['grad_x'], atol=2e-5, what='model grad_x')
+    for (n, _), g in zip(model.named_parameters(), grads[1:]):
+        assert_close(g, case['grad_params'][n], atol=1e-4, rtol=1e-4, what=f'grad {n}')
+
+
+def test_models_golden(dev, golden):
+    from pytorch_geometric_amd.nn import GAT, GCN, GraphSAGE
+    M = golden['models']
+    _run_model(GraphSAGE(16, 32, num_layers=3, out_channels=8), M['graphsage'], golden, dev)
+    _run_model(GCN(16, 16, num_layers=2, out_channels=7), M['gcn'], golden, dev)
+    _run_model(GAT(16, 32, num_layers=3, out_channels=5, heads=4), M['gat'], golden, dev)
+
+
+def test_permutation_flow_and_int32(dev, golden):
+    """testing/asserts.py:81-88 (edge-permutation invariance), test_gcn_conv.py:107-115 (flow),
+    test_message_passing.py:686-703 (int32 edge_index)."""
+    from pytorch_geometric_amd.nn import GCNConv, SAGEConv
+    gr = golden['graph']
+    x, ei = gr['x'].to(dev), gr['edge_index'].to(dev)
+    torch.manual_seed(0)
+    conv = SAGEConv(16, 8).to(dev)
+    out = conv(x, ei)
+    perm = torch.randperm(ei.size(1), generator=gen(0)).to(dev)
+    assert_close(conv(x, ei[:, perm].contiguous()), out.cpu())
+    assert_close(conv(x, ei.int()), out.cpu(), rtol=0, atol=0)
+    conv1 = GCNConv(16, 8, flow='source_to_target').to(dev)
+    conv2 = GCNConv(16, 8, flow='target_to_source').to(dev)
+    conv2.load_state_dict(conv1.state_dict())
+    assert_close(conv2(x, ei.flip(0).contiguous()), conv1(x, ei).cpu())
+
+
+def test_bipartite_and_handle_input(dev):
+    """SAGEConv on (x_src, x_dst) with an explicit EdgeIndex handle (test_sage_conv.py:30-45)."""
+    import pytorch_geometric_amd as pga
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd.nn import SAGEConv
+    g = gen(4)
+    x1, x2 = torch.randn(30, 8, generator=g), torch.randn(20, 8, generator=g)
+    ei = torch.stack([torch.randint(0, 30, (200, ), generator=g),
+                      torch.randint(0, 20, (200, ), generator=g)])
+    torch.manual_seed(1)
+    conv = SAGEConv((8, 8), 12)
+    ref = O.sage_conv(x1, ei, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight, 'mean',
+                      x_dst=x2)
+    conv = conv.to(dev)
+    out = conv((x1.to(dev), x2.to(dev)), ei.to(dev))
+    assert_close(out, ref.detach())
+    h = pga.EdgeIndex(ei.to(dev), (30, 20))
+    assert_close(conv((x1.to(dev), x2.to(dev)), h), ref.detach())
+    out = conv((x1.to(dev), None), ei.to(dev), size=(30, 20))
+    ref2 = O.sage_conv(x1, ei, conv.lin_l.weight.cpu(), conv.lin_l.bias.cpu(), None, 'mean',
+                       num_dst=20)
+    assert_close(out, ref2.detach())
+
+
+def test_out_of_range_edge_index(dev):
+    """test_message_passing.py:201-213: IndexError on invalid indices (unfused path)."""
+    from pytorch_geometric_amd.nn import SAGEConv
+    conv = SAGEConv(4, 4).to(dev)
+    x = torch.randn(3, 4, device=dev)
+    for fuse in (False, True):
+        conv.fuse = fuse
+        with pytest.raises(IndexError, match='larger than 2'):
+            conv(x, torch.tensor([[0, 3], [1, 0]], device=dev))
+        with pytest.raises(IndexError, match='negative indices'):
+            conv(x, torch.tensor([[0, -1], [1, 0]], device=dev))
+    with pytest.raises(ValueError, match='integer'):
+        conv(x, torch.tensor([[0., 1.], [1., 0.]], device=dev))
+
+
+def test_trim_to_layer_model(dev):
+    """basic_gnn.py:229-243: hop-ordered batches only aggregate a prefix per layer."""
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd.nn import GraphSAGE
+    g = gen(8)
+    nodes_per_hop, edges_per_hop = [4, 10, 30], [12, 60]
+    n = sum(nodes_per_hop)
+    # hop h edges point from hop-(h+1) nodes to hop-h nodes
+    e0 = torch.stack([torch.randint(4, 14, (12, ), generator=g),
+                      torch.randint(0, 4, (12, ), generator=g)])
+    e1 = torch.stack([torch.randint(14, 44, (60, ), generator=g),
+                      torch.randint(4, 14, (60, ), generator=g)])
+    ei = torch.cat([e0, e1], dim=1)
+    x = torch.randn(n, 6, generator=g)
+    torch.manual_seed(2)
+    model = GraphSAGE(6, 10, num_layers=2, out_channels=3)
+    st = model.state_dict()
+    params = [(st[f'convs.{i}.lin_l.weight'], st[f'convs.{i}.lin_l.bias'],
+               st[f'convs.{i}.lin_r.weight']) for i in range(2)]
+    ref = O.graphsage(x, ei, params)[:4]
+    model = model.to(dev)
+    full = model(x.to(dev), ei.to(dev))[:4]
+    trimmed = model(x.to(dev), ei.to(dev), num_sampled_nodes_per_hop=nodes_per_hop,
+                    num_sampled_edges_per_hop=edges_per_hop)[:4]
+    assert_close(full, ref.detach())
+    assert_close(trimmed, ref.detach())

@@ -1,0 +1,328 @@
+"""scatter / segment / softmax / spmm / gather: HIP path (through the C ABI) vs the oracle and the
+reference's golden vectors.  fp32 tolerance 1e-5 (north_star), integers bit-exact."""
+import pytest
+import torch
+
+from oracle import pyg_oracle as O
+from tests._util import assert_close, gen, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def run_grad(fn, inputs, grad_out):
+    leaves = [t.clone().requires_grad_(True) if t.is_floating_point() else t for t in inputs]
+    out = fn(*leaves)
+    fl = [t for t in leaves if t.is_floating_point()]
+    grads = torch.autograd.grad(out, fl, grad_out.to(out.device), allow_unused=True)
+    return out.detach(), grads
+
+
+# ---- scatter ---------------------------------------------------------------------------------------
+def test_scatter_golden(dev, golden):
+    import pytorch_geometric_amd as pga
+    sc = golden['scatter']
+    src, index = sc['src'].to(dev), sc['index'].to(dev)
+    for red in ['sum', 'mean', 'min', 'max', 'mul']:
+        out, (gs, ) = run_grad(lambda s: pga.utils.scatter(s, index, 0, sc['dim_size'], red),
+                               [src], sc[red]['grad_out'])
+        assert_close(out, sc[red]['out'], what=f'scatter {red}')
+        assert_close(gs, sc[red]['grad_src'], what=f'scatter {red} grad')
+    d = sc['dim1_mean']
+    out, (gs, ) = run_grad(lambda s: pga.utils.scatter(s, d['index'].to(dev), 1, 6, 'mean'),
+                           [d['src'].to(dev)], d['grad_out'])
+    assert_close(out, d['out'])
+    assert_close(gs, d['grad_src'])
+    m = sc['dim1_max_nosize']
+    out, (gs, ) = run_grad(lambda s: pga.utils.scatter(s, d['index'].to(dev), -2, None, 'max'),
+                           [d['src'].to(dev)], m['grad_out'])
+    assert_close(out, m['out'])
+    assert_close(gs, m['grad_src'])
+    v = sc['vec_sum']
+    assert_close(pga.utils.scatter(v['src'].to(dev), v['index'].to(dev)), v['out'])
+    # 'any': every output row equals one of the contributing rows
+    out = pga.utils.scatter(src, index, 0, sc['dim_size'], 'any').cpu()
+    for g in range(sc['dim_size']):
+        rows = sc['src'][sc['index'] == g]
+        for f in range(out.size(1)):
+            assert (rows.numel() == 0 and out[g, f] == 0) or (out[g, f] == rows[:, f]).any()
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+@pytest.mark.parametrize('F', [1, 3, 64, 100, 257])
+def test_scatter_vs_oracle(dev, dtype, F):
+    import pytorch_geometric_amd as pga
+    g = gen(F)
+    src = torch.randn(5000, F, generator=g)
+    src[::5] = torch.randint(-2, 3, (1000, F), generator=g).float()
+    index = torch.randint(0, 300, (5000, ), generator=g).to(dtype)
+    go = torch.randn(320, F, generator=g)
+    for red in ['sum', 'mean', 'min', 'max']:
+        ref, (rg, ) = run_grad(lambda s: O.scatter(s, index.long(), 0, 320, red), [src], go)
+        out, (gs, ) = run_grad(lambda s: pga.utils.scatter(s, index.to(dev), 0, 320, red),
+                               [src.to(dev)], go)
+        assert_close(out, ref, atol=2e-5, what=f'{red} F={F}')
+        assert_close(gs, rg, atol=2e-5, what=f'{red} grad F={F}')
+
+
+def test_scatter_errors(dev):
+    import pytorch_geometric_amd as pga
+    src = torch.randn(2, 5, 2, device=dev)
+    idx = torch.tensor([0, 1, 0, 1, 0], device=dev)
+    with pytest.raises(ValueError, match='must be one-dimensional'):
+        pga.utils.scatter(src, idx.view(1, -1))
+    with pytest.raises(ValueError, match='must lay between 0 and 2'):
+        pga.utils.scatter(src, idx, dim=3)
+    with pytest.raises(ValueError, match="invalid `reduce` argument 'std'"):
+        pga.utils.scatter(src, idx, dim=1, reduce='std')
+    with pytest.raises(pga.PygAmdError, match='no CPU fallback'):
+        pga.utils.scatter(torch.randn(4, 2), torch.tensor([0, 0, 1, 1]))
+    agg = pga.nn.MeanAggregation()
+    with pytest.raises(ValueError, match="invalid 'dim_size'"):
+        agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
+    with pytest.raises(ValueError, match='invalid dimension'):
+        agg(torch.randn(5, 3, device=dev), idx, dim=2)
+
+
+def test_scatter_empty(dev):
+    import pytorch_geometric_amd as pga
+    out = pga.utils.scatter(torch.empty(0, 4, device=dev), torch.empty(0, dtype=torch.long,
+                                                                       device=dev))
+    assert out.shape == (0, 4)
+    out = pga.utils.scatter(torch.empty(0, 4, device=dev),
+                            torch.empty(0, dtype=torch.long, device=dev), dim_size=3,
+                            reduce='max')
+    assert out.shape == (3, 4) and (out == 0).all()
+
+
+def test_scatter_argmax(dev, golden):
+    import pytorch_geometric_amd as pga
+    k = golden['scatter']['argmax_known']
+    got = pga.utils.scatter_argmax(k['src'].to(dev), k['index'].to(dev), dim_size=6)
+    assert got.tolist() == [3, 5, 1, 4, 5, 5]
+    r = golden['scatter']['argmax_rand']
+    for dt in (torch.int64, torch.int32):
+        got = pga.utils.scatter_argmax(r['src'].to(dev), r['index'].to(dt).to(dev),
+                                       dim_size=r['dim_size'])
+        assert_close(got.long(), r['out'])
+
+
+# ---- segment ---------------------------------------------------------------------------------------
+def test_segment_golden(dev, golden):
+    import pytorch_geometric_amd as pga
+    sg = golden['segment']
+    for red in ['sum', 'mean', 'min', 'max']:
+        out, (gs, ) = run_grad(lambda s: pga.utils.segment(s, sg['ptr'].to(dev), red),
+                               [sg['src'].to(dev)], sg[red]['grad_out'])
+        assert_close(out, sg[red]['out'], what=f'segment {red}')
+        assert_close(gs, sg[red]['grad_src'], what=f'segment {red} grad')
+
+
+@pytest.mark.parametrize('F', [1, 8, 47, 256, 600])
+def test_segment_vs_oracle(dev, F):
+    import pytorch_geometric_amd as pga
+    g = gen(F + 1)
+    lens = torch.randint(0, 40, (200, ), generator=g)
+    lens[7] = 3000  # one long segment
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    src = torch.randn(int(ptr[-1]), F, generator=g)
+    for red in ['sum', 'mean', 'min', 'max']:
+        ref = O.segment(src, ptr, red)
+        out = pga.utils.segment(src.to(dev), ptr.to(dev), red)
+        assert_close(out, ref, atol=1e-4 if red == 'sum' else 1e-5, what=f'{red} F={F}')
+        out32 = pga.utils.segment(src.to(dev), ptr.int().to(dev), red)
+        assert_close(out32, out.cpu(), rtol=0, atol=0)
+
+
+# ---- softmax ---------------------------------------------------------------------------------------
+def test_softmax_golden(dev, golden):
+    import pytorch_geometric_amd as pga
+    sm = golden['softmax']
+    k = sm['known']
+    assert pga.utils.softmax(k['src'].to(dev), k['index'].to(dev)).tolist() == [0.5, 0.5, 1, 1]
+    assert pga.utils.softmax(k['src'].to(dev), None, k['ptr'].to(dev)).tolist() == [0.5, 0.5, 1,
+                                                                                   1]
+    i = sm['index']
+    out, (gs, ) = run_grad(lambda s: pga.utils.softmax(s, i['index'].to(dev), num_nodes=11),
+                           [i['src'].to(dev)], i['grad_out'])
+    assert_close(out, i['out'])
+    assert_close(gs, i['grad_src'])
+    p = sm['ptr']
+    out, (gs, ) = run_grad(lambda s: pga.utils.softmax(s, None, p['ptr'].to(dev)),
+                           [i['src'].to(dev)], p['grad_out'])
+    assert_close(out, p['out'])
+    assert_close(gs, p['grad_src'])
+    u = sm['unsorted']
+    out, (gs, ) = run_grad(lambda s: pga.utils.softmax(s, u['index'].to(dev), num_nodes=11),
+                           [u['src'].to(dev)], u['grad_out'])
+    assert_close(out, u['out'])
+    assert_close(gs, u['grad_src'])
+    d = sm['dim1']
+    out, (gs, ) = run_grad(
+        lambda s: pga.utils.softmax(s, i['index'].to(dev), num_nodes=11, dim=-1),
+        [d['src'].to(dev)], d['grad_out'])
+    assert_close(out, d['out'])
+    assert_close(gs, d['grad_src'])
+
+
+@pytest.mark.parametrize('H', [1, 2, 8, 3, 64, 100])
+def test_segment_softmax_vs_oracle(dev, H):
+    import pytorch_geometric_amd as pga
+    g = gen(H + 40)
+    lens = torch.randint(0, 30, (300, ), generator=g)
+    lens[11] = 2500
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    src = torch.randn(int(ptr[-1]), H, generator=g) * 4
+    go = torch.randn(src.shape, generator=g)
+    ref, (rg, ) = run_grad(lambda s: O.softmax(s, None, ptr), [src], go)
+    out, (gs, ) = run_grad(lambda s: pga.utils.softmax(s, None, ptr.to(dev)), [src.to(dev)], go)
+    assert_close(out, ref, what=f'softmax H={H}')
+    assert_close(gs, rg, what=f'softmax grad H={H}')
+    if H == 1:  # 1-D input
+        out1 = pga.utils.softmax(src.view(-1).to(dev), None, ptr.to(dev))
+        assert_close(out1, ref.view(-1))
+
+
+# ---- gather --------------------------------------------------------------------------------------
+@pytest.mark.parametrize('F', [1, 5, 100, 256])
+def test_gather_bit_exact(dev, F):
+    from pytorch_geometric_amd._functions import GatherFunction
+    g = gen(F)
+    x = torch.randn(1000, F, generator=g)
+    idx = torch.randint(0, 1000, (7777, ), generator=g)
+    for dt in (torch.int64, torch.int32):
+        xx = x.to(dev).requires_grad_(True)
+        out = GatherFunction.apply(xx, idx.to(dt).to(dev), True)
+        assert_close(out, x.index_select(0, idx), rtol=0, atol=0)  # indexing: bit-exact
+        go = torch.randn(7777, F, generator=gen(1))
+        out.backward(go.to(dev))
+        ref = torch.zeros(1000, F).index_add_(0, idx, go)
+        assert_close(xx.grad, ref, atol=1e-4)
+    with pytest.raises(IndexError):
+        GatherFunction.apply(x.to(dev), torch.tensor([0, 1000], device=dev), True)
+
+
+# ---- CSR SpMM --------------------------------------------------------------------------------------
+WIDTHS = [1, 4, 7, 16, 47, 64, 100, 128, 256, 320, 500, 520, 1100]
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+@pytest.mark.parametrize('F', WIDTHS)
+def test_spmm_sum_mean_vs_oracle(dev, dtype, F):
+    import pytorch_geometric_amd as pga
+    ei = random_graph(400, 300, 6000, seed=F, dtype=dtype, skew=True)
+    g = gen(F + 7)
+    x = torch.randn(400, F, generator=g)
+    go = torch.randn(300, F, generator=g)
+    h = pga.EdgeIndex(ei.to(dev), (400, 300))
+    for red in ['sum', 'mean']:
+        ref, (rg, ) = run_grad(lambda t: O.spmm(ei.long(), t, 300, red), [x], go)
+        out, (gx, ) = run_grad(lambda t: pga.utils.spmm(h, t, red), [x.to(dev)], go)
+        assert_close(out, ref, atol=5e-5, what=f'spmm {red} F={F}')
+        assert_close(gx, rg, atol=5e-5, what=f'spmm {red} grad F={F}')
+
+
+@pytest.mark.parametrize('F', [3, 16, 100, 256, 600])
+def test_spmm_minmax_vs_oracle(dev, F):
+    import pytorch_geometric_amd as pga
+    ei = random_graph(200, 150, 3000, seed=F + 1, skew=True)
+    g = gen(F + 9)
+    x = torch.randn(200, F, generator=g)
+    x[::2] = torch.randint(-1, 2, (100, F), generator=g).float()  # ties, zeros
+    go = torch.randn(150, F, generator=g)
+    h = pga.EdgeIndex(ei.to(dev), (200, 150))
+    for red in ['min', 'max']:
+        ref, (rg, ) = run_grad(lambda t: O.spmm(ei, t, 150, red), [x], go)
+        out, (gx, ) = run_grad(lambda t: pga.utils.spmm(h, t, red), [x.to(dev)], go)
+        assert_close(out, ref, rtol=0, atol=0, what=f'spmm {red} F={F}')  # selection: exact
+        assert_close(gx, rg, what=f'spmm {red} grad F={F}')
+
+
+@pytest.mark.parametrize('F,H', [(1, 1), (16, 1), (100, 1), (256, 1), (64, 8), (256, 8),
+                                 (320, 8), (6, 2), (21, 3)])
+def test_spmm_weighted_vs_oracle(dev, F, H):
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd._functions import SpmmFunction
+    ei = random_graph(300, 250, 5000, seed=F + H, skew=True)
+    g = gen(F * 3 + H)
+    x = torch.randn(300, F, generator=g)
+    w = torch.rand(5000, generator=g) if H == 1 else torch.rand(5000, H, generator=g)
+    go = torch.randn(250, F, generator=g)
+    h = pga.EdgeIndex(ei.to(dev), (300, 250))
+
+    def ref_fn(t, ww):
+        if H == 1:
+            return O.spmm(ei, t, 250, 'sum', ww)
+        return O.propagate(t.view(300, H, F // H), ei, 250, 'sum', ww).reshape(250, F)
+
+    ref, (rgx, rgw) = run_grad(ref_fn, [x, w], go)
+    out, (gx, gw) = run_grad(lambda t, ww: SpmmFunction.apply(t, ww, h, 'sum', 'coo'),
+                             [x.to(dev), w.to(dev)], go)
+    assert_close(out, ref, atol=5e-5, what='weighted out')
+    assert_close(gx, rgx, atol=5e-5, what='weighted grad_x')
+    assert_close(gw, rgw, atol=1e-4, rtol=1e-4, what='weighted grad_w')
+    # the same weights handed over in by-destination slot order
+    perm = h.by_dst().perm.long()
+    w_slot = w.to(dev)[perm]
+    out2, (gx2, gw2) = run_grad(lambda t, ww: SpmmFunction.apply(t, ww, h, 'sum', 'slot'),
+                                [x.to(dev), w_slot], go)
+    assert_close(out2, ref, atol=5e-5, what='slot-order out')
+    assert_close(gx2, rgx, atol=5e-5, what='slot-order grad_x')
+    assert_close(gw2, rgw[perm.cpu()], atol=1e-4, rtol=1e-4, what='slot-order grad_w')
+
+
+def test_spmm_golden(dev, golden):
+    import pytorch_geometric_amd as pga
+    gr, sp = golden['graph'], golden['spmm']
+    h = pga.EdgeIndex(sp['edge_index'].to(dev), (gr['N'], gr['N']))
+    for red in ['sum', 'mean', 'min', 'max']:
+        assert_close(pga.utils.spmm(h, gr['x'].to(dev), red), sp[red]['out'], what=red)
+    for red in ['sum', 'mean']:
+        out, (gx, ) = run_grad(lambda t: pga.utils.spmm(h, t, red), [gr['x'].to(dev)],
+                               sp[red]['grad_out'])
+        assert_close(gx, sp[red]['grad_x'], what=f'{red} grad')
+
+
+@pytest.mark.parametrize('F', [100, 256, 47])
+def test_spmm_hub_rows(dev, F, monkeypatch):
+    """Rows longer than the hub threshold take the chunked two-stage path."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    monkeypatch.setattr(_native, 'HUB_THRESHOLD', 64)
+    monkeypatch.setattr(_native, 'HUB_CHUNK', 48)
+    orig = _native.hub_plan
+    monkeypatch.setattr(_native, 'hub_plan', lambda ptr, threshold=None, chunk=None: orig(
+        ptr, 64, 48))
+    ei = random_graph(500, 120, 20_000, seed=F, skew=True)
+    x = torch.randn(500, F, generator=gen(F))
+    go = torch.randn(120, F, generator=gen(F + 1))
+    h = pga.EdgeIndex(ei.to(dev), (500, 120))
+    assert h.by_dst().hub[2] > 0
+    for red in ['sum', 'mean']:
+        ref, (rg, ) = run_grad(lambda t: O.spmm(ei, t, 120, red), [x], go)
+        out, (gx, ) = run_grad(lambda t: pga.utils.spmm(h, t, red), [x.to(dev)], go)
+        assert_close(out, ref, atol=2e-4, rtol=2e-5, what=f'hub {red}')
+        assert_close(gx, rg, atol=2e-4, rtol=2e-5, what=f'hub {red} grad')
+
+
+def test_spmm_strided_io(dev):
+    """Aggregate out of / into a wider buffer (leading dimension > F)."""
+    from pytorch_geometric_amd import _native
+    import pytorch_geometric_amd as pga
+    ei = random_graph(100, 100, 1500, seed=3)
+    big = torch.randn(100, 512, generator=gen(2))
+    h = pga.EdgeIndex(ei.to(dev), (100, 100))
+    fwd = h.by_dst()
+    bd = big.to(dev)
+    out_buf = torch.zeros(100, 512, device=dev)
+    _native.spmm_csr(fwd.ptr, fwd.idx, bd[:, 256:], 'mean', n_rows=100, out=out_buf[:, :256])
+    ref = O.spmm(ei, big[:, 256:].contiguous(), 100, 'mean')
+    assert_close(out_buf[:, :256], ref)
+    assert (out_buf[:, 256:] == 0).all()
+
+
+def test_empty_graph_and_isolated_rows(dev):
+    import pytorch_geometric_amd as pga
+    h = pga.EdgeIndex(torch.empty(2, 0, dtype=torch.long, device=dev), (5, 4))
+    for red in ['sum', 'mean', 'min', 'max']:
+        out = pga.utils.spmm(h, torch.randn(5, 8, device=dev), red)
+        assert out.shape == (4, 8) and (out == 0).all()
