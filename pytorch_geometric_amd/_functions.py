@@ -6,8 +6,15 @@ import torch
 from torch import Tensor
 from torch.autograd import Function
 
+import math
+
 from . import _native
 from .edge_index import CSR, EdgeIndex
+
+
+def _rows(t: Tensor) -> Tensor:
+    """[n, ...] -> [n, prod(...)] (also for empty tensors, where reshape(n, -1) is ambiguous)."""
+    return t.reshape(t.size(0), math.prod(t.shape[1:]))
 
 
 class SpmmFunction(Function):
@@ -29,7 +36,7 @@ class SpmmFunction(Function):
                              f"{graph.num_src_nodes} source nodes")
         ctx.graph, ctx.reduce, ctx.w_order = graph, reduce, w_order
         ctx.x_shape = x.shape
-        x2 = x.reshape(x.size(0), -1)
+        x2 = _rows(x)
         if reduce in ('min', 'max'):
             if w is not None:
                 raise NotImplementedError("edge weights are not supported for min/max")
@@ -46,7 +53,7 @@ class SpmmFunction(Function):
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         graph, reduce = ctx.graph, ctx.reduce
-        g2 = grad_out.reshape(grad_out.size(0), -1)
+        g2 = _rows(grad_out)
         grad_x = grad_w = None
         if reduce in ('min', 'max'):
             x2, out = ctx.saved_tensors
@@ -84,13 +91,13 @@ class GatherFunction(Function):
     def forward(ctx, x: Tensor, index: Tensor, check_bounds: bool):
         ctx.save_for_backward(index)
         ctx.x_shape = x.shape
-        out = _native.gather_rows(x.reshape(x.size(0), -1), index, check_bounds)
+        out = _native.gather_rows(_rows(x), index, check_bounds)
         return out.view(index.numel(), *x.shape[1:])
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         (index,) = ctx.saved_tensors
-        g = _native.scatter_rows(grad_out.reshape(grad_out.size(0), -1), index, ctx.x_shape[0],
+        g = _native.scatter_rows(_rows(grad_out), index, ctx.x_shape[0],
                                  'sum')
         return g.view(ctx.x_shape), None, None
 
@@ -100,7 +107,7 @@ class ScatterFunction(Function):
 
     @staticmethod
     def forward(ctx, src: Tensor, index: Tensor, dim_size: int, reduce: str):
-        s2 = src.reshape(src.size(0), -1)
+        s2 = _rows(src)
         ctx.reduce, ctx.src_shape = reduce, src.shape
         if reduce == 'mean':
             out, count = _native.scatter_rows(s2, index, dim_size, reduce, return_count=True)
@@ -119,7 +126,7 @@ class ScatterFunction(Function):
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         reduce = ctx.reduce
-        g2 = grad_out.reshape(grad_out.size(0), -1)
+        g2 = _rows(grad_out)
         if reduce in ('sum', 'add'):
             (index,) = ctx.saved_tensors
             grad = _native.gather_rows(g2, index)
@@ -144,7 +151,7 @@ class SegmentFunction(Function):
 
     @staticmethod
     def forward(ctx, src: Tensor, ptr: Tensor, reduce: str):
-        s2 = src.reshape(src.size(0), -1)
+        s2 = _rows(src)
         n_seg = ptr.numel() - 1
         out = _native.spmm_csr(ptr, None, s2, reduce, n_rows=n_seg)
         ctx.reduce, ctx.src_shape = reduce, src.shape
@@ -157,7 +164,7 @@ class SegmentFunction(Function):
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         reduce = ctx.reduce
-        g2 = grad_out.reshape(grad_out.size(0), -1)
+        g2 = _rows(grad_out)
         n = ctx.src_shape[0]
         if reduce in ('min', 'max'):
             ptr, s2, out = ctx.saved_tensors
@@ -183,7 +190,7 @@ class SegmentSoftmaxFunction(Function):
 
     @staticmethod
     def forward(ctx, src: Tensor, ptr: Tensor):
-        s2 = src.reshape(src.size(0), -1)
+        s2 = _rows(src)
         out = _native.segment_softmax_forward(s2, ptr)
         ctx.save_for_backward(out, ptr)
         ctx.src_shape = src.shape

@@ -297,9 +297,8 @@ template <bool IS_MAX>
 __device__ __forceinline__ bool better_val(float v, float best) {
   // NaN propagates (torch amax/amin semantics): a NaN beats any non-NaN.
   const bool vn = (v != v), bn = (best != best);
-  if (bn) return false;
-  if (vn) return true;
-  return IS_MAX ? (v > best) : (v < best);
+  const bool cmp = IS_MAX ? (v > best) : (v < best);
+  return (!bn) & (vn | cmp);
 }
 
 template <typename IdxT, int VW, int LPR, int CH, bool IS_MAX, bool IDENT>
@@ -372,10 +371,9 @@ __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
           for (int i = 0; i < VW; ++i) {
             const float val = v[u][c2].v[i];
             // the first valid slot always wins over the (arg == -1) initial state
-            if (ok[u] && (barg[c2][i] < 0 || better_val<IS_MAX>(val, best[c2][i]))) {
-              best[c2][i] = val;
-              barg[c2][i] = slot;
-            }
+            const bool take = ok[u] & ((barg[c2][i] < 0) | better_val<IS_MAX>(val, best[c2][i]));
+            best[c2][i] = take ? val : best[c2][i];
+            barg[c2][i] = take ? slot : barg[c2][i];
           }
         }
       }
@@ -390,20 +388,16 @@ __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
       for (int i = 0; i < VW; ++i) {
         const float ov = bcast_lane(best[c][i], lane ^ off);
         const IdxT oa = bcast_lane(barg[c][i], lane ^ off);
-        bool take = false;
-        if (oa >= 0) {
-          if (barg[c][i] < 0) {
-            take = true;
-          } else if (better_val<IS_MAX>(ov, best[c][i])) {
-            take = true;
-          } else if (!better_val<IS_MAX>(best[c][i], ov) && oa < barg[c][i]) {
-            take = true;
-          }
-        }
-        if (take) {
-          best[c][i] = ov;
-          barg[c][i] = oa;
-        }
+        // Branch-free on purpose: hipcc 7.2 drops the guarded assignment of the nested-if form
+        // of this update for VW = 4 (found by tests/test_gpu_ops.py::test_spmm_minmax_vs_oracle).
+        const bool other_valid = oa >= 0;
+        const bool mine_empty = barg[c][i] < 0;
+        const bool other_better = better_val<IS_MAX>(ov, best[c][i]);
+        const bool mine_better = better_val<IS_MAX>(best[c][i], ov);
+        const bool tie_earlier = (!other_better) & (!mine_better) & (oa < barg[c][i]);
+        const bool take = other_valid & (mine_empty | other_better | tie_earlier);
+        best[c][i] = take ? ov : best[c][i];
+        barg[c][i] = take ? oa : barg[c][i];
       }
     }
   }
