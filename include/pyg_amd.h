@@ -149,6 +149,8 @@ typedef struct {
   int64_t n_chunks;
   int64_t hub_threshold;
   int64_t hub_chunk;
+  int32_t accumulate;        /* SUM/MEAN only: out += result (fused "x_root + aggregate") */
+  int32_t reserved;
 } pygamd_spmm_args;
 
 PYGAMD_API int pygamd_spmm_csr_workspace_bytes(const pygamd_spmm_args* args, size_t* bytes);
@@ -183,6 +185,12 @@ PYGAMD_API int pygamd_sddmm_csr(const void* rowptr, const void* col, const void*
                                 int idx_dtype, const float* grad_out, int64_t ldg,
                                 const float* x, int64_t ldx, int64_t n_rows, int64_t F,
                                 int32_t w_heads, int32_t head_dim, float* grad_w, void* stream);
+
+/* ---- a17: bias gradient of Linear --------------------------------------------------------------
+ * out[f] = sum_r x[r, f]  (grad_bias = grad_out.sum(0), nn/dense/linear.py:121-127 backward).
+ * `out` is zeroed internally; partial sums are combined with fp32 atomics.                     */
+PYGAMD_API int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t F, float* out,
+                             void* stream);
 
 /* ---- a2: gather (index_select along dim 0) --------------------------------------------------
  * out[e, :] = x[index[e], :]  (nn/conv/message_passing.py:263-290, collect.jinja:118-127).

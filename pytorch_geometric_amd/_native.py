@@ -165,7 +165,8 @@ timing_sink = None
 def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
              n_rows: Optional[int] = None, eid: Optional[Tensor] = None,
              w: Optional[Tensor] = None, src_scale: Optional[Tensor] = None,
-             hub=None, out: Optional[Tensor] = None, return_arg: bool = False):
+             hub=None, out: Optional[Tensor] = None, return_arg: bool = False,
+             accumulate: bool = False):
     """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h."""
     _require_device(rowptr, col, x, eid, w, src_scale)
     lib = _lib.load()
@@ -203,6 +204,7 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     a.ldx, a.ldo = _ld(x2), _ld(out)
     a.idx_dtype, a.reduce = _idx_dtype(rowptr), red
     a.w_heads, a.head_dim = w_heads, head_dim
+    a.accumulate = 1 if accumulate else 0
     ws, ws_bytes = None, 0
     if hub is not None and hub[2] > 0 and red in (_lib.SUM, _lib.MEAN):
         hub_rows, hub_cptr, n_hub, n_chunks = hub
@@ -225,6 +227,17 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
                       'weighted': w is not None, 'src_scale': src_scale is not None,
                       'n_hub': a.n_hub}, ev0, ev1))
     return (out, arg) if return_arg else out
+
+
+def colsum(x: Tensor) -> Tensor:
+    """x.sum(0) for a 2-D fp32 tensor (bias gradient)."""
+    _require_device(x)
+    lib = _lib.load()
+    x2 = _f32_rows(x, 'x')
+    out = torch.empty(x2.size(1), dtype=torch.float32, device=x.device)
+    check(lib.pygamd_colsum(_p(x2), _ld(x2), x2.size(0), x2.size(1), _p(out), _stream(x)),
+          'colsum')
+    return out
 
 
 def spmm_tie_count(rowptr, col, x, out, count_self: bool) -> Tensor:

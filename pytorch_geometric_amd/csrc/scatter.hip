@@ -176,6 +176,36 @@ __global__ void __launch_bounds__(kBlock)
   if (g < dim_size && arg[g] < 0) arg[g] = static_cast<IdxT>(dim_size - 1);
 }
 
+// ---- column sum (bias gradient) -------------------------------------------------------------
+// A 256-thread block covers `groups = 256 / F` rows per pass with thread t on column t % F, so
+// consecutive lanes read consecutive addresses of a contiguous [rows, F] block; row-group
+// partials meet in LDS and each block issues F atomics.
+__global__ void __launch_bounds__(kBlock)
+    colsum_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int64_t F,
+                  float* __restrict__ out) {
+  __shared__ float part[kBlock];
+  for (int64_t f0 = 0; f0 < F; f0 += kBlock) {
+    const int width = static_cast<int>(F - f0 < kBlock ? F - f0 : kBlock);
+    const int groups = kBlock / width;
+    const int col = threadIdx.x % width;
+    const int rg = threadIdx.x / width;
+    float acc = 0.f;
+    if (rg < groups) {
+      for (int64_t r = static_cast<int64_t>(blockIdx.x) * groups + rg; r < n_rows;
+           r += static_cast<int64_t>(gridDim.x) * groups)
+        acc += x[r * ldx + f0 + col];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (rg == 0) {
+      float s = 0.f;
+      for (int g = 0; g < groups; ++g) s += part[g * width + col];
+      atomicAdd(out + f0 + col, s);
+    }
+    __syncthreads();
+  }
+}
+
 static unsigned flat_grid(int64_t total) {
   int64_t blocks = ceil_div(total, kBlock);
   if (blocks < 1) blocks = 1;
@@ -214,6 +244,26 @@ static int launch_scatter(const float* src, int64_t lds, const IdxT* idx, int64_
 using namespace pygamd;
 
 extern "C" {
+
+int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t F, float* out,
+                  void* stream) {
+  if (n_rows < 0 || F < 0 || ldx < F) return PYGAMD_ERR_INVALID_ARG;
+  if (F == 0) return PYGAMD_OK;
+  if (!out) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  PYGAMD_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * F, st));
+  if (n_rows == 0) return PYGAMD_OK;
+  if (!x) return PYGAMD_ERR_INVALID_ARG;
+  const int width = static_cast<int>(F < kBlock ? F : kBlock);
+  const int groups = kBlock / width;
+  int64_t blocks = ceil_div(n_rows, static_cast<int64_t>(groups) * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, x,
+                     ldx, n_rows, F, out);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
 
 int pygamd_gather_rows(const float* x, int64_t ldx, int64_t n_src, const void* index,
                        int idx_dtype, int64_t n, int64_t F, float* out, int64_t ldo,

@@ -35,6 +35,7 @@ struct SpmmDev {
   int64_t n_rows, F, ldx, ldo;
   int w_heads, head_dim;
   int mean;
+  int accumulate;  // out[i] += result instead of out[i] = result
   int64_t hub_threshold;
 };
 
@@ -214,6 +215,11 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
         Vec<VW> o;
 #pragma unroll
         for (int i = 0; i < VW; ++i) o.v[i] = a.mean ? acc[c][i] / cntf : acc[c][i];
+        if (a.accumulate) {
+          const Vec<VW> old = load_vec<VW>(orow + fo[c]);
+#pragma unroll
+          for (int i = 0; i < VW; ++i) o.v[i] += old.v[i];
+        }
         store_vec<VW>(orow + fo[c], o);
       }
     }
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(kBlock)
     spmm_hub_combine(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ hub_rows,
                      const IdxT* __restrict__ hub_chunk_ptr, int64_t n_hub,
                      const float* __restrict__ partial, float* __restrict__ out, int64_t F,
-                     int64_t ldo, int mean) {
+                     int64_t ldo, int mean, int accumulate) {
   const int lane = lane_id();
   const int64_t h = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   if (h >= n_hub) return;
@@ -288,7 +294,8 @@ __global__ void __launch_bounds__(kBlock)
   for (int64_t f = lane; f < F; f += kWave) {
     float s = 0.f;
     for (int64_t c = c0; c < c1; ++c) s += partial[c * F + f];
-    out[row * ldo + f] = mean ? s / cntf : s;
+    s = mean ? s / cntf : s;
+    out[row * ldo + f] = accumulate ? out[row * ldo + f] + s : s;
   }
 }
 
@@ -511,6 +518,7 @@ static SpmmDev<IdxT> make_dev(const pygamd_spmm_args* p) {
   a.w_heads = p->w_heads < 1 ? 1 : p->w_heads;
   a.head_dim = (p->w_heads > 1) ? p->head_dim : static_cast<int>(p->F > 0 ? p->F : 1);
   a.mean = (p->reduce == PYGAMD_MEAN);
+  a.accumulate = p->accumulate;
   a.hub_threshold = (p->n_hub > 0) ? p->hub_threshold : 0;
   return a;
 }
@@ -556,7 +564,7 @@ static int launch_sum(const pygamd_spmm_args* p, const Shape& s, float* partial,
     hipLaunchKernelGGL((spmm_hub_combine<IdxT>), cgrid, dim3(kBlock), 0, st, a.rowptr,
                        static_cast<const IdxT*>(p->hub_rows),
                        static_cast<const IdxT*>(p->hub_chunk_ptr), p->n_hub, partial, a.out,
-                       a.F, a.ldo, a.mean);
+                       a.F, a.ldo, a.mean, a.accumulate);
     PYGAMD_LAUNCH_CHECK();
   }
   return PYGAMD_OK;
@@ -629,7 +637,7 @@ static int validate(const pygamd_spmm_args* p) {
     return PYGAMD_ERR_UNSUPPORTED;
   if (p->n_rows > 0 && p->F > 0 && (!p->rowptr || !p->x || !p->out)) return PYGAMD_ERR_INVALID_ARG;
   const bool mm = (p->reduce == PYGAMD_MIN || p->reduce == PYGAMD_MAX);
-  if (mm && (p->w || p->src_scale)) return PYGAMD_ERR_UNSUPPORTED;
+  if (mm && (p->w || p->src_scale || p->accumulate)) return PYGAMD_ERR_UNSUPPORTED;
   if (p->w && p->w_heads > 1) {
     if (p->head_dim < 1 || static_cast<int64_t>(p->head_dim) * p->w_heads != p->F)
       return PYGAMD_ERR_INVALID_ARG;

@@ -1,0 +1,201 @@
+"""Whole-stack fusion of GraphSAGE (aggregate -> lin_l/lin_r GEMM -> bias
+-> ReLU without the extra ``[N, F]`` HBM round trips).
+
+Two per-layer schedules, chosen by width (both compute ``lin_l(aggr_j x_j) + lin_r(x_i) + b``):
+
+* ``post`` (``F_in <= F_out``, the reference's order — aggregate at the input width): the
+  aggregation writes straight into the LEFT half of a ``[N, 2 F_in]`` buffer whose RIGHT half
+  already holds the layer input (the previous layer's GEMM wrote it there, ReLU applied in place),
+  so ``lin_l(agg) + lin_r(x)`` is ONE GEMM against ``[W_l | W_r]`` with the bias folded in and no
+  ``cat`` / ``add`` pass ever runs.  Backward: one GEMM for both weight gradients, one for
+  ``[grad_agg | grad_root]``, and the transposed SpMM ACCUMULATES into the ``grad_root`` half
+  (``accumulate = 1`` in ``pygamd_spmm_csr``), which is then the next layer's incoming gradient.
+
+* ``pre`` (``F_out < F_in``, e.g. the 256 -> 47 output layer): mean/sum aggregation is linear, so
+  ``aggr_j(x_j) W_l^T == aggr_j(x_j W_l^T)``; transform first with ``[W_l ; W_r]`` in one GEMM and
+  aggregate at the (4-padded) OUTPUT width, accumulating onto the root term.  Same math, 256/48 x
+  fewer gathered bytes in both directions.  (GCNConv in the reference uses exactly this
+  transform-then-propagate order, nn/conv/gcn_conv.py:260-263.)
+
+Numerics: identical operations up to fp32 summation order; tests/test_gpu_layers.py pins both
+schedules against the oracle and the layer-by-layer path at 1e-5.
+
+GEMMs are plain library calls (rocBLAS / hipBLASLt through ``torch.mm``) on strided views."""
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from ... import _native
+from ...edge_index import EdgeIndex
+
+
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class FusedSageStack(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, graph: EdgeIndex, aggr: str, reorder: bool,
+                *params: Optional[Tensor]):
+        # params = (W_l, b_l | None, W_r) per layer
+        L = len(params) // 3
+        fwd = graph.by_dst()
+        N = x.size(0)
+        if fwd.n_rows != N or fwd.n_cols != N:
+            raise ValueError('the fused GraphSAGE stack needs a square (non-bipartite) graph')
+        dev = x.device
+        dims = [(params[3 * i].size(1), params[3 * i].size(0)) for i in range(L)]  # (Fi, Fo)
+        modes = ['pre' if (reorder and _pad4(Fo) < Fi) else 'post' for Fi, Fo in dims]
+
+        def new_input(layer):
+            """(buffer to save, view that receives this layer's input)"""
+            Fi = dims[layer][0]
+            if modes[layer] == 'post':
+                buf = torch.empty(N, 2 * Fi, dtype=torch.float32, device=dev)
+                return buf, buf[:, Fi:]
+            buf = torch.empty(N, Fi, dtype=torch.float32, device=dev)
+            return buf, buf
+
+        if modes[0] == 'pre' and x.is_contiguous():
+            buf, inp = x, x
+        else:
+            buf, inp = new_input(0)
+            inp.copy_(x)
+        bufs: List[Tensor] = []
+        wmats: List[Tensor] = []
+        out = None
+        for layer in range(L):
+            W_l, b, W_r = params[3 * layer:3 * layer + 3]
+            Fi, Fo = dims[layer]
+            last = layer == L - 1
+            if last:
+                nbuf, dst = None, torch.empty(N, Fo, dtype=torch.float32, device=dev)
+                out = dst
+            else:
+                nbuf, dst = new_input(layer + 1)
+            if modes[layer] == 'post':
+                _native.spmm_csr(fwd.ptr, fwd.idx, inp, aggr, n_rows=N, hub=fwd.hub,
+                                 out=buf[:, :Fi])
+                wmat = torch.cat([W_l, W_r], dim=1)  # [Fo, 2 Fi]
+                if b is not None:
+                    torch.addmm(b, buf, wmat.t(), out=dst)
+                else:
+                    torch.mm(buf, wmat.t(), out=dst)
+            else:
+                Fp = _pad4(Fo)
+                wmat = torch.zeros(2 * Fp, Fi, dtype=torch.float32, device=dev)  # [W_l ; W_r]
+                wmat[:Fo] = W_l
+                wmat[Fp:Fp + Fo] = W_r
+                if b is not None:
+                    bias = torch.zeros(2 * Fp, dtype=torch.float32, device=dev)
+                    bias[Fp:Fp + Fo] = b
+                    y = torch.addmm(bias, inp, wmat.t())
+                else:
+                    y = torch.mm(inp, wmat.t())
+                # y = [x W_l^T | x W_r^T + b];  right += aggr(left)
+                _native.spmm_csr(fwd.ptr, fwd.idx, y[:, :Fp], aggr, n_rows=N, hub=fwd.hub,
+                                 out=y[:, Fp:], accumulate=True)
+                dst.copy_(y[:, Fp:Fp + Fo])
+            if not last:
+                dst.relu_()
+            bufs.append(buf)
+            wmats.append(wmat)
+            buf, inp = nbuf, dst
+        ctx.graph, ctx.aggr, ctx.L, ctx.dims, ctx.modes = graph, aggr, L, dims, modes
+        ctx.has_bias = [params[3 * i + 1] is not None for i in range(L)]
+        ctx.save_for_backward(*bufs, *wmats)
+        return out
+
+    @staticmethod
+    def _input_view(ctx, bufs, layer) -> Tensor:
+        Fi = ctx.dims[layer][0]
+        return bufs[layer][:, Fi:] if ctx.modes[layer] == 'post' else bufs[layer]
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        L, graph, aggr = ctx.L, ctx.graph, ctx.aggr
+        saved = ctx.saved_tensors
+        bufs, wmats = saved[:L], saved[L:]
+        bwd = graph.by_src()
+        scale = graph.by_dst().inv_degree() if aggr == 'mean' else None
+        N = grad_out.size(0)
+        grads: List[Optional[Tensor]] = [None] * (3 * L)
+        g = grad_out if grad_out.stride(1) == 1 else grad_out.contiguous()
+        grad_x = None
+        for layer in reversed(range(L)):
+            buf, wmat = bufs[layer], wmats[layer]
+            Fi, Fo = ctx.dims[layer]
+            if layer < L - 1:
+                h_next = FusedSageStack._input_view(ctx, bufs, layer + 1)  # post-ReLU output
+                g = torch.ops.aten.threshold_backward(g, h_next, 0)
+            if ctx.has_bias[layer]:
+                grads[3 * layer + 1] = _native.colsum(g)
+            need_input_grad = layer > 0 or ctx.needs_input_grad[0]
+            if ctx.modes[layer] == 'post':
+                gw = torch.mm(g.t(), buf)  # [Fo, 2 Fi] = [grad W_l | grad W_r]
+                grads[3 * layer] = gw[:, :Fi]
+                grads[3 * layer + 2] = gw[:, Fi:]
+                if need_input_grad:
+                    gcat = torch.mm(g, wmat)  # [N, 2 Fi] = [grad_agg | grad_root]
+                    _native.spmm_csr(bwd.ptr, bwd.idx, gcat[:, :Fi], 'sum', n_rows=N,
+                                     src_scale=scale, hub=bwd.hub, out=gcat[:, Fi:],
+                                     accumulate=True)
+                    g = gcat[:, Fi:]
+            else:
+                Fp = _pad4(Fo)
+                gy = torch.empty(N, 2 * Fp, dtype=torch.float32, device=g.device)
+                if Fp != Fo:
+                    gy[:, Fp + Fo:].zero_()
+                gy[:, Fp:Fp + Fo].copy_(g)
+                # grad wrt (x W_l^T) = A^T (g / deg);  grad wrt (x W_r^T) = g
+                _native.spmm_csr(bwd.ptr, bwd.idx, gy[:, Fp:], 'sum', n_rows=N, src_scale=scale,
+                                 hub=bwd.hub, out=gy[:, :Fp])
+                x_in = buf
+                gw = torch.mm(gy.t(), x_in)  # [2 Fp, Fi]
+                grads[3 * layer] = gw[:Fo]
+                grads[3 * layer + 2] = gw[Fp:Fp + Fo]
+                if need_input_grad:
+                    g = torch.mm(gy, wmat)  # [N, Fi]
+            if layer == 0 and need_input_grad:
+                grad_x = g.contiguous()
+        return (grad_x, None, None, None, *grads)
+
+
+def eligible(model, x, edge_index, trim: bool) -> bool:
+    """Conditions under which the fused stack computes exactly what the layer loop does."""
+    from ..conv import SAGEConv
+    if trim or not getattr(model, 'fuse_stack', True):
+        return False
+    if not (isinstance(x, Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return False
+    if not isinstance(model.act, torch.nn.ReLU):
+        return False
+    if model.dropout.p > 0 and model.training:
+        return False
+    aggr = None
+    for conv in model.convs:
+        if not isinstance(conv, SAGEConv) or not conv.fuse:
+            return False
+        if conv.aggr not in ('mean', 'sum', 'add') or not conv.root_weight:
+            return False
+        if conv.normalize or conv.project or conv.flow != 'source_to_target':
+            return False
+        if aggr is not None and conv.aggr != aggr:
+            return False
+        aggr = conv.aggr
+    if isinstance(edge_index, EdgeIndex):
+        return edge_index.sparse_size == (x.size(0), x.size(0))
+    return isinstance(edge_index, Tensor) and edge_index.dim() == 2
+
+
+def run(model, x: Tensor, edge_index) -> Tensor:
+    from ...edge_index import as_edge_index
+    graph = as_edge_index(edge_index, x.size(0), x.size(0))
+    params = []
+    for conv in model.convs:
+        params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
+    aggr = model.convs[0].aggr
+    reorder = bool(getattr(model, 'reorder_narrow_layers', True))
+    return FusedSageStack.apply(x, graph, 'sum' if aggr == 'add' else aggr, reorder, *params)

@@ -107,10 +107,23 @@ class GCN(BasicGNN):
 
 
 class GraphSAGE(BasicGNN):
-    """:class:`SAGEConv` stack (basic_gnn.py:434-476)."""
+    """:class:`SAGEConv` stack (basic_gnn.py:434-476).  With plain mean/sum layers, ReLU and no
+    dropout the whole stack runs through :mod:`._fused_sage` (set ``fuse_stack = False`` to force
+    the layer-by-layer path)."""
+    fuse_stack: bool = True
 
     def init_conv(self, in_channels, out_channels: int, **kwargs) -> MessagePassing:
         return SAGEConv(in_channels, out_channels, **kwargs)
+
+    def forward(self, x: Tensor, edge_index, edge_weight: Optional[Tensor] = None,
+                edge_attr: Optional[Tensor] = None,
+                num_sampled_nodes_per_hop: Optional[List[int]] = None,
+                num_sampled_edges_per_hop: Optional[List[int]] = None) -> Tensor:
+        from . import _fused_sage
+        if _fused_sage.eligible(self, x, edge_index, num_sampled_nodes_per_hop is not None):
+            return _fused_sage.run(self, x, edge_index)
+        return super().forward(x, edge_index, edge_weight, edge_attr,
+                               num_sampled_nodes_per_hop, num_sampled_edges_per_hop)
 
 
 class GAT(BasicGNN):

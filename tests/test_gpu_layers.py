@@ -191,3 +191,48 @@ def test_trim_to_layer_model(dev):
                     num_sampled_edges_per_hop=edges_per_hop)[:4]
     assert_close(full, ref.detach())
     assert_close(trimmed, ref.detach())
+
+
+def test_fused_sage_stack_matches_layer_loop_and_oracle(dev):
+    """The whole-stack fusion (one GEMM per layer on [agg | x], accumulate-SpMM backward) against
+    the layer-by-layer path and the oracle, values and every gradient."""
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd.nn import GraphSAGE
+    from tests._util import random_graph
+    g = gen(21)
+    n = 500
+    ei = random_graph(n, n, 9000, seed=21, skew=True)
+    x = torch.randn(n, 20, generator=g)
+    go = torch.randn(n, 7, generator=g)
+    torch.manual_seed(5)
+    model = GraphSAGE(20, 32, num_layers=3, out_channels=7)
+    st = model.state_dict()
+    params = [(st[f'convs.{i}.lin_l.weight'].clone().requires_grad_(True),
+               st[f'convs.{i}.lin_l.bias'].clone().requires_grad_(True),
+               st[f'convs.{i}.lin_r.weight'].clone().requires_grad_(True)) for i in range(3)]
+    xr = x.clone().requires_grad_(True)
+    ref = O.graphsage(xr, ei, params)
+    ref.backward(go)
+    model = model.to(dev)
+    results = {}
+    for fused in (True, 'reference-order', False):
+        model.fuse_stack = bool(fused)
+        model.reorder_narrow_layers = fused is True  # 32 -> 7 output layer: transform first
+        model.zero_grad()
+        xg = x.to(dev).requires_grad_(True)
+        out = model(xg, ei.to(dev))
+        out.backward(go.to(dev))
+        results[fused] = (out.detach().cpu(), xg.grad.cpu(),
+                          [p.grad.detach().cpu().clone() for p in model.parameters()])
+    for fused in (True, 'reference-order', False):
+        out, gx, gp = results[fused]
+        assert_close(out, ref.detach(), atol=2e-5, what=f'fused={fused} out')
+        assert_close(gx, xr.grad, atol=2e-5, what=f'fused={fused} grad_x')
+        flat_ref = [t.grad for layer in params for t in layer]
+        for got, want in zip(gp, flat_ref):
+            assert_close(got, want, atol=1e-4, rtol=1e-4, what=f'fused={fused} param grad')
+    # x without grad (the bench configuration): no layer-0 input gradient is computed
+    model.fuse_stack = True
+    out = model(x.to(dev), ei.to(dev))
+    out.backward(go.to(dev))
+    assert_close(out, ref.detach(), atol=2e-5)

@@ -339,3 +339,37 @@ def test_empty_graph_and_isolated_rows(dev):
     for red in ['sum', 'mean', 'min', 'max']:
         out = pga.utils.spmm(h, torch.randn(5, 8, device=dev), red)
         assert out.shape == (4, 8) and (out == 0).all()
+
+
+@pytest.mark.parametrize('F', [1, 47, 100, 256, 300, 700])
+def test_colsum(dev, F):
+    from pytorch_geometric_amd import _native
+    x = torch.randn(10_001, F, generator=gen(F))
+    got = _native.colsum(x.to(dev))
+    assert_sum_close(got, x.sum(0), x.double().sum(0), what=f'colsum F={F}',
+                     abs_sum=x.abs().sum(0))
+    wide = torch.randn(500, 2 * F, generator=gen(F + 1))
+    got = _native.colsum(wide.to(dev)[:, F:])  # strided view
+    assert_sum_close(got, wide[:, F:].sum(0), wide[:, F:].double().sum(0),
+                     abs_sum=wide[:, F:].abs().sum(0))
+    assert _native.colsum(torch.empty(0, F, device=dev)).abs().sum() == 0
+
+
+def test_spmm_accumulate(dev, monkeypatch):
+    """accumulate=1: out += A x (the fused 'x_root + aggregate' of the SAGE backward)."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    monkeypatch.setattr(_native, 'HUB_THRESHOLD', 64)
+    monkeypatch.setattr(_native, 'HUB_CHUNK', 64)
+    ei = random_graph(300, 300, 8000, seed=12, skew=True)
+    h = pga.EdgeIndex(ei.to(dev), (300, 300))
+    fwd = h.by_dst()
+    assert fwd.hub[2] > 0
+    for F in (100, 256, 7):
+        buf = torch.randn(300, 2 * F, generator=gen(F))
+        bd = buf.to(dev)
+        _native.spmm_csr(fwd.ptr, fwd.idx, bd[:, :F], 'mean', n_rows=300, hub=fwd.hub,
+                         out=bd[:, F:], accumulate=True)
+        ref = buf[:, F:] + O.spmm(ei, buf[:, :F].contiguous(), 300, 'mean')
+        assert_close(bd[:, F:], ref, atol=2e-5, what=f'accumulate F={F}')
+        assert_close(bd[:, :F], buf[:, :F], rtol=0, atol=0)
