@@ -1,0 +1,231 @@
+"""``install()`` — plug the MI355X kernels into an importable ``torch_geometric`` so that the
+reference's own ``nn.conv.*`` / ``nn.aggr.*`` modules pick them up unchanged.
+
+The reference has no plugin registry: ``torch_geometric.backend`` is a module of flags
+(torch_geometric/backend.py:5-11) and its dispatchers are plain functions imported by name in ~60
+modules.  ``install()`` therefore
+
+1. publishes itself on ``torch_geometric.backend`` (``backend.mi355x`` = this module,
+   ``backend.use_mi355x`` flag, ``None`` = auto like ``use_segment_matmul``) — seam S5;
+2. rebinds the dispatcher functions ``scatter``, ``segment``, ``softmax``, ``index_sort``,
+   ``scatter_argmax`` in EVERY loaded ``torch_geometric*`` module whose attribute ``is`` the
+   original function — seam S3 (utils/__init__.py:5-10,36);
+3. wraps ``propagate`` of the hot conv classes (SAGEConv, GCNConv, GraphConv, GATConv) so that a
+   plain ``edge_index`` tensor is sorted once (cached handle) and gather -> message -> aggregate
+   runs as ONE CSR SpMM — the fused route the reference only takes for sparse ``adj_t`` inputs
+   (nn/conv/message_passing.py:469-479).
+
+Every wrapper STEPS ASIDE to the original reference function for anything that is not a float32
+HIP tensor, under ``torch.compile`` / TorchScript, or when ``backend.use_mi355x`` is False —
+exactly where the reference steps aside for its own extensions (utils/_scatter.py:85,
+edge_index.py:1946).  ``uninstall()`` restores every binding.
+"""
+import sys
+from typing import Any, Callable, Dict, List, Tuple
+
+import torch
+from torch import Tensor
+
+_state: Dict[str, Any] = {'installed': False, 'rebinds': [], 'classes': []}
+
+
+def _enabled() -> bool:
+    import torch_geometric
+    flag = getattr(torch_geometric.backend, 'use_mi355x', None)
+    if flag is False:
+        return False
+    if torch.jit.is_scripting():
+        return False
+    try:
+        if torch_geometric.is_compiling():
+            return False
+    except Exception:  # pragma: no cover
+        pass
+    return True
+
+
+def _ours(t: Any) -> bool:
+    return isinstance(t, Tensor) and t.is_cuda and t.dtype == torch.float32
+
+
+def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
+    from . import utils as U
+
+    def scatter(src, index, dim=0, dim_size=None, reduce='sum'):
+        if _ours(src) and _enabled():
+            return U.scatter(src, index, dim, dim_size, reduce)
+        return orig['scatter'](src, index, dim, dim_size, reduce)
+
+    def segment(src, ptr, reduce='sum'):
+        if _ours(src) and ptr.dim() == 1 and _enabled():
+            return U.segment(src, ptr, reduce)
+        return orig['segment'](src, ptr, reduce)
+
+    def softmax(src, index=None, ptr=None, num_nodes=None, dim=0):
+        if _ours(src) and _enabled():
+            return U.softmax(src, index, ptr, num_nodes, dim)
+        return orig['softmax'](src, index, ptr, num_nodes, dim)
+
+    def index_sort(inputs, max_value=None, stable=False):
+        if (isinstance(inputs, Tensor) and inputs.is_cuda and inputs.dim() == 1
+                and inputs.dtype in (torch.int32, torch.int64) and _enabled()):
+            return U.index_sort(inputs, max_value, stable)
+        return orig['index_sort'](inputs, max_value, stable)
+
+    def scatter_argmax(src, index, dim=0, dim_size=None):
+        if _ours(src) and src.dim() == 1 and _enabled():
+            return U.scatter_argmax(src, index, dim, dim_size)
+        return orig['scatter_argmax'](src, index, dim, dim_size)
+
+    new = dict(scatter=scatter, segment=segment, softmax=softmax, index_sort=index_sort,
+               scatter_argmax=scatter_argmax)
+    for name, fn in new.items():
+        fn.__wrapped__ = orig[name]
+        fn.__doc__ = orig[name].__doc__
+        fn.__name__ = name
+    return new
+
+
+def _sweep(old: Callable, new: Callable) -> List[Tuple[Any, str, Callable]]:
+    """Rebind every attribute of every loaded torch_geometric module that IS ``old``."""
+    done = []
+    for modname, mod in list(sys.modules.items()):
+        if mod is None or not (modname == 'torch_geometric'
+                               or modname.startswith('torch_geometric.')):
+            continue
+        for attr, val in list(vars(mod).items()):
+            if val is old:
+                setattr(mod, attr, new)
+                done.append((mod, attr, old))
+    return done
+
+
+# ---- fused propagate for the reference's own conv classes ------------------------------------
+def _fused_propagate(conv, edge_index, size, kwargs):
+    """Returns the aggregated tensor, or NotImplemented when this call must take the reference
+    path."""
+    from ._functions import SpmmFunction
+    from .edge_index import as_edge_index
+    if not (_enabled() and getattr(conv, 'fuse', True)) or getattr(conv, 'explain', False):
+        return NotImplemented
+    if not (isinstance(edge_index, Tensor) and type(edge_index) is Tensor and edge_index.is_cuda
+            and not edge_index.is_sparse and edge_index.dim() == 2 and edge_index.size(0) == 2
+            and edge_index.dtype in (torch.int32, torch.int64)):
+        return NotImplemented
+    if conv._propagate_forward_pre_hooks or conv._propagate_forward_hooks:
+        return NotImplemented
+    if getattr(conv, 'decomposed_layers', 1) != 1:
+        return NotImplemented
+    aggr = conv.aggr if isinstance(conv.aggr, str) else None
+    if aggr not in ('sum', 'add', 'mean', 'max', 'min'):
+        return NotImplemented
+    x = kwargs.get('x')
+    x_src, x_dst = (x if isinstance(x, (tuple, list)) else (x, x))
+    if not _ours(x_src):
+        return NotImplemented
+    name = type(conv).__name__
+    weight, order = None, 'coo'
+    if name in ('SAGEConv', ):
+        extra = set(kwargs) - {'x'}
+    elif name in ('GCNConv', 'GraphConv'):
+        weight = kwargs.get('edge_weight')
+        extra = set(kwargs) - {'x', 'edge_weight'}
+    elif name == 'GATConv':
+        weight = kwargs.get('alpha')
+        extra = set(kwargs) - {'x', 'alpha'}
+        if weight is None:
+            return NotImplemented
+    else:
+        return NotImplemented
+    if extra or (weight is not None and not _ours(weight)):
+        return NotImplemented
+    if weight is not None and aggr in ('max', 'min'):
+        return NotImplemented
+    node_dim = conv.node_dim + x_src.dim() if conv.node_dim < 0 else conv.node_dim
+    if node_dim != 0:
+        return NotImplemented
+    s2t = conv.flow == 'source_to_target'
+    n_src = x_src.size(0)
+    n_dst = x_dst.size(0) if isinstance(x_dst, Tensor) else None
+    if size is not None:
+        s_src, s_dst = (size[0], size[1]) if s2t else (size[1], size[0])
+        n_src = s_src if s_src is not None else n_src
+        n_dst = s_dst if s_dst is not None else n_dst
+    if n_dst is None:
+        n_dst = n_src
+    graph = as_edge_index(edge_index, n_src, n_dst, flip=not s2t)
+    reduce = 'sum' if aggr == 'add' else aggr
+    if weight is not None and weight.dim() == 1 and x_src.dim() > 2:
+        return NotImplemented
+    out = SpmmFunction.apply(x_src, weight, graph, reduce, order)
+    return conv.update(out)
+
+
+def _wrap_propagate(cls) -> Callable:
+    orig = cls.propagate
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        res = _fused_propagate(self, edge_index, size, kwargs)
+        if res is NotImplemented:
+            return orig(self, edge_index, size, **kwargs)
+        return res
+
+    propagate.__wrapped__ = orig
+    propagate.__module__ = getattr(orig, '__module__', propagate.__module__)
+    return propagate
+
+
+def install() -> None:
+    """Idempotent.  Needs ``torch_geometric`` importable; raises ImportError otherwise."""
+    if _state['installed']:
+        return
+    import torch_geometric
+    import torch_geometric.backend as pyg_backend
+    import torch_geometric.nn  # noqa: F401  (make sure the conv modules are loaded before sweeping)
+    import torch_geometric.utils as pyg_utils
+    from torch_geometric.utils import _scatter as pyg_scatter
+
+    orig = {
+        'scatter': pyg_utils.scatter, 'segment': pyg_utils.segment,
+        'softmax': pyg_utils.softmax, 'index_sort': pyg_utils.index_sort,
+        'scatter_argmax': pyg_scatter.scatter_argmax,
+    }
+    new = _make_dispatchers(orig)
+    for name in orig:
+        _state['rebinds'] += _sweep(orig[name], new[name])
+
+    from torch_geometric.nn.conv import GATConv, GCNConv, GraphConv, SAGEConv
+    for cls in (SAGEConv, GCNConv, GraphConv, GATConv):
+        had_own = 'propagate' in cls.__dict__
+        prev = cls.__dict__.get('propagate')
+        cls.propagate = _wrap_propagate(cls)
+        _state['classes'].append((cls, had_own, prev))
+
+    pyg_backend.mi355x = sys.modules[__name__]
+    if not hasattr(pyg_backend, 'use_mi355x'):
+        pyg_backend.use_mi355x = None  # None = auto (on for float32 HIP tensors)
+    _state['installed'] = True
+
+
+def uninstall() -> None:
+    if not _state['installed']:
+        return
+    import torch_geometric.backend as pyg_backend
+    for mod, attr, old in _state['rebinds']:
+        setattr(mod, attr, old)
+    for cls, had_own, prev in _state['classes']:
+        if had_own:
+            cls.propagate = prev
+        else:
+            try:
+                delattr(cls, 'propagate')
+            except AttributeError:  # pragma: no cover
+                pass
+    for attr in ('mi355x', 'use_mi355x'):
+        if hasattr(pyg_backend, attr):
+            delattr(pyg_backend, attr)
+    _state.update(installed=False, rebinds=[], classes=[])
+
+
+def is_installed() -> bool:
+    return bool(_state['installed'])
