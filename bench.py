@@ -43,6 +43,23 @@ def spmm_algorithmic_bytes(info) -> float:
     return float(total)
 
 
+def pmc_traffic(args, N, E, F_dom):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_spmm_f256.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE).  Counters
+    cannot be read from inside this process, so the number is only reported when this run is the
+    workload the counters were collected on; otherwise null."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_spmm_f256.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except OSError:
+        return None
+    w = d['workload']
+    same = (w['N'] == N and w['E'] == E and w['F'] == F_dom and not args.uniform
+            and w['index_dtype'] == args.index_dtype)
+    return d['traffic_bytes_per_launch'] if same else None
+
+
 def cpu_baseline(scale: float, steps: int = 2):
     """The reference's CPU scatter path (index_select -> scatter_add_ -> divide; oracle port,
     torch ATen CPU kernels on all host cores) on a `scale` x products-shaped sample."""
@@ -84,6 +101,9 @@ def main():
     ap.add_argument('--uniform', action='store_true', help='uniform instead of power-law graph')
     ap.add_argument('--cpu-scale', type=float, default=1 / 64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-tuned-gemm', action='store_true',
+                    help='use the default rocBLAS/hipBLASLt heuristics instead of the shipped '
+                         'TunableOp table')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -105,6 +125,10 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     pga.load_library()  # fail loudly if the HIP library is missing
+    tuned = False
+    if not args.no_tuned_gemm:
+        from pytorch_geometric_amd.tuning import enable_tuned_gemms
+        tuned = enable_tuned_gemms()
 
     idx_dtype = torch.int64 if args.index_dtype == 'int64' else torch.int32
     t_gen = time.perf_counter()
@@ -173,7 +197,7 @@ def main():
     spmm_ms_per_step = sum(ms for g in groups.values() for _, ms in g) / args.steps
     roofline = {
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(args, N, E, dom_F),
         'kernel': f'spmm_sum_rows<F={dom_F}> (pygamd_spmm_csr, fwd mean + transposed bwd)',
         'launches_timed': len(dom), 'avg_launch_ms': round(avg_ms, 4),
         'algorithmic_bytes_per_launch': alg_bytes,
@@ -196,6 +220,11 @@ def main():
                 'edges_per_step_per_gpu': 3 * E, 'scale': args.scale,
                 'parallelism': f'dp{world} (graph replicas, one flat-bucket all-reduce/step)',
                 'graph_gen_s': round(t_gen, 1),
+                'gemm': ('rocBLAS/hipBLASLt via torch.mm, solution per shape from '
+                         'pytorch_geometric_amd/tuning (TunableOp, read-only)' if tuned else
+                         'rocBLAS/hipBLASLt via torch.mm, default heuristics'),
+                'schedule': 'fused stack: [agg|x] single GEMM per layer; 256->47 layer '
+                            'transforms first and aggregates at width 48',
             },
             'roofline': roofline,
         }

@@ -1,11 +1,13 @@
-from .aggr import (Aggregation, MaxAggregation, MeanAggregation, MinAggregation, MulAggregation,
-                   SumAggregation)
-from .conv import GATConv, GCNConv, MessagePassing, SAGEConv, gcn_norm
+from .aggr import (Aggregation, FusedAggregation, MaxAggregation, MeanAggregation,
+                   MinAggregation, MulAggregation, MultiAggregation, StdAggregation,
+                   SumAggregation, VarAggregation)
+from .conv import GATConv, GCNConv, MessagePassing, RGCNConv, SAGEConv, gcn_norm
 from .dense import Linear
 from .models import GAT, GCN, BasicGNN, GraphSAGE
 
 __all__ = [
     'Aggregation', 'SumAggregation', 'MeanAggregation', 'MaxAggregation', 'MinAggregation',
-    'MulAggregation', 'MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv', 'Linear',
+    'MulAggregation', 'VarAggregation', 'StdAggregation', 'FusedAggregation',
+    'MultiAggregation', 'MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv', 'RGCNConv', 'Linear',
     'BasicGNN', 'GCN', 'GraphSAGE', 'GAT',
 ]

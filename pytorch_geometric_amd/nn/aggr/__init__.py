@@ -1,6 +1,8 @@
 from .base import Aggregation
 from .basic import (MaxAggregation, MeanAggregation, MinAggregation, MulAggregation,
                     SumAggregation, aggregation_resolver)
+from .fused import FusedAggregation, MultiAggregation, StdAggregation, VarAggregation
 
 __all__ = ['Aggregation', 'SumAggregation', 'MeanAggregation', 'MaxAggregation',
-           'MinAggregation', 'MulAggregation', 'aggregation_resolver']
+           'MinAggregation', 'MulAggregation', 'VarAggregation', 'StdAggregation',
+           'FusedAggregation', 'MultiAggregation', 'aggregation_resolver']

@@ -1,0 +1,209 @@
+import weakref
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+from torch.nn import Parameter
+
+from ... import _native
+from ..._functions import SpmmFunction
+from ...edge_index import CSR, EdgeIndex, build_csr
+from ...utils._segment_matmul import segment_matmul
+from ..inits import glorot, zeros
+from .message_passing import MessagePassing
+
+
+class RelationalHandle:
+    r"""Per-(graph, edge_type) cache for :class:`RGCNConv`: the edges stably sorted by
+    ``(relation, destination)`` so that every non-empty ``(r, i)`` pair is one contiguous segment.
+
+    * ``pair_graph``  — handle over ``[E]`` edges -> ``[S]`` pair segments (rows = pairs, columns =
+      source nodes): one SpMM gives the per-relation neighbourhood mean ``agg[s]``;
+    * ``rel_ptr``     — ``[R+1]`` ranges of pairs per relation (pairs are sorted by relation): the
+      segments of ``segment_matmul``;
+    * ``out_graph``   — handle pairs -> destination nodes: one SpMM (sum) scatters the transformed
+      pair rows back onto the nodes.
+
+    Everything is built with the same bit-exact sort / pointer kernels as :class:`EdgeIndex`."""
+
+    def __init__(self, edge_index: Tensor, edge_type: Tensor, num_src: int, num_dst: int,
+                 num_relations: int):
+        dev = edge_index.device
+        src, dst = edge_index[0], edge_index[1]
+        key = edge_type.to(torch.int64) * num_dst + dst.to(torch.int64)
+        skey, perm = _native.index_sort(key, max_value=num_relations * num_dst)
+        # pair boundaries: positions where the sorted key changes
+        E = key.numel()
+        if E > 0:
+            new = torch.ones(E, dtype=torch.bool, device=dev)
+            new[1:] = skey[1:] != skey[:-1]
+            starts = new.nonzero().view(-1)
+            pair_key = skey[starts]
+            seg_ptr = torch.cat([starts, torch.tensor([E], device=dev)])
+        else:
+            pair_key = skey
+            seg_ptr = torch.zeros(1, dtype=torch.int64, device=dev)
+        S = pair_key.numel()
+        self.num_pairs = S
+        pair_rel = torch.div(pair_key, num_dst, rounding_mode='floor')
+        pair_dst = pair_key - pair_rel * num_dst
+        src_sorted = _native.permute_index(src.to(torch.int64), perm)
+        # edges -> pairs (rows = pairs).  The COO form is only needed for the transposed handle.
+        pair_of_edge = _native.ptr2index(seg_ptr, E)
+        self.pair_graph = EdgeIndex(torch.stack([src_sorted, pair_of_edge]), (num_src, S),
+                                    sort_order='col', validate=False)
+        self.rel_ptr = tuple(_native.index2ptr(pair_rel, num_relations).tolist())
+        # pairs -> destination nodes
+        self.out_graph = EdgeIndex(torch.stack([torch.arange(S, device=dev), pair_dst]),
+                                   (S, num_dst), sort_order='row', validate=False)
+
+
+class RGCNConv(MessagePassing):
+    r"""Relational graph convolution
+    ``x_i' = root x_i + sum_r mean_{j in N_r(i)} W_r x_j + b`` — constructor, parameters
+    (``weight``, optional ``comp``, ``root``, ``bias``; glorot / zeros init) and semantics of the
+    default branch of ``torch_geometric.nn.RGCNConv`` (torch_geometric/nn/conv/rgcn_conv.py:92-290),
+    including ``num_bases`` (weights composed from bases) and ``num_blocks`` (block-diagonal).
+
+    Instead of the reference's Python loop over relations (mask -> nonzero -> gather -> scatter ->
+    matmul, 474 times for FB15k-237) the layer sorts the edges by ``(relation, destination)`` once
+    (cached), aggregates every ``(r, i)`` neighbourhood with ONE SpMM, transforms the pair rows
+    with a relation-segmented matmul and sums them per destination with a second SpMM.
+    """
+
+    def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int,
+                 num_relations: int, num_bases: Optional[int] = None,
+                 num_blocks: Optional[int] = None, aggr: str = 'mean', root_weight: bool = True,
+                 is_sorted: bool = False, bias: bool = True, **kwargs):
+        kwargs.setdefault('aggr', aggr)
+        super().__init__(node_dim=0, **kwargs)
+        if num_bases is not None and num_blocks is not None:
+            raise ValueError('Can not apply both basis-decomposition and '
+                             'block-diagonal-decomposition at the same time.')
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_relations = num_relations
+        self.num_bases = num_bases
+        self.num_blocks = num_blocks
+        self.is_sorted = is_sorted
+        if isinstance(in_channels, int):
+            in_channels = (in_channels, in_channels)
+        self.in_channels_l = in_channels[0]
+        if num_bases is not None:
+            self.weight = Parameter(torch.empty(num_bases, in_channels[0], out_channels))
+            self.comp = Parameter(torch.empty(num_relations, num_bases))
+        elif num_blocks is not None:
+            assert in_channels[0] % num_blocks == 0 and out_channels % num_blocks == 0
+            self.weight = Parameter(torch.empty(num_relations, num_blocks,
+                                                in_channels[0] // num_blocks,
+                                                out_channels // num_blocks))
+            self.register_parameter('comp', None)
+        else:
+            self.weight = Parameter(torch.empty(num_relations, in_channels[0], out_channels))
+            self.register_parameter('comp', None)
+        if root_weight:
+            self.root = Parameter(torch.empty(in_channels[1], out_channels))
+        else:
+            self.register_parameter('root', None)
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self._handle_cache = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        super().reset_parameters()
+        glorot(self.weight)
+        glorot(self.comp)
+        glorot(self.root)
+        zeros(self.bias)
+
+    def _handle(self, edge_index: Tensor, edge_type: Tensor, n_src: int,
+                n_dst: int) -> RelationalHandle:
+        hit = self._handle_cache
+        if hit is not None:
+            r_ei, r_et, v_ei, v_et, size, handle = hit
+            if (r_ei() is edge_index and r_et() is edge_type and v_ei == edge_index._version
+                    and v_et == edge_type._version and size == (n_src, n_dst)):
+                return handle
+        handle = RelationalHandle(edge_index, edge_type, n_src, n_dst, self.num_relations)
+        self._handle_cache = (weakref.ref(edge_index), weakref.ref(edge_type),
+                              edge_index._version, edge_type._version, (n_src, n_dst), handle)
+        return handle
+
+    def forward(self, x: Union[Optional[Tensor], Tuple[Optional[Tensor], Tensor]], edge_index,
+                edge_type: Optional[Tensor] = None) -> Tensor:
+        x_l = x[0] if isinstance(x, tuple) else x
+        if x_l is None:
+            x_l = torch.arange(self.in_channels_l, device=self.weight.device)
+        x_r = x[1] if isinstance(x, tuple) else x_l
+        assert edge_type is not None
+        if not torch.is_floating_point(x_r) and self.num_blocks is not None:
+            raise ValueError('Block-diagonal decomposition not supported '
+                             'for non-continuous input features.')
+        weight = self.weight
+        if self.num_bases is not None:  # basis decomposition (rgcn_conv.py:203-205)
+            weight = (self.comp @ weight.view(self.num_bases, -1)).view(
+                self.num_relations, self.in_channels_l, self.out_channels)
+
+        if not torch.is_floating_point(x_l):
+            # node-index inputs: the per-relation embedding lookup weight[r, x_j]
+            out = self._index_inputs(x_l, x_r, edge_index, edge_type, weight)
+        else:
+            n_src, n_dst = x_l.size(0), x_r.size(0)
+            ei = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
+            h = self._handle(ei, edge_type, n_src, n_dst)
+            reduce = 'sum' if self.aggr == 'add' else self.aggr
+            # (1) per-(relation, destination) neighbourhood reduce at the input width
+            agg = SpmmFunction.apply(x_l, None, h.pair_graph, reduce, 'coo')  # [S, F_in]
+            # (2) relation-segmented transform
+            if self.num_blocks is not None:
+                B = self.num_blocks
+                S = agg.size(0)
+                t = agg.view(S, B, -1).transpose(0, 1).reshape(B * S, -1)  # block-major rows
+                ptr = [0]
+                # segments = (block, relation) in block-major order
+                for b in range(B):
+                    ptr += [b * S + p for p in h.rel_ptr[1:]]
+                w = weight.transpose(0, 1).reshape(B * self.num_relations, weight.size(2),
+                                                   weight.size(3))
+                t = segment_matmul(t, ptr, w)  # [B*S, out/B]
+                t = t.view(B, S, -1).transpose(0, 1).reshape(S, -1)
+            else:
+                t = segment_matmul(agg, h.rel_ptr, weight)  # [S, F_out]
+            # (3) sum the pair rows of every destination
+            out = SpmmFunction.apply(t, None, h.out_graph, 'sum', 'coo')
+
+        root = self.root
+        if root is not None:
+            if not torch.is_floating_point(x_r):
+                out = out + root[x_r]
+            else:
+                out = out + x_r @ root
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+    def _index_inputs(self, x_l, x_r, edge_index, edge_type, weight):
+        # rgcn_conv.py:262-268: out += propagate(masked edges, x = weight[r, x_l])
+        out = torch.zeros(x_r.size(0), self.out_channels, device=x_r.device)
+        ei = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
+        for r in range(self.num_relations):
+            tmp = ei[:, edge_type == r]
+            if tmp.size(1) == 0:
+                continue
+            out = out + self.propagate(tmp.contiguous(), x=weight[r, x_l],
+                                       size=(x_l.size(0), x_r.size(0)))
+        return out
+
+    def message(self, x_j: Tensor) -> Tensor:
+        return x_j
+
+    def message_and_aggregate(self, graph: EdgeIndex, x: Tensor) -> Tensor:
+        return SpmmFunction.apply(x, None, graph, 'sum' if self.aggr == 'add' else self.aggr,
+                                  'coo')
+
+    def __repr__(self) -> str:
+        return (f'{self.__class__.__name__}({self.in_channels}, '
+                f'{self.out_channels}, num_relations={self.num_relations})')

@@ -6,11 +6,12 @@ from ._index_sort import index_sort
 from ._degree import degree
 from .num_nodes import maybe_num_nodes
 from ._trim_to_layer import trim_to_layer
+from ._segment_matmul import segment_matmul
 from .loop import (add_remaining_self_loops, add_self_loops, contains_self_loops,
                    remove_self_loops)
 
 __all__ = [
     'scatter', 'scatter_argmax', 'segment', 'softmax', 'spmm', 'index_sort', 'degree',
-    'maybe_num_nodes', 'trim_to_layer', 'add_remaining_self_loops', 'add_self_loops', 'contains_self_loops',
+    'maybe_num_nodes', 'trim_to_layer', 'segment_matmul', 'add_remaining_self_loops', 'add_self_loops', 'contains_self_loops',
     'remove_self_loops',
 ]

@@ -236,3 +236,67 @@ def test_fused_sage_stack_matches_layer_loop_and_oracle(dev):
     out = model(x.to(dev), ei.to(dev))
     out.backward(go.to(dev))
     assert_close(out, ref.detach(), atol=2e-5)
+
+
+def test_rgcn_conv_golden(dev, golden):
+    """config 5 (a16): per-relation mean + W_r, incl. basis and block-diagonal decompositions."""
+    from pytorch_geometric_amd.nn import RGCNConv
+    gr, L = golden['graph'], golden['layers']
+    args = (gr['edge_index'], gr['edge_type'])
+    _run_layer(RGCNConv(16, 10, num_relations=5), L['rgcn'], gr['x'], dev, *args)
+    _run_layer(RGCNConv(16, 12, num_relations=5, num_blocks=4), L['rgcn_blocks'], gr['x'], dev,
+               *args)
+    _run_layer(RGCNConv(16, 10, num_relations=5, num_bases=3), L['rgcn_bases'], gr['x'], dev,
+               *args)
+
+
+def test_rgcn_conv_vs_oracle_skewed_relations(dev):
+    """FB15k-237-like relation histogram (Zipf), empty relations, int32 indices, sum aggregation."""
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd.nn import RGCNConv
+    from tests._util import random_graph
+    g = gen(33)
+    n, e, R = 300, 6000, 40
+    ei = random_graph(n, n, e, seed=33, skew=True)
+    et = (torch.rand(e, generator=g).pow(3) * R).long().clamp(max=R - 1)
+    et[et == 7] = 8  # relation 7 is empty
+    x = torch.randn(n, 12, generator=g)
+    go = torch.randn(n, 9, generator=g)
+    for aggr in ('mean', 'sum'):
+        torch.manual_seed(3)
+        conv = RGCNConv(12, 9, num_relations=R, aggr=aggr)
+        w, r, b = (conv.weight.detach().clone().requires_grad_(True),
+                   conv.root.detach().clone().requires_grad_(True),
+                   conv.bias.detach().clone().requires_grad_(True))
+        xr = x.clone().requires_grad_(True)
+        ref = O.rgcn_conv(xr, ei, et, w, r, b, aggr)
+        ref.backward(go)
+        conv = conv.to(dev)
+        xg = x.to(dev).requires_grad_(True)
+        out = conv(xg, ei.int().to(dev), et.to(dev))
+        out.backward(go.to(dev))
+        assert_close(out, ref.detach(), atol=5e-5, what=f'rgcn {aggr}')
+        assert_close(xg.grad, xr.grad, atol=5e-5, what=f'rgcn {aggr} grad_x')
+        assert_close(conv.weight.grad, w.grad, atol=1e-4, rtol=1e-4, what='grad weight')
+        assert_close(conv.root.grad, r.grad, atol=1e-4, rtol=1e-4, what='grad root')
+
+
+def test_segment_matmul(dev):
+    """pyg_lib.ops.segment_matmul contract vs HeteroLinear's naive loop (nn/dense/linear.py:248)."""
+    from pytorch_geometric_amd.utils import segment_matmul
+    g = gen(5)
+    x = torch.randn(50, 6, generator=g)
+    w = torch.randn(4, 6, 3, generator=g)
+    ptr = torch.tensor([0, 10, 10, 35, 50])
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = torch.cat([xr[ptr[i]:ptr[i + 1]] @ wr[i] for i in range(4)])
+    go = torch.randn(50, 3, generator=g)
+    ref.backward(go)
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    out = segment_matmul(xg, ptr.to(dev), wg)
+    out.backward(go.to(dev))
+    assert_close(out, ref.detach())
+    assert_close(xg.grad, xr.grad)
+    assert_close(wg.grad, wr.grad, atol=2e-5)
+    with pytest.raises(ValueError):
+        segment_matmul(xg, torch.tensor([0, 50]), wg)

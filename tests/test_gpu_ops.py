@@ -373,3 +373,37 @@ def test_spmm_accumulate(dev, monkeypatch):
         ref = buf[:, F:] + O.spmm(ei, buf[:, :F].contiguous(), 300, 'mean')
         assert_close(bd[:, F:], ref, atol=2e-5, what=f'accumulate F={F}')
         assert_close(bd[:, :F], buf[:, :F], rtol=0, atol=0)
+
+
+def test_fused_and_multi_aggregation(dev):
+    """test/nn/aggr/test_fused.py:9-42: FusedAggregation equals the individual aggregations,
+    values and gradients; test_basic.py:66-75: var against the manual formula."""
+    import pytorch_geometric_amd.nn as nn
+    g = gen(77)
+    x = torch.randn(400, 6, generator=g)
+    index = torch.randint(0, 30, (400, ), generator=g)
+    names = ['sum', 'mean', 'min', 'max', 'mul', 'var', 'std']
+    ref_mods = {'sum': 'sum', 'mean': 'mean', 'min': 'min', 'max': 'max', 'mul': 'mul'}
+    xr = x.clone().requires_grad_(True)
+    refs = {k: O.scatter(xr, index, 0, 32, v) for k, v in ref_mods.items()}
+    mean2 = O.scatter(xr * xr, index, 0, 32, 'mean')
+    refs['var'] = mean2 - refs['mean'] * refs['mean']
+    s = refs['var'].clamp(min=1e-5).sqrt()
+    refs['std'] = s.masked_fill(s <= 1e-5 ** 0.5, 0.0)
+    go = [torch.randn(32, 6, generator=g) for _ in names]
+    sum(((refs[n] * w).sum() for n, w in zip(names, go))).backward()
+    fused = nn.FusedAggregation(names)
+    xg = x.to(dev).requires_grad_(True)
+    outs = fused(xg, index.to(dev), dim_size=32)
+    sum(((o * w.to(dev)).sum() for o, w in zip(outs, go))).backward()
+    for n, o in zip(names, outs):
+        tol = 5e-4 if n in ('mul', ) else 2e-5
+        assert_close(o, refs[n].detach(), atol=tol, rtol=1e-4, what=n)
+    assert_close(xg.grad, xr.grad, atol=2e-3, rtol=1e-3, what='fused grad')
+    multi = nn.MultiAggregation(['mean', 'max', 'std'])
+    out = multi(x.to(dev), index.to(dev), dim_size=32)
+    assert out.shape == (32, 18)
+    assert_close(out[:, :6], refs['mean'].detach(), atol=2e-5)
+    assert_close(out[:, 6:12], refs['max'].detach(), atol=0, rtol=0)
+    with pytest.raises(ValueError, match='not fusable'):
+        nn.FusedAggregation([nn.MultiAggregation(['sum', 'max'])])
