@@ -7,8 +7,8 @@ import sys
 def short(n):
     n = n.replace('void ', '')
     if n.startswith('Cijk'):
-        return ('hipBLASLt ' + n.split('_UserArgs_')[0][5:14] + ' '
-                + n.split('_UserArgs_')[1].split('_MI')[0])
+        m = re.search(r'_(MT\d+x\d+x\d+)_', n)
+        return 'rocBLAS/hipBLASLt ' + n[5:14] + ' ' + (m.group(1) if m else '')
     if 'rocprim' in n:
         m = re.search(r'detail::(radix_sort\w+|partition_impl|transform_impl)', n)
         return 'rocprim ' + (m.group(1) if m else n[:60])

@@ -1,0 +1,114 @@
+"""BASELINE.json configs 1, 3 and 5 at their full (synthetic-shape) sizes: HIP path vs the CPU
+oracle on identical seeded inputs, forward values and input/parameter gradients.  (Config 2 at full
+size is covered by tests/test_gpu_scale.py through properties and by bench.py; config 4 needs the
+sampler)"""
+import pytest
+import torch
+
+from oracle import pyg_oracle as O
+from tests._util import assert_close, gen
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_gcn_cora_shape(dev):
+    """GCNConv 2-layer on a Cora-shaped graph (N=2,708, E=10,556 mirrored pairs, F=1,433, 7
+    classes), examples/gcn.py plumbing: GCN(1433, 16, 2 layers, out 7), cached normalisation."""
+    from pytorch_geometric_amd.nn import GCN
+    g = gen(0)
+    n, pairs = 2708, 5278
+    u = torch.randint(0, n, (pairs, ), generator=g)
+    v = torch.randint(0, n, (pairs, ), generator=g)
+    ei = torch.stack([torch.cat([u, v]), torch.cat([v, u])])
+    x = torch.rand(n, 1433, generator=g)
+    x = x / x.sum(1, keepdim=True)  # NormalizeFeatures
+    go = torch.randn(n, 7, generator=g)
+    torch.manual_seed(0)
+    model = GCN(1433, 16, num_layers=2, out_channels=7, cached=True)
+    st = {k: v.clone() for k, v in model.state_dict().items()}
+    params = [(st[f'convs.{i}.lin.weight'].requires_grad_(True),
+               st[f'convs.{i}.bias'].requires_grad_(True)) for i in range(2)]
+    ref = O.gcn(x, ei, params)
+    ref.backward(go)
+    model = model.to(dev).eval()
+    out = model(x.to(dev), ei.to(dev))
+    out.backward(go.to(dev))
+    out2 = model(x.to(dev), ei.to(dev))  # second call hits the cached normalisation + handle
+    assert_close(out, ref.detach(), what='gcn out')
+    assert_close(out2, ref.detach(), what='gcn out (cached)')
+    for i in range(2):
+        assert_close(model.convs[i].lin.weight.grad, params[i][0].grad, atol=2e-5,
+                     what=f'lin{i} grad')
+        assert_close(model.convs[i].bias.grad, params[i][1].grad, atol=2e-5, what=f'b{i} grad')
+
+
+def test_config3_gat_arxiv_shape(dev):
+    """GATConv 3-layer heads=8 on an ogbn-arxiv-shaped graph (N=169,343, E=1,166,243): edge
+    softmax + multi-head weighted aggregation, widths 8x32 / 8x32 / 8x40 (mean over heads)."""
+    from pytorch_geometric_amd.nn import GAT
+    g = gen(2)
+    n, e = 169_343, 1_166_243
+    ei = torch.randint(0, n, (2, e), generator=g)
+    x = torch.randn(n, 128, generator=g)
+    torch.manual_seed(2)
+    model = GAT(128, 256, num_layers=3, out_channels=40, heads=8)
+    st = {k: v.clone() for k, v in model.state_dict().items()}
+    params = [(st[f'convs.{i}.lin.weight'], st[f'convs.{i}.att_src'], st[f'convs.{i}.att_dst'],
+               st[f'convs.{i}.bias']) for i in range(3)]
+    go = torch.randn(n, 40, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = O.gat(xr, ei, params, heads=8)
+    ref.backward(go)
+    model = model.to(dev).eval()
+    xg = x.to(dev).requires_grad_(True)
+    out = model(xg, ei.to(dev))
+    out.backward(go.to(dev))
+    assert_close(out, ref.detach(), atol=2e-5, what='gat out')
+    assert_close(xg.grad, xr.grad, atol=2e-5, what='gat grad_x')
+
+
+def test_config5_rgcn_fb15k237_shape(dev):
+    """RGCNConv 2-layer on an FB15k-237-shaped graph (N=14,541, E=544,230, 474 relations with a
+    Zipf histogram): dense-weight variant RGCNConv(64, 64, 474) and the block-diagonal variant of
+    examples/rgcn_link_pred.py (num_blocks=5; width 100 here to keep the CPU oracle in seconds)."""
+    from pytorch_geometric_amd.nn import RGCNConv
+    g = gen(4)
+    n, e, R = 14_541, 544_230, 474
+    ei = torch.randint(0, n, (2, e), generator=g)
+    et = (torch.rand(e, generator=g).pow(4) * R).long().clamp(max=R - 1)
+    go = torch.randn(n, 64, generator=g)
+    x = torch.randn(n, 64, generator=g)
+    torch.manual_seed(4)
+    convs = [RGCNConv(64, 64, R), RGCNConv(64, 64, R)]
+    xr = x.clone().requires_grad_(True)
+    h = xr
+    ws = []
+    for i, c in enumerate(convs):
+        w = [c.weight.detach().clone().requires_grad_(True),
+             c.root.detach().clone().requires_grad_(True),
+             c.bias.detach().clone().requires_grad_(True)]
+        ws.append(w)
+        h = O.rgcn_conv(h, ei, et, *w)
+        if i == 0:
+            h = h.relu()
+    h.backward(go)
+    xg = x.to(dev).requires_grad_(True)
+    hg = xg
+    eid, etd = ei.to(dev), et.to(dev)
+    for i, c in enumerate(convs):
+        c.to(dev)
+        hg = c(hg, eid, etd)
+        if i == 0:
+            hg = hg.relu()
+    hg.backward(go.to(dev))
+    assert_close(hg, h.detach(), atol=5e-5, what='rgcn out')
+    assert_close(xg.grad, xr.grad, atol=5e-5, what='rgcn grad_x')
+    assert_close(convs[0].weight.grad, ws[0][0].grad, atol=1e-4, rtol=1e-4, what='rgcn grad W')
+    # block-diagonal decomposition
+    torch.manual_seed(5)
+    conv = RGCNConv(100, 100, R, num_blocks=5)
+    x2 = torch.randn(n, 100, generator=g)
+    ref = O.rgcn_conv_blocks(x2, ei, et, conv.weight.detach(), conv.root.detach(),
+                             conv.bias.detach())
+    out = conv.to(dev)(x2.to(dev), eid, etd)
+    assert_close(out, ref, atol=5e-5, what='rgcn blocks out')

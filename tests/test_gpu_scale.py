@@ -55,9 +55,10 @@ def test_spmm_properties_full_size(products, F):
     # linearity: A(2a - 3b) = 2 A a - 3 A b
     out_b = pga.utils.spmm(h, b, 'sum')
     out_c = pga.utils.spmm(h, 2 * a - 3 * b, 'sum')
+    # (rounding scales with the sum of |terms| of a row, up to ~16 k terms on hub rows)
     err = (out_c - (2 * out_a - 3 * out_b)).abs()
-    scale = (2 * out_a.abs() + 3 * out_b.abs()).clamp(min=1.0)
-    assert float((err / scale).max()) < 1e-5
+    scale = pga.utils.spmm(h, 2 * a.abs() + 3 * b.abs(), 'sum').clamp(min=1.0)
+    assert float((err / scale).max()) < 2e-6
     # mean = sum / clamp(deg, 1); rows without in-edges are exactly 0
     indeg = h.by_dst().degree()
     mean = pga.utils.spmm(h, a, 'mean')
