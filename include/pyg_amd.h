@@ -192,6 +192,24 @@ PYGAMD_API int pygamd_sddmm_csr(const void* rowptr, const void* col, const void*
 PYGAMD_API int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t F, float* out,
                              void* stream);
 
+/* ---- a16/a17: segment_matmul (grouped GEMM over row segments, fp32 MFMA) ---------------------
+ * Replaces pyg_lib.ops.segment_matmul(x, ptr, weight) (nn/conv/rgcn_conv.py:288,
+ * nn/dense/linear.py:255):  out[ptr[g]:ptr[g+1]] = x[ptr[g]:ptr[g+1]] @ W[g].
+ * `tiles` is a device array of int32 triples (segment, first row, rows <= tile_rows) covering
+ * every non-empty segment in chunks of pygamd_segment_matmul_tile_rows() rows; W[g] is addressed
+ * as w[g * w_seg_stride + k * w_stride_k + n * w_stride_n] so the same entry point computes the
+ * input gradient (W^T: swap the two strides).  _wgrad: grad_w[g] = x[seg]^T @ g[seg] ([K, N]
+ * row-major per segment; empty segments give 0).                                               */
+PYGAMD_API int pygamd_segment_matmul_tile_rows(void);
+PYGAMD_API int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w,
+                                     int64_t w_seg_stride, int64_t w_stride_k,
+                                     int64_t w_stride_n, const int32_t* tiles, int64_t n_tiles,
+                                     int64_t K, int64_t N, float* out, int64_t ldo,
+                                     void* stream);
+PYGAMD_API int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g,
+                                           int64_t ldg, const int64_t* ptr, int64_t n_seg,
+                                           int64_t K, int64_t N, float* grad_w, void* stream);
+
 /* ---- a2: gather (index_select along dim 0) --------------------------------------------------
  * out[e, :] = x[index[e], :]  (nn/conv/message_passing.py:263-290, collect.jinja:118-127).
  * Out-of-range indices set *err_flag (device int32, optional) to 1 and read row 0.             */

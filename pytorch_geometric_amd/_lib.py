@@ -59,6 +59,11 @@ SIGNATURES = {
     'pygamd_sddmm_csr': (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                  c_int32, c_int32, _P, _P]),
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    'pygamd_segment_matmul_tile_rows': (c_int, []),
+    'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64,
+                                      c_int64, c_int64, _P, c_int64, _P]),
+    'pygamd_segment_matmul_wgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64,
+                                            c_int64, _P, _P]),
     'pygamd_gather_rows': (c_int, [_P, c_int64, c_int64, _P, c_int, c_int64, c_int64, _P,
                                    c_int64, _P, _P]),
     'pygamd_scatter_init': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),

@@ -415,3 +415,59 @@ def gat_edge_softmax_backward(rowptr, col, alpha_src, alpha_dst, alpha, grad_alp
                                                float(slope), _p(g_src), _p(g_dst),
                                                _stream(a_s)), 'gat_edge_softmax_backward')
     return g_src, g_dst
+
+
+# ---- segment_matmul (grouped GEMM, fp32 MFMA) ---------------------------------------------------
+_segmm_plans = {}
+
+
+def segmm_plan(ptr_host: tuple, device):
+    """(tiles int32 [T,3] on device, T, ptr int64 on device) for a host pointer tuple; cached."""
+    key = (ptr_host, str(device))
+    hit = _segmm_plans.get(key)
+    if hit is not None:
+        return hit
+    tm = _lib.load().pygamd_segment_matmul_tile_rows()
+    tiles = []
+    for g in range(len(ptr_host) - 1):
+        a, b = ptr_host[g], ptr_host[g + 1]
+        for r in range(a, b, tm):
+            tiles.append((g, r, min(tm, b - r)))
+    t = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 3).to(device)
+    p = torch.tensor(ptr_host, dtype=torch.int64).to(device)
+    if len(_segmm_plans) > 32:
+        _segmm_plans.pop(next(iter(_segmm_plans)))
+    _segmm_plans[key] = (t, len(tiles), p)
+    return _segmm_plans[key]
+
+
+def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False) -> Tensor:
+    """out[seg] = x[seg] @ W[g]  (or @ W[g]^T when transpose_w) — W is [G, K, N] contiguous."""
+    _require_device(x, w)
+    lib = _lib.load()
+    tiles, n_tiles, _ = plan
+    x2 = _f32_rows(x, 'x')
+    w = w.contiguous()
+    G, Kw, Nw = w.shape
+    if transpose_w:
+        K, N, sk, sn = Nw, Kw, 1, Nw
+    else:
+        K, N, sk, sn = Kw, Nw, Nw, 1
+    if x2.size(1) != K:
+        raise ValueError(f"'inputs' has {x2.size(1)} columns but the weights expect {K}")
+    out = torch.empty(x2.size(0), N, dtype=torch.float32, device=x.device)
+    check(lib.pygamd_segment_matmul(_p(x2), _ld(x2), _p(w), Kw * Nw, sk, sn, _p(tiles), n_tiles,
+                                    K, N, _p(out), _ld(out), _stream(x)), 'segment_matmul')
+    return out
+
+
+def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int) -> Tensor:
+    """grad_W[g] = x[seg]^T @ grad[seg] -> [G, K, N]."""
+    _require_device(x, g)
+    lib = _lib.load()
+    x2, g2 = _f32_rows(x, 'x'), _f32_rows(g, 'grad')
+    K, N = x2.size(1), g2.size(1)
+    gw = torch.empty(n_seg, K, N, dtype=torch.float32, device=x.device)
+    check(lib.pygamd_segment_matmul_wgrad(_p(x2), _ld(x2), _p(g2), _ld(g2), _p(plan[2]), n_seg,
+                                          K, N, _p(gw), _stream(x)), 'segment_matmul_wgrad')
+    return gw

@@ -1,0 +1,166 @@
+// segmm.hip — segment_matmul (grouped GEMM over row segments) on the fp32 matrix cores.
+//
+//   out[ptr[g] : ptr[g+1]] = x[ptr[g] : ptr[g+1]] @ W[g]          (pyg_lib.ops.segment_matmul,
+//   torch_geometric/nn/conv/rgcn_conv.py:288, nn/dense/linear.py:255)
+//
+// MFMA-bound (the one GEMM-shaped op on this path): v_mfma_f32_32x32x2_f32, exact fp32
+// (bitwise an fmaf chain), fragment maps per cdna_hip_programming.md §3:
+//   A: lane l holds A[i = l & 31][k = l >> 5];  B: lane l holds B[k = l >> 5][j = l & 31];
+//   D: reg r of lane l is D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+// ONE launch covers every segment: the host builds a table of (segment, first row, rows) tiles of
+// 64 rows; a 256-thread workgroup (2 x 2 waves) owns a 64 x 128 output tile, stages the A tile
+// through LDS (row stride 17 floats: conflict-free column reads) and streams B (the segment's
+// weight, L2-resident) straight from global with coalesced 128-byte rows.
+#include "common.h"
+
+namespace pygamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTM = 64;    // rows per tile
+constexpr int kTN = 128;   // cols per workgroup
+constexpr int kTK = 16;    // k chunk staged in LDS
+
+__global__ void __launch_bounds__(kBlock)
+    segmm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                 int64_t w_seg_stride, int64_t w_sk, int64_t w_sn,
+                 const int32_t* __restrict__ tiles, int K, int N, float* __restrict__ out,
+                 int64_t ldo) {
+  __shared__ float As[kTM][kTK + 1];
+  const int t = blockIdx.x;
+  const int seg = tiles[3 * t];
+  const int64_t row0 = tiles[3 * t + 1];
+  const int rows = tiles[3 * t + 2];
+  const int n0 = blockIdx.y * kTN;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int col0 = n0 + wn * 64 + (lane & 31);
+  const int col1 = col0 + 32;
+  const float* __restrict__ wseg = w + static_cast<int64_t>(seg) * w_seg_stride;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    acc0[i] = 0.f;
+    acc1[i] = 0.f;
+  }
+  const int lr = threadIdx.x >> 2;        // 0..63: row of the A tile this thread loads
+  const int lk = (threadIdx.x & 3) * 4;   // 0,4,8,12: first k of its 4 values
+  for (int k0 = 0; k0 < K; k0 += kTK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + lk + j;
+      As[lr][lk + j] = (lr < rows && k < K) ? x[(row0 + lr) * ldx + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kTK; kk += 2) {
+      const int kl = kk + (lane >> 5);
+      const int k = k0 + kl;
+      const float a = As[wm * 32 + (lane & 31)][kl];
+      const float b0 = (k < K && col0 < N) ? wseg[k * w_sk + col0 * w_sn] : 0.f;
+      const float b1 = (k < K && col1 < N) ? wseg[k * w_sk + col1 * w_sn] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    if (r < rows) {
+      float* __restrict__ orow = out + (row0 + r) * ldo;
+      if (col0 < N) orow[col0] = acc0[i];
+      if (col1 < N) orow[col1] = acc1[i];
+    }
+  }
+}
+
+// grad_W[g] = x[seg]^T @ grad[seg]: one wave per (segment, 32 k-columns, 64 n-columns); the
+// reduction runs over the segment's rows two at a time (the MFMA's k = 2), operands straight
+// from global (both 128-byte coalesced per half-wave).
+__global__ void __launch_bounds__(kWave)
+    segmm_wgrad_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g,
+                       int64_t ldg, const int64_t* __restrict__ ptr, int K, int N,
+                       float* __restrict__ gw) {
+  const int seg = blockIdx.x;
+  const int k0 = blockIdx.y * 32;
+  const int n0 = blockIdx.z * 64;
+  const int lane = threadIdx.x;
+  const int64_t ra = ptr[seg], rb = ptr[seg + 1];
+  const int kc = k0 + (lane & 31);
+  const int col0 = n0 + (lane & 31), col1 = col0 + 32;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    acc0[i] = 0.f;
+    acc1[i] = 0.f;
+  }
+  for (int64_t r = ra; r < rb; r += 8) {
+    float a[4], b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t rr = r + 2 * u + (lane >> 5);
+      const bool ok = rr < rb;
+      a[u] = (ok && kc < K) ? x[rr * ldx + kc] : 0.f;
+      b0[u] = (ok && col0 < N) ? g[rr * ldg + col0] : 0.f;
+      b1[u] = (ok && col1 < N) ? g[rr * ldg + col1] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b1[u], acc1, 0, 0, 0);
+    }
+  }
+  float* __restrict__ gseg = gw + static_cast<int64_t>(seg) * K * N;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int kr = k0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    if (kr < K) {
+      if (col0 < N) gseg[static_cast<int64_t>(kr) * N + col0] = acc0[i];
+      if (col1 < N) gseg[static_cast<int64_t>(kr) * N + col1] = acc1[i];
+    }
+  }
+}
+
+}  // namespace pygamd
+
+using namespace pygamd;
+
+extern "C" {
+
+int pygamd_segment_matmul_tile_rows(void) { return kTM; }
+
+int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w, int64_t w_seg_stride,
+                          int64_t w_stride_k, int64_t w_stride_n, const int32_t* tiles,
+                          int64_t n_tiles, int64_t K, int64_t N, float* out, int64_t ldo,
+                          void* stream) {
+  if (n_tiles < 0 || K < 0 || N < 0 || ldx < K || ldo < N || K > INT32_MAX || N > INT32_MAX)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (n_tiles == 0 || N == 0) return PYGAMD_OK;
+  if (!x || !w || !tiles || !out) return PYGAMD_ERR_INVALID_ARG;
+  const dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>(ceil_div(N, kTN)));
+  hipLaunchKernelGGL(segmm_kernel, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, w,
+                     w_seg_stride, w_stride_k, w_stride_n, tiles, static_cast<int>(K),
+                     static_cast<int>(N), out, ldo);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg,
+                                const int64_t* ptr, int64_t n_seg, int64_t K, int64_t N,
+                                float* grad_w, void* stream) {
+  if (n_seg < 0 || K < 0 || N < 0 || ldx < K || ldg < N || K > INT32_MAX || N > INT32_MAX)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (n_seg == 0 || K == 0 || N == 0) return PYGAMD_OK;
+  if (!x || !g || !ptr || !grad_w) return PYGAMD_ERR_INVALID_ARG;
+  if (ceil_div(K, 32) > 65535 || ceil_div(N, 64) > 65535) return PYGAMD_ERR_UNSUPPORTED;
+  const dim3 grid(static_cast<unsigned>(n_seg), static_cast<unsigned>(ceil_div(K, 32)),
+                  static_cast<unsigned>(ceil_div(N, 64)));
+  hipLaunchKernelGGL(segmm_wgrad_kernel, grid, dim3(kWave), 0, as_stream(stream), x, ldx, g, ldg,
+                     ptr, static_cast<int>(K), static_cast<int>(N), grad_w);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+}  // extern "C"

@@ -472,29 +472,113 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---- SDDMM ----------------------------------------------------------------------------------
-template <typename IdxT>
+// grad_w[e(k), h] = <grad_out[i, head h], x[col[k], head h]> for every slot k of row i.  Same
+// mapping as the SpMM: one wave per destination row, the row of grad_out stays in registers, slot
+// indices are staged 64 at a time, U source rows are in flight per lane.  The per-head dot product
+// is finished with a SEGMENTED xor-free shuffle reduction over the lanes that share a head
+// (p += shfl_down(p, 2^s) while lane + 2^s is still inside the head): exact for any head width
+// that is a multiple of VW, e.g. 8 lanes for C = 32, 10 lanes for C = 40.
+template <typename IdxT, int VW, int LPR, int CH>
 __global__ void __launch_bounds__(kBlock)
     sddmm_rows(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ col,
                const IdxT* __restrict__ eid, const float* __restrict__ grad_out, int64_t ldg,
                const float* __restrict__ x, int64_t ldx, int64_t n_rows, int64_t F, int w_heads,
-               int head_dim, float* __restrict__ grad_w) {
+               int head_dim, int use_atomic, float* __restrict__ grad_w) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = (CH == 1) ? (LPR < 4 ? LPR : 4) : 2;
+  constexpr int STEP = EPI * U;
   const int lane = lane_id();
   const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
   if (row >= n_rows) return;
   const IdxT start = rowptr[row];
   const IdxT end = rowptr[row + 1];
-  const float* __restrict__ g = grad_out + row * ldg;
-  for (IdxT k = start; k < end; ++k) {
-    const int64_t c = col ? static_cast<int64_t>(col[k]) : static_cast<int64_t>(k);
-    const int64_t e = eid ? static_cast<int64_t>(eid[k]) : static_cast<int64_t>(k);
-    const float* __restrict__ xr = x + c * ldx;
-    for (int h = 0; h < w_heads; ++h) {
-      const int64_t f0 = static_cast<int64_t>(h) * head_dim;
-      float p = 0.f;
-      for (int64_t f = lane; f < head_dim; f += kWave) p = fmaf(g[f0 + f], xr[f0 + f], p);
+  int fo[CH], head[CH];
+  bool fv[CH];
+  feature_slots<VW, LPR, CH>(lane, F, head_dim, fo, fv, head);
+  const int sub = lane / LPR;
+  // segment bookkeeping: which shuffle distances stay inside my (sub-group, head) segment, and
+  // whether I am the first lane of it
+  int okmask[CH];
+  bool first[CH];
+  Vec<VW> gv[CH];
 #pragma unroll
-      for (int off = kWave / 2; off > 0; off >>= 1) p += __shfl_xor(p, off, kWave);
-      if (lane == 0) grad_w[e * w_heads + h] = p;
+  for (int c = 0; c < CH; ++c) {
+    const int hid = fv[c] ? head[c] : -1 - lane;
+    okmask[c] = 0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const int off = 1 << s;
+      const int oh = __shfl_down(hid, off, kWave);
+      const bool same = (lane + off < kWave) && ((lane + off) / LPR == sub) && (oh == hid);
+      okmask[c] |= same ? (1 << s) : 0;
+    }
+    const int ph = __shfl_up(hid, 1, kWave);
+    first[c] = fv[c] && ((lane % LPR) == 0 || ph != hid);
+    if (fv[c]) {
+      gv[c] = load_vec<VW>(grad_out + row * ldg + fo[c]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) gv[c].v[i] = 0.f;
+    }
+  }
+  for (IdxT base = start; base < end; base += kWave) {
+    const IdxT rem = end - base;
+    const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+    IdxT myc = 0, mye = 0;
+    if (lane < cnt) {
+      const IdxT k = base + lane;
+      myc = col ? col[k] : k;
+      mye = eid ? eid[k] : k;
+    }
+    for (int j = 0; j < cnt; j += STEP) {
+      float p[U][CH];
+      IdxT e[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = j + u * EPI + sub;
+        ok[u] = k < cnt;
+        const int kk = ok[u] ? k : cnt - 1;
+        IdxT c;
+        if constexpr (EPI == 1) {
+          c = bcast_uniform(myc, kk);
+          e[u] = bcast_uniform(mye, kk);
+        } else {
+          c = bcast_lane(myc, kk);
+          e[u] = bcast_lane(mye, kk);
+        }
+        const float* __restrict__ xr = x + static_cast<int64_t>(c) * ldx;
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+          float acc = 0.f;
+          if (fv[c2] && ok[u]) {
+            const Vec<VW> v = load_vec<VW>(xr + fo[c2]);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) acc = fmaf(v.v[i], gv[c2].v[i], acc);
+          }
+          p[u][c2] = acc;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+          float v = p[u][c2];
+#pragma unroll
+          for (int s = 0; s < 6; ++s) {
+            const float o = __shfl_down(v, 1 << s, kWave);
+            v += ((okmask[c2] >> s) & 1) ? o : 0.f;
+          }
+          if (first[c2] && ok[u]) {
+            float* dst = grad_w + static_cast<int64_t>(e[u]) * w_heads + head[c2];
+            if (use_atomic) {
+              atomicAdd(dst, v);
+            } else {
+              *dst = v;
+            }
+          }
+        }
+      }
     }
   }
 }
@@ -627,6 +711,52 @@ static int launch_vw(const pygamd_spmm_args* p, const Shape& s, float* partial, 
   }
 }
 
+template <typename IdxT, int VW, int LPR, int CH>
+static int launch_sddmm_shape(const Shape& s, const void* rowptr, const void* col,
+                              const void* eid, const float* grad_out, int64_t ldg, const float* x,
+                              int64_t ldx, int64_t n_rows, int64_t F, int w_heads, int head_dim,
+                              int use_atomic, float* grad_w, hipStream_t st) {
+  dim3 grid(wave_grid(n_rows), s.tiles);
+  hipLaunchKernelGGL((sddmm_rows<IdxT, VW, LPR, CH>), grid, dim3(kBlock), 0, st,
+                     static_cast<const IdxT*>(rowptr), static_cast<const IdxT*>(col),
+                     static_cast<const IdxT*>(eid), grad_out, ldg, x, ldx, n_rows, F, w_heads,
+                     head_dim, use_atomic, grad_w);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+template <typename IdxT>
+static int launch_sddmm(const Shape& s, const void* rowptr, const void* col, const void* eid,
+                        const float* grad_out, int64_t ldg, const float* x, int64_t ldx,
+                        int64_t n_rows, int64_t F, int w_heads, int head_dim, int use_atomic,
+                        float* grad_w, hipStream_t st) {
+#define PYGAMD_SDDMM(VW, LPR, CH)                                                               \
+  return launch_sddmm_shape<IdxT, VW, LPR, CH>(s, rowptr, col, eid, grad_out, ldg, x, ldx,     \
+                                               n_rows, F, w_heads, head_dim, use_atomic, grad_w, \
+                                               st)
+  if (s.vw == 4) {
+    switch (s.lpr) {
+      case 4: PYGAMD_SDDMM(4, 4, 1);
+      case 8: PYGAMD_SDDMM(4, 8, 1);
+      case 16: PYGAMD_SDDMM(4, 16, 1);
+      case 32: PYGAMD_SDDMM(4, 32, 1);
+      default:
+        if (s.ch == 2) PYGAMD_SDDMM(4, 64, 2);
+        PYGAMD_SDDMM(4, 64, 1);
+    }
+  }
+  switch (s.lpr) {
+    case 4: PYGAMD_SDDMM(1, 4, 1);
+    case 8: PYGAMD_SDDMM(1, 8, 1);
+    case 16: PYGAMD_SDDMM(1, 16, 1);
+    case 32: PYGAMD_SDDMM(1, 32, 1);
+    default:
+      if (s.ch == 2) PYGAMD_SDDMM(1, 64, 2);
+      PYGAMD_SDDMM(1, 64, 1);
+  }
+#undef PYGAMD_SDDMM
+}
+
 static int validate(const pygamd_spmm_args* p) {
   if (!p) return PYGAMD_ERR_INVALID_ARG;
   if (p->n_rows < 0 || p->F < 0 || p->ldx < p->F || p->ldo < p->F) return PYGAMD_ERR_INVALID_ARG;
@@ -719,18 +849,26 @@ int pygamd_sddmm_csr(const void* rowptr, const void* col, const void* eid, int i
                      const float* grad_out, int64_t ldg, const float* x, int64_t ldx,
                      int64_t n_rows, int64_t F, int32_t w_heads, int32_t head_dim, float* grad_w,
                      void* stream) {
-  if (n_rows < 0 || F < 0 || w_heads < 1) return PYGAMD_ERR_INVALID_ARG;
-  if (n_rows == 0) return PYGAMD_OK;
+  if (n_rows < 0 || F < 0 || w_heads < 1 || ldg < F || ldx < F) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows == 0 || F == 0) return PYGAMD_OK;
   if (!rowptr || !grad_out || !x || !grad_w) return PYGAMD_ERR_INVALID_ARG;
   const int hd = (w_heads > 1) ? head_dim : static_cast<int>(F);
   if (static_cast<int64_t>(hd) * w_heads != F) return PYGAMD_ERR_INVALID_ARG;
+  // shape selection mirrors the SpMM (vector width must divide the head width)
+  pygamd_spmm_args probe = {};
+  probe.F = F;
+  probe.ldx = ldx;
+  probe.ldo = ldg;
+  probe.x = x;
+  probe.out = const_cast<float*>(grad_out);
+  probe.w_heads = w_heads;
+  probe.head_dim = hd;
+  const Shape s = pick_shape(&probe);
+  const int use_atomic = (s.ch > 1 || s.tiles > 1) ? 1 : 0;  // a head may span two lane groups
+  hipStream_t st = as_stream(stream);
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
-    hipLaunchKernelGGL((sddmm_rows<IdxT>), dim3(wave_grid(n_rows)), dim3(kBlock), 0,
-                       as_stream(stream), static_cast<const IdxT*>(rowptr),
-                       static_cast<const IdxT*>(col), static_cast<const IdxT*>(eid), grad_out,
-                       ldg, x, ldx, n_rows, F, w_heads, hd, grad_w);
-    PYGAMD_LAUNCH_CHECK();
-    return PYGAMD_OK;
+    return launch_sddmm<IdxT>(s, rowptr, col, eid, grad_out, ldg, x, ldx, n_rows, F, w_heads, hd,
+                              use_atomic, grad_w, st);
   });
 }
 

@@ -1,0 +1,15 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_configs
+rm -rf $OUT; mkdir -p $OUT
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o trace --output-format csv -- python $GRAFT_REPO_ROOT/scripts/time_configs.py > $OUT/stdout.log 2>&1)
+grep config $OUT/stdout.log
+python - <<PY
+import csv, re
+rows = list(csv.DictReader(open('$OUT/trace_kernel_stats.csv')))
+for r in rows[:28]:
+    n = r['Name'].replace('void ', '')
+    if n.startswith('Cijk'): n = 'GEMM ' + (re.search(r'_(MT\d+x\d+x\d+)_', n) or [0,''])[1]
+    print(f"{int(r['TotalDurationNs'])/1e6:9.2f} ms  x{r['Calls']:>5}  avg {float(r['AverageNs'])/1e3:9.1f} us  {n[:100]}")
+PY

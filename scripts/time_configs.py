@@ -5,7 +5,8 @@ import time
 
 import torch
 
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_geometric_amd.nn import GAT, GCN, RGCNConv  # noqa: E402
 
 dev = torch.device('cuda:0')
@@ -49,7 +50,7 @@ def step3():
 
 
 t = timeit(step3)
-print(f'config3 GAT/arxiv-shape     : {t:8.3f} ms/step  ({3 * (e + n) / t / 1e6:.1f} M edges/s)')
+print(f'config3 GAT/arxiv-shape     : {t:8.3f} ms/step  ({3 * (e + n) / t / 1e3:.1f} M edges/s)')
 
 n, e, R = 14_541, 544_230, 474
 ei = torch.randint(0, n, (2, e), generator=g).to(dev)
@@ -65,4 +66,4 @@ def step5():
 
 
 t = timeit(step5, warm=2, steps=5)
-print(f'config5 RGCN/FB15k-237-shape: {t:8.3f} ms/step  ({2 * e / t / 1e6:.1f} M edges/s)')
+print(f'config5 RGCN/FB15k-237-shape: {t:8.3f} ms/step  ({2 * e / t / 1e3:.1f} M edges/s)')

@@ -300,3 +300,18 @@ def test_segment_matmul(dev):
     assert_close(wg.grad, wr.grad, atol=2e-5)
     with pytest.raises(ValueError):
         segment_matmul(xg, torch.tensor([0, 50]), wg)
+    # widths that need several k / n tiles, ragged segment sizes, K not a multiple of the chunk
+    for K, N in [(100, 100), (500, 64), (33, 130)]:
+        x = torch.randn(700, K, generator=g)
+        w = torch.randn(6, K, N, generator=g) / K ** 0.5
+        ptr = [0, 1, 1, 70, 200, 201, 700]
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = torch.cat([xr[ptr[i]:ptr[i + 1]] @ wr[i] for i in range(6)])
+        go = torch.randn(700, N, generator=g)
+        ref.backward(go)
+        xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        out = segment_matmul(xg, ptr, wg)
+        out.backward(go.to(dev))
+        assert_close(out, ref.detach(), atol=2e-5, what=f'segmm {K}x{N}')
+        assert_close(xg.grad, xr.grad, atol=2e-5, what=f'segmm grad_x {K}x{N}')
+        assert_close(wg.grad, wr.grad, atol=1e-4, rtol=1e-4, what=f'segmm grad_w {K}x{N}')
