@@ -7,8 +7,8 @@ modules.  ``install()`` therefore
 
 1. publishes itself on ``torch_geometric.backend`` (``backend.mi355x`` = this module,
    ``backend.use_mi355x`` flag, ``None`` = auto like ``use_segment_matmul``) — seam S5;
-2. rebinds the dispatcher functions ``scatter``, ``segment``, ``softmax``, ``index_sort``,
-   ``scatter_argmax`` in EVERY loaded ``torch_geometric*`` module whose attribute ``is`` the
+2. rebinds the dispatcher functions ``scatter``, ``segment``, ``softmax``, ``spmm``,
+   ``index_sort``, ``scatter_argmax`` in EVERY loaded ``torch_geometric*`` module whose attribute ``is`` the
    original function — seam S3 (utils/__init__.py:5-10,36);
 3. wraps ``propagate`` of the hot conv classes (SAGEConv, GCNConv, GraphConv, GATConv) so that a
    plain ``edge_index`` tensor is sorted once (cached handle) and gather -> message -> aggregate
@@ -77,8 +77,15 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
             return U.scatter_argmax(src, index, dim, dim_size)
         return orig['scatter_argmax'](src, index, dim, dim_size)
 
+    def spmm(src, other, reduce='sum'):
+        if (isinstance(src, Tensor) and type(src) is Tensor and src.is_cuda and _ours(other)
+                and src.layout in (torch.sparse_csr, torch.sparse_coo, torch.sparse_csc)
+                and src.dim() == 2 and src.values().dim() == 1 and _enabled()):
+            return U.spmm(src, other, reduce)
+        return orig['spmm'](src, other, reduce)
+
     new = dict(scatter=scatter, segment=segment, softmax=softmax, index_sort=index_sort,
-               scatter_argmax=scatter_argmax)
+               scatter_argmax=scatter_argmax, spmm=spmm)
     for name, fn in new.items():
         fn.__wrapped__ = orig[name]
         fn.__doc__ = orig[name].__doc__
@@ -120,6 +127,8 @@ def _fused_propagate(conv, edge_index, size, kwargs):
     if aggr not in ('sum', 'add', 'mean', 'max', 'min'):
         return NotImplemented
     x = kwargs.get('x')
+    if isinstance(x, (tuple, list)) and conv.flow != 'source_to_target':
+        return NotImplemented  # (x_src, x_dst) swap roles under target_to_source: keep it simple
     x_src, x_dst = (x if isinstance(x, (tuple, list)) else (x, x))
     if not _ours(x_src):
         return NotImplemented
@@ -188,7 +197,7 @@ def install() -> None:
     orig = {
         'scatter': pyg_utils.scatter, 'segment': pyg_utils.segment,
         'softmax': pyg_utils.softmax, 'index_sort': pyg_utils.index_sort,
-        'scatter_argmax': pyg_scatter.scatter_argmax,
+        'scatter_argmax': pyg_scatter.scatter_argmax, 'spmm': pyg_utils.spmm,
     }
     new = _make_dispatchers(orig)
     for name in orig:

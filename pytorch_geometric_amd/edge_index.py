@@ -114,6 +114,18 @@ class EdgeIndex:
         self._csc: Optional[CSR] = None   # sorted by source (transposed / backward)
         self._slot_map = None
 
+    @classmethod
+    def from_csr(cls, rowptr: Tensor, col: Tensor, sparse_size: Tuple[int, int]) -> 'EdgeIndex':
+        """Handle for an ``adj_t`` already in CSR form (rows = destinations, ``col`` = sources;
+        ``sparse_size = (num_src, num_dst)``): no sort is needed for the forward."""
+        dst = _native.ptr2index(rowptr, col.numel())
+        ei = torch.stack([col, dst])
+        self = cls(ei, sparse_size, sort_order='col', validate=False)
+        perm = torch.arange(col.numel(), dtype=col.dtype, device=col.device)
+        self._csr = CSR(rowptr.contiguous(), col.contiguous(), perm, sparse_size[1],
+                        sparse_size[0])
+        return self
+
     # -- accessors -------------------------------------------------------------------------------
     @property
     def num_edges(self) -> int:

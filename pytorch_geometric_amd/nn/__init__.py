@@ -2,12 +2,12 @@ from .aggr import (Aggregation, FusedAggregation, MaxAggregation, MeanAggregatio
                    MinAggregation, MulAggregation, MultiAggregation, StdAggregation,
                    SumAggregation, VarAggregation)
 from .conv import GATConv, GCNConv, MessagePassing, RGCNConv, SAGEConv, gcn_norm
-from .dense import Linear
+from .dense import HeteroLinear, Linear
 from .models import GAT, GCN, BasicGNN, GraphSAGE
 
 __all__ = [
     'Aggregation', 'SumAggregation', 'MeanAggregation', 'MaxAggregation', 'MinAggregation',
     'MulAggregation', 'VarAggregation', 'StdAggregation', 'FusedAggregation',
-    'MultiAggregation', 'MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv', 'RGCNConv', 'Linear',
+    'MultiAggregation', 'MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv', 'RGCNConv', 'Linear', 'HeteroLinear',
     'BasicGNN', 'GCN', 'GraphSAGE', 'GAT',
 ]

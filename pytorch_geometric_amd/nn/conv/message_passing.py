@@ -178,6 +178,9 @@ class MessagePassing(torch.nn.Module):
         return self.update(out, **self._select(self._upd_params, coll, 'update'))
 
     def _can_fuse(self, kwargs: Dict[str, Any]) -> bool:
+        if self.flow != 'source_to_target' and any(isinstance(v, (tuple, list))
+                                                   for v in kwargs.values()):
+            return False  # (src, dst) pairs swap roles; take the general path
         return self.aggr in ('sum', 'add', 'mean', 'min', 'max')
 
     def edge_updater(self, edge_index, size: Optional[Tuple[int, int]] = None, **kwargs):

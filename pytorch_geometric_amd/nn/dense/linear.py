@@ -59,3 +59,71 @@ class Linear(torch.nn.Module):
     def __repr__(self) -> str:
         return (f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, '
                 f'bias={self.bias is not None})')
+
+
+class HeteroLinear(torch.nn.Module):
+    r"""One linear map per node/edge type: ``out[k] = x[k] @ W[type_vec[k]] + b[type_vec[k]]`` —
+    constructor, parameters (``weight [T, in, out]``, ``bias [T, out]``) and forward of
+    ``torch_geometric.nn.HeteroLinear`` (torch_geometric/nn/dense/linear.py:170-329).  Rows are
+    stably sorted by type (HIP radix sort), transformed by ONE grouped fp32-MFMA GEMM
+    (``segment_matmul``) and restored to their original order."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_types: int,
+                 is_sorted: bool = False, bias: bool = True,
+                 weight_initializer: Optional[str] = None,
+                 bias_initializer: Optional[str] = None):
+        super().__init__()
+        if in_channels <= 0:
+            raise ValueError("lazy initialisation (in_channels=-1) is not supported")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_types = num_types
+        self.is_sorted = is_sorted
+        self.weight_initializer = weight_initializer
+        self.bias_initializer = bias_initializer
+        self.weight = Parameter(torch.empty(num_types, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.empty(num_types, out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.weight_initializer == 'glorot':
+            inits.glorot(self.weight)
+        elif self.weight_initializer == 'uniform':
+            bound = 1.0 / math.sqrt(self.in_channels)
+            torch.nn.init.uniform_(self.weight.data, -bound, bound)
+        elif self.weight_initializer in ('kaiming_uniform', None):
+            inits.kaiming_uniform(self.weight, fan=self.in_channels, a=math.sqrt(5))
+        else:
+            raise RuntimeError(f"Weight initializer '{self.weight_initializer}' not supported")
+        if self.bias is not None:
+            if self.bias_initializer == 'zeros':
+                inits.zeros(self.bias)
+            elif self.bias_initializer is None:
+                inits.uniform(self.in_channels, self.bias)
+            else:
+                raise RuntimeError(f"Bias initializer '{self.bias_initializer}' not supported")
+
+    def forward(self, x: Tensor, type_vec: Tensor) -> Tensor:
+        from ... import _native
+        from ..._functions import GatherFunction
+        from ...utils import segment_matmul
+        perm = None
+        if not self.is_sorted:
+            type_vec, perm = _native.index_sort(type_vec, max_value=self.num_types)
+            x = GatherFunction.apply(x, perm, False)
+        type_ptr = _native.index2ptr(type_vec, self.num_types)
+        out = segment_matmul(x, type_ptr, self.weight)
+        if self.bias is not None:
+            out = out + GatherFunction.apply(self.bias, type_vec, False)
+        if perm is not None:  # restore the original order
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel(), device=perm.device)
+            out = GatherFunction.apply(out, inv, False)
+        return out
+
+    def __repr__(self) -> str:
+        return (f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, '
+                f'num_types={self.num_types}, bias={self.bias is not None})')

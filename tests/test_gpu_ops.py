@@ -407,3 +407,45 @@ def test_fused_and_multi_aggregation(dev):
     assert_close(out[:, 6:12], refs['max'].detach(), atol=0, rtol=0)
     with pytest.raises(ValueError, match='not fusable'):
         nn.FusedAggregation([nn.MultiAggregation(['sum', 'max'])])
+
+
+def test_spmm_torch_sparse_inputs(dev):
+    """utils/_spmm.py:57-111: adj_t given as torch.sparse CSR / COO / CSC (rows = destinations)."""
+    import pytorch_geometric_amd as pga
+    ei = random_graph(90, 70, 1500, seed=41)
+    ei = torch.unique(ei, dim=1)  # sparse constructors need coalesced entries
+    g = gen(41)
+    val = torch.rand(ei.size(1), generator=g) + 0.5
+    x = torch.randn(90, 24, generator=g)
+    adj_coo = torch.sparse_coo_tensor(torch.stack([ei[1], ei[0]]), val, (70, 90)).coalesce()
+    ref = {red: torch.sparse.mm(adj_coo.to_sparse_csr(), x, red) for red in ['sum', 'mean']}
+    for adj in (adj_coo.to_sparse_csr(), adj_coo, adj_coo.to_sparse_csc()):
+        ad = adj.to(dev)
+        for red in ['sum', 'mean']:
+            assert_close(pga.utils.spmm(ad, x.to(dev), red), ref[red], atol=2e-5,
+                         what=f'{adj.layout} {red}')
+    # gradient w.r.t. the dense operand
+    xg = x.to(dev).requires_grad_(True)
+    pga.utils.spmm(adj_coo.to_sparse_csr().to(dev), xg, 'sum').sum().backward()
+    assert_close(xg.grad, (adj_coo.to_dense().t() @ torch.ones(70, 24)), atol=2e-5)
+
+
+def test_hetero_linear(dev):
+    """nn/dense/linear.py:248-252 (forward_naive) is the in-tree oracle for HeteroLinear."""
+    from pytorch_geometric_amd.nn import HeteroLinear
+    g = gen(52)
+    x = torch.randn(300, 10, generator=g)
+    tv = torch.randint(0, 5, (300, ), generator=g)
+    tv[tv == 2] = 3  # an empty type
+    torch.manual_seed(1)
+    lin = HeteroLinear(10, 6, num_types=5)
+    w, b = lin.weight.detach(), lin.bias.detach()
+    ref = torch.stack([x[i] @ w[tv[i]] + b[tv[i]] for i in range(300)])
+    lin = lin.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    out = lin(xg, tv.to(dev))
+    assert_close(out, ref, atol=2e-5)
+    out.sum().backward()
+    ref_gx = torch.stack([w[tv[i]].sum(1) for i in range(300)])
+    assert_close(xg.grad, ref_gx, atol=2e-5)
+    assert lin.weight.grad.shape == (5, 10, 6) and float(lin.weight.grad[2].abs().sum()) == 0
