@@ -277,6 +277,22 @@ PYGAMD_API int pygamd_gat_edge_softmax_backward(const void* rowptr, const void* 
                                                 int64_t H, float slope, float* grad_alpha_src,
                                                 float* grad_alpha_dst, void* stream);
 
+/* ---- §8(f)-1 (next): one hop of uniform neighbour sampling without replacement ---------------
+ * Device-side counterpart of torch.ops.pyg.neighbor_sample (sampler/neighbor_sampler.py:550-577)
+ * on a CSC graph (colptr over destinations, row = source of every slot).  For frontier node
+ * frontier[f] the caller provides offsets[f] / offsets[f+1] with offsets[f+1]-offsets[f] =
+ * min(deg, k) (or deg for k < 0); the kernel writes, for every sampled slot, the global source
+ * id, f (the position of the destination in the frontier) and the CSC slot (-> edge id through
+ * the handle's permutation).  deg <= count: all neighbours; else a uniform subset (Floyd's
+ * algorithm, counter-based hash of (seed, node, draw): reproducible).  max_per_node = the largest
+ * bounded count requested (<= pygamd_sample_max_fanout(); pass 0 when every node takes all).    */
+PYGAMD_API int pygamd_sample_max_fanout(void);
+PYGAMD_API int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
+                                       const void* frontier, int64_t n_frontier,
+                                       const void* offsets, int64_t max_per_node, uint64_t seed,
+                                       void* src_out, void* dstpos_out, void* slot_out,
+                                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ fallback: if the library is missing (and cannot be built) or a call fails, we ra
 import ctypes
 import os
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
-                    c_void_p)
+                    c_uint64, c_void_p)
 
 from . import _build
 
@@ -64,6 +64,9 @@ SIGNATURES = {
                                       c_int64, c_int64, _P, c_int64, _P]),
     'pygamd_segment_matmul_wgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64,
                                             c_int64, _P, _P]),
+    'pygamd_sample_max_fanout': (c_int, []),
+    'pygamd_sample_neighbors': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, c_uint64, _P, _P,
+                                        _P, _P]),
     'pygamd_gather_rows': (c_int, [_P, c_int64, c_int64, _P, c_int, c_int64, c_int64, _P,
                                    c_int64, _P, _P]),
     'pygamd_scatter_init': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),

@@ -471,3 +471,20 @@ def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int) -> Tensor:
     check(lib.pygamd_segment_matmul_wgrad(_p(x2), _ld(x2), _p(g2), _ld(g2), _p(plan[2]), n_seg,
                                           K, N, _p(gw), _stream(x)), 'segment_matmul_wgrad')
     return gw
+
+
+# ---- neighbour sampling (one hop) ---------------------------------------------------------------
+def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Tensor, total: int,
+                     max_per_node: int, seed: int):
+    """(src_global, dst_pos_in_frontier, csc_slot) for the sampled in-edges of `frontier`."""
+    _require_device(colptr, row, frontier, offsets)
+    lib = _lib.load()
+    src = torch.empty(total, dtype=colptr.dtype, device=colptr.device)
+    dstpos = torch.empty_like(src)
+    slot = torch.empty_like(src)
+    if total > 0:
+        check(lib.pygamd_sample_neighbors(_p(colptr), _p(row), _idx_dtype(colptr), _p(frontier),
+                                          frontier.numel(), _p(offsets), max_per_node,
+                                          seed & 0xFFFFFFFFFFFFFFFF, _p(src), _p(dstpos),
+                                          _p(slot), _stream(colptr)), 'sample_neighbors')
+    return src, dstpos, slot

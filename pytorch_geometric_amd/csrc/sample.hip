@@ -1,0 +1,103 @@
+// sample.hip — uniform neighbour sampling without replacement on a CSC graph:
+// the device-side counterpart of torch.ops.pyg.neighbor_sample for one hop
+// (torch_geometric/sampler/neighbor_sampler.py:550-577: colptr, row, seed nodes, fan-out k).
+//
+// One wavefront per frontier node v.  If deg(v) <= k every in-neighbour is taken (lanes copy the
+// slot range, coalesced).  Otherwise lane 0 draws a uniform k-subset of the deg(v) slots with
+// Floyd's algorithm (k <= 64 draws, O(k^2) membership checks in LDS) from a counter-based hash
+// of (seed, v, draw), so a batch is reproducible from its seed regardless of scheduling; lanes
+// 0..k-1 then emit one edge each.  HBM-bound integer work: 3 index reads + 3 index writes per
+// sampled edge.
+#include "common.h"
+
+namespace pygamd {
+
+constexpr int kMaxFanout = 64;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    sample_neighbors_kernel(const IdxT* __restrict__ colptr, const IdxT* __restrict__ row,
+                            const IdxT* __restrict__ frontier, int64_t n_frontier,
+                            const IdxT* __restrict__ offsets, uint64_t seed,
+                            IdxT* __restrict__ src_out, IdxT* __restrict__ dstpos_out,
+                            IdxT* __restrict__ slot_out) {
+  __shared__ int chosen[kWavesPerBlock][kMaxFanout];
+  const int lane = lane_id();
+  const int w = wave_in_block();
+  const int64_t f = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + w;
+  if (f >= n_frontier) return;
+  const int64_t v = frontier[f];
+  const int64_t s = colptr[v];
+  const int64_t deg = static_cast<int64_t>(colptr[v + 1]) - s;
+  const int64_t o = offsets[f];
+  const int64_t cnt = static_cast<int64_t>(offsets[f + 1]) - o;
+  if (cnt <= 0) return;
+  if (deg <= cnt) {  // take every in-neighbour
+    for (int64_t t = lane; t < deg; t += kWave) {
+      src_out[o + t] = row[s + t];
+      dstpos_out[o + t] = static_cast<IdxT>(f);
+      slot_out[o + t] = static_cast<IdxT>(s + t);
+    }
+    return;
+  }
+  // Floyd: for j = deg-k .. deg-1: t = U{0..j}; insert t, or j if t is already chosen
+  if (lane == 0) {
+    int c = 0;
+    const uint64_t key = mix64(seed ^ mix64(static_cast<uint64_t>(v)));
+    for (int64_t j = deg - cnt; j < deg; ++j) {
+      const uint64_t r = mix64(key + static_cast<uint64_t>(c));
+      int t = static_cast<int>(__umul64hi(r, static_cast<uint64_t>(j + 1)));
+      bool dup = false;
+      for (int q = 0; q < c; ++q) dup |= (chosen[w][q] == t);
+      chosen[w][c++] = dup ? static_cast<int>(j) : t;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < cnt) {
+    const int64_t t = chosen[w][lane];
+    src_out[o + lane] = row[s + t];
+    dstpos_out[o + lane] = static_cast<IdxT>(f);
+    slot_out[o + lane] = static_cast<IdxT>(s + t);
+  }
+}
+
+}  // namespace pygamd
+
+using namespace pygamd;
+
+extern "C" {
+
+int pygamd_sample_max_fanout(void) { return kMaxFanout; }
+
+int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
+                            const void* frontier, int64_t n_frontier, const void* offsets,
+                            int64_t max_per_node, uint64_t seed, void* src_out,
+                            void* dstpos_out, void* slot_out, void* stream) {
+  if (n_frontier < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n_frontier == 0) return PYGAMD_OK;
+  if (!colptr || !row || !frontier || !offsets || !src_out || !dstpos_out || !slot_out)
+    return PYGAMD_ERR_INVALID_ARG;
+  // a bounded fan-out larger than the LDS draw table is not supported (k < 0 = "all" is)
+  if (max_per_node > kMaxFanout) return PYGAMD_ERR_UNSUPPORTED;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const unsigned grid = static_cast<unsigned>(ceil_div(n_frontier, kWavesPerBlock));
+    hipLaunchKernelGGL((sample_neighbors_kernel<IdxT>), dim3(grid), dim3(kBlock), 0,
+                       as_stream(stream), static_cast<const IdxT*>(colptr),
+                       static_cast<const IdxT*>(row), static_cast<const IdxT*>(frontier),
+                       n_frontier, static_cast<const IdxT*>(offsets), seed,
+                       static_cast<IdxT*>(src_out), static_cast<IdxT*>(dstpos_out),
+                       static_cast<IdxT*>(slot_out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+}  // extern "C"

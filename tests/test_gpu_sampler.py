@@ -1,0 +1,102 @@
+"""GPU neighbour sampler + loader.  The reference sampler cannot run in the
+build container (no pyg-lib), so the contract of SamplerOutput is pinned through properties."""
+import pytest
+import torch
+
+from oracle import pyg_oracle as O
+from tests._util import assert_close, gen, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_contract(out, ei, seeds, fanouts):
+    node, row, col, edge = out.node.cpu(), out.row.cpu(), out.col.cpu(), out.edge.cpu()
+    n_hops = len(fanouts)
+    assert len(out.num_sampled_nodes) == n_hops + 1 and len(out.num_sampled_edges) == n_hops
+    assert sum(out.num_sampled_nodes) == node.numel() and sum(out.num_sampled_edges) == row.numel()
+    assert torch.equal(node[:seeds.numel()], seeds)               # seeds first
+    assert node.unique().numel() == node.numel()                  # no duplicate nodes
+    # every sampled edge is the original edge `edge`, relabelled through `node`
+    assert torch.equal(node[row], ei[0, edge]) and torch.equal(node[col], ei[1, edge])
+    assert edge.unique().numel() == edge.numel()                  # without replacement
+    indeg = torch.bincount(ei[1], minlength=int(ei.max()) + 1)
+    nb = [0] + torch.tensor(out.num_sampled_nodes).cumsum(0).tolist()
+    eb = [0] + torch.tensor(out.num_sampled_edges).cumsum(0).tolist()
+    for h, k in enumerate(fanouts):
+        r, c = row[eb[h]:eb[h + 1]], col[eb[h]:eb[h + 1]]
+        if c.numel() == 0:
+            continue
+        # hop h edges end in the hop-h frontier and start no later than the hop-(h+1) nodes
+        assert int(c.min()) >= nb[h] and int(c.max()) < nb[h + 1] and int(r.max()) < nb[h + 2]
+        assert bool((c[1:] >= c[:-1]).all())                      # ordered by destination
+        got = torch.bincount(c - nb[h], minlength=nb[h + 1] - nb[h])
+        deg = indeg[node[nb[h]:nb[h + 1]]]
+        want = deg if k < 0 else deg.clamp(max=k)
+        assert torch.equal(got, want)                             # min(deg, k) per destination
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_sampler_contract(dev, dtype):
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    n = 3000
+    ei = random_graph(n, n, 40_000, seed=1, skew=True)
+    seeds = torch.randperm(n, generator=gen(2))[:200]
+    for fanouts in ([15, 10, 5], [3, -1], [64], [-1, -1]):
+        s = NeighborSampler(ei.to(dtype).to(dev), n, fanouts, seed=7)
+        out = s.sample_from_nodes(seeds.to(dev))
+        _check_contract(out, ei, seeds, fanouts)
+        assert int((s._local != -1).sum()) == 0                   # map reset for the next batch
+        out2 = s.sample_from_nodes(seeds.to(dev), seed=7)         # same seed -> same batch
+        out3 = s.sample_from_nodes(seeds.to(dev), seed=7)
+        assert torch.equal(out2.edge, out3.edge) and torch.equal(out2.node, out3.node)
+    with pytest.raises(ValueError):
+        NeighborSampler(ei.to(dev), n, [65])
+
+
+def test_sampler_marginals_are_uniform(dev):
+    """A destination with 20 in-neighbours, k = 5: every neighbour is drawn ~25 % of the time."""
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    src = torch.arange(1, 21)
+    ei = torch.stack([src, torch.zeros(20, dtype=torch.long)])
+    s = NeighborSampler(ei.to(dev), 21, [5])
+    seeds = torch.zeros(1, dtype=torch.long, device=dev)
+    counts = torch.zeros(20)
+    trials = 4000
+    for t in range(trials):
+        out = s.sample_from_nodes(seeds, seed=t)
+        counts[out.edge.cpu()] += 1
+    p = counts / trials
+    assert float(counts.sum()) == trials * 5
+    assert float((p - 0.25).abs().max()) < 0.04, p            # 3.5 sigma ~ 0.024
+
+
+def test_full_neighbourhood_batches_reproduce_full_graph_outputs(dev):
+    """k = -1 on every hop: the model on the sampled subgraph equals the full-graph model at the
+    seeds (with and without trim_to_layer) — loader, relabelling, gather and layers end to end."""
+    from pytorch_geometric_amd.loader import NeighborLoader
+    from pytorch_geometric_amd.nn import GraphSAGE
+    n = 800
+    ei = random_graph(n, n, 6000, seed=5)
+    g = gen(5)
+    x = torch.randn(n, 12, generator=g)
+    y = torch.randint(0, 4, (n, ), generator=g)
+    torch.manual_seed(1)
+    model = GraphSAGE(12, 16, num_layers=2, out_channels=4)
+    st = model.state_dict()
+    params = [(st[f'convs.{i}.lin_l.weight'], st[f'convs.{i}.lin_l.bias'],
+               st[f'convs.{i}.lin_r.weight']) for i in range(2)]
+    ref = O.graphsage(x, ei, params)
+    model = model.to(dev)
+    loader = NeighborLoader(x.to(dev), ei.to(dev), [-1, -1], batch_size=100, y=y.to(dev),
+                            input_nodes=torch.arange(300, device=dev))
+    assert len(loader) == 3
+    for batch in loader:
+        assert torch.equal(batch.n_id[:batch.batch_size], batch.input_id)
+        assert_close(batch.x, x[batch.n_id.cpu()], rtol=0, atol=0)
+        assert torch.equal(batch.y.cpu(), y[batch.n_id.cpu()])
+        out = model(batch.x, batch.edge_index)[:batch.batch_size]
+        assert_close(out, ref[batch.input_id.cpu()].detach(), atol=2e-5)
+        out_t = model(batch.x, batch.edge_index,
+                      num_sampled_nodes_per_hop=batch.num_sampled_nodes,
+                      num_sampled_edges_per_hop=batch.num_sampled_edges)[:batch.batch_size]
+        assert_close(out_t, ref[batch.input_id.cpu()].detach(), atol=2e-5)
