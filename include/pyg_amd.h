@@ -217,6 +217,15 @@ PYGAMD_API int pygamd_gather_rows(const float* x, int64_t ldx, int64_t n_src, co
                                   int idx_dtype, int64_t n, int64_t F, float* out, int64_t ldo,
                                   int32_t* err_flag, void* stream);
 
+/* Fused gather -> scale -> scatter-add on an unsorted edge list (the COO
+ * fallback of the SpMM for graphs used once, e.g. the backward of a sampled mini-batch):
+ *   out[scatter_idx[e], :] += (scale ? scale[gather_idx[e]] : 1) * (w ? w[e] : 1) * x[gather_idx[e], :]
+ * `out` must be initialised by the caller (usually zeros); fp32 atomics.                        */
+PYGAMD_API int pygamd_gather_scatter_add(const float* x, int64_t ldx, const void* gather_idx,
+                                         const void* scatter_idx, int idx_dtype,
+                                         const float* scale, const float* w, int64_t n_edges,
+                                         int64_t F, float* out, int64_t ldo, void* stream);
+
 /* ---- a5: scatter (unsorted COO, atomics) ----------------------------------------------------
  * out[index[e], :] (reduce)= src[e, :]   (utils/_scatter.py:14-138).  `out` must be
  * pre-initialised by pygamd_scatter_init; MEAN/MIN/MAX need `count` ([dim_size] float, zeroed)

@@ -68,13 +68,24 @@ class SpmmFunction(Function):
         if reduce == 'mean' and w is not None:
             g2 = g2 * fwd.inv_degree().view(-1, 1)
         if ctx.needs_input_grad[0]:
-            bwd = graph.by_src()
-            eid = None
-            if w is not None:
-                eid = bwd.perm if ctx.w_order == 'coo' else graph.src_slot_to_dst_slot()
             scale = fwd.inv_degree() if (reduce == 'mean' and w is None) else None
-            grad_x = _native.spmm_csr(bwd.ptr, bwd.idx, g2, 'sum', n_rows=bwd.n_rows, eid=eid,
-                                      w=w, src_scale=scale, hub=bwd.hub)
+            if graph.atomic_backward and (w is None or w.dim() == 1):
+                # graph used once (sampled batch): edge-parallel atomics on the COO list
+                # instead of sorting by source
+                w_coo = w
+                if w is not None and ctx.w_order == 'slot':
+                    w_coo = torch.empty_like(w)
+                    w_coo[fwd.perm.long()] = w
+                ei = graph.edge_index
+                grad_x = _native.gather_scatter_add(g2, ei[1], ei[0], graph.num_src_nodes,
+                                                    scale=scale, w=w_coo)
+            else:
+                bwd = graph.by_src()
+                eid = None
+                if w is not None:
+                    eid = bwd.perm if ctx.w_order == 'coo' else graph.src_slot_to_dst_slot()
+                grad_x = _native.spmm_csr(bwd.ptr, bwd.idx, g2, 'sum', n_rows=bwd.n_rows,
+                                          eid=eid, w=w, src_scale=scale, hub=bwd.hub)
             grad_x = grad_x.view(ctx.x_shape)
         if w is not None and ctx.needs_input_grad[1]:
             eid = fwd.perm if ctx.w_order == 'coo' else None

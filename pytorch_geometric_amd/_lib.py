@@ -69,6 +69,8 @@ SIGNATURES = {
                                         _P, _P]),
     'pygamd_gather_rows': (c_int, [_P, c_int64, c_int64, _P, c_int, c_int64, c_int64, _P,
                                    c_int64, _P, _P]),
+    'pygamd_gather_scatter_add': (c_int, [_P, c_int64, _P, _P, c_int, _P, _P, c_int64, c_int64,
+                                          _P, c_int64, _P]),
     'pygamd_scatter_init': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
     'pygamd_scatter_rows': (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P, c_int64,
                                     c_int64, c_int, _P, _P, _P]),

@@ -488,3 +488,22 @@ def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Ten
                                           seed & 0xFFFFFFFFFFFFFFFF, _p(src), _p(dstpos),
                                           _p(slot), _stream(colptr)), 'sample_neighbors')
     return src, dstpos, slot
+
+
+def gather_scatter_add(x: Tensor, gather_idx: Tensor, scatter_idx: Tensor, n_out: int,
+                       scale: Optional[Tensor] = None, w: Optional[Tensor] = None) -> Tensor:
+    """out[scatter_idx[e]] += scale[gather_idx[e]] * w[e] * x[gather_idx[e]] (zeros-initialised)."""
+    _require_device(x, gather_idx, scatter_idx, scale, w)
+    lib = _lib.load()
+    x2 = _f32_rows(x, 'x')
+    F = x2.size(1)
+    out = torch.zeros(n_out, F, dtype=torch.float32, device=x.device)
+    gi, si = gather_idx.contiguous(), scatter_idx.contiguous()
+    if scale is not None:
+        scale = scale.contiguous()
+    if w is not None:
+        w = w.contiguous()
+    check(lib.pygamd_gather_scatter_add(_p(x2), _ld(x2), _p(gi), _p(si), _idx_dtype(gi),
+                                        _p(scale), _p(w), gi.numel(), F, _p(out), _ld(out),
+                                        _stream(x)), 'gather_scatter_add')
+    return out

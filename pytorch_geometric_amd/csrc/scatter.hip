@@ -134,6 +134,37 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- fused gather -> scale -> scatter-add on an UNSORTED edge list (no [E, F] intermediate) ---
+// out[scatter_idx[e], :] += scale[gather_idx[e]] * w[e] * x[gather_idx[e], :]
+// The edge-parallel fallback of the CSR SpMM for graphs that are used once (mini-batches): the
+// backward of a destination-sorted batch would otherwise need a second sort.  fp32 atomics
+// (native on CDNA), so the sum order is not deterministic.
+template <typename IdxT, int VW>
+__global__ void __launch_bounds__(kBlock)
+    gather_scatter_add_kernel(const float* __restrict__ x, int64_t ldx,
+                              const IdxT* __restrict__ gather_idx,
+                              const IdxT* __restrict__ scatter_idx,
+                              const float* __restrict__ scale, const float* __restrict__ w,
+                              int64_t n_edges, int64_t units, int64_t F, float* __restrict__ out,
+                              int64_t ldo) {
+  const int64_t total = n_edges * units;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t e = t / units;
+    const int64_t f = (t - e * units) * VW;
+    if (f >= F) continue;
+    const int64_t j = gather_idx[e];
+    const int64_t i = scatter_idx[e];
+    float m = 1.f;
+    if (scale) m *= scale[j];
+    if (w) m *= w[e];
+    const Vec<VW> v = load_vec<VW>(x + j * ldx + f);
+    float* dst = out + i * ldo + f;
+#pragma unroll
+    for (int q = 0; q < VW; ++q) atomicAdd(dst + q, v.v[q] * m);
+  }
+}
+
 // ---- scatter_argmax (1-D) -------------------------------------------------------------------
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
@@ -283,6 +314,33 @@ int pygamd_gather_rows(const float* x, int64_t ldx, int64_t n_src, const void* i
       hipLaunchKernelGGL((gather_rows_kernel<IdxT, 1>), dim3(flat_grid(n * F)), dim3(kBlock), 0,
                          as_stream(stream), x, ldx, n_src, static_cast<const IdxT*>(index), n, F,
                          F, out, ldo, err_flag);
+    }
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_gather_scatter_add(const float* x, int64_t ldx, const void* gather_idx,
+                              const void* scatter_idx, int idx_dtype, const float* scale,
+                              const float* w, int64_t n_edges, int64_t F, float* out,
+                              int64_t ldo, void* stream) {
+  if (n_edges < 0 || F < 0 || ldx < F || ldo < F) return PYGAMD_ERR_INVALID_ARG;
+  if (n_edges == 0 || F == 0) return PYGAMD_OK;
+  if (!x || !gather_idx || !scatter_idx || !out) return PYGAMD_ERR_INVALID_ARG;
+  const bool v4 = (F % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    if (v4) {
+      const int64_t units = F / 4;
+      hipLaunchKernelGGL((gather_scatter_add_kernel<IdxT, 4>), dim3(flat_grid(n_edges * units)),
+                         dim3(kBlock), 0, as_stream(stream), x, ldx,
+                         static_cast<const IdxT*>(gather_idx),
+                         static_cast<const IdxT*>(scatter_idx), scale, w, n_edges, units, F, out,
+                         ldo);
+    } else {
+      hipLaunchKernelGGL((gather_scatter_add_kernel<IdxT, 1>), dim3(flat_grid(n_edges * F)),
+                         dim3(kBlock), 0, as_stream(stream), x, ldx,
+                         static_cast<const IdxT*>(gather_idx),
+                         static_cast<const IdxT*>(scatter_idx), scale, w, n_edges, F, F, out, ldo);
     }
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;

@@ -113,6 +113,9 @@ class EdgeIndex:
         self._csr: Optional[CSR] = None   # sorted by destination (aggregation / forward)
         self._csc: Optional[CSR] = None   # sorted by source (transposed / backward)
         self._slot_map = None
+        # True: the backward of an aggregation runs the edge-parallel atomic kernel on the COO
+        # list instead of building the source-sorted form (graphs used once: sampled batches)
+        self.atomic_backward = False
 
     @classmethod
     def from_csr(cls, rowptr: Tensor, col: Tensor, sparse_size: Tuple[int, int]) -> 'EdgeIndex':
@@ -125,6 +128,40 @@ class EdgeIndex:
         self._csr = CSR(rowptr.contiguous(), col.contiguous(), perm, sparse_size[1],
                         sparse_size[0])
         return self
+
+    @classmethod
+    def from_sorted_batch(cls, edge_index: Tensor, num_nodes: int,
+                          max_in_degree: Optional[int] = None) -> 'EdgeIndex':
+        """Handle for a sampled mini-batch whose edges are already ordered by destination (the
+        sampler emits them hop by hop and, inside a hop, by destination): no sort, no range
+        check, no host sync; the backward uses the atomic COO kernel (the batch is used once)."""
+        self = cls(edge_index, (num_nodes, num_nodes), sort_order='col', validate=False)
+        self.atomic_backward = True
+        csr = self.by_dst()
+        if max_in_degree is not None and max_in_degree <= _native.HUB_THRESHOLD:
+            csr._hub = (None, None, 0, 0)  # fan-out bounded: no row needs splitting
+        return self
+
+    def trim(self, num_nodes: int, num_edges: int) -> 'EdgeIndex':
+        """Prefix handle for ``trim_to_layer`` on hop-ordered batches: keeps the first
+        ``num_edges`` edges and the first ``num_nodes`` nodes.  Destination-sorted handles are
+        trimmed without re-sorting: ``ptr`` is clipped at ``num_edges``."""
+        ei = self.edge_index.narrow(1, 0, num_edges)
+        if self.sort_order != 'col' or self._csr is None:
+            out = EdgeIndex(ei, (num_nodes, num_nodes), sort_order=self.sort_order,
+                            validate=False)
+            out.atomic_backward = self.atomic_backward
+            return out
+        out = EdgeIndex(ei, (num_nodes, num_nodes), sort_order='col', validate=False)
+        out.atomic_backward = self.atomic_backward
+        full = self._csr
+        ptr = full.ptr.narrow(0, 0, num_nodes + 1).clamp(max=num_edges)
+        csr = CSR(ptr, full.idx.narrow(0, 0, num_edges), full.perm.narrow(0, 0, num_edges),
+                  num_nodes, num_nodes)
+        if full._hub is not None and full._hub[2] == 0:
+            csr._hub = (None, None, 0, 0)
+        out._csr = csr
+        return out
 
     # -- accessors -------------------------------------------------------------------------------
     @property

@@ -10,6 +10,7 @@ import torch
 from torch import Tensor
 
 from . import _native
+from .edge_index import EdgeIndex
 from .sampler import NeighborSampler
 
 
@@ -20,6 +21,7 @@ class Batch:
     x: Tensor
     y: Optional[Tensor]
     edge_index: Tensor
+    graph: EdgeIndex       # destination-sorted handle of `edge_index` (no sort, no host sync)
     n_id: Tensor
     e_id: Tensor
     input_id: Tensor
@@ -61,7 +63,11 @@ class NeighborLoader:
         out = self.sampler.sample_from_nodes(seeds)
         x = _native.gather_rows(self.x, out.node)  # filter_data: x[n_id]
         y = None if self.y is None else self.y[out.node]
-        return Batch(x=x, y=y, edge_index=torch.stack([out.row, out.col]), n_id=out.node,
+        ei = torch.stack([out.row, out.col])
+        fan = self.sampler.num_neighbors
+        graph = EdgeIndex.from_sorted_batch(
+            ei, out.node.numel(), max_in_degree=None if min(fan) < 0 else max(fan))
+        return Batch(x=x, y=y, edge_index=ei, graph=graph, n_id=out.node,
                      e_id=out.edge, input_id=seeds if input_id is None else input_id,
                      batch_size=seeds.numel(), num_sampled_nodes=out.num_sampled_nodes,
                      num_sampled_edges=out.num_sampled_edges)

@@ -186,6 +186,8 @@ def eligible(model, x, edge_index, trim: bool) -> bool:
             return False
         aggr = conv.aggr
     if isinstance(edge_index, EdgeIndex):
+        if edge_index.atomic_backward:  # single-use batch handle: keep the no-sort layer path
+            return False
         return edge_index.sparse_size == (x.size(0), x.size(0))
     return isinstance(edge_index, Tensor) and edge_index.dim() == 2
 

@@ -45,7 +45,10 @@ for b in range(args.batches + 5):
     yb = y[out.node[:seeds.numel()]]
     torch.cuda.synchronize(); t2 = time.perf_counter()
     opt.zero_grad()
-    logits = model(xb, torch.stack([out.row, out.col]),
+    from pytorch_geometric_amd import EdgeIndex
+    graph = EdgeIndex.from_sorted_batch(torch.stack([out.row, out.col]), out.node.numel(),
+                                        max_in_degree=15)
+    logits = model(xb, graph,
                    num_sampled_nodes_per_hop=out.num_sampled_nodes,
                    num_sampled_edges_per_hop=out.num_sampled_edges)[:seeds.numel()]
     F.cross_entropy(logits, yb).backward()

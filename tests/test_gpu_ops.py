@@ -449,3 +449,23 @@ def test_hetero_linear(dev):
     ref_gx = torch.stack([w[tv[i]].sum(1) for i in range(300)])
     assert_close(xg.grad, ref_gx, atol=2e-5)
     assert lin.weight.grad.shape == (5, 10, 6) and float(lin.weight.grad[2].abs().sum()) == 0
+
+
+@pytest.mark.parametrize('F', [5, 64, 256])
+def test_gather_scatter_add(dev, F):
+    """Edge-parallel atomic fallback == the CSR kernel on the transposed handle."""
+    from pytorch_geometric_amd import _native
+    ei = random_graph(200, 150, 4000, seed=F)
+    g = gen(F)
+    x = torch.randn(150, F, generator=g)
+    scale = torch.rand(150, generator=g)
+    w = torch.rand(4000, generator=g)
+    got = _native.gather_scatter_add(x.to(dev), ei[1].to(dev), ei[0].to(dev), 200,
+                                     scale=scale.to(dev), w=w.to(dev))
+    msg = x[ei[1]] * (scale[ei[1]] * w).view(-1, 1)
+    ref = torch.zeros(200, F).index_add_(0, ei[0], msg)
+    ex = torch.zeros(200, F, dtype=torch.double).index_add_(0, ei[0], msg.double())
+    assert_sum_close(got, ref, ex, what=f'gather_scatter_add F={F}')
+    got = _native.gather_scatter_add(x.to(dev), ei[1].int().to(dev), ei[0].int().to(dev), 200)
+    ref = torch.zeros(200, F).index_add_(0, ei[0], x[ei[1]])
+    assert_sum_close(got, ref, ref.double(), what='plain')

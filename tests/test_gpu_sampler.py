@@ -100,3 +100,16 @@ def test_full_neighbourhood_batches_reproduce_full_graph_outputs(dev):
                       num_sampled_nodes_per_hop=batch.num_sampled_nodes,
                       num_sampled_edges_per_hop=batch.num_sampled_edges)[:batch.batch_size]
         assert_close(out_t, ref[batch.input_id.cpu()].detach(), atol=2e-5)
+        # the pre-sorted batch handle (no sort, atomic backward): same values, same gradients
+        grads = {}
+        for key, graph in (('tensor', batch.edge_index), ('handle', batch.graph)):
+            model.zero_grad()
+            xb = batch.x.clone().requires_grad_(True)
+            o = model(xb, graph, num_sampled_nodes_per_hop=batch.num_sampled_nodes,
+                      num_sampled_edges_per_hop=batch.num_sampled_edges)[:batch.batch_size]
+            assert_close(o, ref[batch.input_id.cpu()].detach(), atol=2e-5, what=key)
+            o.square().sum().backward()
+            grads[key] = (xb.grad.clone(), [p.grad.clone() for p in model.parameters()])
+        assert_close(grads['handle'][0], grads['tensor'][0].cpu(), atol=2e-5, what='grad_x')
+        for a, b in zip(grads['handle'][1], grads['tensor'][1]):
+            assert_close(a, b.cpu(), atol=1e-4, rtol=1e-4, what='param grads')
