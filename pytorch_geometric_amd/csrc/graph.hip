@@ -33,19 +33,26 @@ static int index_sort_impl(const void* keys_in, int64_t n, int64_t max_value, vo
   return PYGAMD_OK;
 }
 
-// ptr[v] = number of entries < v  (index sorted ascending).  One thread per entry i fills
-// ptr[index[i-1]+1 .. index[i]] = i; the last thread also fills the tail with n.
+// ptr[v] = number of entries < v  (index sorted ascending) = lower_bound(index, v).  One thread
+// per OUTPUT row and a binary search over the sorted index: perfectly balanced, also when most
+// rows are empty (a sampled mini-batch: the last hop's nodes have no in-edges, so a "fill the
+// gap" formulation would leave half a million sequential stores to one thread).
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
     index2ptr_kernel(const IdxT* __restrict__ index, int64_t n, int64_t size,
                      IdxT* __restrict__ ptr) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i > n) return;
-  int64_t lo = (i == 0) ? 0 : static_cast<int64_t>(index[i - 1]) + 1;
-  int64_t hi = (i == n) ? size : static_cast<int64_t>(index[i]);
-  if (lo < 0) lo = 0;        // out-of-range values never write outside ptr[0..size]
-  if (hi > size) hi = size;  // (callers validate the range; this only keeps memory safe)
-  for (int64_t v = lo; v <= hi; ++v) ptr[v] = static_cast<IdxT>(i);
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (v > size) return;
+  int64_t lo = 0, hi = n;  // first position whose value is >= v
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (static_cast<int64_t>(index[mid]) < v) {
+      lo = mid + 1;
+    } else {
+      hi = mid;
+    }
+  }
+  ptr[v] = static_cast<IdxT>(lo);
 }
 
 // index[k] = the row r with ptr[r] <= k < ptr[r+1]  (upper_bound - 1 per output element).
@@ -251,7 +258,7 @@ int pygamd_index2ptr(const void* index, int idx_dtype, int64_t n, int64_t size, 
   if (n < 0 || size < 0 || !ptr_out) return PYGAMD_ERR_INVALID_ARG;
   if (n > 0 && !index) return PYGAMD_ERR_INVALID_ARG;
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
-    const unsigned grid = static_cast<unsigned>(ceil_div(n + 1, kBlock));
+    const unsigned grid = static_cast<unsigned>(ceil_div(size + 1, kBlock));
     hipLaunchKernelGGL((index2ptr_kernel<IdxT>), dim3(grid), dim3(kBlock), 0, as_stream(stream),
                        static_cast<const IdxT*>(index), n, size, static_cast<IdxT*>(ptr_out));
     PYGAMD_LAUNCH_CHECK();
