@@ -150,7 +150,8 @@ typedef struct {
   int64_t hub_threshold;
   int64_t hub_chunk;
   int32_t accumulate;        /* SUM/MEAN only: out += result (fused "x_root + aggregate") */
-  int32_t reserved;
+  int32_t hub_phase;         /* 0: rows + hubs; 1: non-hub rows only; 2: hub rows only (lets a
+                                caller run row ranges as separate launches and the hubs once)  */
 } pygamd_spmm_args;
 
 PYGAMD_API int pygamd_spmm_csr_workspace_bytes(const pygamd_spmm_args* args, size_t* bytes);

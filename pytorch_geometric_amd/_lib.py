@@ -29,7 +29,7 @@ class SpmmArgs(Structure):
         ('ldo', c_int64), ('idx_dtype', c_int32), ('reduce', c_int32), ('w_heads', c_int32),
         ('head_dim', c_int32), ('hub_rows', c_void_p), ('hub_chunk_ptr', c_void_p),
         ('n_hub', c_int64), ('n_chunks', c_int64), ('hub_threshold', c_int64),
-        ('hub_chunk', c_int64), ('accumulate', c_int32), ('reserved', c_int32),
+        ('hub_chunk', c_int64), ('accumulate', c_int32), ('hub_phase', c_int32),
     ]
 
 

@@ -166,7 +166,7 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
              n_rows: Optional[int] = None, eid: Optional[Tensor] = None,
              w: Optional[Tensor] = None, src_scale: Optional[Tensor] = None,
              hub=None, out: Optional[Tensor] = None, return_arg: bool = False,
-             accumulate: bool = False):
+             accumulate: bool = False, hub_phase: int = 0):
     """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h."""
     _require_device(rowptr, col, x, eid, w, src_scale)
     lib = _lib.load()
@@ -205,14 +205,16 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     a.idx_dtype, a.reduce = _idx_dtype(rowptr), red
     a.w_heads, a.head_dim = w_heads, head_dim
     a.accumulate = 1 if accumulate else 0
+    a.hub_phase = hub_phase
     ws, ws_bytes = None, 0
     if hub is not None and hub[2] > 0 and red in (_lib.SUM, _lib.MEAN):
         hub_rows, hub_cptr, n_hub, n_chunks = hub
         a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), hub_cptr.data_ptr()
         a.n_hub, a.n_chunks = n_hub, n_chunks
         a.hub_threshold, a.hub_chunk = HUB_THRESHOLD, HUB_CHUNK
-        ws_bytes = n_chunks * F * 4
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        if hub_phase != 1:
+            ws_bytes = n_chunks * F * 4
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     sink = timing_sink
     if sink is not None:
         ev0 = torch.cuda.Event(enable_timing=True)

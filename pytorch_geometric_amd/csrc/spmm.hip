@@ -633,11 +633,13 @@ template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
 static int launch_sum(const pygamd_spmm_args* p, const Shape& s, float* partial,
                       hipStream_t st) {
   SpmmDev<IdxT> a = make_dev<IdxT>(p);
-  dim3 grid(wave_grid(p->n_rows), s.tiles);
-  hipLaunchKernelGGL((spmm_sum_rows<IdxT, VW, LPR, CH, WMODE, IDENT>), grid, dim3(kBlock), 0, st,
-                     a);
-  PYGAMD_LAUNCH_CHECK();
-  if (p->n_hub > 0) {
+  if (p->hub_phase != 2) {
+    dim3 grid(wave_grid(p->n_rows), s.tiles);
+    hipLaunchKernelGGL((spmm_sum_rows<IdxT, VW, LPR, CH, WMODE, IDENT>), grid, dim3(kBlock), 0,
+                       st, a);
+    PYGAMD_LAUNCH_CHECK();
+  }
+  if (p->n_hub > 0 && p->hub_phase != 1) {
     dim3 hgrid(wave_grid(p->n_chunks), s.tiles);
     hipLaunchKernelGGL((spmm_hub_chunks<IdxT, VW, LPR, CH, WMODE, IDENT>), hgrid, dim3(kBlock),
                        0, st, a, static_cast<const IdxT*>(p->hub_rows),
@@ -775,6 +777,7 @@ static int validate(const pygamd_spmm_args* p) {
   if (p->n_hub > 0 && (!p->hub_rows || !p->hub_chunk_ptr || p->hub_chunk < 1 ||
                        p->hub_threshold < 1 || p->n_chunks < p->n_hub))
     return PYGAMD_ERR_INVALID_ARG;
+  if (p->hub_phase < 0 || p->hub_phase > 2) return PYGAMD_ERR_INVALID_ARG;
   return PYGAMD_OK;
 }
 
