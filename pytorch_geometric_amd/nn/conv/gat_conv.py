@@ -14,16 +14,23 @@ from ..inits import glorot, zeros
 from .message_passing import MessagePassing
 
 
-class GATConv(MessagePassing):
-    r"""Graph attention operator — constructor, parameters (``lin`` / ``lin_src`` / ``lin_dst``,
-    ``att_src``, ``att_dst``, optional ``lin_edge`` / ``att_edge`` / ``res``, ``bias``) and forward
-    semantics of ``torch_geometric.nn.GATConv`` (torch_geometric/nn/conv/gat_conv.py:130-413):
-    ``alpha_ij = softmax_j(leaky_relu(a_src . W x_j + a_dst . W x_i))``, messages
-    ``alpha_ij * W x_j`` summed per destination, heads concatenated or averaged.
+def _glorot_linear(n_in: int, n_out: int) -> Linear:
+    return Linear(n_in, n_out, bias=False, weight_initializer='glorot')
 
-    Fused path (no ``edge_attr``): ONE kernel builds the logits from the two ``[N, H]`` node terms
-    and normalises them per destination row (never materialising the gathered logits), ONE
-    multi-head weighted SpMM aggregates ``[N, H*C]`` rows.
+
+class GATConv(MessagePassing):
+    r"""Graph attention operator with the constructor arguments, parameter names (``lin`` or
+    ``lin_src`` / ``lin_dst``, ``att_src``, ``att_dst``, optional ``lin_edge`` / ``att_edge`` /
+    ``res``, ``bias``) and forward semantics of ``torch_geometric.nn.GATConv``
+    (torch_geometric/nn/conv/gat_conv.py:130-413):
+
+    .. math:: \alpha_{ij} = \mathrm{softmax}_j\,\mathrm{LeakyReLU}(a_s^\top W x_j + a_d^\top W x_i),
+              \qquad x_i' = \big\Vert_h \sum_j \alpha^h_{ij} W^h x_j \;(\text{or the head mean}).
+
+    Fused path (no edge features): ONE kernel builds the logits from the two ``[N, H]`` node terms
+    and normalises them per destination row (the gathered logits are never materialised), ONE
+    multi-head weighted SpMM aggregates the ``[N, H*C]`` rows.  With ``edge_dim`` or
+    ``fuse = False`` the layer takes the general gather -> ``edge_update`` -> scatter route.
     """
 
     def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int,
@@ -33,44 +40,26 @@ class GATConv(MessagePassing):
                  bias: bool = True, residual: bool = False, **kwargs):
         kwargs.setdefault('aggr', 'add')
         super().__init__(node_dim=0, **kwargs)
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.heads = heads
-        self.concat = concat
-        self.negative_slope = negative_slope
-        self.dropout = dropout
-        self.add_self_loops = add_self_loops
-        self.edge_dim = edge_dim
-        self.fill_value = fill_value
-        self.residual = residual
-        self.lin = self.lin_src = self.lin_dst = None
-        if isinstance(in_channels, int):
-            self.lin = Linear(in_channels, heads * out_channels, bias=False,
-                              weight_initializer='glorot')
-        else:
-            self.lin_src = Linear(in_channels[0], heads * out_channels, False,
-                                  weight_initializer='glorot')
-            self.lin_dst = Linear(in_channels[1], heads * out_channels, False,
-                                  weight_initializer='glorot')
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
+        self.add_self_loops, self.edge_dim = add_self_loops, edge_dim
+        self.fill_value, self.residual = fill_value, residual
+        width = heads * out_channels
+        shared = isinstance(in_channels, int)
+        # one shared projection for homogeneous inputs, two for (source, destination) pairs
+        self.lin = _glorot_linear(in_channels, width) if shared else None
+        self.lin_src = None if shared else _glorot_linear(in_channels[0], width)
+        self.lin_dst = None if shared else _glorot_linear(in_channels[1], width)
         self.att_src = Parameter(torch.empty(1, heads, out_channels))
         self.att_dst = Parameter(torch.empty(1, heads, out_channels))
-        if edge_dim is not None:
-            self.lin_edge = Linear(edge_dim, heads * out_channels, bias=False,
-                                   weight_initializer='glorot')
-            self.att_edge = Parameter(torch.empty(1, heads, out_channels))
-        else:
-            self.lin_edge = None
-            self.register_parameter('att_edge', None)
-        total_out_channels = out_channels * (heads if concat else 1)
-        if residual:
-            self.res = Linear(in_channels if isinstance(in_channels, int) else in_channels[1],
-                              total_out_channels, bias=False, weight_initializer='glorot')
-        else:
-            self.register_parameter('res', None)
-        if bias:
-            self.bias = Parameter(torch.empty(total_out_channels))
-        else:
-            self.register_parameter('bias', None)
+        self.lin_edge = None if edge_dim is None else _glorot_linear(edge_dim, width)
+        self.register_parameter(
+            'att_edge', None if edge_dim is None else Parameter(torch.empty(1, heads,
+                                                                             out_channels)))
+        out_width = width if concat else out_channels
+        dst_in = in_channels if shared else in_channels[1]
+        self.res = _glorot_linear(dst_in, out_width) if residual else None
+        self.register_parameter('bias', Parameter(torch.empty(out_width)) if bias else None)
         self._loop_cache = None
         self.reset_parameters()
 
@@ -79,21 +68,37 @@ class GATConv(MessagePassing):
         for lin in (self.lin, self.lin_src, self.lin_dst, self.lin_edge, self.res):
             if lin is not None:
                 lin.reset_parameters()
-        glorot(self.att_src)
-        glorot(self.att_dst)
-        glorot(self.att_edge)
+        for att in (self.att_src, self.att_dst, self.att_edge):
+            glorot(att)
         zeros(self.bias)
 
+    # -- pieces of forward -------------------------------------------------------------------------
+    def _project(self, x):
+        """(x_src [N_s, H, C], x_dst [N_d, H, C] | None, residual | None)."""
+        H, C = self.heads, self.out_channels
+        pair = not isinstance(x, Tensor)
+        raw_src, raw_dst = x if pair else (x, x)
+        assert raw_src.dim() == 2, "Static graphs not supported in 'GATConv'"
+        res = self.res(raw_dst) if (self.res is not None and raw_dst is not None) else None
+        f_src = self.lin if self.lin is not None else self.lin_src
+        f_dst = self.lin if self.lin is not None else self.lin_dst
+        x_src = f_src(raw_src).view(-1, H, C)
+        if raw_dst is None:
+            x_dst = None
+        elif not pair and self.lin is not None:
+            x_dst = x_src  # same tensor, same projection
+        else:
+            x_dst = f_dst(raw_dst).view(-1, H, C)
+        return x_src, x_dst, res
+
     def _with_self_loops(self, edge_index: Tensor, edge_attr: Optional[Tensor], num_nodes: int):
-        """remove_self_loops + add_self_loops (gat_conv.py:334-346).  Without edge features the
-        result is cached per input tensor so the sorted handle of the augmented graph is reused
-        across forward calls."""
-        if edge_attr is None:
-            hit = self._loop_cache
-            if hit is not None:
-                ref, version, n, out = hit
-                if ref() is edge_index and version == edge_index._version and n == num_nodes:
-                    return out, None
+        """Drop existing self-loops, then add one per node (gat_conv.py:334-346).  Without edge
+        features the augmented edge list is cached per input tensor, so the sorted handle built
+        for it is reused by later forward calls."""
+        if edge_attr is None and self._loop_cache is not None:
+            ref, version, n, cached = self._loop_cache
+            if ref() is edge_index and version == edge_index._version and n == num_nodes:
+                return cached, None
         ei, ea = remove_self_loops(edge_index, edge_attr)
         ei, ea = add_self_loops(ei, ea, fill_value=self.fill_value, num_nodes=num_nodes)
         if edge_attr is None:
@@ -104,95 +109,61 @@ class GATConv(MessagePassing):
                 edge_attr: Optional[Tensor] = None, size: Optional[Tuple[int, int]] = None,
                 return_attention_weights: Optional[bool] = None):
         H, C = self.heads, self.out_channels
-        res: Optional[Tensor] = None
-        if isinstance(x, Tensor):
-            assert x.dim() == 2, "Static graphs not supported in 'GATConv'"
-            if self.res is not None:
-                res = self.res(x)
-            if self.lin is not None:
-                x_src = x_dst = self.lin(x).view(-1, H, C)
-            else:
-                assert self.lin_src is not None and self.lin_dst is not None
-                x_src = self.lin_src(x).view(-1, H, C)
-                x_dst = self.lin_dst(x).view(-1, H, C)
-        else:
-            x_src, x_dst = x
-            assert x_src.dim() == 2, "Static graphs not supported in 'GATConv'"
-            if x_dst is not None and self.res is not None:
-                res = self.res(x_dst)
-            if self.lin is not None:
-                x_src = self.lin(x_src).view(-1, H, C)
-                if x_dst is not None:
-                    x_dst = self.lin(x_dst).view(-1, H, C)
-            else:
-                assert self.lin_src is not None and self.lin_dst is not None
-                x_src = self.lin_src(x_src).view(-1, H, C)
-                if x_dst is not None:
-                    x_dst = self.lin_dst(x_dst).view(-1, H, C)
-        x = (x_src, x_dst)
-        alpha_src = (x_src * self.att_src).sum(dim=-1)
-        alpha_dst = None if x_dst is None else (x_dst * self.att_dst).sum(-1)
-        alpha = (alpha_src, alpha_dst)
+        x_src, x_dst, res = self._project(x)
+        a_src = (x_src * self.att_src).sum(dim=-1)
+        a_dst = None if x_dst is None else (x_dst * self.att_dst).sum(dim=-1)
 
         if self.add_self_loops and isinstance(edge_index, Tensor):
-            num_nodes = x_src.size(0)
-            if x_dst is not None:
-                num_nodes = min(num_nodes, x_dst.size(0))
-            num_nodes = min(size) if size is not None else num_nodes
-            edge_index, edge_attr = self._with_self_loops(edge_index, edge_attr, num_nodes)
+            n = x_src.size(0) if x_dst is None else min(x_src.size(0), x_dst.size(0))
+            n = min(size) if size is not None else n
+            edge_index, edge_attr = self._with_self_loops(edge_index, edge_attr, n)
 
-        fused = (self.fuse and edge_attr is None and alpha_dst is not None
-                 and self.flow == 'source_to_target')
-        if fused:
+        use_fused = (self.fuse and edge_attr is None and a_dst is not None
+                     and self.flow == 'source_to_target')
+        if use_fused:
             n_src = x_src.size(0)
             n_dst = x_dst.size(0) if size is None else size[1]
             graph = as_edge_index(edge_index, n_src, n_dst)
-            alpha_slot = GatEdgeSoftmaxFunction.apply(alpha_src, alpha_dst[:n_dst].contiguous(),
-                                                      graph, self.negative_slope)
-            att = F.dropout(alpha_slot, p=self.dropout, training=self.training)
-            out = SpmmFunction.apply(x_src.reshape(n_src, H * C), att, graph, 'sum', 'slot')
+            alpha_slot = GatEdgeSoftmaxFunction.apply(a_src, a_dst[:n_dst].contiguous(), graph,
+                                                      self.negative_slope)
+            weights = F.dropout(alpha_slot, p=self.dropout, training=self.training)
+            out = SpmmFunction.apply(x_src.reshape(n_src, H * C), weights, graph, 'sum', 'slot')
             out = out.view(-1, H, C)
-            alpha_out = None
-            if return_attention_weights is not None:
-                alpha_out = torch.empty_like(alpha_slot)
-                alpha_out[graph.by_dst().perm.long()] = alpha_slot
+            alpha = None
+            if return_attention_weights is not None:  # back to the caller's edge order
+                alpha = torch.empty_like(alpha_slot)
+                alpha[graph.by_dst().perm.long()] = alpha_slot
         else:
-            alpha_out = self.edge_updater(edge_index, alpha=alpha, edge_attr=edge_attr,
-                                          size=size)
-            fuse, self.fuse = self.fuse, False
+            alpha = self.edge_updater(edge_index, alpha=(a_src, a_dst), edge_attr=edge_attr,
+                                      size=size)
+            keep, self.fuse = self.fuse, False
             try:
-                out = self.propagate(edge_index, x=x, alpha=alpha_out, size=size)
+                out = self.propagate(edge_index, x=(x_src, x_dst), alpha=alpha, size=size)
             finally:
-                self.fuse = fuse
+                self.fuse = keep
 
-        if self.concat:
-            out = out.view(-1, self.heads * self.out_channels)
-        else:
-            out = out.mean(dim=1)
+        out = out.reshape(-1, H * C) if self.concat else out.mean(dim=1)
         if res is not None:
             out = out + res
         if self.bias is not None:
             out = out + self.bias
-        if return_attention_weights is not None:
-            ei = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
-            return out, (ei, alpha_out)
-        return out
+        if return_attention_weights is None:
+            return out
+        coo = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
+        return out, (coo, alpha)
 
     def edge_update(self, alpha_j: Tensor, alpha_i: Optional[Tensor],
                     edge_attr: Optional[Tensor], index: Tensor, ptr: Optional[Tensor],
                     dim_size: Optional[int]) -> Tensor:
-        alpha = alpha_j if alpha_i is None else alpha_j + alpha_i
+        logits = alpha_j if alpha_i is None else alpha_j + alpha_i
         if index.numel() == 0:
-            return alpha
+            return logits
         if edge_attr is not None and self.lin_edge is not None:
-            if edge_attr.dim() == 1:
-                edge_attr = edge_attr.view(-1, 1)
-            edge_attr = self.lin_edge(edge_attr)
-            edge_attr = edge_attr.view(-1, self.heads, self.out_channels)
-            alpha = alpha + (edge_attr * self.att_edge).sum(dim=-1)
-        alpha = F.leaky_relu(alpha, self.negative_slope)
-        alpha = softmax(alpha, index, ptr, dim_size)
-        return F.dropout(alpha, p=self.dropout, training=self.training)
+            e = edge_attr.view(-1, 1) if edge_attr.dim() == 1 else edge_attr
+            e = self.lin_edge(e).view(-1, self.heads, self.out_channels)
+            logits = logits + (e * self.att_edge).sum(dim=-1)
+        att = softmax(F.leaky_relu(logits, self.negative_slope), index, ptr, dim_size)
+        return F.dropout(att, p=self.dropout, training=self.training)
 
     def message(self, x_j: Tensor, alpha: Tensor) -> Tensor:
         return alpha.unsqueeze(-1) * x_j
@@ -201,5 +172,5 @@ class GATConv(MessagePassing):
         raise NotImplementedError  # fusion is driven from forward() (needs slot-ordered alpha)
 
     def __repr__(self) -> str:
-        return (f'{self.__class__.__name__}({self.in_channels}, '
-                f'{self.out_channels}, heads={self.heads})')
+        return (f'{type(self).__name__}({self.in_channels}, {self.out_channels}, '
+                f'heads={self.heads})')

@@ -17,57 +17,47 @@ def gcn_norm(edge_index: Tensor, edge_weight: Optional[Tensor] = None,
              num_nodes: Optional[int] = None, improved: bool = False,
              add_self_loops: bool = True, flow: str = 'source_to_target',
              dtype: Optional[torch.dtype] = None) -> Tuple[Tensor, Tensor]:
-    r"""Symmetric normalisation ``D^-1/2 (A + I) D^-1/2`` on a COO edge list — same steps as
-    torch_geometric/nn/conv/gcn_conv.py:45-113 (tensor branch): add the remaining self-loops with
-    weight ``fill_value``, degree by scatter-add over the destination, ``deg^-1/2`` with inf -> 0,
-    per-edge weight ``dis[row] * w * dis[col]``."""
-    fill_value = 2. if improved else 1.
-    assert flow in ('source_to_target', 'target_to_source')
-    num_nodes = maybe_num_nodes(edge_index, num_nodes)
+    r"""``D^-1/2 (A + c I) D^-1/2`` on a COO edge list, ``c = 2`` if ``improved`` else ``1`` — the
+    tensor branch of torch_geometric/nn/conv/gcn_conv.py:45-113: remaining self-loops are added
+    with weight ``c``, the degree is the scatter-add of the weights over the receiving endpoint,
+    isolated nodes get ``deg^-1/2 = 0``, and every edge is scaled by both endpoint factors."""
+    if flow not in ('source_to_target', 'target_to_source'):
+        raise ValueError(f"invalid flow '{flow}'")
+    n = maybe_num_nodes(edge_index, num_nodes)
     if add_self_loops:
-        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, fill_value,
-                                                           num_nodes)
+        loop_weight = 2.0 if improved else 1.0
+        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, loop_weight, n)
     if edge_weight is None:
-        edge_weight = torch.ones((edge_index.size(1), ), dtype=dtype or torch.float32,
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype or torch.float32,
                                  device=edge_index.device)
-    row, col = edge_index[0], edge_index[1]
-    idx = col if flow == 'source_to_target' else row
-    deg = scatter(edge_weight, idx, dim=0, dim_size=num_nodes, reduce='sum')
-    deg_inv_sqrt = deg.pow(-0.5)
-    deg_inv_sqrt = deg_inv_sqrt.masked_fill(deg_inv_sqrt == float('inf'), 0)
-    edge_weight = deg_inv_sqrt[row] * edge_weight * deg_inv_sqrt[col]
-    return edge_index, edge_weight
+    receiver = edge_index[1] if flow == 'source_to_target' else edge_index[0]
+    inv_sqrt = scatter(edge_weight, receiver, dim=0, dim_size=n, reduce='sum').pow(-0.5)
+    inv_sqrt = torch.where(torch.isinf(inv_sqrt), torch.zeros_like(inv_sqrt), inv_sqrt)
+    return edge_index, inv_sqrt[edge_index[0]] * edge_weight * inv_sqrt[edge_index[1]]
 
 
 class GCNConv(MessagePassing):
-    r"""Graph convolution ``X' = D^-1/2 (A + I) D^-1/2 X W + b`` — constructor, parameters
-    (``lin`` with glorot init, ``bias`` zeros) and forward order (normalise -> transform ->
-    propagate at the OUTPUT width -> bias) of ``torch_geometric.nn.GCNConv``
-    (torch_geometric/nn/conv/gcn_conv.py:116-274)."""
+    r"""Graph convolution ``X' = D^-1/2 (A + I) D^-1/2 X W + b`` with the constructor arguments,
+    parameters (``lin.weight`` glorot, ``bias`` zeros) and the normalise -> transform -> propagate
+    (at the OUTPUT width) -> bias order of ``torch_geometric.nn.GCNConv``
+    (torch_geometric/nn/conv/gcn_conv.py:116-274).  ``cached=True`` keeps the normalised edge list,
+    and with it the sorted graph handle, across calls."""
 
     def __init__(self, in_channels: int, out_channels: int, improved: bool = False,
                  cached: bool = False, add_self_loops: Optional[bool] = None,
                  normalize: bool = True, bias: bool = True, **kwargs):
         kwargs.setdefault('aggr', 'add')
         super().__init__(**kwargs)
-        if add_self_loops is None:
-            add_self_loops = normalize
+        add_self_loops = normalize if add_self_loops is None else add_self_loops
         if add_self_loops and not normalize:
-            raise ValueError(f"'{self.__class__.__name__}' does not support "
-                             f"adding self-loops to the graph when no "
-                             f"on-the-fly normalization is applied")
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.improved = improved
-        self.cached = cached
-        self.add_self_loops = add_self_loops
-        self.normalize = normalize
+            raise ValueError(f"'{type(self).__name__}' does not support adding self-loops to "
+                             f"the graph when no on-the-fly normalization is applied")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached = improved, cached
+        self.add_self_loops, self.normalize = add_self_loops, normalize
         self._cached_edge_index = None
         self.lin = Linear(in_channels, out_channels, bias=False, weight_initializer='glorot')
-        if bias:
-            self.bias = Parameter(torch.empty(out_channels))
-        else:
-            self.register_parameter('bias', None)
+        self.register_parameter('bias', Parameter(torch.empty(out_channels)) if bias else None)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -76,28 +66,25 @@ class GCNConv(MessagePassing):
         zeros(self.bias)
         self._cached_edge_index = None
 
+    def _normalized(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor]):
+        if self._cached_edge_index is not None:
+            return self._cached_edge_index
+        out = gcn_norm(edge_index, edge_weight, x.size(self.node_dim), self.improved,
+                       self.add_self_loops, self.flow, x.dtype)
+        if self.cached:
+            self._cached_edge_index = out
+        return out
+
     def forward(self, x: Tensor, edge_index, edge_weight: Optional[Tensor] = None) -> Tensor:
         if isinstance(x, (tuple, list)):
-            raise ValueError(f"'{self.__class__.__name__}' received a tuple "
-                             f"of node features as input while this layer "
-                             f"does not support bipartite message passing. "
-                             f"Please try other layers such as 'SAGEConv' or "
+            raise ValueError(f"'{type(self).__name__}' received a tuple of node features as "
+                             f"input while this layer does not support bipartite message "
+                             f"passing. Please try other layers such as 'SAGEConv' or "
                              f"'GraphConv' instead")
         if self.normalize and isinstance(edge_index, Tensor):
-            cache = self._cached_edge_index
-            if cache is None:
-                edge_index, edge_weight = gcn_norm(edge_index, edge_weight,
-                                                   x.size(self.node_dim), self.improved,
-                                                   self.add_self_loops, self.flow, x.dtype)
-                if self.cached:
-                    self._cached_edge_index = (edge_index, edge_weight)
-            else:
-                edge_index, edge_weight = cache[0], cache[1]
-        x = self.lin(x)
-        out = self.propagate(edge_index, x=x, edge_weight=edge_weight)
-        if self.bias is not None:
-            out = out + self.bias
-        return out
+            edge_index, edge_weight = self._normalized(x, edge_index, edge_weight)
+        out = self.propagate(edge_index, x=self.lin(x), edge_weight=edge_weight)
+        return out if self.bias is None else out + self.bias
 
     def message(self, x_j: Tensor, edge_weight: Optional[Tensor]) -> Tensor:
         return x_j if edge_weight is None else edge_weight.view(-1, 1) * x_j

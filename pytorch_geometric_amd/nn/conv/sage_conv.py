@@ -8,67 +8,62 @@ from ...edge_index import EdgeIndex
 from ..dense.linear import Linear
 from .message_passing import MessagePassing
 
+PairOrTensor = Union[Tensor, Tuple[Tensor, Optional[Tensor]]]
+
 
 class SAGEConv(MessagePassing):
-    r"""GraphSAGE operator ``x_i' = W_1 x_i + W_2 * mean_{j in N(i)} x_j`` — same constructor,
-    parameters (``lin_l``, ``lin_r``, optional ``lin``) and forward semantics as
-    ``torch_geometric.nn.SAGEConv`` (torch_geometric/nn/conv/sage_conv.py:68-152).
+    r"""GraphSAGE operator ``x_i' = W_r x_i + W_l * aggr_{j in N(i)} x_j`` with the constructor
+    arguments, parameter names (``lin_l``, ``lin_r``, ``lin`` when ``project=True``) and forward
+    semantics of ``torch_geometric.nn.SAGEConv`` (torch_geometric/nn/conv/sage_conv.py:68-152),
+    so ``state_dict``s interchange.
 
     The neighbourhood reduction runs at the INPUT width as one CSR SpMM launch
-    (``message_and_aggregate``); the two linear maps are library GEMMs.
+    (``message_and_aggregate``); the linear maps are library GEMMs.
     """
 
     def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int,
                  aggr: str = 'mean', normalize: bool = False, root_weight: bool = True,
                  project: bool = False, bias: bool = True, **kwargs):
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.normalize = normalize
-        self.root_weight = root_weight
-        self.project = project
-        if isinstance(in_channels, int):
-            in_channels = (in_channels, in_channels)
         super().__init__(aggr, **kwargs)
-        if self.project:
-            if in_channels[0] <= 0:
-                raise ValueError(f"'{self.__class__.__name__}' does not support lazy "
-                                 f"initialization with `project=True`")
-            self.lin = Linear(in_channels[0], in_channels[0], bias=True)
-        self.lin_l = Linear(in_channels[0], out_channels, bias=bias)
-        if self.root_weight:
-            self.lin_r = Linear(in_channels[1], out_channels, bias=False)
+        dims = (in_channels, in_channels) if isinstance(in_channels, int) else tuple(in_channels)
+        if min(dims) <= 0:
+            raise ValueError(f"'{type(self).__name__}' needs explicit input sizes (lazy "
+                             f"initialization is not supported)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.normalize, self.root_weight, self.project = normalize, root_weight, project
+        src_dim, dst_dim = dims
+        if project:  # Eq. (3) of the paper: x_j <- relu(W x_j + b) before aggregating
+            self.lin = Linear(src_dim, src_dim, bias=True)
+        self.lin_l = Linear(src_dim, out_channels, bias=bias)
+        if root_weight:
+            self.lin_r = Linear(dst_dim, out_channels, bias=False)
         self.reset_parameters()
+
+    def _linears(self):
+        return [getattr(self, n) for n in ('lin', 'lin_l', 'lin_r') if hasattr(self, n)]
 
     def reset_parameters(self):
         super().reset_parameters()
-        if self.project:
-            self.lin.reset_parameters()
-        self.lin_l.reset_parameters()
-        if self.root_weight:
-            self.lin_r.reset_parameters()
+        for lin in self._linears():
+            lin.reset_parameters()
 
-    def forward(self, x: Union[Tensor, Tuple[Tensor, Optional[Tensor]]], edge_index,
+    def forward(self, x: PairOrTensor, edge_index,
                 size: Optional[Tuple[int, int]] = None) -> Tensor:
-        if isinstance(x, Tensor):
-            x = (x, x)
-        if self.project and hasattr(self, 'lin'):
-            x = (self.lin(x[0]).relu(), x[1])
-        out = self.propagate(edge_index, x=x, size=size)
-        out = self.lin_l(out)
-        x_r = x[1]
-        if self.root_weight and x_r is not None:
-            out = out + self.lin_r(x_r)
-        if self.normalize:
-            out = F.normalize(out, p=2., dim=-1)
-        return out
+        x_src, x_dst = (x, x) if isinstance(x, Tensor) else x
+        if self.project:
+            x_src = self.lin(x_src).relu()
+        h = self.lin_l(self.propagate(edge_index, x=(x_src, x_dst), size=size))
+        if self.root_weight and x_dst is not None:
+            h = h + self.lin_r(x_dst)
+        return F.normalize(h, p=2.0, dim=-1) if self.normalize else h
 
     def message(self, x_j: Tensor) -> Tensor:
         return x_j
 
     def message_and_aggregate(self, graph: EdgeIndex, x) -> Tensor:
-        return SpmmFunction.apply(x[0], None, graph, 'sum' if self.aggr == 'add' else self.aggr,
-                                  'coo')
+        reduce = {'add': 'sum'}.get(self.aggr, self.aggr)
+        return SpmmFunction.apply(x[0], None, graph, reduce, 'coo')
 
     def __repr__(self) -> str:
-        return (f'{self.__class__.__name__}({self.in_channels}, '
-                f'{self.out_channels}, aggr={self.aggr})')
+        return (f'{type(self).__name__}({self.in_channels}, {self.out_channels}, '
+                f'aggr={self.aggr})')

@@ -1,36 +1,42 @@
-"""Parameter initialisers with the reference's formulas (torch_geometric/nn/inits.py:8-60)."""
+"""Parameter initialisers: the distributions of torch_geometric/nn/inits.py:8-60 (uniform,
+kaiming-uniform, glorot, constants), applied to plain tensors / parameters; ``None`` is ignored so
+optional parameters can be passed unconditionally."""
 import math
-from typing import Any
+from typing import Optional
 
 from torch import Tensor
 
 
-def uniform(size: int, value: Any):
-    if isinstance(value, Tensor):
-        bound = 1.0 / math.sqrt(size)
-        value.data.uniform_(-bound, bound)
+def _symmetric_uniform_(tensor: Optional[Tensor], bound: float) -> None:
+    if tensor is not None:
+        tensor.data.uniform_(-bound, bound)
 
 
-def kaiming_uniform(value: Any, fan: int, a: float):
-    if isinstance(value, Tensor):
-        bound = math.sqrt(6 / ((1 + a**2) * fan))
-        value.data.uniform_(-bound, bound)
+def uniform(size: int, value: Optional[Tensor]) -> None:
+    """U(-1/sqrt(size), 1/sqrt(size))."""
+    _symmetric_uniform_(value, 1.0 / math.sqrt(size))
 
 
-def glorot(value: Any):
-    if isinstance(value, Tensor):
-        stdv = math.sqrt(6.0 / (value.size(-2) + value.size(-1)))
-        value.data.uniform_(-stdv, stdv)
+def kaiming_uniform(value: Optional[Tensor], fan: int, a: float) -> None:
+    """He-uniform with negative slope ``a`` and the given fan."""
+    _symmetric_uniform_(value, math.sqrt(6.0 / ((1.0 + a * a) * fan)))
 
 
-def constant(value: Any, fill_value: float):
-    if isinstance(value, Tensor):
+def glorot(value: Optional[Tensor]) -> None:
+    """Xavier-uniform over the last two dimensions."""
+    if value is not None:
+        fan_sum = value.size(-2) + value.size(-1)
+        _symmetric_uniform_(value, math.sqrt(6.0 / fan_sum))
+
+
+def constant(value: Optional[Tensor], fill_value: float) -> None:
+    if value is not None:
         value.data.fill_(fill_value)
 
 
-def zeros(value: Any):
-    constant(value, 0.)
+def zeros(value: Optional[Tensor]) -> None:
+    constant(value, 0.0)
 
 
-def ones(value: Any):
-    constant(value, 1.)
+def ones(value: Optional[Tensor]) -> None:
+    constant(value, 1.0)

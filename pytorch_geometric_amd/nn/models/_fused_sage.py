@@ -58,11 +58,15 @@ class FusedSageStack(Function):
             buf = torch.empty(N, Fi, dtype=torch.float32, device=dev)
             return buf, buf
 
+        agg_src0 = None
         if modes[0] == 'pre' and x.is_contiguous():
             buf, inp = x, x
         else:
             buf, inp = new_input(0)
             inp.copy_(x)
+            if x.is_contiguous():
+                agg_src0 = x  # gather from the dense original: rows are not split by the
+                #               2F-stride of the [agg | x] buffer (matters for F = 100)
         bufs: List[Tensor] = []
         wmats: List[Tensor] = []
         out = None
@@ -76,7 +80,8 @@ class FusedSageStack(Function):
             else:
                 nbuf, dst = new_input(layer + 1)
             if modes[layer] == 'post':
-                _native.spmm_csr(fwd.ptr, fwd.idx, inp, aggr, n_rows=N, hub=fwd.hub,
+                src = agg_src0 if (layer == 0 and agg_src0 is not None) else inp
+                _native.spmm_csr(fwd.ptr, fwd.idx, src, aggr, n_rows=N, hub=fwd.hub,
                                  out=buf[:, :Fi])
                 wmat = torch.cat([W_l, W_r], dim=1)  # [Fo, 2 Fi]
                 if b is not None:
