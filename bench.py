@@ -91,8 +91,102 @@ def cpu_baseline(scale: float, steps: int = 2):
     }
 
 
+def run_minibatch(args, rank, local_rank, world, dev):
+    """BASELINE config 4 (informational second mode; the default mode is the metric's config):
+    GraphSAGE(128, 256, 3 layers, 172 classes) + NeighborLoader [15, 10, 5], batch 1024 per rank,
+    on a synthetic papers100M-shaped graph replicated on every GPU; seeds are sharded across ranks
+    (examples/multi_gpu/distributed_sampling.py:70-71), sampling and feature gather run on the
+    GPU, the only exchange is ONE flat-bucket gradient all-reduce per step."""
+    import torch.distributed as dist
+
+    from pytorch_geometric_amd.data_parallel import (FlatGradBucket, broadcast_parameters,
+                                                     shard_seeds)
+    from pytorch_geometric_amd.datasets import powerlaw_undirected
+    from pytorch_geometric_amd.loader import NeighborLoader
+    from pytorch_geometric_amd.nn import GraphSAGE
+    scale = args.scale if args.scale != 1.0 else 1 / 16
+    N = int(111_059_956 * scale)
+    E = int(1_615_685_872 * scale) // 2 * 2
+    ei = powerlaw_undirected(N, E, seed=3).to(dev)  # same graph on every rank (replicated)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(N, 128, device=dev, generator=g)
+    y = torch.randint(0, 172, (N, ), device=dev, generator=g)
+    train_idx = torch.randperm(N, generator=torch.Generator().manual_seed(11))[:max(N // 90, 1024)]
+    seeds = shard_seeds(train_idx, rank, world)
+    fan = [15, 10, 5]
+    loader = NeighborLoader(x, ei, fan, batch_size=1024, y=y, input_nodes=seeds, shuffle=True,
+                            drop_last=True, seed=17 + rank)
+    torch.manual_seed(0)
+    model = GraphSAGE(128, 256, num_layers=3, out_channels=172).to(dev)
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def batches():
+        while True:
+            for b in loader:
+                yield b
+
+    it = batches()
+    edges = 0
+
+    def step():
+        nonlocal edges
+        b = next(it)
+        bucket.zero_()
+        out = model(b.x, b.graph, num_sampled_nodes_per_hop=b.num_sampled_nodes,
+                    num_sampled_edges_per_hop=b.num_sampled_edges)[:b.batch_size]
+        loss = F.cross_entropy(out, b.y[:b.batch_size])
+        loss.backward()
+        bucket.all_reduce_mean()
+        opt.step()
+        ne = b.num_sampled_edges  # layer l aggregates the edges of hops 0 .. L-1-l
+        edges += sum(sum(ne[:len(ne) - l]) for l in range(len(ne)))
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    edges = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(loss).item()
+    t = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tm = t[:1].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        t[0] = tm[0]
+    elapsed, total_edges = float(t[0]), float(t[1])
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'edges/sec (fwd+bwd) 3-layer SAGE + NeighborLoader [15,10,5], '
+                      'papers100M shape (BASELINE config 4, informational)',
+            'value': total_edges / elapsed, 'unit': 'edges/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'GraphSAGE(128->256->256->172) mini-batch training, batch '
+                                   f'1024 seeds/rank, fan-out {fan}, trim_to_layer, synthetic '
+                                   f'papers100M shape x {scale:g} (N={N}, E={E}) replicated per '
+                                   f'GPU, GPU sampler + gather',
+                       'parallelism': f'dp{world} (seed sharding, one flat-bucket '
+                                      f'all-reduce/step)'}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', choices=['fullbatch', 'minibatch'], default='fullbatch',
+                    help="'fullbatch' = BASELINE config 2 (the metric's configuration); "
+                         "'minibatch' = config 4, informational")
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
@@ -129,6 +223,13 @@ def main():
     if not args.no_tuned_gemm:
         from pytorch_geometric_amd.tuning import enable_tuned_gemms
         tuned = enable_tuned_gemms()
+
+    if args.mode == 'minibatch':
+        run_minibatch(args, rank, local_rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     idx_dtype = torch.int64 if args.index_dtype == 'int64' else torch.int32
     t_gen = time.perf_counter()

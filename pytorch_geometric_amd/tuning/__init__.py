@@ -21,6 +21,8 @@ def enable_tuned_gemms(path: str = CSV) -> bool:
         tunable.tuning_enable(False)
         if hasattr(tunable, 'record_untuned_enable'):
             tunable.record_untuned_enable(False)
+        if hasattr(tunable, 'write_file_on_exit'):
+            tunable.write_file_on_exit(False)  # read-only: never rewrite the shipped table
         tunable.set_filename(path, insert_device_ordinal=False)
         return bool(tunable.read_file(path))
     except Exception:
