@@ -493,13 +493,16 @@ def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Ten
 
 
 def gather_scatter_add(x: Tensor, gather_idx: Tensor, scatter_idx: Tensor, n_out: int,
-                       scale: Optional[Tensor] = None, w: Optional[Tensor] = None) -> Tensor:
-    """out[scatter_idx[e]] += scale[gather_idx[e]] * w[e] * x[gather_idx[e]] (zeros-initialised)."""
-    _require_device(x, gather_idx, scatter_idx, scale, w)
+                       scale: Optional[Tensor] = None, w: Optional[Tensor] = None,
+                       out: Optional[Tensor] = None) -> Tensor:
+    """out[scatter_idx[e]] += scale[gather_idx[e]] * w[e] * x[gather_idx[e]]; ``out`` defaults to
+    zeros, or accumulates into the given (row-strided) buffer."""
+    _require_device(x, gather_idx, scatter_idx, scale, w, out)
     lib = _lib.load()
     x2 = _f32_rows(x, 'x')
     F = x2.size(1)
-    out = torch.zeros(n_out, F, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.zeros(n_out, F, dtype=torch.float32, device=x.device)
     gi, si = gather_idx.contiguous(), scatter_idx.contiguous()
     if scale is not None:
         scale = scale.contiguous()

@@ -119,7 +119,11 @@ class GraphSAGE(BasicGNN):
                 edge_attr: Optional[Tensor] = None,
                 num_sampled_nodes_per_hop: Optional[List[int]] = None,
                 num_sampled_edges_per_hop: Optional[List[int]] = None) -> Tensor:
-        from . import _fused_sage
+        from . import _fused_sage, _fused_sage_hops
+        if _fused_sage_hops.eligible(self, x, edge_index, num_sampled_nodes_per_hop,
+                                     num_sampled_edges_per_hop):
+            return _fused_sage_hops.run(self, x, edge_index, num_sampled_nodes_per_hop,
+                                        num_sampled_edges_per_hop)
         if _fused_sage.eligible(self, x, edge_index, num_sampled_nodes_per_hop is not None):
             return _fused_sage.run(self, x, edge_index)
         return super().forward(x, edge_index, edge_weight, edge_attr,

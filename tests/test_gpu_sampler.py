@@ -113,3 +113,37 @@ def test_full_neighbourhood_batches_reproduce_full_graph_outputs(dev):
         assert_close(grads['handle'][0], grads['tensor'][0].cpu(), atol=2e-5, what='grad_x')
         for a, b in zip(grads['handle'][1], grads['tensor'][1]):
             assert_close(a, b.cpu(), atol=1e-4, rtol=1e-4, what='param grads')
+
+
+def test_hop_aware_fused_stack_matches_layer_loop(dev):
+    """Sampled batch [10, 5, 3]: the hop-aware fused stack (prefix SpMM + one GEMM per layer over
+    the needed rows only) equals the trimmed layer loop on every returned row, and in every
+    gradient (x and parameters)."""
+    from pytorch_geometric_amd.loader import NeighborLoader
+    from pytorch_geometric_amd.nn import GraphSAGE
+    n = 5000
+    ei = random_graph(n, n, 60_000, seed=9, skew=True)
+    g = gen(9)
+    x = torch.randn(n, 12, generator=g)
+    torch.manual_seed(4)
+    model = GraphSAGE(12, 16, num_layers=3, out_channels=5).to(dev)
+    loader = NeighborLoader(x.to(dev), ei.to(dev), [10, 5, 3], batch_size=64,
+                            input_nodes=torch.arange(128, device=dev))
+    for batch in loader:
+        res = {}
+        for fused in (True, False):
+            model.fuse_stack = fused
+            model.zero_grad()
+            xb = batch.x.clone().requires_grad_(True)
+            out = model(xb, batch.graph, num_sampled_nodes_per_hop=batch.num_sampled_nodes,
+                        num_sampled_edges_per_hop=batch.num_sampled_edges)
+            w = torch.linspace(0.5, 1.5, out.numel(), device=dev).view_as(out)
+            (out * w).sum().backward()
+            res[fused] = (out.detach(), xb.grad.clone(),
+                          [p.grad.clone() for p in model.parameters()])
+        assert res[True][0].shape == res[False][0].shape  # the reference's output rows
+        assert_close(res[True][0], res[False][0].cpu(), atol=2e-5, what='hop stack out')
+        assert_close(res[True][1], res[False][1].cpu(), atol=2e-5, what='hop stack grad_x')
+        for a, b in zip(res[True][2], res[False][2]):
+            assert_close(a, b.cpu(), atol=1e-4, rtol=1e-4, what='hop stack param grad')
+    model.fuse_stack = True
