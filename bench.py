@@ -33,13 +33,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 
 def spmm_algorithmic_bytes(info) -> float:
     """E*(4F + b) + (N_rows + 1)*b + N_rows*4F  (+ N*4 for the mean's degree
-    vector when it is read as a per-source scale)."""
+    vector when it is read as a per-source scale, + N_rows*4F when the launch accumulates onto
+    its output, i.e. the fused `grad_root + A^T grad_agg` of the backward)."""
     b, Fw = info['idx_bytes'], info['F']
     total = info['nnz'] * (4 * Fw + b) + (info['n_rows'] + 1) * b + info['n_rows'] * 4 * Fw
     if info['src_scale']:
         total += info['n_src'] * 4
     if info['weighted']:
         total += info['nnz'] * 4
+    if info.get('accumulate'):
+        total += info['n_rows'] * 4 * Fw  # out += result: the old rows are read as well
     return float(total)
 
 

@@ -227,7 +227,7 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
         sink.append(({'n_rows': n_rows, 'n_src': x2.size(0), 'nnz': nnz, 'F': F,
                       'reduce': reduce, 'idx_bytes': rowptr.element_size(),
                       'weighted': w is not None, 'src_scale': src_scale is not None,
-                      'n_hub': a.n_hub}, ev0, ev1))
+                      'accumulate': bool(accumulate), 'n_hub': a.n_hub}, ev0, ev1))
     return (out, arg) if return_arg else out
 
 
