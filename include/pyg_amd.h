@@ -270,6 +270,20 @@ PYGAMD_API int pygamd_segment_softmax_backward(const float* out, const float* gr
                                                const void* ptr, int idx_dtype, int64_t n_seg,
                                                int64_t H, float* grad_src, void* stream);
 
+/* ---- a15: GAT node terms ----------------------------------------------------------------------
+ * out_a[n,h] = sum_c x[n, h*C + c] * att_a[h*C + c]  (and out_b with att_b when given) — the
+ * `(x * att).sum(-1)` pair of nn/conv/gat_conv.py:330-332 in one pass over x.  Backward:
+ * grad_x[n,f] = grad_a[n,h(f)] att_a[f] + grad_b[n,h(f)] att_b[f]  (grad_x may be NULL),
+ * grad_att_a[f] = sum_n grad_a[n,h(f)] x[n,f]  (zeroed internally, atomics).                     */
+PYGAMD_API int pygamd_head_dot_forward(const float* x, int64_t ldx, const float* att_a,
+                                       const float* att_b, int64_t n_rows, int64_t H, int64_t C,
+                                       float* out_a, float* out_b, void* stream);
+PYGAMD_API int pygamd_head_dot_backward(const float* x, int64_t ldx, const float* att_a,
+                                        const float* att_b, const float* grad_a,
+                                        const float* grad_b, int64_t n_rows, int64_t H,
+                                        int64_t C, float* grad_x, int64_t ldg,
+                                        float* grad_att_a, float* grad_att_b, void* stream);
+
 /* ---- a15: fused GAT edge logits ------------------------------------------------------------
  * nn/conv/gat_conv.py:387-406 on a dst-sorted handle: for slot k in row i,
  *   logit = leaky_relu(alpha_src[col[k],h] + alpha_dst[i,h], slope); softmax over the row.

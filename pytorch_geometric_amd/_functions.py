@@ -233,3 +233,34 @@ class GatEdgeSoftmaxFunction(Function):
         g_src, g_dst = _native.gat_edge_softmax_backward(fwd.ptr, fwd.idx, alpha_src, alpha_dst,
                                                          alpha, grad_alpha, ctx.slope)
         return g_src, g_dst, None, None
+
+
+class HeadDotFunction(Function):
+    """(a_src, a_dst) = ((x * att_src).sum(-1), (x * att_dst).sum(-1)) for x [N, H, C] and
+    att_* [1, H, C] (nn/conv/gat_conv.py:330-332) — one pass over x, one fused backward."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, att_a: Tensor, att_b: Optional[Tensor]):
+        N, H, C = x.shape
+        out_a, out_b = _native.head_dot_forward(x.reshape(N, H * C), att_a.reshape(-1),
+                                                None if att_b is None else att_b.reshape(-1),
+                                                H, C)
+        if att_b is None:
+            raise ValueError('HeadDotFunction needs both attention vectors')
+        ctx.save_for_backward(x, att_a, att_b)
+        ctx.has_b = True
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, grad_a: Tensor, grad_b: Tensor):
+        x, att_a, att_b = ctx.saved_tensors
+        N, H, C = x.shape
+        if grad_a is None:
+            grad_a = x.new_zeros(N, H)
+        if ctx.has_b and grad_b is None:
+            grad_b = x.new_zeros(N, H)
+        gx, ga, gb = _native.head_dot_backward(
+            x.reshape(N, H * C), att_a.reshape(-1), None if att_b is None else att_b.reshape(-1),
+            grad_a, grad_b if ctx.has_b else None, H, C, ctx.needs_input_grad[0])
+        return (None if gx is None else gx.view(N, H, C), ga.view(att_a.shape),
+                None if gb is None else gb.view(att_b.shape))

@@ -512,3 +512,41 @@ def gather_scatter_add(x: Tensor, gather_idx: Tensor, scatter_idx: Tensor, n_out
                                         _p(scale), _p(w), gi.numel(), F, _p(out), _ld(out),
                                         _stream(x)), 'gather_scatter_add')
     return out
+
+
+# ---- GAT node terms ----------------------------------------------------------------------------
+def head_dot_forward(x: Tensor, att_a: Tensor, att_b: Optional[Tensor], H: int, C: int):
+    """(a, b) with a[n,h] = <x[n,h,:], att_a[h,:]>; x is [N, H*C]."""
+    _require_device(x, att_a, att_b)
+    lib = _lib.load()
+    x2 = _f32_rows(x, 'x')
+    n = x2.size(0)
+    att_a = att_a.contiguous()
+    out_a = torch.empty(n, H, dtype=torch.float32, device=x.device)
+    out_b = None
+    if att_b is not None:
+        att_b = att_b.contiguous()
+        out_b = torch.empty(n, H, dtype=torch.float32, device=x.device)
+    check(lib.pygamd_head_dot_forward(_p(x2), _ld(x2), _p(att_a), _p(att_b), n, H, C, _p(out_a),
+                                      _p(out_b), _stream(x)), 'head_dot_forward')
+    return out_a, out_b
+
+
+def head_dot_backward(x: Tensor, att_a: Tensor, att_b: Optional[Tensor], grad_a: Tensor,
+                      grad_b: Optional[Tensor], H: int, C: int, need_grad_x: bool):
+    _require_device(x, att_a, att_b, grad_a, grad_b)
+    lib = _lib.load()
+    x2 = _f32_rows(x, 'x')
+    n = x2.size(0)
+    att_a, grad_a = att_a.contiguous(), grad_a.contiguous()
+    g_att_a = torch.empty(H * C, dtype=torch.float32, device=x.device)
+    g_att_b = None
+    if att_b is not None:
+        att_b, grad_b = att_b.contiguous(), grad_b.contiguous()
+        g_att_b = torch.empty(H * C, dtype=torch.float32, device=x.device)
+    grad_x = torch.empty(n, H * C, dtype=torch.float32, device=x.device) if need_grad_x else None
+    check(lib.pygamd_head_dot_backward(_p(x2), _ld(x2), _p(att_a), _p(att_b), _p(grad_a),
+                                       _p(grad_b), n, H, C, _p(grad_x),
+                                       H * C if grad_x is not None else 0, _p(g_att_a),
+                                       _p(g_att_b), _stream(x)), 'head_dot_backward')
+    return grad_x, g_att_a, g_att_b

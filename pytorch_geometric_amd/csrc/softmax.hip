@@ -143,6 +143,67 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- GAT node terms: a_src[n,h] = <x[n,h,:], att_src[h,:]>, a_dst likewise ---------------------
+// (nn/conv/gat_conv.py:330-332: `(x * att).sum(-1)` twice = 4 elementwise/reduce launches and
+// their 6 backward launches in the reference).  One wave per node, one pass over x[n, :].
+__global__ void __launch_bounds__(kBlock)
+    head_dot_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ att_a,
+                        const float* __restrict__ att_b, int64_t n_rows, int H, int C,
+                        float* __restrict__ out_a, float* __restrict__ out_b) {
+  const int lane = lane_id();
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  if (n >= n_rows) return;
+  const float* __restrict__ xr = x + n * ldx;
+  for (int h = 0; h < H; ++h) {
+    float pa = 0.f, pb = 0.f;
+    for (int c = lane; c < C; c += kWave) {
+      const float v = xr[h * C + c];
+      pa = fmaf(v, att_a[h * C + c], pa);
+      if (att_b) pb = fmaf(v, att_b[h * C + c], pb);
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      pa += __shfl_xor(pa, off, kWave);
+      pb += __shfl_xor(pb, off, kWave);
+    }
+    if (lane == 0) {
+      out_a[n * H + h] = pa;
+      if (att_b) out_b[n * H + h] = pb;
+    }
+  }
+}
+
+// grad_x[n,f] = ga[n,h(f)] att_a[f] + gb[n,h(f)] att_b[f];  grad_att_a[f] = sum_n ga[n,h(f)] x[n,f]
+// Thread t of a 256-thread block owns column f = f0 + t for a strip of rows; the two column sums
+// leave the block through atomics (grad_att_* zeroed by the host wrapper).
+__global__ void __launch_bounds__(kBlock)
+    head_dot_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ att_a,
+                        const float* __restrict__ att_b, const float* __restrict__ ga,
+                        const float* __restrict__ gb, int64_t n_rows, int H, int C,
+                        int64_t rows_per_block, float* __restrict__ grad_x, int64_t ldg,
+                        float* __restrict__ grad_att_a, float* __restrict__ grad_att_b) {
+  const int64_t F = static_cast<int64_t>(H) * C;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n_rows) r1 = n_rows;
+  for (int64_t f = threadIdx.x; f < F; f += kBlock) {
+    const int h = static_cast<int>(f / C);
+    const float wa = att_a[f];
+    const float wb = att_b ? att_b[f] : 0.f;
+    float sa = 0.f, sb = 0.f;
+    for (int64_t n = r0; n < r1; ++n) {
+      const float xv = x[n * ldx + f];
+      const float va = ga[n * H + h];
+      const float vb = gb ? gb[n * H + h] : 0.f;
+      sa = fmaf(va, xv, sa);
+      sb = fmaf(vb, xv, sb);
+      if (grad_x) grad_x[n * ldg + f] = va * wa + vb * wb;
+    }
+    atomicAdd(grad_att_a + f, sa);
+    if (grad_att_b) atomicAdd(grad_att_b + f, sb);
+  }
+}
+
 }  // namespace pygamd
 
 using namespace pygamd;
@@ -179,6 +240,43 @@ int pygamd_segment_softmax_backward(const float* out, const float* grad_out, con
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });
+}
+
+int pygamd_head_dot_forward(const float* x, int64_t ldx, const float* att_a, const float* att_b,
+                            int64_t n_rows, int64_t H, int64_t C, float* out_a, float* out_b,
+                            void* stream) {
+  if (n_rows < 0 || H < 1 || C < 1 || ldx < H * C) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows == 0) return PYGAMD_OK;
+  if (!x || !att_a || !out_a || (att_b && !out_b)) return PYGAMD_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(head_dot_fwd_kernel,
+                     dim3(static_cast<unsigned>(ceil_div(n_rows, kWavesPerBlock))), dim3(kBlock),
+                     0, as_stream(stream), x, ldx, att_a, att_b, n_rows, static_cast<int>(H),
+                     static_cast<int>(C), out_a, out_b);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+int pygamd_head_dot_backward(const float* x, int64_t ldx, const float* att_a, const float* att_b,
+                             const float* grad_a, const float* grad_b, int64_t n_rows, int64_t H,
+                             int64_t C, float* grad_x, int64_t ldg, float* grad_att_a,
+                             float* grad_att_b, void* stream) {
+  if (n_rows < 0 || H < 1 || C < 1 || ldx < H * C) return PYGAMD_ERR_INVALID_ARG;
+  if (!att_a || !grad_att_a || (att_b && (!grad_b || !grad_att_b)))
+    return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  PYGAMD_HIP_CHECK(hipMemsetAsync(grad_att_a, 0, sizeof(float) * H * C, st));
+  if (grad_att_b) PYGAMD_HIP_CHECK(hipMemsetAsync(grad_att_b, 0, sizeof(float) * H * C, st));
+  if (n_rows == 0) return PYGAMD_OK;
+  if (!x || !grad_a || (grad_x && ldg < H * C)) return PYGAMD_ERR_INVALID_ARG;
+  int64_t blocks = ceil_div(n_rows, 64);
+  if (blocks > 4096) blocks = 4096;
+  const int64_t rows_per_block = ceil_div(n_rows, blocks);
+  blocks = ceil_div(n_rows, rows_per_block);
+  hipLaunchKernelGGL(head_dot_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+                     st, x, ldx, att_a, att_b, grad_a, grad_b, n_rows, static_cast<int>(H),
+                     static_cast<int>(C), rows_per_block, grad_x, ldg, grad_att_a, grad_att_b);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
 }
 
 int pygamd_gat_edge_softmax_forward(const void* rowptr, const void* col, int idx_dtype,

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.nn import Parameter
 
-from ..._functions import GatEdgeSoftmaxFunction, SpmmFunction
+from ..._functions import GatEdgeSoftmaxFunction, HeadDotFunction, SpmmFunction
 from ...edge_index import EdgeIndex, as_edge_index
 from ...utils import add_self_loops, remove_self_loops, softmax
 from ..dense.linear import Linear
@@ -110,8 +110,11 @@ class GATConv(MessagePassing):
                 return_attention_weights: Optional[bool] = None):
         H, C = self.heads, self.out_channels
         x_src, x_dst, res = self._project(x)
-        a_src = (x_src * self.att_src).sum(dim=-1)
-        a_dst = None if x_dst is None else (x_dst * self.att_dst).sum(dim=-1)
+        if x_dst is x_src and x_src.is_cuda and self.fuse:
+            a_src, a_dst = HeadDotFunction.apply(x_src, self.att_src, self.att_dst)
+        else:
+            a_src = (x_src * self.att_src).sum(dim=-1)
+            a_dst = None if x_dst is None else (x_dst * self.att_dst).sum(dim=-1)
 
         if self.add_self_loops and isinstance(edge_index, Tensor):
             n = x_src.size(0) if x_dst is None else min(x_src.size(0), x_dst.size(0))

@@ -469,3 +469,24 @@ def test_gather_scatter_add(dev, F):
     got = _native.gather_scatter_add(x.to(dev), ei[1].int().to(dev), ei[0].int().to(dev), 200)
     ref = torch.zeros(200, F).index_add_(0, ei[0], x[ei[1]])
     assert_sum_close(got, ref, ref.double(), what='plain')
+
+
+@pytest.mark.parametrize('H,C', [(8, 32), (8, 40), (1, 7), (3, 100)])
+def test_head_dot(dev, H, C):
+    """GAT node terms (x * att).sum(-1) for both attention vectors in one pass + fused backward."""
+    from pytorch_geometric_amd._functions import HeadDotFunction
+    g = gen(H * C)
+    x = torch.randn(777, H, C, generator=g)
+    a, b = torch.randn(1, H, C, generator=g), torch.randn(1, H, C, generator=g)
+    ga, gb = torch.randn(777, H, generator=g), torch.randn(777, H, generator=g)
+    xr, ar, br = (t.clone().requires_grad_(True) for t in (x, a, b))
+    ra, rb = (xr * ar).sum(-1), (xr * br).sum(-1)
+    ((ra * ga).sum() + (rb * gb).sum()).backward()
+    xg, ag, bg = (t.to(dev).requires_grad_(True) for t in (x, a, b))
+    oa, ob = HeadDotFunction.apply(xg, ag, bg)
+    ((oa * ga.to(dev)).sum() + (ob * gb.to(dev)).sum()).backward()
+    assert_close(oa, ra.detach(), atol=2e-5)
+    assert_close(ob, rb.detach(), atol=2e-5)
+    assert_close(xg.grad, xr.grad, atol=2e-5)
+    assert_sum_close(ag.grad, ar.grad, ar.grad.double(), atol=2e-4, what='grad att_src')
+    assert_sum_close(bg.grad, br.grad, br.grad.double(), atol=2e-4, what='grad att_dst')
