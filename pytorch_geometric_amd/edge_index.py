@@ -113,6 +113,7 @@ class EdgeIndex:
         self._csr: Optional[CSR] = None   # sorted by destination (aggregation / forward)
         self._csc: Optional[CSR] = None   # sorted by source (transposed / backward)
         self._slot_map = None
+        self._flipped: Optional['EdgeIndex'] = None
         # True: the backward of an aggregation runs the edge-parallel atomic kernel on the COO
         # list instead of building the source-sorted form (graphs used once: sampled batches)
         self.atomic_backward = False
@@ -197,6 +198,52 @@ class EdgeIndex:
             self._csc = build_csr(src, dst, self.num_src_nodes, self.num_dst_nodes,
                                   is_sorted=self.sort_order == 'row')
         return self._csc
+
+    # -- the reference's accessor names (torch_geometric/edge_index.py:626-663, 727-776, 970-1026)
+    def get_csr(self):
+        """``((rowptr, col), perm)``: pointer over ``edge_index[0]``, ``col = edge_index[1]`` sorted
+        by row (stable), ``perm`` = sorted position -> COO position."""
+        c = self.by_src()
+        return (c.ptr, c.idx), c.perm
+
+    def get_csc(self):
+        """``((colptr, row), perm)``: pointer over ``edge_index[1]``, ``row = edge_index[0]``
+        sorted by column (stable)."""
+        c = self.by_dst()
+        return (c.ptr, c.idx), c.perm
+
+    def sort_by(self, sort_order: str):
+        """``(sorted EdgeIndex, perm)`` with ``edge_index[:, perm]`` ordered by ``'row'``
+        (``edge_index[0]``) or ``'col'`` (``edge_index[1]``); stable, bit-identical to
+        ``torch.sort(stable=True)`` on the key row."""
+        if sort_order not in ('row', 'col'):
+            raise ValueError(f"invalid sort_order '{sort_order}'")
+        if self.sort_order == sort_order:
+            return self, None
+        c = self.by_src() if sort_order == 'row' else self.by_dst()
+        keys = _native.ptr2index(c.ptr, c.idx.numel())
+        ei = torch.stack([keys, c.idx]) if sort_order == 'row' else torch.stack([c.idx, keys])
+        out = EdgeIndex(ei, self.sparse_size, sort_order=sort_order, validate=False)
+        return out, c.perm
+
+    def matmul(self, other: Tensor, input_value: Optional[Tensor] = None, reduce: str = 'sum',
+               transpose: bool = False) -> Tensor:
+        r"""Sparse-dense product with the handle as the matrix ``A[edge_index[0], edge_index[1]]``
+        (``EdgeIndex.matmul``, edge_index.py:970-1026): ``A @ other`` reduces ``other[col]`` onto
+        the rows; ``transpose=True`` gives ``A^T @ other``, i.e. what ``propagate`` computes
+        (messages from ``edge_index[0]`` onto ``edge_index[1]``)."""
+        from ._functions import SpmmFunction
+        reduce = 'sum' if reduce == 'add' else reduce
+        if reduce not in ('sum', 'mean', 'min', 'max'):
+            raise ValueError(f"`reduce` argument '{reduce}' not supported")
+        if transpose:
+            return SpmmFunction.apply(other, input_value, self, reduce, 'coo')
+        if self._flipped is None:
+            flipped = EdgeIndex(self.edge_index.flip(0).contiguous(),
+                                (self.sparse_size[1], self.sparse_size[0]), validate=False)
+            flipped._csr, flipped._csc = self._csc, self._csr  # the sorted forms swap roles
+            self._flipped = flipped
+        return SpmmFunction.apply(other, input_value, self._flipped, reduce, 'coo')
 
     def fill_cache_(self) -> 'EdgeIndex':
         self.by_dst().hub

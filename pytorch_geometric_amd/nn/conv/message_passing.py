@@ -49,6 +49,9 @@ class MessagePassing(torch.nn.Module):
         self._msg_params = _params(self.message)
         self._upd_params = _params(self.update)[1:]
         self._edge_params = _params(self.edge_update)
+        self._propagate_forward_pre_hooks = {}
+        self._propagate_forward_hooks = {}
+        self._hook_id = 0
         has_fused = type(self).message_and_aggregate is not MessagePassing.message_and_aggregate
         self._fused_params = _params(self.message_and_aggregate)[1:] if has_fused else None
         self.fuse = has_fused
@@ -155,9 +158,42 @@ class MessagePassing(torch.nn.Module):
             sel[n] = v
         return sel
 
+    # -- hooks (message_passing.py:461-464, 558-561; seam S4 of SURVEY.md §8(b)) -------------------
+    def _register(self, table: dict, hook):
+        self._hook_id += 1
+        key = self._hook_id
+        table[key] = hook
+
+        class _Handle:
+            def remove(_self):
+                table.pop(key, None)
+
+        return _Handle()
+
+    def register_propagate_forward_pre_hook(self, hook):
+        """``hook(module, (edge_index, size, kwargs))`` may return a replacement triple; runs
+        before anything else in ``propagate`` — e.g. to swap a raw ``edge_index`` for a handle."""
+        return self._register(self._propagate_forward_pre_hooks, hook)
+
+    def register_propagate_forward_hook(self, hook):
+        """``hook(module, (edge_index, size, kwargs), output)`` may return a replacement output."""
+        return self._register(self._propagate_forward_hooks, hook)
+
     # -- the hot path -----------------------------------------------------------------------------
     def propagate(self, edge_index, size: Optional[Tuple[int, int]] = None, **kwargs) -> Tensor:
         r"""Gather -> message -> aggregate -> update (message_passing.py:421-563)."""
+        for hook in list(self._propagate_forward_pre_hooks.values()):
+            res = hook(self, (edge_index, size, kwargs))
+            if res is not None:
+                edge_index, size, kwargs = res
+        out = self._propagate(edge_index, size, kwargs)
+        for hook in list(self._propagate_forward_hooks.values()):
+            res = hook(self, (edge_index, size, kwargs), out)
+            if res is not None:
+                out = res
+        return out
+
+    def _propagate(self, edge_index, size, kwargs) -> Tensor:
         size = self._check_input(edge_index, size)
         if self.fuse and self._fused_params is not None and self._can_fuse(kwargs):
             coll = self._collect(self._msg_params, edge_index, size, kwargs, lift=False)

@@ -108,3 +108,39 @@ def test_index_minmax(dev):
     assert _native.index_minmax(t.to(dev)) == (int(t.min()), int(t.max()))
     assert _native.index_minmax(t.int().to(dev)) == (int(t.min()), int(t.max()))
     assert _native.index_minmax(torch.empty(0, dtype=torch.long, device=dev))[1] == -1
+
+
+def test_reference_accessor_names_and_matmul(dev):
+    """get_csr / get_csc / sort_by / matmul with the reference's EdgeIndex semantics
+    (test/test_edge_index.py:360, 733-775, 995-1052: every route equals gather+scatter)."""
+    import pytorch_geometric_amd as pga
+    ei = random_graph(60, 80, 1200, seed=3)
+    h = pga.EdgeIndex(ei.to(dev), (60, 80))
+    (rowptr, col), perm = h.get_csr()
+    ptr, idx, p = O.csr_from_coo(ei[0], ei[1], 60)
+    assert_close(rowptr, ptr); assert_close(col, idx); assert_close(perm, p)
+    (colptr, row), perm = h.get_csc()
+    ptr, idx, p = O.csr_from_coo(ei[1], ei[0], 80)
+    assert_close(colptr, ptr); assert_close(row, idx); assert_close(perm, p)
+    for order, key in (('row', 0), ('col', 1)):
+        s, perm = h.sort_by(order)
+        ref_perm = ei[key].sort(stable=True).indices
+        assert_close(perm, ref_perm)
+        assert_close(s.edge_index, ei[:, ref_perm])
+        assert s.sort_by(order)[1] is None
+    g = gen(8)
+    x_cols = torch.randn(80, 9, generator=g)   # A is [60, 80]: A @ x needs 80 rows
+    x_rows = torch.randn(60, 9, generator=g)
+    val = torch.rand(1200, generator=g)
+    for red in ('sum', 'mean', 'max'):
+        ref = O.scatter(x_cols[ei[1]], ei[0], 0, 60, red)
+        assert_close(h.matmul(x_cols.to(dev), reduce=red), ref, atol=2e-5, what=f'A@x {red}')
+        ref_t = O.scatter(x_rows[ei[0]], ei[1], 0, 80, red)
+        assert_close(h.matmul(x_rows.to(dev), reduce=red, transpose=True), ref_t, atol=2e-5)
+    ref = O.scatter(x_cols[ei[1]] * val.view(-1, 1), ei[0], 0, 60, 'sum')
+    xc = x_cols.to(dev).requires_grad_(True)
+    out = h.matmul(xc, input_value=val.to(dev))
+    assert_close(out, ref, atol=2e-5)
+    out.sum().backward()
+    ref_g = O.scatter(val.view(-1, 1).expand(-1, 9), ei[1], 0, 80, 'sum')
+    assert_close(xc.grad, ref_g, atol=2e-5)

@@ -130,3 +130,25 @@ def test_bench_byte_model():
     for Fw, scaled in [(100, False), (256, False), (256, False), (256, True), (256, True)]:
         total += bench.spmm_algorithmic_bytes(dict(info, F=Fw, src_scale=scaled))
     assert 285e9 < total < 295e9
+
+
+def test_propagate_hooks_run_without_a_gpu():
+    """test/nn/conv/test_message_passing.py hooks: a pre-hook can replace the inputs, a post-hook
+    the output; handles remove themselves."""
+    import pytorch_geometric_amd as pga
+    conv = pga.nn.SAGEConv(4, 4)
+    seen = []
+
+    def pre(module, inputs):
+        seen.append('pre')
+        raise RuntimeError('stop here')  # proves the hook ran before any kernel was needed
+
+    h = conv.register_propagate_forward_pre_hook(pre)
+    with pytest.raises(RuntimeError, match='stop here'):
+        conv(torch.randn(3, 4), torch.zeros(2, 2, dtype=torch.long))
+    assert seen == ['pre']
+    h.remove()
+    assert not conv._propagate_forward_pre_hooks
+    post = conv.register_propagate_forward_hook(lambda m, i, o: o)
+    assert len(conv._propagate_forward_hooks) == 1
+    post.remove()
