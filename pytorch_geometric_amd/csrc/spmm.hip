@@ -139,7 +139,7 @@ __device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT sta
       if constexpr (IDENT) {
         myc = k;
       } else {
-        myc = a.col[k];
+        myc = __builtin_nontemporal_load(&a.col[k]);  // streamed once: keep L2 for feature rows
       }
       if constexpr (WMODE != 0) {
         mye = a.eid ? a.eid[k] : k;
@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
 #pragma unroll
           for (int i = 0; i < VW; ++i) o.v[i] += old.v[i];
         }
-        store_vec<VW>(orow + fo[c], o);
+#pragma unroll
+        for (int i = 0; i < VW; ++i) __builtin_nontemporal_store(o.v[i], orow + fo[c] + i);
       }
     }
   }
