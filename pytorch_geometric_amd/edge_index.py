@@ -109,6 +109,11 @@ class EdgeIndex:
                         f"{hi}). Please ensure that all indices in 'edge_index' point to valid "
                         f"indices in the interval [0, {n}) in your node feature matrix and try "
                         f"again.")
+        if validate and sort_order is not None and edge_index.size(1) > 1:
+            key = edge_index[0] if sort_order == 'row' else edge_index[1]
+            if not bool((key[1:] >= key[:-1]).all()):
+                raise ValueError(f"'edge_index' is not sorted by {sort_order} although "
+                                 f"sort_order='{sort_order}' was given")
         self.sort_order = sort_order
         self._csr: Optional[CSR] = None   # sorted by destination (aggregation / forward)
         self._csc: Optional[CSR] = None   # sorted by source (transposed / backward)

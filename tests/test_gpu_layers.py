@@ -315,3 +315,24 @@ def test_segment_matmul(dev):
         assert_close(out, ref.detach(), atol=2e-5, what=f'segmm {K}x{N}')
         assert_close(xg.grad, xr.grad, atol=2e-5, what=f'segmm grad_x {K}x{N}')
         assert_close(wg.grad, wr.grad, atol=1e-4, rtol=1e-4, what=f'segmm grad_w {K}x{N}')
+
+
+def test_unfused_path_flow_and_sort_order_validation(dev):
+    """fuse=False with flow='target_to_source' equals the fused path on the flipped edge list;
+    a wrong sort_order claim is rejected."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd.nn import SAGEConv
+    from tests._util import random_graph
+    ei = random_graph(50, 50, 600, seed=2).to(dev)
+    x = torch.randn(50, 6, generator=gen(2)).to(dev)
+    torch.manual_seed(0)
+    a = SAGEConv(6, 5, flow='target_to_source').to(dev)
+    b = SAGEConv(6, 5).to(dev)
+    b.load_state_dict(a.state_dict())
+    ref = b(x, ei.flip(0).contiguous())
+    a.fuse = False
+    assert_close(a(x, ei), ref.cpu(), atol=2e-5)
+    a.fuse = True
+    assert_close(a(x, ei), ref.cpu(), atol=2e-5)
+    with pytest.raises(ValueError, match='not sorted'):
+        pga.EdgeIndex(ei, (50, 50), sort_order='col')

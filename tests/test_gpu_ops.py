@@ -490,3 +490,40 @@ def test_head_dot(dev, H, C):
     assert_close(xg.grad, xr.grad, atol=2e-5)
     assert_sum_close(ag.grad, ar.grad, ar.grad.double(), atol=2e-4, what='grad att_src')
     assert_sum_close(bg.grad, br.grad, br.grad.double(), atol=2e-4, what='grad att_dst')
+
+
+def test_spmm_arg_output_and_weighted_mean(dev):
+    """arg_out of min/max (first slot on ties, -1 for empty rows) and the mean-with-weights route."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd._functions import SpmmFunction
+    ei = random_graph(120, 90, 1500, seed=14, skew=True)
+    g = gen(14)
+    x = torch.randint(-2, 3, (120, 12), generator=g).float()  # many ties
+    h = pga.EdgeIndex(ei.to(dev), (120, 90))
+    fwd = h.by_dst()
+    for red in ('max', 'min'):
+        out, arg = _native.spmm_csr(fwd.ptr, fwd.idx, x.to(dev), red, n_rows=90, return_arg=True)
+        out, arg = out.cpu(), arg.cpu()
+        ptr, idx = fwd.ptr.cpu(), fwd.idx.cpu()
+        for r in range(90):
+            s, e = int(ptr[r]), int(ptr[r + 1])
+            if e == s:
+                assert (arg[r] == -1).all() and (out[r] == 0).all()
+                continue
+            vals = x[idx[s:e]]
+            best = vals.max(0).values if red == 'max' else vals.min(0).values
+            first = (vals == best).int().argmax(0) + s  # first slot attaining the extremum
+            assert torch.equal(out[r], best) and torch.equal(arg[r], first)
+    w = torch.rand(1500, generator=g)
+    xf = torch.randn(120, 12, generator=g)
+    xr, wr = xf.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = O.propagate(xr, ei, 90, 'mean', wr)
+    go = torch.randn(90, 12, generator=g)
+    ref.backward(go)
+    xg, wg = xf.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    out = SpmmFunction.apply(xg, wg, h, 'mean', 'coo')
+    out.backward(go.to(dev))
+    assert_close(out, ref.detach(), atol=2e-5)
+    assert_close(xg.grad, xr.grad, atol=2e-5)
+    assert_close(wg.grad, wr.grad, atol=5e-5, rtol=1e-4)
