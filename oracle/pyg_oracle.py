@@ -238,6 +238,12 @@ def sage_conv(x, edge_index, w_l, b_l, w_r, aggr='mean', num_dst=None, x_dst=Non
     return out
 
 
+def graph_conv(x, edge_index, w_rel, b_rel, w_root, edge_weight=None, aggr='add'):
+    """nn/conv/graph_conv.py:78-95: ``lin_rel(aggr_j e_ji x_j) + lin_root(x_i)``."""
+    out = F.linear(propagate(x, edge_index, x.size(0), aggr, edge_weight), w_rel, b_rel)
+    return out + F.linear(x, w_root)
+
+
 def gcn_conv(x, edge_index, w, b, edge_weight=None, improved=False, add_self_loops_=True,
              normalize=True):
     """nn/conv/gcn_conv.py:227-268: normalise -> lin -> propagate(add) -> bias."""

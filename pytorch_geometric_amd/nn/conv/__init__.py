@@ -3,5 +3,6 @@ from .sage_conv import SAGEConv
 from .gcn_conv import GCNConv, gcn_norm
 from .gat_conv import GATConv
 from .rgcn_conv import RGCNConv
+from .graph_conv import GraphConv
 
-__all__ = ['MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv', 'RGCNConv']
+__all__ = ['MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv', 'RGCNConv', 'GraphConv']

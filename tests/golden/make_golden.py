@@ -17,7 +17,8 @@ sys.path.insert(0, os.environ.get('PYG_REFERENCE', '/root/reference'))
 import torch_geometric  # noqa: E402
 import torch_geometric.typing as pyg_typing  # noqa: E402
 from torch_geometric.index import index2ptr, ptr2index  # noqa: E402
-from torch_geometric.nn import GAT, GCN, GATConv, GCNConv, GraphSAGE, RGCNConv, SAGEConv  # noqa
+from torch_geometric.nn import (GAT, GCN, GATConv, GCNConv, GraphConv, GraphSAGE,  # noqa
+                                RGCNConv, SAGEConv)
 from torch_geometric.nn.conv.gcn_conv import gcn_norm  # noqa: E402
 from torch_geometric.utils import (add_remaining_self_loops, add_self_loops, index_sort,  # noqa
                                    remove_self_loops, scatter, segment, softmax, spmm,
@@ -195,6 +196,9 @@ L['rgcn_blocks'] = layer_case(RGCNConv(16, 12, num_relations=5, num_blocks=4), 2
                               edge_type)
 L['rgcn_bases'] = layer_case(RGCNConv(16, 10, num_relations=5, num_bases=3), 211, edge_index,
                              edge_type)
+L['graph_add_weighted'] = layer_case(GraphConv(16, 10, aggr='add'), 212, edge_index, edge_weight)
+L['graph_mean'] = layer_case(GraphConv(16, 10, aggr='mean'), 213, edge_index)
+L['graph_max'] = layer_case(GraphConv(16, 10, aggr='max'), 214, edge_index)
 G['layers'] = L
 
 # GAT attention weights (return_attention_weights)

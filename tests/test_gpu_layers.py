@@ -336,3 +336,16 @@ def test_unfused_path_flow_and_sort_order_validation(dev):
     assert_close(a(x, ei), ref.cpu(), atol=2e-5)
     with pytest.raises(ValueError, match='not sorted'):
         pga.EdgeIndex(ei, (50, 50), sort_order='col')
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_graph_conv_golden(dev, golden, fuse):
+    from pytorch_geometric_amd.nn import GraphConv
+    gr, L = golden['graph'], golden['layers']
+    for name, kw, args in [('graph_add_weighted', dict(aggr='add'),
+                            (gr['edge_index'], gr['edge_weight'])),
+                           ('graph_mean', dict(aggr='mean'), (gr['edge_index'], )),
+                           ('graph_max', dict(aggr='max'), (gr['edge_index'], ))]:
+        conv = GraphConv(16, 10, **kw)
+        conv.fuse = fuse
+        _run_layer(conv, L[name], gr['x'], dev, *args)

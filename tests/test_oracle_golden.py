@@ -168,6 +168,12 @@ def test_layers(golden):
     _check_layer(L['gat_noloops'],
                  lambda x, a_s, a_d, b, w: O.gat_conv(x, ei, w, a_s, a_d, b, 2, 6,
                                                       add_self_loops_=False), gat_names)
+    gc = ['lin_rel.weight', 'lin_rel.bias', 'lin_root.weight']
+    _check_layer(L['graph_add_weighted'],
+                 lambda x, w, b, r: O.graph_conv(x, ei, w, b, r, ew, 'add'), gc)
+    _check_layer(L['graph_mean'], lambda x, w, b, r: O.graph_conv(x, ei, w, b, r, None, 'mean'),
+                 gc)
+    _check_layer(L['graph_max'], lambda x, w, b, r: O.graph_conv(x, ei, w, b, r, None, 'max'), gc)
     _check_layer(L['rgcn'], lambda x, w, r, b: O.rgcn_conv(x, ei, et, w, r, b),
                  ['weight', 'root', 'bias'])
     _check_layer(L['rgcn_blocks'], lambda x, w, r, b: O.rgcn_conv_blocks(x, ei, et, w, r, b),
