@@ -200,7 +200,8 @@ PYGAMD_API int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_
  * every non-empty segment in chunks of pygamd_segment_matmul_tile_rows() rows; W[g] is addressed
  * as w[g * w_seg_stride + k * w_stride_k + n * w_stride_n] so the same entry point computes the
  * input gradient (W^T: swap the two strides).  _wgrad: grad_w[g] = x[seg]^T @ g[seg] ([K, N]
- * row-major per segment; empty segments give 0).                                               */
+ * row-major per segment; empty segments give 0); `chunks` uses the same triple format with any
+ * chunk length (long segments are split so no wave walks a whole relation; fp32 atomics).      */
 PYGAMD_API int pygamd_segment_matmul_tile_rows(void);
 PYGAMD_API int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w,
                                      int64_t w_seg_stride, int64_t w_stride_k,
@@ -208,8 +209,9 @@ PYGAMD_API int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w
                                      int64_t K, int64_t N, float* out, int64_t ldo,
                                      void* stream);
 PYGAMD_API int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g,
-                                           int64_t ldg, const int64_t* ptr, int64_t n_seg,
-                                           int64_t K, int64_t N, float* grad_w, void* stream);
+                                           int64_t ldg, const int32_t* chunks, int64_t n_chunks,
+                                           int64_t n_seg, int64_t K, int64_t N, float* grad_w,
+                                           void* stream);
 
 /* ---- a2: gather (index_select along dim 0) --------------------------------------------------
  * out[e, :] = x[index[e], :]  (nn/conv/message_passing.py:263-290, collect.jinja:118-127).

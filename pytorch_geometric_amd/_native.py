@@ -423,8 +423,12 @@ def gat_edge_softmax_backward(rowptr, col, alpha_src, alpha_dst, alpha, grad_alp
 _segmm_plans = {}
 
 
+WGRAD_CHUNK_ROWS = 2048
+
+
 def segmm_plan(ptr_host: tuple, device):
-    """(tiles int32 [T,3] on device, T, ptr int64 on device) for a host pointer tuple; cached."""
+    """(tiles int32 [T,3], T, wgrad chunks int32 [C,3], C) on `device` for a host pointer tuple;
+    cached.  Tiles cover every non-empty segment in 64-row pieces, chunks in 2048-row pieces."""
     key = (ptr_host, str(device))
     hit = _segmm_plans.get(key)
     if hit is not None:
@@ -435,11 +439,16 @@ def segmm_plan(ptr_host: tuple, device):
         a, b = ptr_host[g], ptr_host[g + 1]
         for r in range(a, b, tm):
             tiles.append((g, r, min(tm, b - r)))
+    chunks = []
+    for g in range(len(ptr_host) - 1):
+        a, b = ptr_host[g], ptr_host[g + 1]
+        for r in range(a, b, WGRAD_CHUNK_ROWS):
+            chunks.append((g, r, min(WGRAD_CHUNK_ROWS, b - r)))
     t = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 3).to(device)
-    p = torch.tensor(ptr_host, dtype=torch.int64).to(device)
+    c = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 3).to(device)
     if len(_segmm_plans) > 32:
         _segmm_plans.pop(next(iter(_segmm_plans)))
-    _segmm_plans[key] = (t, len(tiles), p)
+    _segmm_plans[key] = (t, len(tiles), c, len(chunks))
     return _segmm_plans[key]
 
 
@@ -447,14 +456,15 @@ def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False) -> Ten
     """out[seg] = x[seg] @ W[g]  (or @ W[g]^T when transpose_w) — W is [G, K, N] contiguous."""
     _require_device(x, w)
     lib = _lib.load()
-    tiles, n_tiles, _ = plan
+    tiles, n_tiles = plan[0], plan[1]
     x2 = _f32_rows(x, 'x')
+    if transpose_w:
+        # materialise W^T once (tiny next to the activations): the kernel then streams weight
+        # rows with coalesced 128-byte loads instead of gathering a column per lane
+        w = w.transpose(1, 2)
     w = w.contiguous()
     G, Kw, Nw = w.shape
-    if transpose_w:
-        K, N, sk, sn = Nw, Kw, 1, Nw
-    else:
-        K, N, sk, sn = Kw, Nw, Nw, 1
+    K, N, sk, sn = Kw, Nw, Nw, 1
     if x2.size(1) != K:
         raise ValueError(f"'inputs' has {x2.size(1)} columns but the weights expect {K}")
     out = torch.empty(x2.size(0), N, dtype=torch.float32, device=x.device)
@@ -470,8 +480,9 @@ def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int) -> Tensor:
     x2, g2 = _f32_rows(x, 'x'), _f32_rows(g, 'grad')
     K, N = x2.size(1), g2.size(1)
     gw = torch.empty(n_seg, K, N, dtype=torch.float32, device=x.device)
-    check(lib.pygamd_segment_matmul_wgrad(_p(x2), _ld(x2), _p(g2), _ld(g2), _p(plan[2]), n_seg,
-                                          K, N, _p(gw), _stream(x)), 'segment_matmul_wgrad')
+    check(lib.pygamd_segment_matmul_wgrad(_p(x2), _ld(x2), _p(g2), _ld(g2), _p(plan[2]), plan[3],
+                                          n_seg, K, N, _p(gw), _stream(x)),
+          'segment_matmul_wgrad')
     return gw
 
 

@@ -76,18 +76,23 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// grad_W[g] = x[seg]^T @ grad[seg]: one wave per (segment, 32 k-columns, 64 n-columns); the
-// reduction runs over the segment's rows two at a time (the MFMA's k = 2), operands straight
-// from global (both 128-byte coalesced per half-wave).
+// grad_W[g] = x[seg]^T @ grad[seg]: one wave per (row chunk of a segment, 32 k-columns, 64
+// n-columns); the reduction runs over the chunk's rows two at a time (the MFMA's k = 2), operands
+// straight from global (both 128-byte coalesced per half-wave).  Long segments are split into
+// chunks by the host table so that no single wave walks a 100k-row relation; chunks of one
+// segment meet in grad_w through fp32 atomics (grad_w is zeroed first), single-chunk segments
+// could store directly but share the same path for simplicity.
 __global__ void __launch_bounds__(kWave)
     segmm_wgrad_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g,
-                       int64_t ldg, const int64_t* __restrict__ ptr, int K, int N,
+                       int64_t ldg, const int32_t* __restrict__ chunks, int K, int N,
                        float* __restrict__ gw) {
-  const int seg = blockIdx.x;
+  const int t = blockIdx.x;
+  const int seg = chunks[3 * t];
+  const int64_t ra = chunks[3 * t + 1];
+  const int64_t rb = ra + chunks[3 * t + 2];
   const int k0 = blockIdx.y * 32;
   const int n0 = blockIdx.z * 64;
   const int lane = threadIdx.x;
-  const int64_t ra = ptr[seg], rb = ptr[seg + 1];
   const int kc = k0 + (lane & 31);
   const int col0 = n0 + (lane & 31), col1 = col0 + 32;
   f32x16 acc0, acc1;
@@ -117,8 +122,8 @@ __global__ void __launch_bounds__(kWave)
   for (int i = 0; i < 16; ++i) {
     const int kr = k0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
     if (kr < K) {
-      if (col0 < N) gseg[static_cast<int64_t>(kr) * N + col0] = acc0[i];
-      if (col1 < N) gseg[static_cast<int64_t>(kr) * N + col1] = acc1[i];
+      if (col0 < N) atomicAdd(gseg + static_cast<int64_t>(kr) * N + col0, acc0[i]);
+      if (col1 < N) atomicAdd(gseg + static_cast<int64_t>(kr) * N + col1, acc1[i]);
     }
   }
 }
@@ -148,17 +153,22 @@ int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w, int64_t w
 }
 
 int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg,
-                                const int64_t* ptr, int64_t n_seg, int64_t K, int64_t N,
-                                float* grad_w, void* stream) {
-  if (n_seg < 0 || K < 0 || N < 0 || ldx < K || ldg < N || K > INT32_MAX || N > INT32_MAX)
+                                const int32_t* chunks, int64_t n_chunks, int64_t n_seg,
+                                int64_t K, int64_t N, float* grad_w, void* stream) {
+  if (n_seg < 0 || n_chunks < 0 || K < 0 || N < 0 || ldx < K || ldg < N || K > INT32_MAX ||
+      N > INT32_MAX)
     return PYGAMD_ERR_INVALID_ARG;
   if (n_seg == 0 || K == 0 || N == 0) return PYGAMD_OK;
-  if (!x || !g || !ptr || !grad_w) return PYGAMD_ERR_INVALID_ARG;
+  if (!grad_w) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  PYGAMD_HIP_CHECK(hipMemsetAsync(grad_w, 0, sizeof(float) * n_seg * K * N, st));
+  if (n_chunks == 0) return PYGAMD_OK;
+  if (!x || !g || !chunks) return PYGAMD_ERR_INVALID_ARG;
   if (ceil_div(K, 32) > 65535 || ceil_div(N, 64) > 65535) return PYGAMD_ERR_UNSUPPORTED;
-  const dim3 grid(static_cast<unsigned>(n_seg), static_cast<unsigned>(ceil_div(K, 32)),
+  const dim3 grid(static_cast<unsigned>(n_chunks), static_cast<unsigned>(ceil_div(K, 32)),
                   static_cast<unsigned>(ceil_div(N, 64)));
-  hipLaunchKernelGGL(segmm_wgrad_kernel, grid, dim3(kWave), 0, as_stream(stream), x, ldx, g, ldg,
-                     ptr, static_cast<int>(K), static_cast<int>(N), grad_w);
+  hipLaunchKernelGGL(segmm_wgrad_kernel, grid, dim3(kWave), 0, st, x, ldx, g, ldg, chunks,
+                     static_cast<int>(K), static_cast<int>(N), grad_w);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }
