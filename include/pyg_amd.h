@@ -319,6 +319,20 @@ PYGAMD_API int pygamd_sample_neighbors(const void* colptr, const void* row, int 
                                        void* src_out, void* dstpos_out, void* slot_out,
                                        void* stream);
 
+/* cnt[f] = min(deg(frontier[f]), k) (k < 0: deg) — the per-node sample counts of one hop.        */
+PYGAMD_API int pygamd_sample_counts(const void* colptr, int idx_dtype, const void* frontier,
+                                    int64_t n, int64_t k, void* cnt_out, void* stream);
+/* Relabelling of the sampled sources (global -> local ids, new nodes in order of first
+ * appearance, deterministic).  `local_map` has one entry per graph node; entries
+ * not in the batch hold a value below -(m+1) (the host side uses the type's minimum).
+ * phase 0 "claim":  local[src[e]] = max(local[src[e]], -(e+2));
+ * phase 1 "flag":   flag_or_scan[e] = (local[src[e]] == -(e+2));        (caller scans inclusively)
+ * phase 2 "assign": claimants write local[s] = base + rank and out[rank] = s (out = new nodes);
+ * phase 3 "lookup": out[e] = local[src[e]].                                                      */
+PYGAMD_API int pygamd_relabel(int phase, const void* src, int idx_dtype, int64_t m,
+                              void* local_map, int64_t* flag_or_scan, int64_t base, void* out,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

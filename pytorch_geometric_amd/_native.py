@@ -561,3 +561,36 @@ def head_dot_backward(x: Tensor, att_a: Tensor, att_b: Optional[Tensor], grad_a:
                                        H * C if grad_x is not None else 0, _p(g_att_a),
                                        _p(g_att_b), _stream(x)), 'head_dot_backward')
     return grad_x, g_att_a, g_att_b
+
+
+def sample_counts(colptr: Tensor, frontier: Tensor, k: int) -> Tensor:
+    _require_device(colptr, frontier)
+    lib = _lib.load()
+    cnt = torch.empty_like(frontier)
+    check(lib.pygamd_sample_counts(_p(colptr), _idx_dtype(colptr), _p(frontier),
+                                   frontier.numel(), k, _p(cnt), _stream(colptr)),
+          'sample_counts')
+    return cnt
+
+
+def relabel_new_nodes(src_global: Tensor, local_map: Tensor, base: int):
+    """Assigns local ids base, base+1, ... to the sources not yet in `local_map` (order of first
+    appearance) and returns (new_nodes, row_local).  One host sync (the number of new nodes)."""
+    _require_device(src_global, local_map)
+    lib = _lib.load()
+    m = src_global.numel()
+    dt = _idx_dtype(src_global)
+    st = _stream(src_global)
+    if m == 0:
+        return src_global.new_empty(0), src_global.new_empty(0)
+    check(lib.pygamd_relabel(0, _p(src_global), dt, m, _p(local_map), None, 0, None, st))
+    flag = torch.empty(m, dtype=torch.int64, device=src_global.device)
+    check(lib.pygamd_relabel(1, _p(src_global), dt, m, _p(local_map), _p(flag), 0, None, st))
+    scan = torch.cumsum(flag, 0)
+    n_new = int(scan[-1])  # host sync: sizes the next hop (the frontier)
+    new_nodes = torch.empty(n_new, dtype=src_global.dtype, device=src_global.device)
+    check(lib.pygamd_relabel(2, _p(src_global), dt, m, _p(local_map), _p(scan), base,
+                             _p(new_nodes) if n_new > 0 else _p(flag), st))
+    rows = torch.empty_like(src_global)
+    check(lib.pygamd_relabel(3, _p(src_global), dt, m, _p(local_map), None, 0, _p(rows), st))
+    return new_nodes, rows

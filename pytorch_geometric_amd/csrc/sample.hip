@@ -69,6 +69,75 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// cnt[f] = min(deg(frontier[f]), k)   (k < 0: deg)
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    sample_counts_kernel(const IdxT* __restrict__ colptr, const IdxT* __restrict__ frontier,
+                         int64_t n, int64_t k, IdxT* __restrict__ cnt) {
+  const int64_t f = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (f >= n) return;
+  const int64_t v = frontier[f];
+  const int64_t deg = static_cast<int64_t>(colptr[v + 1]) - static_cast<int64_t>(colptr[v]);
+  cnt[f] = static_cast<IdxT>((k >= 0 && deg > k) ? k : deg);
+}
+
+// ---- relabelling: global ids of the sampled sources -> local ids, new nodes in order of first
+// appearance (what the reference's hash-map insertion produces), deterministic:
+//   claim : local[s] = max(local[s], -(e + 2))  -> the smallest e wins among duplicates; entries
+//           that already hold a local id (>= 0) are never lowered
+//   flag  : flag[e] = (local[src[e]] == -(e + 2))
+//   (inclusive scan of flag on the caller's side)
+//   assign: the claimant writes local[s] = base + scan[e] - 1 and new_nodes[scan[e] - 1] = s
+//   lookup: row[e] = local[src[e]]
+template <typename IdxT>
+__device__ __forceinline__ void atomic_max_idx(IdxT* p, IdxT v);
+template <>
+__device__ __forceinline__ void atomic_max_idx<int32_t>(int32_t* p, int32_t v) {
+  atomicMax(p, v);
+}
+template <>
+__device__ __forceinline__ void atomic_max_idx<int64_t>(int64_t* p, int64_t v) {
+  atomicMax(reinterpret_cast<long long*>(p), static_cast<long long>(v));
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    relabel_claim_kernel(const IdxT* __restrict__ src, int64_t m, IdxT* __restrict__ local) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e < m) atomic_max_idx<IdxT>(local + src[e], static_cast<IdxT>(-(e + 2)));
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    relabel_flag_kernel(const IdxT* __restrict__ src, int64_t m, const IdxT* __restrict__ local,
+                        int64_t* __restrict__ flag) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e < m) flag[e] = (static_cast<int64_t>(local[src[e]]) == -(e + 2)) ? 1 : 0;
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    relabel_assign_kernel(const IdxT* __restrict__ src, int64_t m,
+                          const int64_t* __restrict__ scan, int64_t base,
+                          IdxT* __restrict__ local, IdxT* __restrict__ new_nodes) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= m) return;
+  const int64_t prev = (e == 0) ? 0 : scan[e - 1];
+  if (scan[e] != prev) {  // this entry claimed its source
+    const IdxT s = src[e];
+    local[s] = static_cast<IdxT>(base + prev);
+    new_nodes[prev] = s;
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    relabel_lookup_kernel(const IdxT* __restrict__ src, int64_t m, const IdxT* __restrict__ local,
+                          IdxT* __restrict__ out) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e < m) out[e] = local[src[e]];
+}
+
 }  // namespace pygamd
 
 using namespace pygamd;
@@ -95,6 +164,54 @@ int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
                        n_frontier, static_cast<const IdxT*>(offsets), seed,
                        static_cast<IdxT*>(src_out), static_cast<IdxT*>(dstpos_out),
                        static_cast<IdxT*>(slot_out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_sample_counts(const void* colptr, int idx_dtype, const void* frontier, int64_t n,
+                         int64_t k, void* cnt_out, void* stream) {
+  if (n < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0) return PYGAMD_OK;
+  if (!colptr || !frontier || !cnt_out) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((sample_counts_kernel<IdxT>),
+                       dim3(static_cast<unsigned>(ceil_div(n, kBlock))), dim3(kBlock), 0,
+                       as_stream(stream), static_cast<const IdxT*>(colptr),
+                       static_cast<const IdxT*>(frontier), n, k, static_cast<IdxT*>(cnt_out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_relabel(int phase, const void* src, int idx_dtype, int64_t m, void* local_map,
+                   int64_t* flag_or_scan, int64_t base, void* out, void* stream) {
+  if (m < 0 || phase < 0 || phase > 3) return PYGAMD_ERR_INVALID_ARG;
+  if (m == 0) return PYGAMD_OK;
+  if (!src || !local_map) return PYGAMD_ERR_INVALID_ARG;
+  if ((phase == 1 || phase == 2) && !flag_or_scan) return PYGAMD_ERR_INVALID_ARG;
+  if ((phase == 2 || phase == 3) && !out) return PYGAMD_ERR_INVALID_ARG;
+  const dim3 grid(static_cast<unsigned>(ceil_div(m, kBlock)));
+  hipStream_t st = as_stream(stream);
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const IdxT* s = static_cast<const IdxT*>(src);
+    IdxT* local = static_cast<IdxT*>(local_map);
+    switch (phase) {
+      case 0:
+        hipLaunchKernelGGL((relabel_claim_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, local);
+        break;
+      case 1:
+        hipLaunchKernelGGL((relabel_flag_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, local,
+                           flag_or_scan);
+        break;
+      case 2:
+        hipLaunchKernelGGL((relabel_assign_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m,
+                           flag_or_scan, base, local, static_cast<IdxT*>(out));
+        break;
+      default:
+        hipLaunchKernelGGL((relabel_lookup_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, local,
+                           static_cast<IdxT*>(out));
+    }
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });

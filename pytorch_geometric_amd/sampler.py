@@ -4,7 +4,8 @@ Mirrors the contract of ``torch_geometric.sampler.NeighborSampler._sample`` ->
 ``torch.ops.pyg.neighbor_sample`` (torch_geometric/sampler/neighbor_sampler.py:550-620): a CSC
 graph, seed nodes and a fan-out per hop in; ``SamplerOutput(node, row, col, edge,
 num_sampled_nodes, num_sampled_edges)`` out (torch_geometric/sampler/base.py:168-214) — nodes
-ordered seeds first, then hop by hop; edges ordered hop by hop and, inside a hop, by destination;
+ordered seeds first, then hop by hop in order of first appearance (the reference's hash-map
+insertion order); edges ordered hop by hop and, inside a hop, by destination;
 ``row`` / ``col`` are local source / destination indices into ``node``; ``edge`` are positions in
 the original ``edge_index``.  Uniform without replacement, directed, non-disjoint.
 
@@ -58,8 +59,10 @@ class NeighborSampler:
             raise ValueError('bounded fan-outs above 64 are not supported (use -1 for all)')
         self.seed = seed
         self._calls = 0
-        # global -> local id map, -1 = not in the current batch; reset after every batch
-        self._local = torch.full((num_nodes, ), -1, dtype=self.colptr.dtype,
+        # global -> local id map; the dtype's minimum = not in the current batch (it must sort
+        # below every claim value of pygamd_relabel); reset after every batch
+        self._unset = torch.iinfo(self.colptr.dtype).min
+        self._local = torch.full((num_nodes, ), self._unset, dtype=self.colptr.dtype,
                                  device=self.colptr.device)
 
     @torch.no_grad()
@@ -79,8 +82,7 @@ class NeighborSampler:
                 num_nodes_hop.append(0)
                 num_edges_hop.append(0)
                 continue
-            deg = self.colptr[frontier + 1] - self.colptr[frontier]
-            cnt = deg if k < 0 else deg.clamp(max=k)
+            cnt = _native.sample_counts(self.colptr, frontier, k)
             offsets = torch.zeros(frontier.numel() + 1, dtype=dt, device=dev)
             torch.cumsum(cnt, 0, out=offsets[1:])
             total = int(offsets[-1])  # host sync: sizes the hop's outputs (the reference's
@@ -88,17 +90,9 @@ class NeighborSampler:
             src_g, dstpos, slot = _native.sample_neighbors(
                 self.colptr, self.row, frontier, offsets, total, max(k, 0),
                 (rng * 1_000_003 + hop) & 0x7FFFFFFFFFFFFFFF)
-            # relabel: new nodes = sampled sources not seen yet, in ascending global id
-            if total > 0:
-                skey, _ = _native.index_sort(src_g, max_value=self.num_nodes)
-                first = torch.ones(total, dtype=torch.bool, device=dev)
-                first[1:] = skey[1:] != skey[:-1]
-                uniq = skey[first]
-                new = uniq[local[uniq] < 0]
-            else:
-                new = src_g
-            local[new] = torch.arange(n_nodes, n_nodes + new.numel(), dtype=dt, device=dev)
-            rows.append(local[src_g])
+            # relabel: new nodes = sampled sources not seen yet, in order of first appearance
+            new, row_local = _native.relabel_new_nodes(src_g, local, n_nodes)
+            rows.append(row_local)
             cols.append(dstpos + frontier_base)
             edges.append(self.perm[slot])
             nodes.append(new)
@@ -107,7 +101,7 @@ class NeighborSampler:
             frontier, frontier_base = new, n_nodes
             n_nodes += new.numel()
         node = torch.cat(nodes)
-        local[node] = -1  # leave the map clean for the next batch
+        local[node] = self._unset  # leave the map clean for the next batch
         cat = (lambda xs: torch.cat(xs) if xs else torch.empty(0, dtype=dt, device=dev))
         return SamplerOutput(node=node, row=cat(rows), col=cat(cols), edge=cat(edges),
                              num_sampled_nodes=num_nodes_hop, num_sampled_edges=num_edges_hop)

@@ -33,6 +33,14 @@ def _check_contract(out, ei, seeds, fanouts):
         deg = indeg[node[nb[h]:nb[h + 1]]]
         want = deg if k < 0 else deg.clamp(max=k)
         assert torch.equal(got, want)                             # min(deg, k) per destination
+        # the hop's new nodes are numbered in order of first appearance among its edges (the
+        # reference sampler's hash-map insertion order)
+        fresh = r[r >= nb[h + 1]]
+        if fresh.numel():
+            running_max = torch.cummax(fresh, 0).values
+            first = torch.ones_like(fresh, dtype=torch.bool)
+            first[1:] = fresh[1:] > running_max[:-1]
+            assert torch.equal(fresh[first], torch.arange(nb[h + 1], nb[h + 2]))
 
 
 @pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
@@ -45,7 +53,7 @@ def test_sampler_contract(dev, dtype):
         s = NeighborSampler(ei.to(dtype).to(dev), n, fanouts, seed=7)
         out = s.sample_from_nodes(seeds.to(dev))
         _check_contract(out, ei, seeds, fanouts)
-        assert int((s._local != -1).sum()) == 0                   # map reset for the next batch
+        assert int((s._local != s._unset).sum()) == 0                   # map reset for the next batch
         out2 = s.sample_from_nodes(seeds.to(dev), seed=7)         # same seed -> same batch
         out3 = s.sample_from_nodes(seeds.to(dev), seed=7)
         assert torch.equal(out2.edge, out3.edge) and torch.equal(out2.node, out3.node)
