@@ -92,6 +92,23 @@ PYGAMD_API int pygamd_permute_index(const void* src, int idx_dtype, const int64_
 PYGAMD_API int pygamd_cast_index(const int64_t* src, int64_t n, int idx_dtype, void* out,
                                  void* stream);
 
+/* ---- (f)-4: sort_edge_index / coalesce (torch_geometric/utils/_sort_edge_index.py:105-113,
+ * utils/_coalesce.py:131-176).  Like the reference, both sort the compound key
+ * major * num_nodes + minor (major = row when by_row) with index_sort; these entry points build
+ * the keys, flag the first entry of every run of equal sorted keys, and decode sorted keys back
+ * into (row, col) — compacted to one entry per run when `scan` (the inclusive scan of the run
+ * flags) is given, in which case gid_orig[perm[i]] (perm == NULL: gid_orig[i]) receives the run
+ * slot of every original edge so that edge attributes can be merged with one scatter.
+ * num_nodes^2 must fit int64 (the reference raises the same condition, _coalesce.py:134-135).   */
+PYGAMD_API int pygamd_edge_key(const void* row, const void* col, int idx_dtype, int64_t E,
+                               int64_t num_nodes, int by_row, int64_t* key_out, void* stream);
+PYGAMD_API int pygamd_run_flags(const int64_t* key_sorted, int64_t E, int64_t* flag_out,
+                                void* stream);
+PYGAMD_API int pygamd_edge_unkey(const int64_t* key_sorted, const int64_t* scan,
+                                 const int64_t* perm, int64_t E, int64_t num_nodes, int by_row,
+                                 int idx_dtype, void* out_row, void* out_col, int64_t* gid_orig,
+                                 void* stream);
+
 /* ---- a10: hub plan for a CSR handle ---------------------------------------------------------
  * Rows with more than `threshold` stored entries ("hubs", power-law graphs) are split into
  * chunks of `chunk` entries so no single wavefront walks an unbounded row.  Produces, in

@@ -211,6 +211,77 @@ def add_remaining_self_loops(edge_index, edge_attr=None, fill_value=None, num_no
     return torch.cat([edge_index[:, mask], loop], dim=1), edge_attr
 
 
+# ---- utils/_sort_edge_index.py, utils/_coalesce.py, utils/undirected.py ---------------------------
+def _compound_key(edge_index: Tensor, num_nodes: int, sort_by_row: bool) -> Tensor:
+    major, minor = (edge_index[0], edge_index[1]) if sort_by_row else (edge_index[1],
+                                                                         edge_index[0])
+    return major.long() * num_nodes + minor.long()
+
+
+def sort_edge_index(edge_index: Tensor, edge_attr=None, num_nodes: Optional[int] = None,
+                    sort_by_row: bool = True):
+    """utils/_sort_edge_index.py:103-133: sort the key row*n+col (col*n+row), permute everything.
+    Returns (edge_index, edge_attr) — attr a tensor, a list of tensors or None."""
+    n = int(edge_index.max()) + 1 if num_nodes is None and edge_index.numel() else (num_nodes
+                                                                                     or 0)
+    perm = torch.sort(_compound_key(edge_index, n, sort_by_row), stable=True).indices
+    if isinstance(edge_attr, (list, tuple)):
+        return edge_index[:, perm], [a[perm] for a in edge_attr]
+    return edge_index[:, perm], None if edge_attr is None else edge_attr[perm]
+
+
+def coalesce(edge_index: Tensor, edge_attr=None, num_nodes: Optional[int] = None,
+             reduce: str = 'sum', is_sorted: bool = False, sort_by_row: bool = True):
+    """utils/_coalesce.py:131-193: sort by the compound key, keep the first edge of every run of
+    equal keys, merge the attributes of a run with scatter(reduce)."""
+    n = int(edge_index.max()) + 1 if num_nodes is None and edge_index.numel() else (num_nodes
+                                                                                     or 0)
+    key = _compound_key(edge_index, n, sort_by_row)
+    attrs = list(edge_attr) if isinstance(edge_attr, (list, tuple)) else edge_attr
+    if not is_sorted:
+        key, perm = torch.sort(key, stable=True)
+        edge_index = edge_index[:, perm]
+        if isinstance(attrs, list):
+            attrs = [a[perm] for a in attrs]
+        elif attrs is not None:
+            attrs = attrs[perm]
+    first = torch.ones_like(key, dtype=torch.bool)
+    first[1:] = key[1:] != key[:-1]
+    if bool(first.all()):
+        return edge_index, attrs
+    group = first.long().cumsum(0) - 1
+    n_out = int(first.sum())
+    edge_index = edge_index[:, first]
+    if isinstance(attrs, list):
+        attrs = [scatter(a, group, 0, n_out, reduce) for a in attrs]
+    elif attrs is not None:
+        attrs = scatter(attrs, group, 0, n_out, reduce)
+    return edge_index, attrs
+
+
+def to_undirected(edge_index: Tensor, edge_attr=None, num_nodes: Optional[int] = None,
+                  reduce: str = 'add'):
+    """utils/undirected.py:176-190: append the reversed edges (attributes repeated), coalesce."""
+    both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    if isinstance(edge_attr, (list, tuple)):
+        edge_attr = [torch.cat([a, a], dim=0) for a in edge_attr]
+    elif edge_attr is not None:
+        edge_attr = torch.cat([edge_attr, edge_attr], dim=0)
+    return coalesce(both, edge_attr, num_nodes, reduce)
+
+
+def is_undirected(edge_index: Tensor, edge_attr: Optional[Tensor] = None,
+                  num_nodes: Optional[int] = None) -> bool:
+    """utils/undirected.py:57-80: the row-sorted list must be the transpose of the column-sorted
+    list, attributes included."""
+    a_idx, a_attr = sort_edge_index(edge_index, edge_attr, num_nodes, True)
+    b_idx, b_attr = sort_edge_index(edge_index, edge_attr, num_nodes, False)
+    same = torch.equal(a_idx[0], b_idx[1]) and torch.equal(a_idx[1], b_idx[0])
+    if same and edge_attr is not None:
+        same = torch.equal(a_attr, b_attr)
+    return same
+
+
 # ---- layers ----------------------------------------------------------------------------------------
 def gcn_norm(edge_index, edge_weight=None, num_nodes=None, improved=False,
              add_self_loops_=True):

@@ -594,3 +594,40 @@ def relabel_new_nodes(src_global: Tensor, local_map: Tensor, base: int):
     rows = torch.empty_like(src_global)
     check(lib.pygamd_relabel(3, _p(src_global), dt, m, _p(local_map), None, 0, _p(rows), st))
     return new_nodes, rows
+
+
+def edge_key(row: Tensor, col: Tensor, num_nodes: int, by_row: bool) -> Tensor:
+    _require_device(row, col)
+    lib = _lib.load()
+    row, col = row.contiguous(), col.contiguous()
+    key = torch.empty(row.numel(), dtype=torch.int64, device=row.device)
+    check(lib.pygamd_edge_key(_p(row), _p(col), _idx_dtype(row), row.numel(), num_nodes,
+                              int(by_row), _p(key), _stream(row)), 'edge_key')
+    return key
+
+
+def edge_unkey(key_sorted: Tensor, num_nodes: int, by_row: bool, dtype: torch.dtype,
+               scan: Optional[Tensor] = None, perm: Optional[Tensor] = None,
+               n_out: Optional[int] = None, want_groups: bool = False):
+    """(edge_index [2, n_out], gid_orig | None)"""
+    _require_device(key_sorted)
+    lib = _lib.load()
+    E = key_sorted.numel()
+    out = torch.empty(2, E if n_out is None else n_out, dtype=dtype, device=key_sorted.device)
+    gid = (torch.empty(E, dtype=torch.int64, device=key_sorted.device)
+           if (want_groups and scan is not None) else None)
+    check(lib.pygamd_edge_unkey(_p(key_sorted), None if scan is None else _p(scan),
+                                None if perm is None else _p(perm), E, num_nodes, int(by_row),
+                                _idx_dtype(out), _p(out[0]), _p(out[1]),
+                                None if gid is None else _p(gid), _stream(key_sorted)),
+          'edge_unkey')
+    return out, gid
+
+
+def run_flags(key_sorted: Tensor) -> Tensor:
+    _require_device(key_sorted)
+    lib = _lib.load()
+    flag = torch.empty_like(key_sorted)
+    check(lib.pygamd_run_flags(_p(key_sorted), key_sorted.numel(), _p(flag),
+                               _stream(key_sorted)), 'run_flags')
+    return flag

@@ -8,7 +8,7 @@ modules.  ``install()`` therefore
 1. publishes itself on ``torch_geometric.backend`` (``backend.mi355x`` = this module,
    ``backend.use_mi355x`` flag, ``None`` = auto like ``use_segment_matmul``) — seam S5;
 2. rebinds the dispatcher functions ``scatter``, ``segment``, ``softmax``, ``spmm``,
-   ``index_sort``, ``scatter_argmax`` in EVERY loaded ``torch_geometric*`` module whose attribute ``is`` the
+   ``index_sort``, ``scatter_argmax``, ``sort_edge_index``, ``coalesce`` in EVERY loaded ``torch_geometric*`` module whose attribute ``is`` the
    original function — seam S3 (utils/__init__.py:5-10,36);
 3. wraps ``propagate`` of the hot conv classes (SAGEConv, GCNConv, GraphConv, GATConv) so that a
    plain ``edge_index`` tensor is sorted once (cached handle) and gather -> message -> aggregate
@@ -84,8 +84,28 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
             return U.spmm(src, other, reduce)
         return orig['spmm'](src, other, reduce)
 
+    def _plain_edges(edge_index) -> bool:
+        return (type(edge_index) is Tensor and edge_index.is_cuda and edge_index.dim() == 2
+                and edge_index.size(0) == 2
+                and edge_index.dtype in (torch.int32, torch.int64) and _enabled())
+
+    def sort_edge_index(edge_index, edge_attr=U._sort_edge_index.MISSING, num_nodes=None,
+                        sort_by_row=True):
+        if _plain_edges(edge_index):
+            return U.sort_edge_index(edge_index, edge_attr, num_nodes, sort_by_row)
+        return orig['sort_edge_index'](edge_index, edge_attr, num_nodes, sort_by_row)
+
+    def coalesce(edge_index, edge_attr=U._sort_edge_index.MISSING, num_nodes=None, reduce='sum',
+                 is_sorted=False, sort_by_row=True):
+        attrs = edge_attr if isinstance(edge_attr, (list, tuple)) else [edge_attr]
+        if _plain_edges(edge_index) and all(not isinstance(a, Tensor) or _ours(a)
+                                            for a in attrs):
+            return U.coalesce(edge_index, edge_attr, num_nodes, reduce, is_sorted, sort_by_row)
+        return orig['coalesce'](edge_index, edge_attr, num_nodes, reduce, is_sorted, sort_by_row)
+
     new = dict(scatter=scatter, segment=segment, softmax=softmax, index_sort=index_sort,
-               scatter_argmax=scatter_argmax, spmm=spmm)
+               scatter_argmax=scatter_argmax, spmm=spmm, sort_edge_index=sort_edge_index,
+               coalesce=coalesce)
     for name, fn in new.items():
         fn.__wrapped__ = orig[name]
         fn.__doc__ = orig[name].__doc__
@@ -198,6 +218,7 @@ def install() -> None:
         'scatter': pyg_utils.scatter, 'segment': pyg_utils.segment,
         'softmax': pyg_utils.softmax, 'index_sort': pyg_utils.index_sort,
         'scatter_argmax': pyg_scatter.scatter_argmax, 'spmm': pyg_utils.spmm,
+        'sort_edge_index': pyg_utils.sort_edge_index, 'coalesce': pyg_utils.coalesce,
     }
     new = _make_dispatchers(orig)
     for name in orig:

@@ -111,6 +111,48 @@ __global__ void __launch_bounds__(kBlock)
   if (i < n) out[i] = src[perm[i]];
 }
 
+// key[e] = major[e] * n + minor[e]; major = row when by_row, else col
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    edge_key_kernel(const IdxT* __restrict__ row, const IdxT* __restrict__ col, int64_t E,
+                    int64_t n, int by_row, int64_t* __restrict__ key) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int64_t r = row[e], c = col[e];
+  key[e] = by_row ? r * n + c : c * n + r;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    run_flags_kernel(const int64_t* __restrict__ key, int64_t E, int64_t* __restrict__ flag) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < E) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+
+// Decodes sorted keys back into (row, col).  Without `scan` entry i goes to slot i; with the
+// inclusive scan of the run flags only the first entry of every run is written, to slot
+// scan[i] - 1 (coalesce), and every original edge perm[i] learns its slot through `gid_orig`.
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    edge_unkey_kernel(const int64_t* __restrict__ key, const int64_t* __restrict__ scan,
+                      const int64_t* __restrict__ perm, int64_t E, int64_t n, int by_row,
+                      IdxT* __restrict__ out_row, IdxT* __restrict__ out_col,
+                      int64_t* __restrict__ gid_orig) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= E) return;
+  int64_t slot = i;
+  bool write = true;
+  if (scan != nullptr) {
+    slot = scan[i] - 1;
+    write = (i == 0) || (scan[i - 1] != scan[i]);
+    if (gid_orig != nullptr) gid_orig[perm != nullptr ? perm[i] : i] = slot;
+  }
+  if (!write) return;
+  const int64_t k = key[i];
+  const int64_t major = k / n, minor = k - major * n;
+  out_row[slot] = static_cast<IdxT>(by_row ? major : minor);
+  out_col[slot] = static_cast<IdxT>(by_row ? minor : major);
+}
+
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
     cast_index_kernel(const int64_t* __restrict__ src, int64_t n, IdxT* __restrict__ out) {
@@ -308,6 +350,47 @@ int pygamd_permute_index(const void* src, int idx_dtype, const int64_t* perm, in
     hipLaunchKernelGGL((permute_index_kernel<IdxT>), dim3(grid), dim3(kBlock), 0,
                        as_stream(stream), static_cast<const IdxT*>(src), perm, n,
                        static_cast<IdxT*>(out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_edge_key(const void* row, const void* col, int idx_dtype, int64_t E, int64_t num_nodes,
+                    int by_row, int64_t* key_out, void* stream) {
+  if (E < 0 || num_nodes < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (E == 0) return PYGAMD_OK;
+  if (!row || !col || !key_out || num_nodes == 0) return PYGAMD_ERR_INVALID_ARG;
+  if (num_nodes > 3037000499LL) return PYGAMD_ERR_INVALID_ARG;  // n * n would overflow int64
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((edge_key_kernel<IdxT>), dim3(static_cast<unsigned>(ceil_div(E, kBlock))),
+                       dim3(kBlock), 0, as_stream(stream), static_cast<const IdxT*>(row),
+                       static_cast<const IdxT*>(col), E, num_nodes, by_row, key_out);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_run_flags(const int64_t* key_sorted, int64_t E, int64_t* flag_out, void* stream) {
+  if (E < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (E == 0) return PYGAMD_OK;
+  if (!key_sorted || !flag_out) return PYGAMD_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(run_flags_kernel, dim3(static_cast<unsigned>(ceil_div(E, kBlock))),
+                     dim3(kBlock), 0, as_stream(stream), key_sorted, E, flag_out);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+int pygamd_edge_unkey(const int64_t* key_sorted, const int64_t* scan, const int64_t* perm,
+                      int64_t E, int64_t num_nodes, int by_row, int idx_dtype, void* out_row,
+                      void* out_col, int64_t* gid_orig, void* stream) {
+  if (E < 0 || num_nodes < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (E == 0) return PYGAMD_OK;
+  if (!key_sorted || !out_row || !out_col || num_nodes == 0) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((edge_unkey_kernel<IdxT>),
+                       dim3(static_cast<unsigned>(ceil_div(E, kBlock))), dim3(kBlock), 0,
+                       as_stream(stream), key_sorted, scan, perm, E, num_nodes, by_row,
+                       static_cast<IdxT*>(out_row), static_cast<IdxT*>(out_col), gid_orig);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });

@@ -29,5 +29,11 @@ def golden():
 
 
 @pytest.fixture(scope='session')
+def golden_preproc():
+    path = os.path.join(ROOT, 'tests', 'golden', 'golden_preproc_v1.pt')
+    return torch.load(path, map_location='cpu', weights_only=False)
+
+
+@pytest.fixture(scope='session')
 def dev():
     return torch.device('cuda:0')

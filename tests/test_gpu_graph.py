@@ -144,3 +144,68 @@ def test_reference_accessor_names_and_matmul(dev):
     out.sum().backward()
     ref_g = O.scatter(val.view(-1, 1).expand(-1, 9), ei[1], 0, 80, 'sum')
     assert_close(xc.grad, ref_g, atol=2e-5)
+
+
+# ---- sort_edge_index / coalesce / to_undirected --------------------------------
+def test_preprocessing_matches_reference_goldens(dev, golden_preproc):
+    from pytorch_geometric_amd import utils as U
+    from tests import _preproc_cases as P
+    to = lambda t: t.to(dev)  # noqa: E731
+    P.check_sort_edge_index(U, golden_preproc['sort_edge_index'], to)
+    P.check_coalesce(U, golden_preproc['coalesce'], to)
+    P.check_undirected(U, golden_preproc['undirected'], to)
+    C = golden_preproc['coalesce']
+    n = C['num_nodes']
+    # call forms: no attr argument -> edge_index alone; nothing to merge -> attributes reordered
+    assert torch.equal(U.coalesce(to(C['dup']), num_nodes=n).cpu(), C['no_attr'])
+    S = golden_preproc['sort_edge_index']
+    ei, a = U.coalesce(to(S['simple']), to(S['attr_f']), n)
+    assert torch.equal(ei.cpu(), C['simple']['edge_index'])
+    assert torch.equal(a.cpu(), C['simple']['attr'])
+    assert torch.equal(U.to_undirected(to(golden_preproc['undirected']['edge_index'])).cpu(),
+                       golden_preproc['undirected']['no_attr'])
+    # gradient of merged attributes
+    leaf = to(C['attr']).requires_grad_(True)
+    _, a = U.coalesce(to(C['dup']), leaf, n, reduce='mean')
+    (g, ) = torch.autograd.grad(a, leaf, to(C['mean_grad']['grad_out']))
+    assert_close(g, C['mean_grad']['grad_attr'], atol=1e-6, what='coalesce grad')
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_preprocessing_matches_oracle_at_size(dev, dtype):
+    from pytorch_geometric_amd import utils as U
+    n, E = 5000, 300_000
+    ei = random_graph(n, n, E, seed=21, skew=True)          # heavy duplicates on the hubs
+    w = torch.rand(E, generator=gen(22))
+    for by_row in (True, False):
+        got = U.sort_edge_index(ei.to(dtype).to(dev), num_nodes=n, sort_by_row=by_row)
+        want, _ = O.sort_edge_index(ei, None, n, by_row)
+        assert got.dtype == dtype and torch.equal(got.cpu().long(), want)
+        gi, gw = U.coalesce(ei.to(dtype).to(dev), w.to(dev), n, sort_by_row=by_row)
+        wi, ww = O.coalesce(ei, w, n, 'sum', False, by_row)
+        assert torch.equal(gi.cpu().long(), wi)
+        assert_close(gw, ww, atol=1e-5, what='merged weights')
+    # the stable device sort keeps the input order inside a run: attributes match a stable sort
+    gi, ga = U.sort_edge_index(ei.to(dev), torch.arange(E, device=dev), n)
+    wi, wa = O.sort_edge_index(ei, torch.arange(E), n)
+    assert torch.equal(ga.cpu(), wa)
+    und = U.to_undirected(ei.to(dev), num_nodes=n)
+    assert U.is_undirected(und, num_nodes=n) and not U.is_undirected(ei.to(dev), num_nodes=n)
+    assert torch.equal(und.cpu(), O.to_undirected(ei, None, n)[0])
+
+
+def test_preprocessing_edge_cases(dev):
+    from pytorch_geometric_amd import utils as U
+    empty = torch.empty(2, 0, dtype=torch.long, device=dev)
+    assert U.sort_edge_index(empty, num_nodes=4).shape == (2, 0)
+    ei, a = U.coalesce(empty, torch.empty(0, 3, device=dev), 4)
+    assert ei.shape == (2, 0) and a.shape == (0, 3)
+    pair = (torch.tensor([2, 0, 2], device=dev), torch.tensor([1, 3, 1], device=dev))
+    out = U.coalesce(pair, num_nodes=4)                       # tuple in -> tuple out
+    assert isinstance(out, tuple) and out[0].tolist() == [0, 2] and out[1].tolist() == [3, 1]
+    one = torch.tensor([[3], [3]], device=dev)
+    assert U.coalesce(one).tolist() == [[3], [3]]
+    with pytest.raises(ValueError):
+        U.coalesce(one, num_nodes=2**32)                      # key overflow, like the reference
+    with pytest.raises(ValueError):
+        U.sort_edge_index(torch.zeros(3, 4, dtype=torch.long, device=dev))

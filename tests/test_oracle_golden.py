@@ -208,3 +208,19 @@ def test_models(golden):
     params = [(st[f'convs.{i}.lin.weight'], st[f'convs.{i}.att_src'], st[f'convs.{i}.att_dst'],
                st[f'convs.{i}.bias']) for i in range(3)]
     close(O.gat(x, ei, params, heads=4), M['gat']['out'], 1e-5)
+
+
+# ---- preprocessing either side of the path -------------------------------------
+def test_sort_edge_index_coalesce_undirected_match_the_reference(golden_preproc):
+    from tests import _preproc_cases as P
+    P.check_sort_edge_index(O, golden_preproc['sort_edge_index'], lambda t: t)
+    P.check_coalesce(O, golden_preproc['coalesce'], lambda t: t)
+    P.check_undirected(O, golden_preproc['undirected'], lambda t: t)
+    # reference docstring examples (utils/_coalesce.py:107-129, _sort_edge_index.py:92-101)
+    ei = torch.tensor([[1, 1, 2, 3], [3, 3, 1, 2]])
+    out, w = O.coalesce(ei, torch.ones(4))
+    assert out.tolist() == [[1, 2, 3], [3, 1, 2]] and w.tolist() == [2., 1., 1.]
+    assert O.coalesce(ei, None, sort_by_row=False)[0].tolist() == [[2, 3, 1], [1, 2, 3]]
+    ei = torch.tensor([[2, 1, 1, 0], [1, 2, 0, 1]])
+    out, a = O.sort_edge_index(ei, torch.tensor([[1], [2], [3], [4]]))
+    assert out.tolist() == [[0, 1, 1, 2], [1, 0, 2, 1]] and a.view(-1).tolist() == [4, 3, 2, 1]
