@@ -10,7 +10,9 @@ modules.  ``install()`` therefore
 2. rebinds the dispatcher functions ``scatter``, ``segment``, ``softmax``, ``spmm``,
    ``index_sort``, ``scatter_argmax``, ``sort_edge_index``, ``coalesce`` in EVERY loaded ``torch_geometric*`` module whose attribute ``is`` the
    original function — seam S3 (utils/__init__.py:5-10,36);
-3. wraps ``propagate`` of the hot conv classes (SAGEConv, GCNConv, GraphConv, GATConv) so that a
+3. replaces ``torch_geometric.edge_index._spmm`` (what ``EdgeIndex.matmul`` and therefore the
+   reference's ``EdgeIndex`` fused route end in, edge_index.py:1925-1986);
+4. wraps ``propagate`` of the hot conv classes (SAGEConv, GCNConv, GraphConv, GATConv) so that a
    plain ``edge_index`` tensor is sorted once (cached handle) and gather -> message -> aggregate
    runs as ONE CSR SpMM — the fused route the reference only takes for sparse ``adj_t`` inputs
    (nn/conv/message_passing.py:469-479).
@@ -46,6 +48,12 @@ def _enabled() -> bool:
 
 def _ours(t: Any) -> bool:
     return isinstance(t, Tensor) and t.is_cuda and t.dtype == torch.float32
+
+
+def _ours_index(t: Any) -> bool:
+    """A plain (not sparse, not subclassed) ``[2, E]`` int32/int64 edge list on the device."""
+    return (isinstance(t, Tensor) and type(t) is Tensor and t.is_cuda and not t.is_sparse
+            and t.dim() == 2 and t.size(0) == 2 and t.dtype in (torch.int32, torch.int64))
 
 
 def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
@@ -85,9 +93,7 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
         return orig['spmm'](src, other, reduce)
 
     def _plain_edges(edge_index) -> bool:
-        return (type(edge_index) is Tensor and edge_index.is_cuda and edge_index.dim() == 2
-                and edge_index.size(0) == 2
-                and edge_index.dtype in (torch.int32, torch.int64) and _enabled())
+        return _ours_index(edge_index) and _enabled()
 
     def sort_edge_index(edge_index, edge_attr=U._sort_edge_index.MISSING, num_nodes=None,
                         sort_by_row=True):
@@ -133,11 +139,12 @@ def _fused_propagate(conv, edge_index, size, kwargs):
     path."""
     from ._functions import SpmmFunction
     from .edge_index import as_edge_index
-    if not (_enabled() and getattr(conv, 'fuse', True)) or getattr(conv, 'explain', False):
+    # `fuse` is False for layers without `message_and_aggregate` (GATConv,
+    # message_passing.py:154); for the others it stays the user's off switch
+    fuse = True if type(conv).__name__ == 'GATConv' else getattr(conv, 'fuse', True)
+    if not (_enabled() and fuse) or getattr(conv, 'explain', False):
         return NotImplemented
-    if not (isinstance(edge_index, Tensor) and type(edge_index) is Tensor and edge_index.is_cuda
-            and not edge_index.is_sparse and edge_index.dim() == 2 and edge_index.size(0) == 2
-            and edge_index.dtype in (torch.int32, torch.int64)):
+    if not _ours_index(edge_index):
         return NotImplemented
     if conv._propagate_forward_pre_hooks or conv._propagate_forward_hooks:
         return NotImplemented
@@ -147,9 +154,10 @@ def _fused_propagate(conv, edge_index, size, kwargs):
     if aggr not in ('sum', 'add', 'mean', 'max', 'min'):
         return NotImplemented
     x = kwargs.get('x')
-    if isinstance(x, (tuple, list)) and conv.flow != 'source_to_target':
-        return NotImplemented  # (x_src, x_dst) swap roles under target_to_source: keep it simple
+    s2t = conv.flow == 'source_to_target'
     x_src, x_dst = (x if isinstance(x, (tuple, list)) else (x, x))
+    if not s2t:  # x = (x_0, x_1): messages come from x_1 and land on the x_0 side
+        x_src, x_dst = x_dst, x_src
     if not _ours(x_src):
         return NotImplemented
     name = type(conv).__name__
@@ -173,7 +181,6 @@ def _fused_propagate(conv, edge_index, size, kwargs):
     node_dim = conv.node_dim + x_src.dim() if conv.node_dim < 0 else conv.node_dim
     if node_dim != 0:
         return NotImplemented
-    s2t = conv.flow == 'source_to_target'
     n_src = x_src.size(0)
     n_dst = x_dst.size(0) if isinstance(x_dst, Tensor) else None
     if size is not None:
@@ -188,6 +195,34 @@ def _fused_propagate(conv, edge_index, size, kwargs):
         return NotImplemented
     out = SpmmFunction.apply(x_src, weight, graph, reduce, order)
     return conv.update(out)
+
+
+def _make_edge_index_spmm(orig: Callable) -> Callable:
+    """Replacement for ``torch_geometric.edge_index._spmm`` (edge_index.py:1925-1970), which
+    ``EdgeIndex.matmul`` resolves from the module globals at call time: a SORTED reference
+    ``EdgeIndex`` times a dense float32 HIP matrix runs as our CSR SpMM (all four reductions,
+    differentiable in ``other`` AND ``value``).  Unsorted inputs, bad ``reduce`` strings, CPU
+    tensors etc. go to the original, which raises / computes exactly as before."""
+    def _spmm(input, other, value=None, reduce='sum', transpose=False):
+        from ._functions import SpmmFunction
+        from .edge_index import as_edge_index
+        ok = (_ours(other) and other.dim() == 2 and _enabled()
+              and reduce in ('sum', 'add', 'mean', 'min', 'max')
+              and (value is None or (_ours(value) and value.dim() == 1))
+              and (input.is_sorted_by_col if transpose else input.is_sorted_by_row))
+        if not ok:
+            return orig(input, other, value, reduce, transpose)
+        n_row, n_col = input.get_sparse_size(0), input.get_sparse_size(1)
+        data = input._data if hasattr(input, '_data') else input.as_tensor()
+        if transpose:   # out[col] = reduce_e value_e * other[row_e]: rows are the sources
+            graph = as_edge_index(data, n_row, n_col)
+        else:           # out[row] = reduce_e value_e * other[col_e]: columns are the sources
+            graph = as_edge_index(data, n_col, n_row, flip=True)
+        return SpmmFunction.apply(other, value, graph, 'sum' if reduce == 'add' else reduce,
+                                  'coo')
+
+    _spmm.__wrapped__ = orig
+    return _spmm
 
 
 def _wrap_propagate(cls) -> Callable:
@@ -223,6 +258,11 @@ def install() -> None:
     new = _make_dispatchers(orig)
     for name in orig:
         _state['rebinds'] += _sweep(orig[name], new[name])
+
+    import torch_geometric.edge_index as pyg_edge_index
+    orig_spmm = pyg_edge_index._spmm
+    pyg_edge_index._spmm = _make_edge_index_spmm(orig_spmm)
+    _state['rebinds'].append((pyg_edge_index, '_spmm', orig_spmm))
 
     from torch_geometric.nn.conv import GATConv, GCNConv, GraphConv, SAGEConv
     for cls in (SAGEConv, GCNConv, GraphConv, GATConv):
