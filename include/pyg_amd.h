@@ -218,17 +218,21 @@ PYGAMD_API int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_
  * as w[g * w_seg_stride + k * w_stride_k + n * w_stride_n] so the same entry point computes the
  * input gradient (W^T: swap the two strides).  _wgrad: grad_w[g] = x[seg]^T @ g[seg] ([K, N]
  * row-major per segment; empty segments give 0); `chunks` uses the same triple format with any
- * chunk length (long segments are split so no wave walks a whole relation; fp32 atomics).      */
+ * chunk length (long segments are split so no wave walks a whole relation; fp32 atomics).
+ * `blocks` > 1 (block-diagonal weights, RGCNConv(num_blocks=), rgcn_conv.py:222-244): group
+ * g = segment * blocks + b multiplies the column block [b*K, (b+1)*K) of its rows of x by W[g]
+ * into the column block [b*N, (b+1)*N) of out (ldx >= blocks*K, ldo >= blocks*N); no transposed
+ * copies of the activations or the weights are needed.  blocks = 1: plain segment_matmul.      */
 PYGAMD_API int pygamd_segment_matmul_tile_rows(void);
 PYGAMD_API int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w,
                                      int64_t w_seg_stride, int64_t w_stride_k,
                                      int64_t w_stride_n, const int32_t* tiles, int64_t n_tiles,
-                                     int64_t K, int64_t N, float* out, int64_t ldo,
-                                     void* stream);
+                                     int64_t K, int64_t N, int64_t blocks, float* out,
+                                     int64_t ldo, void* stream);
 PYGAMD_API int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g,
                                            int64_t ldg, const int32_t* chunks, int64_t n_chunks,
-                                           int64_t n_seg, int64_t K, int64_t N, float* grad_w,
-                                           void* stream);
+                                           int64_t n_seg, int64_t K, int64_t N, int64_t blocks,
+                                           float* grad_w, void* stream);
 
 /* ---- a2: gather (index_select along dim 0) --------------------------------------------------
  * out[e, :] = x[index[e], :]  (nn/conv/message_passing.py:263-290, collect.jinja:118-127).

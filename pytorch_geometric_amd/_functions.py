@@ -9,7 +9,7 @@ from torch.autograd import Function
 import math
 
 from . import _native
-from .edge_index import CSR, EdgeIndex
+from .edge_index import EdgeIndex
 
 
 def _rows(t: Tensor) -> Tensor:

@@ -61,9 +61,9 @@ SIGNATURES = {
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'pygamd_segment_matmul_tile_rows': (c_int, []),
     'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64,
-                                      c_int64, c_int64, _P, c_int64, _P]),
+                                      c_int64, c_int64, c_int64, _P, c_int64, _P]),
     'pygamd_segment_matmul_wgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64,
-                                            c_int64, c_int64, _P, _P]),
+                                            c_int64, c_int64, c_int64, _P, _P]),
     'pygamd_sample_max_fanout': (c_int, []),
     'pygamd_sample_neighbors': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, c_uint64, _P, _P,
                                         _P, _P]),

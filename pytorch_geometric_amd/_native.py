@@ -426,24 +426,27 @@ _segmm_plans = {}
 WGRAD_CHUNK_ROWS = 2048
 
 
-def segmm_plan(ptr_host: tuple, device):
+def segmm_plan(ptr_host: tuple, device, blocks: int = 1):
     """(tiles int32 [T,3], T, wgrad chunks int32 [C,3], C) on `device` for a host pointer tuple;
-    cached.  Tiles cover every non-empty segment in 64-row pieces, chunks in 2048-row pieces."""
-    key = (ptr_host, str(device))
+    cached.  Tiles cover every non-empty segment in 64-row pieces, chunks in 2048-row pieces.
+    With ``blocks`` > 1 every piece is listed once per column block, as group
+    ``segment * blocks + b`` (the block-diagonal layout of ``pygamd_segment_matmul``)."""
+    key = (ptr_host, str(device), blocks)
     hit = _segmm_plans.get(key)
     if hit is not None:
         return hit
     tm = _lib.load().pygamd_segment_matmul_tile_rows()
-    tiles = []
-    for g in range(len(ptr_host) - 1):
-        a, b = ptr_host[g], ptr_host[g + 1]
-        for r in range(a, b, tm):
-            tiles.append((g, r, min(tm, b - r)))
-    chunks = []
-    for g in range(len(ptr_host) - 1):
-        a, b = ptr_host[g], ptr_host[g + 1]
-        for r in range(a, b, WGRAD_CHUNK_ROWS):
-            chunks.append((g, r, min(WGRAD_CHUNK_ROWS, b - r)))
+
+    def pieces(step):
+        out = []
+        for g in range(len(ptr_host) - 1):
+            a, b = ptr_host[g], ptr_host[g + 1]
+            for r in range(a, b, step):
+                for blk in range(blocks):
+                    out.append((g * blocks + blk, r, min(step, b - r)))
+        return out
+
+    tiles, chunks = pieces(tm), pieces(WGRAD_CHUNK_ROWS)
     t = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 3).to(device)
     c = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 3).to(device)
     if len(_segmm_plans) > 32:
@@ -452,8 +455,10 @@ def segmm_plan(ptr_host: tuple, device):
     return _segmm_plans[key]
 
 
-def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False) -> Tensor:
-    """out[seg] = x[seg] @ W[g]  (or @ W[g]^T when transpose_w) — W is [G, K, N] contiguous."""
+def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False,
+                   blocks: int = 1) -> Tensor:
+    """out[seg] = x[seg] @ W[g]  (or @ W[g]^T when transpose_w) — W is [G, K, N] contiguous.
+    ``blocks`` > 1: x is [S, blocks*K], W is [segments*blocks, K, N], out is [S, blocks*N]."""
     _require_device(x, w)
     lib = _lib.load()
     tiles, n_tiles = plan[0], plan[1]
@@ -465,23 +470,25 @@ def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False) -> Ten
     w = w.contiguous()
     G, Kw, Nw = w.shape
     K, N, sk, sn = Kw, Nw, Nw, 1
-    if x2.size(1) != K:
-        raise ValueError(f"'inputs' has {x2.size(1)} columns but the weights expect {K}")
-    out = torch.empty(x2.size(0), N, dtype=torch.float32, device=x.device)
+    if x2.size(1) != blocks * K:
+        raise ValueError(f"'inputs' has {x2.size(1)} columns but the weights expect "
+                         f"{blocks * K}")
+    out = torch.empty(x2.size(0), blocks * N, dtype=torch.float32, device=x.device)
     check(lib.pygamd_segment_matmul(_p(x2), _ld(x2), _p(w), Kw * Nw, sk, sn, _p(tiles), n_tiles,
-                                    K, N, _p(out), _ld(out), _stream(x)), 'segment_matmul')
+                                    K, N, blocks, _p(out), _ld(out), _stream(x)),
+          'segment_matmul')
     return out
 
 
-def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int) -> Tensor:
-    """grad_W[g] = x[seg]^T @ grad[seg] -> [G, K, N]."""
+def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int, blocks: int = 1) -> Tensor:
+    """grad_W[g] = x[seg]^T @ grad[seg] -> [G, K, N]  (G = n_seg groups incl. blocks)."""
     _require_device(x, g)
     lib = _lib.load()
     x2, g2 = _f32_rows(x, 'x'), _f32_rows(g, 'grad')
-    K, N = x2.size(1), g2.size(1)
+    K, N = x2.size(1) // blocks, g2.size(1) // blocks
     gw = torch.empty(n_seg, K, N, dtype=torch.float32, device=x.device)
     check(lib.pygamd_segment_matmul_wgrad(_p(x2), _ld(x2), _p(g2), _ld(g2), _p(plan[2]), plan[3],
-                                          n_seg, K, N, _p(gw), _stream(x)),
+                                          n_seg, K, N, blocks, _p(gw), _stream(x)),
           'segment_matmul_wgrad')
     return gw
 

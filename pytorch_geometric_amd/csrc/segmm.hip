@@ -24,8 +24,8 @@ constexpr int kTK = 16;    // k chunk staged in LDS
 __global__ void __launch_bounds__(kBlock)
     segmm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                  int64_t w_seg_stride, int64_t w_sk, int64_t w_sn,
-                 const int32_t* __restrict__ tiles, int K, int N, float* __restrict__ out,
-                 int64_t ldo) {
+                 const int32_t* __restrict__ tiles, int K, int N, int blocks,
+                 float* __restrict__ out, int64_t ldo) {
   __shared__ float As[kTM][kTK + 1];
   const int t = blockIdx.x;
   const int seg = tiles[3 * t];
@@ -38,6 +38,10 @@ __global__ void __launch_bounds__(kBlock)
   const int col0 = n0 + wn * 64 + (lane & 31);
   const int col1 = col0 + 32;
   const float* __restrict__ wseg = w + static_cast<int64_t>(seg) * w_seg_stride;
+  // block-diagonal weights: group seg = relation * blocks + b works on column block b
+  const int blk = blocks > 1 ? seg % blocks : 0;
+  x += static_cast<int64_t>(blk) * K;
+  out += static_cast<int64_t>(blk) * N;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(kBlock)
 // could store directly but share the same path for simplicity.
 __global__ void __launch_bounds__(kWave)
     segmm_wgrad_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g,
-                       int64_t ldg, const int32_t* __restrict__ chunks, int K, int N,
+                       int64_t ldg, const int32_t* __restrict__ chunks, int K, int N, int blocks,
                        float* __restrict__ gw) {
   const int t = blockIdx.x;
   const int seg = chunks[3 * t];
@@ -95,6 +99,9 @@ __global__ void __launch_bounds__(kWave)
   const int lane = threadIdx.x;
   const int kc = k0 + (lane & 31);
   const int col0 = n0 + (lane & 31), col1 = col0 + 32;
+  const int blk = blocks > 1 ? seg % blocks : 0;
+  x += static_cast<int64_t>(blk) * K;
+  g += static_cast<int64_t>(blk) * N;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -138,25 +145,27 @@ int pygamd_segment_matmul_tile_rows(void) { return kTM; }
 
 int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w, int64_t w_seg_stride,
                           int64_t w_stride_k, int64_t w_stride_n, const int32_t* tiles,
-                          int64_t n_tiles, int64_t K, int64_t N, float* out, int64_t ldo,
-                          void* stream) {
-  if (n_tiles < 0 || K < 0 || N < 0 || ldx < K || ldo < N || K > INT32_MAX || N > INT32_MAX)
+                          int64_t n_tiles, int64_t K, int64_t N, int64_t blocks, float* out,
+                          int64_t ldo, void* stream) {
+  if (n_tiles < 0 || K < 0 || N < 0 || blocks < 1 || blocks > INT32_MAX || K > INT32_MAX ||
+      N > INT32_MAX || ldx < blocks * K || ldo < blocks * N)
     return PYGAMD_ERR_INVALID_ARG;
   if (n_tiles == 0 || N == 0) return PYGAMD_OK;
   if (!x || !w || !tiles || !out) return PYGAMD_ERR_INVALID_ARG;
   const dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>(ceil_div(N, kTN)));
   hipLaunchKernelGGL(segmm_kernel, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, w,
                      w_seg_stride, w_stride_k, w_stride_n, tiles, static_cast<int>(K),
-                     static_cast<int>(N), out, ldo);
+                     static_cast<int>(N), static_cast<int>(blocks), out, ldo);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }
 
 int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg,
                                 const int32_t* chunks, int64_t n_chunks, int64_t n_seg,
-                                int64_t K, int64_t N, float* grad_w, void* stream) {
-  if (n_seg < 0 || n_chunks < 0 || K < 0 || N < 0 || ldx < K || ldg < N || K > INT32_MAX ||
-      N > INT32_MAX)
+                                int64_t K, int64_t N, int64_t blocks, float* grad_w,
+                                void* stream) {
+  if (n_seg < 0 || n_chunks < 0 || K < 0 || N < 0 || blocks < 1 || blocks > INT32_MAX ||
+      K > INT32_MAX || N > INT32_MAX || ldx < blocks * K || ldg < blocks * N)
     return PYGAMD_ERR_INVALID_ARG;
   if (n_seg == 0 || K == 0 || N == 0) return PYGAMD_OK;
   if (!grad_w) return PYGAMD_ERR_INVALID_ARG;
@@ -168,7 +177,7 @@ int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g, int
   const dim3 grid(static_cast<unsigned>(n_chunks), static_cast<unsigned>(ceil_div(K, 32)),
                   static_cast<unsigned>(ceil_div(N, 64)));
   hipLaunchKernelGGL(segmm_wgrad_kernel, grid, dim3(kWave), 0, st, x, ldx, g, ldg, chunks,
-                     static_cast<int>(K), static_cast<int>(N), grad_w);
+                     static_cast<int>(K), static_cast<int>(N), static_cast<int>(blocks), grad_w);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }

@@ -6,7 +6,6 @@ A 3-layer GraphSAGE has ~0.2-0.3 M parameters (~1 MB): the all-reduce is latency
 so all gradients live in ONE flat buffer and each step issues ONE collective (RCCL through
 ``torch.distributed``'s 'nccl' backend on ROCm, 'gloo' on CPU in the tests)."""
 import math
-from typing import Optional
 
 import torch
 import torch.distributed as dist

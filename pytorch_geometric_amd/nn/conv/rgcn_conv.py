@@ -7,8 +7,8 @@ from torch.nn import Parameter
 
 from ... import _native
 from ..._functions import SpmmFunction
-from ...edge_index import CSR, EdgeIndex, build_csr
-from ...utils._segment_matmul import segment_matmul
+from ...edge_index import EdgeIndex
+from ...utils._segment_matmul import block_segment_matmul, segment_matmul
 from ..inits import glorot, zeros
 from .message_passing import MessagePassing
 
@@ -159,17 +159,8 @@ class RGCNConv(MessagePassing):
             agg = SpmmFunction.apply(x_l, None, h.pair_graph, reduce, 'coo')  # [S, F_in]
             # (2) relation-segmented transform
             if self.num_blocks is not None:
-                B = self.num_blocks
-                S = agg.size(0)
-                t = agg.view(S, B, -1).transpose(0, 1).reshape(B * S, -1)  # block-major rows
-                ptr = [0]
-                # segments = (block, relation) in block-major order
-                for b in range(B):
-                    ptr += [b * S + p for p in h.rel_ptr[1:]]
-                w = weight.transpose(0, 1).reshape(B * self.num_relations, weight.size(2),
-                                                   weight.size(3))
-                t = segment_matmul(t, ptr, w)  # [B*S, out/B]
-                t = t.view(B, S, -1).transpose(0, 1).reshape(S, -1)
+                # block b of a pair row times weight[r, b]: column blocks in place, one launch
+                t = block_segment_matmul(agg, h.rel_ptr, weight)  # [S, F_out]
             else:
                 t = segment_matmul(agg, h.rel_ptr, weight)  # [S, F_out]
             # (3) sum the pair rows of every destination

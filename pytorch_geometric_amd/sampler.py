@@ -22,7 +22,7 @@ import torch
 from torch import Tensor
 
 from . import _native
-from .edge_index import EdgeIndex, as_edge_index
+from .edge_index import as_edge_index
 
 
 @dataclass

@@ -7,21 +7,33 @@ from .. import _native
 
 class _SegmentMatmul(Function):
     @staticmethod
-    def forward(ctx, inputs: Tensor, ptr_host: tuple, other: Tensor):
-        plan = _native.segmm_plan(ptr_host, inputs.device)
-        ctx.plan, ctx.n_seg = plan, other.size(0)
+    def forward(ctx, inputs: Tensor, ptr_host: tuple, other: Tensor, blocks: int = 1):
+        plan = _native.segmm_plan(ptr_host, inputs.device, blocks)
+        ctx.plan, ctx.n_seg, ctx.blocks = plan, other.size(0), blocks
         ctx.save_for_backward(inputs, other)
-        return _native.segment_matmul(inputs, other, plan)
+        return _native.segment_matmul(inputs, other, plan, blocks=blocks)
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         inputs, other = ctx.saved_tensors
         grad_in = grad_other = None
         if ctx.needs_input_grad[0]:
-            grad_in = _native.segment_matmul(grad_out, other, ctx.plan, transpose_w=True)
+            grad_in = _native.segment_matmul(grad_out, other, ctx.plan, transpose_w=True,
+                                             blocks=ctx.blocks)
         if ctx.needs_input_grad[2]:
-            grad_other = _native.segment_matmul_wgrad(inputs, grad_out, ctx.plan, ctx.n_seg)
-        return grad_in, None, grad_other
+            grad_other = _native.segment_matmul_wgrad(inputs, grad_out, ctx.plan, ctx.n_seg,
+                                                      ctx.blocks)
+        return grad_in, None, grad_other, None
+
+
+def block_segment_matmul(inputs: Tensor, ptr_host: tuple, other: Tensor) -> Tensor:
+    r"""Block-diagonal variant used by ``RGCNConv(num_blocks=B)`` (rgcn_conv.py:222-244):
+    ``other`` is ``[R, B, K, N]``; rows of segment ``r`` are multiplied block by block,
+    ``out[s, b*N:(b+1)*N] = inputs[s, b*K:(b+1)*K] @ other[r, b]`` — one launch, no transposes."""
+    R, B, K, N = other.shape
+    if inputs.size(1) != B * K or len(ptr_host) != R + 1:
+        raise ValueError("'inputs' must be [S, B*K] and 'ptr' must hold R + 1 entries")
+    return _SegmentMatmul.apply(inputs, tuple(ptr_host), other.reshape(R * B, K, N), B)
 
 
 def segment_matmul(inputs: Tensor, ptr, other: Tensor) -> Tensor:

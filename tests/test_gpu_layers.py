@@ -317,6 +317,29 @@ def test_segment_matmul(dev):
         assert_close(wg.grad, wr.grad, atol=1e-4, rtol=1e-4, what=f'segmm grad_w {K}x{N}')
 
 
+def test_block_segment_matmul(dev):
+    """Block-diagonal grouped GEMM (RGCNConv num_blocks, rgcn_conv.py:222-244) vs the reference's
+    einsum 'abc,bcd->abd' per relation, values and both gradients."""
+    from pytorch_geometric_amd.utils._segment_matmul import block_segment_matmul
+    g = gen(6)
+    for R, B, K, N, ptr in [(3, 2, 4, 3, (0, 5, 5, 40)), (4, 5, 100, 100, (0, 1, 300, 300, 777)),
+                            (2, 3, 20, 36, (0, 0, 130))]:
+        S = ptr[-1]
+        x = torch.randn(S, B * K, generator=g)
+        w = torch.randn(R, B, K, N, generator=g) / K ** 0.5
+        go = torch.randn(S, B * N, generator=g)
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = torch.cat([torch.einsum('abc,bcd->abd', xr[ptr[r]:ptr[r + 1]].view(-1, B, K),
+                                      wr[r]).reshape(-1, B * N) for r in range(R)])
+        ref.backward(go)
+        xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        out = block_segment_matmul(xg, ptr, wg)
+        out.backward(go.to(dev))
+        assert_close(out, ref.detach(), atol=2e-5, what=f'block segmm {R}x{B}x{K}x{N}')
+        assert_close(xg.grad, xr.grad, atol=2e-5, what='block segmm grad_x')
+        assert_close(wg.grad, wr.grad, atol=1e-4, rtol=1e-4, what='block segmm grad_w')
+
+
 def test_unfused_path_flow_and_sort_order_validation(dev):
     """fuse=False with flow='target_to_source' equals the fused path on the flipped edge list;
     a wrong sort_order claim is rejected."""
