@@ -10,7 +10,9 @@
 // ONE launch covers every segment: the host builds a table of (segment, first row, rows) tiles of
 // 64 rows; a 256-thread workgroup (2 x 2 waves) owns a 64 x 128 output tile, stages the A tile
 // through LDS (row stride 17 floats: conflict-free column reads) and streams B (the segment's
-// weight, L2-resident) straight from global with coalesced 128-byte rows.
+// weight, L2-resident) straight from global with coalesced 128-byte rows; both are prefetched one
+// k chunk ahead into registers (PMC of the unpipelined kernel: 64 % of wave cycles parked in
+// s_waitcnt/barrier, MFMA pipe 31 % busy).
 #include "common.h"
 
 namespace pygamd {
@@ -50,22 +52,46 @@ __global__ void __launch_bounds__(kBlock)
   }
   const int lr = threadIdx.x >> 2;        // 0..63: row of the A tile this thread loads
   const int lk = (threadIdx.x & 3) * 4;   // 0,4,8,12: first k of its 4 values
-  for (int k0 = 0; k0 < K; k0 += kTK) {
+  const bool row_ok = lr < rows;
+  const float* __restrict__ xa = x + (row0 + (row_ok ? lr : 0)) * ldx + lk;
+  const int kh = lane >> 5;               // which of the MFMA's two k values this lane feeds
+  const bool c0_ok = col0 < N, c1_ok = col1 < N;
+  const float* __restrict__ wb0 = wseg + static_cast<int64_t>(c0_ok ? col0 : 0) * w_sn;
+  const float* __restrict__ wb1 = wseg + static_cast<int64_t>(c1_ok ? col1 : 0) * w_sn;
+  // Register double buffer: the global loads of chunk i+1 (A values for the LDS tile, B values
+  // for this lane's MFMA operands) are issued before the MFMAs of chunk i, so their latency is
+  // covered by matrix work of the same wave instead of parking it at s_waitcnt.
+  float a_nx[4], b0_nx[kTK / 2], b1_nx[kTK / 2];
+  auto prefetch = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + lk + j;
-      As[lr][lk + j] = (lr < rows && k < K) ? x[(row0 + lr) * ldx + k] : 0.f;
+    for (int j = 0; j < 4; ++j)
+      a_nx[j] = (row_ok && k0 + lk + j < K) ? xa[k0 + j] : 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < kTK / 2; ++s2) {
+      const int k = k0 + 2 * s2 + kh;
+      const bool k_ok = k < K;
+      const int64_t off = static_cast<int64_t>(k_ok ? k : 0) * w_sk;
+      b0_nx[s2] = (k_ok && c0_ok) ? wb0[off] : 0.f;
+      b1_nx[s2] = (k_ok && c1_ok) ? wb1[off] : 0.f;
+    }
+  };
+  prefetch(0);
+  for (int k0 = 0; k0 < K; k0 += kTK) {
+    float b0[kTK / 2], b1[kTK / 2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) As[lr][lk + j] = a_nx[j];
+#pragma unroll
+    for (int s2 = 0; s2 < kTK / 2; ++s2) {
+      b0[s2] = b0_nx[s2];
+      b1[s2] = b1_nx[s2];
     }
     __syncthreads();
+    if (k0 + kTK < K) prefetch(k0 + kTK);
 #pragma unroll
-    for (int kk = 0; kk < kTK; kk += 2) {
-      const int kl = kk + (lane >> 5);
-      const int k = k0 + kl;
-      const float a = As[wm * 32 + (lane & 31)][kl];
-      const float b0 = (k < K && col0 < N) ? wseg[k * w_sk + col0 * w_sn] : 0.f;
-      const float b1 = (k < K && col1 < N) ? wseg[k * w_sk + col1 * w_sn] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    for (int s2 = 0; s2 < kTK / 2; ++s2) {
+      const float a = As[wm * 32 + (lane & 31)][2 * s2 + kh];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s2], acc1, 0, 0, 0);
     }
     __syncthreads();
   }
@@ -108,16 +134,32 @@ __global__ void __launch_bounds__(kWave)
     acc0[i] = 0.f;
     acc1[i] = 0.f;
   }
-  for (int64_t r = ra; r < rb; r += 8) {
-    float a[4], b0[4], b1[4];
+  const bool k_ok = kc < K, c0_ok = col0 < N, c1_ok = col1 < N;
+  const float* __restrict__ xa = x + (k_ok ? kc : 0);
+  const float* __restrict__ g0 = g + (c0_ok ? col0 : 0);
+  const float* __restrict__ g1 = g + (c1_ok ? col1 : 0);
+  float a_nx[4], b0_nx[4], b1_nx[4];
+  auto prefetch = [&](int64_t r) {  // the 8 rows starting at r, two per MFMA
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t rr = r + 2 * u + (lane >> 5);
       const bool ok = rr < rb;
-      a[u] = (ok && kc < K) ? x[rr * ldx + kc] : 0.f;
-      b0[u] = (ok && col0 < N) ? g[rr * ldg + col0] : 0.f;
-      b1[u] = (ok && col1 < N) ? g[rr * ldg + col1] : 0.f;
+      const int64_t rs = ok ? rr : ra;
+      a_nx[u] = (ok && k_ok) ? xa[rs * ldx] : 0.f;
+      b0_nx[u] = (ok && c0_ok) ? g0[rs * ldg] : 0.f;
+      b1_nx[u] = (ok && c1_ok) ? g1[rs * ldg] : 0.f;
     }
+  };
+  prefetch(ra);
+  for (int64_t r = ra; r < rb; r += 8) {
+    float a[4], b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = a_nx[u];
+      b0[u] = b0_nx[u];
+      b1[u] = b1_nx[u];
+    }
+    if (r + 8 < rb) prefetch(r + 8);  // in flight during the MFMAs below
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[u], acc0, 0, 0, 0);
