@@ -54,11 +54,11 @@ __global__ void __launch_bounds__(kBlock)
   zero_acc(acc01);
   zero_acc(acc10);
   zero_acc(acc11);
-  // A tile: thread -> (row = tid / 2, 16 consecutive k): a wave reads 32 full 128-byte runs
-  const int ar = threadIdx.x >> 1;
-  const int ak = (threadIdx.x & 1) * 16;
-  const bool arow_ok = ar < rows;
-  const float* __restrict__ xa = x + (row0 + (arow_ok ? ar : 0)) * ldx + ak;
+  // A tile: thread -> (k = tid % 32, rows tid / 32 + 8 j): every load instruction of a wave covers
+  // two full 128-byte runs (a per-thread run of consecutive k would touch 64 lines per load)
+  const int ak = threadIdx.x & 31;
+  const int ar = threadIdx.x >> 5;
+  const float* __restrict__ xa = x + row0 * ldx + ak;
   // B tile: thread -> (k = tid / 128 + 2 j, col = tid % 128): 512-byte coalesced weight rows
   const int bc = threadIdx.x & (kTN - 1);
   const int bk = threadIdx.x >> 7;
@@ -66,9 +66,13 @@ __global__ void __launch_bounds__(kBlock)
   const float* __restrict__ wb = wseg + static_cast<int64_t>(bcol_ok ? n0 + bc : 0) * w_sn;
   float a_nx[16], b_nx[16];
   auto prefetch = [&](int k0) {
+    const bool ak_ok = k0 + ak < K;
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-      a_nx[q] = (arow_ok && k0 + ak + q < K) ? xa[k0 + q] : 0.f;
+    for (int q = 0; q < 16; ++q) {
+      const int r = ar + 8 * q;
+      const bool ok = ak_ok && r < rows;
+      a_nx[q] = ok ? xa[static_cast<int64_t>(ok ? r : 0) * ldx + k0] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int k = k0 + bk + 2 * j;
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(kBlock)
   prefetch(0);
   for (int k0 = 0; k0 < K; k0 += kTK) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) As[ar][ak + q] = a_nx[q];
+    for (int q = 0; q < 16; ++q) As[ar + 8 * q][ak] = a_nx[q];
 #pragma unroll
     for (int j = 0; j < 16; ++j) Bs[bk + 2 * j][bc] = b_nx[j];
     __syncthreads();
