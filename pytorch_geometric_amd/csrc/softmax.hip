@@ -143,30 +143,47 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// ---- GAT node terms: a_src[n,h] = <x[n,h,:], att_src[h,:]>, a_dst likewise ---------------------
-// (nn/conv/gat_conv.py:330-332: `(x * att).sum(-1)` twice = 4 elementwise/reduce launches and
-// their 6 backward launches in the reference).  One wave per node, one pass over x[n, :].
+// a[n,h] = sum_c x[n,h,c] att_a[h,c]  (and b with att_b): one wave per node, `lph` (a power of
+// two) lanes per head, so a wave covers 64 / lph heads at once — for the 8-head GAT layers every
+// lane is busy, the row is read once with coalesced (VW = 4: 16-byte) loads and each head costs
+// log2(lph) shuffles instead of a full 64-lane butterfly.
+template <int VW>
 __global__ void __launch_bounds__(kBlock)
     head_dot_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ att_a,
-                        const float* __restrict__ att_b, int64_t n_rows, int H, int C,
+                        const float* __restrict__ att_b, int64_t n_rows, int H, int C, int lph,
                         float* __restrict__ out_a, float* __restrict__ out_b) {
   const int lane = lane_id();
   const int64_t n = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   if (n >= n_rows) return;
   const float* __restrict__ xr = x + n * ldx;
-  for (int h = 0; h < H; ++h) {
+  const int heads_per_pass = kWave / lph;
+  const int j = lane & (lph - 1);
+  for (int h0 = 0; h0 < H; h0 += heads_per_pass) {
+    const int h = h0 + lane / lph;
     float pa = 0.f, pb = 0.f;
-    for (int c = lane; c < C; c += kWave) {
-      const float v = xr[h * C + c];
-      pa = fmaf(v, att_a[h * C + c], pa);
-      if (att_b) pb = fmaf(v, att_b[h * C + c], pb);
+    if (h < H) {
+      for (int c = j * VW; c < C; c += lph * VW) {
+        const int f = h * C + c;
+        if constexpr (VW == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(xr + f);
+          const float4 wa = *reinterpret_cast<const float4*>(att_a + f);
+          pa = fmaf(v.x, wa.x, fmaf(v.y, wa.y, fmaf(v.z, wa.z, fmaf(v.w, wa.w, pa))));
+          if (att_b) {
+            const float4 wb = *reinterpret_cast<const float4*>(att_b + f);
+            pb = fmaf(v.x, wb.x, fmaf(v.y, wb.y, fmaf(v.z, wb.z, fmaf(v.w, wb.w, pb))));
+          }
+        } else {
+          const float v = xr[f];
+          pa = fmaf(v, att_a[f], pa);
+          if (att_b) pb = fmaf(v, att_b[f], pb);
+        }
+      }
     }
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
+    for (int off = lph >> 1; off > 0; off >>= 1) {
       pa += __shfl_xor(pa, off, kWave);
       pb += __shfl_xor(pb, off, kWave);
     }
-    if (lane == 0) {
+    if (h < H && j == 0) {
       out_a[n * H + h] = pa;
       if (att_b) out_b[n * H + h] = pb;
     }
@@ -174,8 +191,9 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // grad_x[n,f] = ga[n,h(f)] att_a[f] + gb[n,h(f)] att_b[f];  grad_att_a[f] = sum_n ga[n,h(f)] x[n,f]
-// Thread t of a 256-thread block owns column f = f0 + t for a strip of rows; the two column sums
-// leave the block through atomics (grad_att_* zeroed by the host wrapper).
+// Thread t of a 256-thread block owns column f = f0 + t for a strip of rows (coalesced row reads
+// and writes, four rows in flight per thread); the two column sums leave the block through
+// atomics (grad_att_* zeroed by the host wrapper; the strips are long, so few atomics meet).
 __global__ void __launch_bounds__(kBlock)
     head_dot_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ att_a,
                         const float* __restrict__ att_b, const float* __restrict__ ga,
@@ -191,7 +209,23 @@ __global__ void __launch_bounds__(kBlock)
     const float wa = att_a[f];
     const float wb = att_b ? att_b[f] : 0.f;
     float sa = 0.f, sb = 0.f;
-    for (int64_t n = r0; n < r1; ++n) {
+    int64_t n = r0;
+    for (; n + 4 <= r1; n += 4) {
+      float xv[4], va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = x[(n + u) * ldx + f];
+        va[u] = ga[(n + u) * H + h];
+        vb[u] = gb ? gb[(n + u) * H + h] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sa = fmaf(va[u], xv[u], sa);
+        sb = fmaf(vb[u], xv[u], sb);
+        if (grad_x) grad_x[(n + u) * ldg + f] = va[u] * wa + vb[u] * wb;
+      }
+    }
+    for (; n < r1; ++n) {
       const float xv = x[n * ldx + f];
       const float va = ga[n * H + h];
       const float vb = gb ? gb[n * H + h] : 0.f;
@@ -207,6 +241,8 @@ __global__ void __launch_bounds__(kBlock)
 }  // namespace pygamd
 
 using namespace pygamd;
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 extern "C" {
 
@@ -248,10 +284,20 @@ int pygamd_head_dot_forward(const float* x, int64_t ldx, const float* att_a, con
   if (n_rows < 0 || H < 1 || C < 1 || ldx < H * C) return PYGAMD_ERR_INVALID_ARG;
   if (n_rows == 0) return PYGAMD_OK;
   if (!x || !att_a || !out_a || (att_b && !out_b)) return PYGAMD_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(head_dot_fwd_kernel,
-                     dim3(static_cast<unsigned>(ceil_div(n_rows, kWavesPerBlock))), dim3(kBlock),
-                     0, as_stream(stream), x, ldx, att_a, att_b, n_rows, static_cast<int>(H),
-                     static_cast<int>(C), out_a, out_b);
+  int lph = 1;  // lanes per head: the largest power of two with H * lph <= 64
+  while (lph * 2 * H <= kWave && lph * 2 <= C) lph *= 2;
+  const bool vec4 = (C % 4 == 0) && (ldx % 4 == 0) && aligned16(x) && aligned16(att_a) &&
+                    (!att_b || aligned16(att_b));
+  const dim3 grid(static_cast<unsigned>(ceil_div(n_rows, kWavesPerBlock)));
+  if (vec4) {
+    hipLaunchKernelGGL((head_dot_fwd_kernel<4>), grid, dim3(kBlock), 0, as_stream(stream), x, ldx,
+                       att_a, att_b, n_rows, static_cast<int>(H), static_cast<int>(C), lph, out_a,
+                       out_b);
+  } else {
+    hipLaunchKernelGGL((head_dot_fwd_kernel<1>), grid, dim3(kBlock), 0, as_stream(stream), x, ldx,
+                       att_a, att_b, n_rows, static_cast<int>(H), static_cast<int>(C), lph, out_a,
+                       out_b);
+  }
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }
@@ -269,7 +315,7 @@ int pygamd_head_dot_backward(const float* x, int64_t ldx, const float* att_a, co
   if (n_rows == 0) return PYGAMD_OK;
   if (!x || !grad_a || (grad_x && ldg < H * C)) return PYGAMD_ERR_INVALID_ARG;
   int64_t blocks = ceil_div(n_rows, 64);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 1024) blocks = 1024;   // 4 per CU: long strips keep the atomics on grad_att rare
   const int64_t rows_per_block = ceil_div(n_rows, blocks);
   blocks = ceil_div(n_rows, rows_per_block);
   hipLaunchKernelGGL(head_dot_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,

@@ -471,7 +471,7 @@ def test_gather_scatter_add(dev, F):
     assert_sum_close(got, ref, ref.double(), what='plain')
 
 
-@pytest.mark.parametrize('H,C', [(8, 32), (8, 40), (1, 7), (3, 100)])
+@pytest.mark.parametrize('H,C', [(8, 32), (8, 40), (1, 7), (3, 100), (70, 4), (2, 256)])
 def test_head_dot(dev, H, C):
     """GAT node terms (x * att).sum(-1) for both attention vectors in one pass + fused backward."""
     from pytorch_geometric_amd._functions import HeadDotFunction
