@@ -209,6 +209,14 @@ PYGAMD_API int pygamd_sddmm_csr(const void* rowptr, const void* col, const void*
  * `out` is zeroed internally; partial sums are combined with fp32 atomics.                     */
 PYGAMD_API int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t F, float* out,
                              void* stream);
+/* ReLU backward fused with the bias gradient of the layer below (nn/models/basic_gnn.py:262-263
+ * `self.act(x)` followed by a conv with bias):  grad_in[r,f] = act[r,f] <= 0 ? 0 : grad[r,f]
+ * (aten::threshold_backward with threshold 0; `act` is the ReLU OUTPUT), and, when colsum_out is
+ * not NULL, colsum_out[f] = sum_r grad_in[r,f] (zeroed internally, fp32 atomics).  grad_in may
+ * alias grad.                                                                                   */
+PYGAMD_API int pygamd_relu_backward_colsum(const float* grad, int64_t ldg, const float* act,
+                                           int64_t lda, int64_t n_rows, int64_t F, float* grad_in,
+                                           int64_t ldo, float* colsum_out, void* stream);
 
 /* ---- a16/a17: segment_matmul (grouped GEMM over row segments, fp32 MFMA) ---------------------
  * Replaces pyg_lib.ops.segment_matmul(x, ptr, weight) (nn/conv/rgcn_conv.py:288,

@@ -59,6 +59,8 @@ SIGNATURES = {
     'pygamd_sddmm_csr': (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                  c_int32, c_int32, _P, _P]),
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    'pygamd_relu_backward_colsum': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P,
+                                            c_int64, _P, _P]),
     'pygamd_segment_matmul_tile_rows': (c_int, []),
     'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64,
                                       c_int64, c_int64, c_int64, _P, c_int64, _P]),

@@ -242,6 +242,22 @@ def colsum(x: Tensor) -> Tensor:
     return out
 
 
+def relu_backward_colsum(grad: Tensor, act: Tensor, want_colsum: bool = True):
+    """(grad * (act > 0) as a new contiguous tensor, its column sums | None) in one pass; ``act``
+    is the ReLU output.  Inputs may be row-strided views."""
+    _require_device(grad, act)
+    lib = _lib.load()
+    g2, a2 = _f32_rows(grad, 'grad'), _f32_rows(act, 'act')
+    if g2.shape != a2.shape:
+        raise ValueError(f'shape mismatch: {tuple(g2.shape)} vs {tuple(a2.shape)}')
+    out = torch.empty(g2.size(0), g2.size(1), dtype=torch.float32, device=grad.device)
+    cs = torch.empty(g2.size(1), dtype=torch.float32, device=grad.device) if want_colsum else None
+    check(lib.pygamd_relu_backward_colsum(_p(g2), _ld(g2), _p(a2), _ld(a2), g2.size(0),
+                                          g2.size(1), _p(out), _ld(out), _p(cs), _stream(grad)),
+          'relu_backward_colsum')
+    return out, cs
+
+
 def spmm_tie_count(rowptr, col, x, out, count_self: bool) -> Tensor:
     _require_device(rowptr, col, x, out)
     lib = _lib.load()

@@ -207,12 +207,16 @@ __global__ void __launch_bounds__(kBlock)
   if (g < dim_size && arg[g] < 0) arg[g] = static_cast<IdxT>(dim_size - 1);
 }
 
-// ---- column sum (bias gradient) -------------------------------------------------------------
+// ---- column sum (bias gradient), optionally fused with the ReLU backward mask ------------------
 // A 256-thread block covers `groups = 256 / F` rows per pass with thread t on column t % F, so
 // consecutive lanes read consecutive addresses of a contiguous [rows, F] block; row-group
-// partials meet in LDS and each block issues F atomics.
+// partials meet in LDS and each block issues F atomics.  MASK: v = act <= 0 ? 0 : x (what
+// aten::threshold_backward computes), written to y before it is summed — one pass instead of
+// mask (read 2, write 1) + column sum (read 1).
+template <bool MASK>
 __global__ void __launch_bounds__(kBlock)
-    colsum_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int64_t F,
+    colsum_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ act,
+                  int64_t lda, float* __restrict__ y, int64_t ldy, int64_t n_rows, int64_t F,
                   float* __restrict__ out) {
   __shared__ float part[kBlock];
   for (int64_t f0 = 0; f0 < F; f0 += kBlock) {
@@ -223,17 +227,25 @@ __global__ void __launch_bounds__(kBlock)
     float acc = 0.f;
     if (rg < groups) {
       for (int64_t r = static_cast<int64_t>(blockIdx.x) * groups + rg; r < n_rows;
-           r += static_cast<int64_t>(gridDim.x) * groups)
-        acc += x[r * ldx + f0 + col];
+           r += static_cast<int64_t>(gridDim.x) * groups) {
+        float v = x[r * ldx + f0 + col];
+        if constexpr (MASK) {
+          v = act[r * lda + f0 + col] <= 0.f ? 0.f : v;
+          y[r * ldy + f0 + col] = v;
+        }
+        acc += v;
+      }
     }
-    part[threadIdx.x] = acc;
-    __syncthreads();
-    if (rg == 0) {
-      float s = 0.f;
-      for (int g = 0; g < groups; ++g) s += part[g * width + col];
-      atomicAdd(out + f0 + col, s);
+    if (out != nullptr) {
+      part[threadIdx.x] = acc;
+      __syncthreads();
+      if (rg == 0) {
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += part[g * width + col];
+        atomicAdd(out + f0 + col, s);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -276,24 +288,43 @@ using namespace pygamd;
 
 extern "C" {
 
-int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t F, float* out,
-                  void* stream) {
-  if (n_rows < 0 || F < 0 || ldx < F) return PYGAMD_ERR_INVALID_ARG;
-  if (F == 0) return PYGAMD_OK;
-  if (!out) return PYGAMD_ERR_INVALID_ARG;
-  hipStream_t st = as_stream(stream);
-  PYGAMD_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * F, st));
+static int launch_colsum(const float* x, int64_t ldx, const float* act, int64_t lda, float* y,
+                         int64_t ldy, int64_t n_rows, int64_t F, float* out, hipStream_t st) {
+  if (out) PYGAMD_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * F, st));
   if (n_rows == 0) return PYGAMD_OK;
-  if (!x) return PYGAMD_ERR_INVALID_ARG;
   const int width = static_cast<int>(F < kBlock ? F : kBlock);
   const int groups = kBlock / width;
   int64_t blocks = ceil_div(n_rows, static_cast<int64_t>(groups) * 16);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(colsum_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, x,
-                     ldx, n_rows, F, out);
+  const dim3 grid(static_cast<unsigned>(blocks));
+  if (act) {
+    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(kBlock), 0, st, x, ldx, act, lda, y, ldy,
+                       n_rows, F, out);
+  } else {
+    hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(kBlock), 0, st, x, ldx, act, lda, y, ldy,
+                       n_rows, F, out);
+  }
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
+}
+
+int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_t F, float* out,
+                  void* stream) {
+  if (n_rows < 0 || F < 0 || ldx < F) return PYGAMD_ERR_INVALID_ARG;
+  if (F == 0) return PYGAMD_OK;
+  if (!out || (n_rows > 0 && !x)) return PYGAMD_ERR_INVALID_ARG;
+  return launch_colsum(x, ldx, nullptr, 0, nullptr, 0, n_rows, F, out, as_stream(stream));
+}
+
+int pygamd_relu_backward_colsum(const float* grad, int64_t ldg, const float* act, int64_t lda,
+                                int64_t n_rows, int64_t F, float* grad_in, int64_t ldo,
+                                float* colsum_out, void* stream) {
+  if (n_rows < 0 || F < 0 || ldg < F || lda < F || ldo < F) return PYGAMD_ERR_INVALID_ARG;
+  if (F == 0) return PYGAMD_OK;
+  if (n_rows > 0 && (!grad || !act || !grad_in)) return PYGAMD_ERR_INVALID_ARG;
+  return launch_colsum(grad, ldg, act, lda, grad_in, ldo, n_rows, F, colsum_out,
+                       as_stream(stream));
 }
 
 int pygamd_gather_rows(const float* x, int64_t ldx, int64_t n_src, const void* index,

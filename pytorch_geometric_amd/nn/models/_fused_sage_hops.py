@@ -87,8 +87,8 @@ class FusedSageHopStack(Function):
             m = ctx.out_rows[l]
             if l < L - 1:
                 h_next = cats[l + 1][:, cats[l + 1].size(1) // 2:]  # post-ReLU rows [0, m)
-                g = torch.ops.aten.threshold_backward(g, h_next, 0)
-            if ctx.has_bias[l]:
+                g, grads[3 * l + 1] = _native.relu_backward_colsum(g, h_next, ctx.has_bias[l])
+            elif ctx.has_bias[l]:
                 grads[3 * l + 1] = _native.colsum(g)
             gw = torch.mm(g.t(), cat[:m])
             grads[3 * l], grads[3 * l + 2] = gw[:, :Fi], gw[:, Fi:]

@@ -527,3 +527,20 @@ def test_spmm_arg_output_and_weighted_mean(dev):
     assert_close(out, ref.detach(), atol=2e-5)
     assert_close(xg.grad, xr.grad, atol=2e-5)
     assert_close(wg.grad, wr.grad, atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize('F', [47, 256, 300])
+def test_relu_backward_colsum(dev, F):
+    """aten::threshold_backward(grad, relu_out, 0) + column sums in one pass, strided inputs."""
+    from pytorch_geometric_amd import _native
+    g = gen(F)
+    n = 1500
+    grad = torch.randn(n, 2 * F, generator=g)[:, F:]
+    act = torch.randn(n, F + 4, generator=g).relu()[:, :F]
+    act[::7] = 0.0
+    want = torch.ops.aten.threshold_backward(grad, act, 0)
+    got, cs = _native.relu_backward_colsum(grad.to(dev), act.to(dev))
+    assert got.is_contiguous() and torch.equal(got.cpu(), want)
+    assert_sum_close(cs, want.sum(0), want.double().sum(0), atol=1e-4, what='bias grad')
+    got, cs = _native.relu_backward_colsum(grad.to(dev), act.to(dev), want_colsum=False)
+    assert cs is None and torch.equal(got.cpu(), want)
