@@ -328,7 +328,8 @@ def main():
                          'pytorch_geometric_amd/tuning (TunableOp, read-only)' if tuned else
                          'rocBLAS/hipBLASLt via torch.mm, default heuristics'),
                 'schedule': 'fused stack: [agg|x] single GEMM per layer; 256->47 layer '
-                            'transforms first and aggregates at width 48',
+                            'transforms first and aggregates at width 48; ReLU backward '
+                            'fused with the bias column sum',
             },
             'roofline': roofline,
         }

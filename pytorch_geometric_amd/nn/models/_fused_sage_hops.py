@@ -20,6 +20,7 @@ from torch.autograd import Function
 
 from ... import _native
 from ...edge_index import EdgeIndex
+from . import _fused_sage
 
 
 class FusedSageHopStack(Function):
@@ -56,12 +57,15 @@ class FusedSageHopStack(Function):
             else:
                 nxt = torch.empty(m, 2 * Fo, dtype=torch.float32, device=dev)
                 dst = nxt[:, Fo:]
-            if b is not None:
-                torch.addmm(b, cat[:m], wmat.t(), out=dst)
+            if b is not None and not last and _fused_sage.RELU_EPILOGUE:
+                torch._addmm_activation(b, cat[:m], wmat.t(), use_gelu=False, out=dst)
             else:
-                torch.mm(cat[:m], wmat.t(), out=dst)
-            if not last:
-                dst.relu_()
+                if b is not None:
+                    torch.addmm(b, cat[:m], wmat.t(), out=dst)
+                else:
+                    torch.mm(cat[:m], wmat.t(), out=dst)
+                if not last:
+                    dst.relu_()
             cats.append(cat)
             wmats.append(wmat)
             ptrs.append(ptr)
