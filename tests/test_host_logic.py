@@ -16,6 +16,12 @@ def test_no_cpu_fallback():
         pga.utils.index_sort(idx)
     with pytest.raises(pga.PygAmdError, match='no CPU fallback'):
         pga.nn.SAGEConv(3, 2)(x, torch.tensor([[0, 1], [1, 0]]))
+    ei = torch.tensor([[0, 1, 1], [1, 0, 0]])
+    for fn in (pga.utils.sort_edge_index, pga.utils.coalesce, pga.utils.to_undirected):
+        with pytest.raises(pga.PygAmdError, match='no CPU fallback'):
+            fn(ei, num_nodes=2)
+    with pytest.raises(pga.PygAmdError, match='no CPU fallback'):
+        pga.utils.segment_matmul(torch.randn(4, 3), [0, 4], torch.randn(1, 3, 2))
 
 
 def test_product_never_imports_the_oracle():
