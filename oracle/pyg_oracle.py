@@ -375,6 +375,28 @@ def rgcn_conv_blocks(x, edge_index, edge_type, weight, root, bias, aggr='mean'):
     return out if bias is None else out + bias
 
 
+def rgcn_weight_from_bases(comp, bases, in_channels, out_channels):
+    """nn/conv/rgcn_conv.py:203-205: weight[r] = sum_b comp[r, b] * bases[b]."""
+    return (comp @ bases.view(bases.size(0), -1)).view(comp.size(0), in_channels, out_channels)
+
+
+def rgcn_conv_index(node_index, edge_index, edge_type, weight, root, bias, aggr='mean',
+                    num_dst=None, by_node_id=False):
+    """Node-index ("featureless") inputs.  RGCNConv (nn/conv/rgcn_conv.py:262-268): per relation,
+    propagate the embedding rows ``weight[r, node_index[j]]`` over the relation's edges and sum
+    the relations.  FastRGCNConv (``by_node_id``, :357-359, :362-374): rows are looked up by the
+    SOURCE NODE id, and a mean is a per-edge 1 / |N_r(i)| weight followed by one scatter-add."""
+    n_dst = node_index.size(0) if num_dst is None else num_dst
+    out = torch.zeros(n_dst, weight.size(2))
+    for r in range(weight.size(0)):
+        tmp = edge_index[:, edge_type == r]
+        look = tmp[0] if by_node_id else node_index[tmp[0]]
+        out = out + scatter(weight[r, look], tmp[1], 0, n_dst, 'sum' if aggr == 'add' else aggr)
+    if root is not None:
+        out = out + root[node_index]
+    return out if bias is None else out + bias
+
+
 # ---- models (nn/models/basic_gnn.py:178-274) ------------------------------------------------------
 def graphsage(x, edge_index, params: List[Tuple[Tensor, Tensor, Tensor]], aggr='mean'):
     """GraphSAGE: SAGEConv layers with ReLU between them, none after the last."""

@@ -6,7 +6,7 @@ from torch import Tensor
 from torch.nn import Parameter
 
 from ... import _native
-from ..._functions import SpmmFunction
+from ..._functions import GatherFunction, SpmmFunction
 from ...edge_index import EdgeIndex
 from ...utils._segment_matmul import block_segment_matmul, segment_matmul
 from ..inits import glorot, zeros
@@ -52,10 +52,23 @@ class RelationalHandle:
         pair_of_edge = _native.ptr2index(seg_ptr, E)
         self.pair_graph = EdgeIndex(torch.stack([src_sorted, pair_of_edge]), (num_src, S),
                                     sort_order='col', validate=False)
+        self._perm, self._pair_of_edge, self._edge_graph = perm, pair_of_edge, None
         self.rel_ptr = tuple(_native.index2ptr(pair_rel, num_relations).tolist())
         # pairs -> destination nodes
         self.out_graph = EdgeIndex(torch.stack([torch.arange(S, device=dev), pair_dst]),
                                    (S, num_dst), sort_order='row', validate=False)
+
+
+    @property
+    def edge_graph(self) -> EdgeIndex:
+        """Handle over per-EDGE message rows -> pair segments (rows = pairs, columns = the
+        original edge ids): aggregates messages that were built edge by edge (node-index
+        inputs).  Built on first use."""
+        if self._edge_graph is None:
+            E = self._perm.numel()
+            self._edge_graph = EdgeIndex(torch.stack([self._perm, self._pair_of_edge]),
+                                         (E, self.num_pairs), sort_order='col', validate=False)
+        return self._edge_graph
 
 
 class RGCNConv(MessagePassing):
@@ -176,17 +189,20 @@ class RGCNConv(MessagePassing):
             out = out + self.bias
         return out
 
-    def _index_inputs(self, x_l, x_r, edge_index, edge_type, weight):
-        # rgcn_conv.py:262-268: out += propagate(masked edges, x = weight[r, x_l])
-        out = torch.zeros(x_r.size(0), self.out_channels, device=x_r.device)
+    def _index_inputs(self, x_l, x_r, edge_index, edge_type, weight, by_node_id=False):
+        """Node-index ("featureless") inputs, rgcn_conv.py:262-268: the message of edge (j, i, r)
+        is the embedding row ``weight[r, x_l[j]]``.  One differentiable row gather builds all
+        messages, one SpMM reduces them per (relation, destination) pair and one sums the pairs
+        of every destination — instead of one masked propagate per relation."""
         ei = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
-        for r in range(self.num_relations):
-            tmp = ei[:, edge_type == r]
-            if tmp.size(1) == 0:
-                continue
-            out = out + self.propagate(tmp.contiguous(), x=weight[r, x_l],
-                                       size=(x_l.size(0), x_r.size(0)))
-        return out
+        n_src, n_dst = x_l.size(0), x_r.size(0)
+        look = ei[0] if by_node_id else x_l[ei[0]]
+        rows = edge_type.to(torch.int64) * weight.size(1) + look.to(torch.int64)
+        msg = GatherFunction.apply(weight.reshape(-1, self.out_channels), rows, True)
+        h = self._handle(ei, edge_type, n_src, n_dst)
+        reduce = 'sum' if self.aggr == 'add' else self.aggr
+        per_pair = SpmmFunction.apply(msg, None, h.edge_graph, reduce, 'coo')
+        return SpmmFunction.apply(per_pair, None, h.out_graph, 'sum', 'coo')
 
     def message(self, x_j: Tensor) -> Tensor:
         return x_j
@@ -198,3 +214,36 @@ class RGCNConv(MessagePassing):
     def __repr__(self) -> str:
         return (f'{self.__class__.__name__}({self.in_channels}, '
                 f'{self.out_channels}, num_relations={self.num_relations})')
+
+
+class FastRGCNConv(RGCNConv):
+    r"""``torch_geometric.nn.FastRGCNConv`` (torch_geometric/nn/conv/rgcn_conv.py:301-374): the
+    same operator as :class:`RGCNConv` restricted to ``aggr`` in ``add`` / ``sum`` / ``mean``.  The
+    reference trades memory for speed there (one ``bmm`` over per-edge weight copies); here both
+    classes already run the sorted, segmented path, so this class only adds the reference's
+    argument checks and its node-index convention: index inputs are looked up by SOURCE NODE id
+    (``rgcn_conv.py:357-359``), i.e. they are meaningful with ``x=None`` and
+    ``in_channels == num_nodes``."""
+
+    def forward(self, x, edge_index, edge_type: Optional[Tensor] = None) -> Tensor:
+        assert self.aggr in ['add', 'sum', 'mean']
+        x_l = x[0] if isinstance(x, tuple) else x
+        if x_l is not None and torch.is_floating_point(x_l):
+            return super().forward(x, edge_index, edge_type)
+        assert edge_type is not None
+        if self.num_blocks is not None:
+            raise ValueError('Block-diagonal decomposition not supported '
+                             'for non-continuous input features.')
+        if x_l is None:
+            x_l = torch.arange(self.in_channels_l, device=self.weight.device)
+        x_r = x[1] if isinstance(x, tuple) else x_l
+        weight = self.weight
+        if self.num_bases is not None:
+            weight = (self.comp @ weight.view(self.num_bases, -1)).view(
+                self.num_relations, self.in_channels_l, self.out_channels)
+        out = self._index_inputs(x_l, x_r, edge_index, edge_type, weight, by_node_id=True)
+        if self.root is not None:
+            out = out + (self.root[x_r] if not torch.is_floating_point(x_r) else x_r @ self.root)
+        if self.bias is not None:
+            out = out + self.bias
+        return out

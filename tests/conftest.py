@@ -35,5 +35,11 @@ def golden_preproc():
 
 
 @pytest.fixture(scope='session')
+def golden_rgcn():
+    path = os.path.join(ROOT, 'tests', 'golden', 'golden_rgcn_v1.pt')
+    return torch.load(path, map_location='cpu', weights_only=False)
+
+
+@pytest.fixture(scope='session')
 def dev():
     return torch.device('cuda:0')

@@ -250,6 +250,42 @@ def test_rgcn_conv_golden(dev, golden):
                *args)
 
 
+def test_fast_rgcn_and_index_inputs_golden(dev, golden, golden_rgcn):
+    """FastRGCNConv and the node-index inputs of both classes against the real reference."""
+    from pytorch_geometric_amd.nn import FastRGCNConv, RGCNConv
+    gr, L = golden['graph'], golden_rgcn['layers']
+    args = (gr['edge_index'], gr['edge_type'])
+    N = gr['x'].size(0)
+    _run_layer(FastRGCNConv(16, 10, num_relations=5), L['fast'], gr['x'], dev, *args)
+    _run_layer(FastRGCNConv(16, 10, num_relations=5, aggr='add'), L['fast_add'], gr['x'], dev,
+               *args)
+    _run_layer(FastRGCNConv(16, 12, num_relations=5, num_blocks=4), L['fast_blocks'], gr['x'],
+               dev, *args)
+    _run_layer(FastRGCNConv(16, 10, num_relations=5, num_bases=3), L['fast_bases'], gr['x'], dev,
+               *args)
+
+    def run_index(conv, case, x):
+        conv.load_state_dict(case['state'])
+        conv = conv.to(dev).eval()
+        out = conv(None if x is None else x.to(dev), *[a.to(dev) for a in args])
+        params = list(conv.parameters())
+        grads = torch.autograd.grad(out, params, case['grad_out'].to(dev), allow_unused=True)
+        assert_close(out, case['out'], what='out')
+        for (n, _), g in zip(conv.named_parameters(), grads):
+            if case['grad_params'][n] is not None:
+                assert_close(g, case['grad_params'][n], atol=5e-5, rtol=5e-5, what=f'grad {n}')
+
+    x_idx = golden_rgcn['x_idx']
+    run_index(RGCNConv(16, 10, num_relations=5), L['rgcn_index'], x_idx)
+    run_index(RGCNConv(16, 10, num_relations=5, aggr='max'), L['rgcn_index_max'], x_idx)
+    run_index(RGCNConv(N, 10, num_relations=5), L['rgcn_none'], None)
+    run_index(FastRGCNConv(N, 10, num_relations=5), L['fast_none'], None)
+    run_index(FastRGCNConv(N, 10, num_relations=5, num_bases=3), L['fast_none_bases'], None)
+    with pytest.raises(AssertionError):
+        FastRGCNConv(16, 10, num_relations=5, aggr='max')(gr['x'].to(dev),
+                                                          *[a.to(dev) for a in args])
+
+
 def test_rgcn_conv_vs_oracle_skewed_relations(dev):
     """FB15k-237-like relation histogram (Zipf), empty relations, int32 indices, sum aggregation."""
     from oracle import pyg_oracle as O

@@ -224,3 +224,42 @@ def test_sort_edge_index_coalesce_undirected_match_the_reference(golden_preproc)
     ei = torch.tensor([[2, 1, 1, 0], [1, 2, 0, 1]])
     out, a = O.sort_edge_index(ei, torch.tensor([[1], [2], [3], [4]]))
     assert out.tolist() == [[0, 1, 1, 2], [1, 0, 2, 1]] and a.view(-1).tolist() == [4, 3, 2, 1]
+
+
+def test_fast_rgcn_and_index_inputs(golden, golden_rgcn):
+    """FastRGCNConv == RGCNConv's math on float inputs; node-index inputs of both classes."""
+    gr, L = golden['graph'], golden_rgcn['layers']
+    ei, et, x_idx = gr['edge_index'], gr['edge_type'], golden_rgcn['x_idx']
+    N = gr['x'].size(0)
+    for c in ('fast', 'fast_add', 'fast_blocks', 'fast_bases'):
+        L[c]['x'] = gr['x']
+    names = ['weight', 'root', 'bias']
+    _check_layer(L['fast'], lambda x, w, r, b: O.rgcn_conv(x, ei, et, w, r, b), names)
+    _check_layer(L['fast_add'], lambda x, w, r, b: O.rgcn_conv(x, ei, et, w, r, b, 'add'), names)
+    _check_layer(L['fast_blocks'], lambda x, w, r, b: O.rgcn_conv_blocks(x, ei, et, w, r, b),
+                 names)
+    _check_layer(L['fast_bases'],
+                 lambda x, w, c, r, b: O.rgcn_conv(
+                     x, ei, et, O.rgcn_weight_from_bases(c, w, 16, 10), r, b),
+                 ['weight', 'comp', 'root', 'bias'])
+
+    def check_index(case, fn, names):
+        leaves = [case['state'][n].clone().requires_grad_(True) for n in names]
+        out = fn(*leaves)
+        close(out, case['out'], 1e-5)
+        grads = torch.autograd.grad(out, leaves, case['grad_out'], allow_unused=True)
+        for n, g in zip(names, grads):
+            if case['grad_params'][n] is not None:
+                close(g, case['grad_params'][n], 1e-4)
+
+    check_index(L['rgcn_index'], lambda w, r, b: O.rgcn_conv_index(x_idx, ei, et, w, r, b), names)
+    check_index(L['rgcn_index_max'],
+                lambda w, r, b: O.rgcn_conv_index(x_idx, ei, et, w, r, b, 'max'), names)
+    ar = torch.arange(N)
+    check_index(L['rgcn_none'], lambda w, r, b: O.rgcn_conv_index(ar, ei, et, w, r, b), names)
+    check_index(L['fast_none'],
+                lambda w, r, b: O.rgcn_conv_index(ar, ei, et, w, r, b, by_node_id=True), names)
+    check_index(L['fast_none_bases'],
+                lambda w, c, r, b: O.rgcn_conv_index(
+                    ar, ei, et, O.rgcn_weight_from_bases(c, w, N, 10), r, b, by_node_id=True),
+                ['weight', 'comp', 'root', 'bias'])
