@@ -144,6 +144,30 @@ def softmax(src: Tensor, index: Optional[Tensor] = None, ptr: Optional[Tensor] =
     return out / out_sum
 
 
+# ---- nn/aggr/basic.py:142-296 (DeeperGCN aggregations) ---------------------------------------------
+def _group_reduce(x, index, ptr, dim_size, reduce):
+    return segment(x, ptr, reduce) if ptr is not None else scatter(x, index, 0, dim_size, reduce)
+
+
+def softmax_aggregation(x, index=None, ptr=None, dim_size=None, t=1.0, semi_grad=False):
+    """nn/aggr/basic.py:196-215: alpha = softmax(x * t) per group, out = sum(x * alpha)."""
+    logits = x * t
+    if semi_grad:
+        with torch.no_grad():
+            alpha = softmax(logits, index, ptr, dim_size)
+    else:
+        alpha = softmax(logits, index, ptr, dim_size)
+    return _group_reduce(x * alpha, index, ptr, dim_size, 'sum')
+
+
+def powermean_aggregation(x, index=None, ptr=None, dim_size=None, p=1.0, lo=1e-4, hi=100.):
+    """nn/aggr/basic.py:275-292: mean of clamp(x)^p, then clamp()^(1/p); p == 1 is a plain mean."""
+    if isinstance(p, (int, float)) and p == 1:
+        return _group_reduce(x, index, ptr, dim_size, 'mean')
+    out = _group_reduce(x.clamp(min=lo, max=hi).pow(p), index, ptr, dim_size, 'mean')
+    return out.clamp(min=lo, max=hi).pow(1. / p)
+
+
 # ---- propagate = gather -> message -> scatter (nn/conv/message_passing.py:421-563) ------------------
 def propagate(x_src: Tensor, edge_index: Tensor, num_dst: int, reduce: str,
               edge_weight: Optional[Tensor] = None) -> Tensor:

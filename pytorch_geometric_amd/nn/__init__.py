@@ -1,6 +1,6 @@
 from .aggr import (Aggregation, FusedAggregation, MaxAggregation, MeanAggregation,
-                   MinAggregation, MulAggregation, MultiAggregation, StdAggregation,
-                   SumAggregation, VarAggregation)
+                   MinAggregation, MulAggregation, MultiAggregation, PowerMeanAggregation,
+                   SoftmaxAggregation, StdAggregation, SumAggregation, VarAggregation)
 from .conv import (FastRGCNConv, GATConv, GCNConv, GraphConv, MessagePassing, RGCNConv, SAGEConv,
                    gcn_norm)
 from .dense import HeteroLinear, Linear
@@ -9,6 +9,6 @@ from .models import GAT, GCN, BasicGNN, GraphSAGE
 __all__ = [
     'Aggregation', 'SumAggregation', 'MeanAggregation', 'MaxAggregation', 'MinAggregation',
     'MulAggregation', 'VarAggregation', 'StdAggregation', 'FusedAggregation',
-    'MultiAggregation', 'MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv', 'RGCNConv', 'FastRGCNConv', 'GraphConv', 'Linear', 'HeteroLinear',
+    'MultiAggregation', 'SoftmaxAggregation', 'PowerMeanAggregation', 'MessagePassing', 'SAGEConv', 'GCNConv', 'gcn_norm', 'GATConv', 'RGCNConv', 'FastRGCNConv', 'GraphConv', 'Linear', 'HeteroLinear',
     'BasicGNN', 'GCN', 'GraphSAGE', 'GAT',
 ]

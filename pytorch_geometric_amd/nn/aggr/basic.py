@@ -49,6 +49,11 @@ def aggregation_resolver(aggr, **kwargs) -> Aggregation:
     """String / module -> :class:`Aggregation` (torch_geometric/nn/resolver.py role)."""
     if isinstance(aggr, Aggregation):
         return aggr
+    if isinstance(aggr, str) and aggr.lower() in ('softmax', 'powermean'):
+        from . import deeper
+        by_name = {"softmax": deeper.SoftmaxAggregation, "powermean": deeper.PowerMeanAggregation}
+        cls = by_name[aggr.lower()]
+        return cls(**kwargs)
     if isinstance(aggr, str) and aggr.lower() in _BY_NAME:
         return _BY_NAME[aggr.lower()](**kwargs)
     raise ValueError(f"Could not resolve aggregation '{aggr}' "

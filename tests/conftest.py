@@ -41,5 +41,11 @@ def golden_rgcn():
 
 
 @pytest.fixture(scope='session')
+def golden_aggr():
+    path = os.path.join(ROOT, 'tests', 'golden', 'golden_aggr_v1.pt')
+    return torch.load(path, map_location='cpu', weights_only=False)
+
+
+@pytest.fixture(scope='session')
 def dev():
     return torch.device('cuda:0')

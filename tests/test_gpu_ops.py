@@ -544,3 +544,30 @@ def test_relu_backward_colsum(dev, F):
     assert_sum_close(cs, want.sum(0), want.double().sum(0), atol=1e-4, what='bias grad')
     got, cs = _native.relu_backward_colsum(grad.to(dev), act.to(dev), want_colsum=False)
     assert cs is None and torch.equal(got.cpu(), want)
+
+
+def test_softmax_and_powermean_aggregation_golden(dev, golden_aggr):
+    """DeeperGCN aggregations (nn/aggr/basic.py:142-296) against the real reference."""
+    from pytorch_geometric_amd import nn
+    from tests._aggr_cases import CASES
+    G = golden_aggr
+    for name, (kind, kw, use_ptr, positive) in CASES.items():
+        case = G['cases'][name]
+        cls = nn.SoftmaxAggregation if kind == 'softmax' else nn.PowerMeanAggregation
+        aggr = cls(**kw).to(dev)
+        x = (G['x'].abs() + 0.1 if positive else G['x']).to(dev).requires_grad_(True)
+        where = (dict(ptr=G['ptr'].to(dev)) if use_ptr
+                 else dict(index=G['index'].to(dev), dim_size=G['dim_size']))
+        out = aggr(x, **where)
+        params = list(aggr.parameters())
+        grads = torch.autograd.grad(out, [x] + params, case['grad_out'].to(dev))
+        assert_close(out, case['out'], atol=2e-5, what=f'{name} out')
+        assert_close(grads[0], case['grad_x'], atol=2e-5, what=f'{name} grad_x')
+        if params:
+            assert_close(grads[1], case['grad_param'], atol=1e-4, rtol=1e-4,
+                         what=f'{name} grad param')
+    with pytest.raises(ValueError):
+        nn.SoftmaxAggregation(learn=True, semi_grad=True)
+    with pytest.raises(ValueError):
+        nn.PowerMeanAggregation(channels=3)
+    assert isinstance(nn.aggr.aggregation_resolver('softmax', t=2.0), nn.SoftmaxAggregation)

@@ -263,3 +263,27 @@ def test_fast_rgcn_and_index_inputs(golden, golden_rgcn):
                 lambda w, c, r, b: O.rgcn_conv_index(
                     ar, ei, et, O.rgcn_weight_from_bases(c, w, N, 10), r, b, by_node_id=True),
                 ['weight', 'comp', 'root', 'bias'])
+
+
+def test_softmax_and_powermean_aggregation(golden_aggr):
+    from tests._aggr_cases import CASES
+    G = golden_aggr
+    for name, (kind, kw, use_ptr, positive) in CASES.items():
+        case = G['cases'][name]
+        x = (G['x'].abs() + 0.1 if positive else G['x']).clone().requires_grad_(True)
+        where = dict(ptr=G['ptr']) if use_ptr else dict(index=G['index'], dim_size=G['dim_size'])
+        value = kw.get('t', kw.get('p', 1.0))
+        param = None
+        if kw.get('learn'):
+            param = torch.full((kw.get('channels', 1), ), value).requires_grad_(True)
+            value = param.view(-1, kw['channels']) if kw.get('channels', 1) != 1 else param
+        if kind == 'softmax':
+            out = O.softmax_aggregation(x, t=value, semi_grad=kw.get('semi_grad', False), **where)
+        else:
+            out = O.powermean_aggregation(x, p=value, **where)
+        close(out, case['out'], 1e-5)
+        leaves = [x] + ([param] if param is not None else [])
+        grads = torch.autograd.grad(out, leaves, case['grad_out'])
+        close(grads[0], case['grad_x'], 1e-5)
+        if param is not None:
+            close(grads[1], case['grad_param'], 1e-4)
