@@ -118,7 +118,7 @@ def run_minibatch(args, rank, local_rank, world, dev):
     seeds = shard_seeds(train_idx, rank, world)
     fan = [15, 10, 5]
     loader = NeighborLoader(x, ei, fan, batch_size=1024, y=y, input_nodes=seeds, shuffle=True,
-                            drop_last=True, seed=17 + rank)
+                            drop_last=True, seed=17 + rank, prefetch=args.prefetch)
     torch.manual_seed(0)
     model = GraphSAGE(128, 256, num_layers=3, out_channels=172).to(dev)
     broadcast_parameters(model)
@@ -162,6 +162,7 @@ def run_minibatch(args, rank, local_rank, world, dev):
     fence()
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(loss).item()
+    it.close()  # stops the loader's prefetch thread
     t = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
     if world > 1:
         tm = t[:1].clone()
@@ -180,7 +181,7 @@ def run_minibatch(args, rank, local_rank, world, dev):
             'config': {'workload': f'GraphSAGE(128->256->256->172) mini-batch training, batch '
                                    f'1024 seeds/rank, fan-out {fan}, trim_to_layer, synthetic '
                                    f'papers100M shape x {scale:g} (N={N}, E={E}) replicated per '
-                                   f'GPU, GPU sampler + gather',
+                                   f'GPU, GPU sampler + gather, {args.prefetch} batch(es) prefetched on a side stream',
                        'parallelism': f'dp{world} (seed sharding, one flat-bucket '
                                       f'all-reduce/step)'}}), flush=True)
 
@@ -194,6 +195,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--scale', type=float, default=1.0, help='fraction of the products shape')
+    ap.add_argument('--prefetch', type=int, default=2,
+                    help='mini-batch mode: batches sampled ahead on a side stream (0 = inline)')
     ap.add_argument('--index-dtype', choices=['int64', 'int32'], default='int64')
     ap.add_argument('--uniform', action='store_true', help='uniform instead of power-law graph')
     ap.add_argument('--cpu-scale', type=float, default=1 / 64)

@@ -148,6 +148,19 @@ class EdgeIndex:
             csr._hub = (None, None, 0, 0)  # fan-out bounded: no row needs splitting
         return self
 
+    def record_stream(self, stream) -> None:
+        """Tell the caching allocator that `stream` uses the tensors of this handle (a handle
+        built on a side stream — the prefetching loader — and consumed on another)."""
+        tensors = [self.edge_index]
+        for csr in (self._csr, self._csc):
+            if csr is not None:
+                tensors += [csr.ptr, csr.idx, csr.perm, csr._inv_deg]
+                if csr._hub is not None:
+                    tensors += [csr._hub[0], csr._hub[1]]
+        for t in tensors:
+            if isinstance(t, Tensor) and t.is_cuda:
+                t.record_stream(stream)
+
     def trim(self, num_nodes: int, num_edges: int) -> 'EdgeIndex':
         """Prefix handle for ``trim_to_layer`` on hop-ordered batches: keeps the first
         ``num_edges`` edges and the first ``num_nodes`` nodes.  Destination-sorted handles are

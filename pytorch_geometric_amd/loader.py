@@ -3,6 +3,8 @@
 BASELINE config 4 — seeds are drawn per batch, the k-hop neighbourhood is sampled ON THE GPU
 (:mod:`.sampler`), features are gathered with the HIP gather kernel (``filter_data``'s
 ``x[n_id]``) and the batch never touches the host."""
+import queue
+import threading
 from dataclasses import dataclass
 from typing import Iterator, List, Optional
 
@@ -29,6 +31,12 @@ class Batch:
     num_sampled_nodes: List[int]
     num_sampled_edges: List[int]
 
+    def record_stream(self, stream) -> None:
+        for t in (self.x, self.y, self.edge_index, self.n_id, self.e_id, self.input_id):
+            if isinstance(t, Tensor) and t.is_cuda:
+                t.record_stream(stream)
+        self.graph.record_stream(stream)
+
 
 class NeighborLoader:
     r"""Iterates over mini-batches of ``batch_size`` seed nodes with their sampled ``k``-hop
@@ -40,12 +48,20 @@ class NeighborLoader:
         num_neighbors: fan-out per hop (``-1`` = all).
         input_nodes: seed pool (default: all nodes); shard it across ranks with
             :func:`pytorch_geometric_amd.data_parallel.shard_seeds`.
+        prefetch: number of batches sampled AHEAD of the consumer (0 = sample inside
+            ``__next__``).  With ``prefetch > 0`` a producer thread samples and gathers on its own
+            HIP stream while the caller trains on the previous batch — the role the reference
+            gives to ``num_workers`` DataLoader processes (loader/node_loader.py:90-152), without
+            leaving the device.  Batches are handed over with an event the consumer's stream
+            waits on.
     """
 
     def __init__(self, x: Tensor, edge_index: Tensor, num_neighbors: List[int],
                  batch_size: int = 1024, y: Optional[Tensor] = None,
                  input_nodes: Optional[Tensor] = None, shuffle: bool = False,
-                 drop_last: bool = False, seed: int = 0):
+                 drop_last: bool = False, seed: int = 0, prefetch: int = 0):
+        self.prefetch = int(prefetch)
+        self._side = None
         self.x, self.y = x, y
         self.num_nodes = x.size(0)
         self.sampler = NeighborSampler(edge_index, self.num_nodes, num_neighbors, seed=seed)
@@ -72,10 +88,71 @@ class NeighborLoader:
                      batch_size=seeds.numel(), num_sampled_nodes=out.num_sampled_nodes,
                      num_sampled_edges=out.num_sampled_edges)
 
-    def __iter__(self) -> Iterator[Batch]:
+    def _plan(self):
         n = self.input_nodes.numel()
         order = (torch.randperm(n, generator=self._gen).to(self.input_nodes.device)
                  if self.shuffle else torch.arange(n, device=self.input_nodes.device))
         for b in range(len(self)):
             sel = order[b * self.batch_size:(b + 1) * self.batch_size]
-            yield self.collate(self.input_nodes[sel], sel)
+            yield self.input_nodes[sel], sel
+
+    def __iter__(self) -> Iterator[Batch]:
+        if self.prefetch <= 0:
+            for seeds, sel in self._plan():
+                yield self.collate(seeds, sel)
+            return
+        yield from self._prefetching_iter()
+
+    def _prefetching_iter(self) -> Iterator[Batch]:
+        dev = self.x.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        side = self._side
+        plan = self._plan()
+        first = next(plan, None)   # the seed tensors are made on the consumer's stream ...
+        side.wait_stream(torch.cuda.current_stream(dev))  # ... before the producer reads them
+        ready: 'queue.Queue' = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def put(item) -> bool:
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def produce():
+            try:
+                torch.cuda.set_device(dev)
+                item = first
+                with torch.cuda.stream(side):
+                    while item is not None and not stop.is_set():
+                        batch = self.collate(*item)
+                        done = torch.cuda.Event()
+                        done.record(side)
+                        if not put((batch, done)):
+                            return
+                        item = next(plan, None)
+                put(None)
+            except BaseException as exc:  # surfaced in the consumer
+                put(exc)
+
+        worker = threading.Thread(target=produce, name='pyg-amd-sampler', daemon=True)
+        worker.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                batch, done = item
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(done)
+                batch.record_stream(cur)
+                yield batch
+        finally:
+            stop.set()
+            worker.join(timeout=10.0)

@@ -155,3 +155,37 @@ def test_hop_aware_fused_stack_matches_layer_loop(dev):
         for a, b in zip(res[True][2], res[False][2]):
             assert_close(a, b.cpu(), atol=1e-4, rtol=1e-4, what='hop stack param grad')
     model.fuse_stack = True
+
+
+def test_prefetching_loader_yields_the_same_batches(dev):
+    """prefetch > 0: a producer thread samples ahead on a side stream; batches (and a training
+    step on them) are identical to the inline loader's."""
+    from pytorch_geometric_amd.loader import NeighborLoader
+    from pytorch_geometric_amd.nn import GraphSAGE
+    n = 5000
+    ei = random_graph(n, n, 60_000, seed=31, skew=True).to(dev)
+    x = torch.randn(n, 24, generator=gen(32)).to(dev)
+    y = torch.randint(0, 5, (n, ), generator=gen(33)).to(dev)
+    torch.manual_seed(3)
+    model = GraphSAGE(24, 32, num_layers=2, out_channels=5).to(dev)
+
+    def run(prefetch):
+        loader = NeighborLoader(x, ei, [6, 4], batch_size=256, y=y, shuffle=True, seed=9,
+                                input_nodes=torch.arange(2000, device=dev), prefetch=prefetch)
+        outs = []
+        for epoch in range(2):
+            for b in loader:
+                out = model(b.x, b.graph, num_sampled_nodes_per_hop=b.num_sampled_nodes,
+                            num_sampled_edges_per_hop=b.num_sampled_edges)[:b.batch_size]
+                outs.append((b.n_id.cpu(), b.e_id.cpu(), b.y.cpu(), out.detach().cpu()))
+        return outs
+
+    inline, ahead = run(0), run(3)
+    assert len(inline) == len(ahead) == 16
+    for a, b in zip(inline, ahead):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert torch.equal(a[3], b[3])
+    # abandoning the iterator mid-epoch stops the producer thread
+    it = iter(NeighborLoader(x, ei, [6, 4], batch_size=256, prefetch=2))
+    next(it)
+    it.close()
