@@ -194,6 +194,19 @@ PYGAMD_API int pygamd_spmm_csr_minmax_backward(const void* rowptr_t, const void*
                                                const float* ntie, int64_t ldo, int64_t n_src,
                                                int64_t F, float* grad_x, int64_t ldg,
                                                void* stream);
+/* The same gradient, destination-driven and in ONE launch (no tie tensor, no by-source sort):
+ * (rowptr, col) is the FORWARD's handle (rows = destinations, col = sources; col == NULL: slot k
+ * is source k, i.e. segment reduce).  Per destination row the neighbours attaining out[i, f] are
+ * counted (+1 for the zero-initialised self when count_self and out == 0), then every attaining
+ * source receives grad_out[i, f] / ties through one fp32 atomic.  grad_x ([n_src, F], ld ldg) is
+ * zeroed internally; sources reached from several destinations are summed in arbitrary order.  */
+PYGAMD_API int pygamd_spmm_csr_minmax_backward_dst(const void* rowptr, const void* col,
+                                                   int idx_dtype, const float* x, int64_t ldx,
+                                                   const float* out, int64_t ldo,
+                                                   const float* grad_out, int64_t ldgo,
+                                                   int64_t n_rows, int64_t n_src, int64_t F,
+                                                   int count_self, float* grad_x, int64_t ldg,
+                                                   void* stream);
 
 /* ---- SDDMM: gradient w.r.t. edge weights ----------------------------------------------------
  * grad_w[e(k), h] = sum_{f in head h} grad_out[i, f] * x[col[k], f] * (src_scale? ...)  for k in

@@ -56,6 +56,9 @@ SIGNATURES = {
                                           c_int64, c_int, _P, _P]),
     'pygamd_spmm_csr_minmax_backward': (c_int, [_P, _P, c_int, _P, c_int64, _P, _P, _P, c_int64,
                                                 c_int64, c_int64, _P, c_int64, _P]),
+    'pygamd_spmm_csr_minmax_backward_dst': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, _P,
+                                                    c_int64, c_int64, c_int64, c_int64, c_int, _P,
+                                                    c_int64, _P]),
     'pygamd_sddmm_csr': (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                  c_int32, c_int32, _P, _P]),
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),

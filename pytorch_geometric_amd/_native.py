@@ -242,6 +242,22 @@ def colsum(x: Tensor) -> Tensor:
     return out
 
 
+def spmm_minmax_backward_dst(rowptr: Tensor, col: Optional[Tensor], x: Tensor, out: Tensor,
+                             grad_out: Tensor, n_src: int, count_self: bool = True) -> Tensor:
+    """Gradient of the min/max aggregation w.r.t. ``x`` (reference tie rule) from the forward's
+    destination-sorted handle, one launch."""
+    _require_device(rowptr, col, x, out, grad_out)
+    lib = _lib.load()
+    x2, o2, g2 = _f32_rows(x, 'x'), _f32_rows(out, 'out'), _f32_rows(grad_out, 'grad_out')
+    F = x2.size(1)
+    grad_x = torch.empty(n_src, F, dtype=torch.float32, device=x.device)
+    check(lib.pygamd_spmm_csr_minmax_backward_dst(
+        _p(rowptr), _p(col), _idx_dtype(rowptr), _p(x2), _ld(x2), _p(o2), _ld(o2), _p(g2),
+        _ld(g2), rowptr.numel() - 1, n_src, F, int(count_self), _p(grad_x), _ld(grad_x),
+        _stream(x)), 'spmm_minmax_backward_dst')
+    return grad_x
+
+
 def relu_backward_colsum(grad: Tensor, act: Tensor, want_colsum: bool = True):
     """(grad * (act > 0) as a new contiguous tensor, its column sums | None) in one pass; ``act``
     is the ReLU output.  Inputs may be row-strided views."""

@@ -472,6 +472,118 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// Destination-driven min/max backward with the reference tie rule, ONE launch: a wave owns
+// destination row i with the forward's lane mapping (slot indices staged 64 at a time, 16-byte
+// source-row loads, U rows in flight).  Pass 1 counts, per feature, the neighbours that attain
+// out[i, f] (+ the zero-initialised self when out == 0, scatter_reduce_(include_self=False)'s
+// backward rule); pass 2 walks the row again and sends grad_out[i, f] / ties to every attaining
+// source with one fp32 atomic.  Gathers the E source rows (twice) instead of the three
+// destination-row gathers per edge of the source-driven form, and needs neither a by-source sort
+// of the graph nor a tie-count tensor: 42 ms instead of 144 ms at the products shape, F = 256
+// (the forward takes 15 ms; the N x F scattered atomics are the larger half of the difference —
+// a single-pass variant that finishes tie-free features inside pass 1 measured the same).
+template <typename IdxT, int VW, int LPR, int CH>
+__global__ void __launch_bounds__(kBlock)
+    spmm_minmax_bwd_dst(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ col,
+                        const float* __restrict__ x, int64_t ldx, const float* __restrict__ out,
+                        int64_t ldo, const float* __restrict__ grad_out, int64_t ldgo,
+                        int64_t n_rows, int64_t F, int count_self, float* __restrict__ grad_x,
+                        int64_t ldg) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = 4;
+  constexpr int STEP = EPI * U;
+  const int lane = lane_id();
+  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (row >= n_rows) return;
+  const IdxT start = rowptr[row];
+  const IdxT end = rowptr[row + 1];
+  int fo[CH], head[CH];
+  bool fv[CH];
+  feature_slots<VW, LPR, CH>(lane, F, 1, fo, fv, head);
+  const int sub = lane / LPR;
+  Vec<VW> o[CH];
+  float ties[CH][VW];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (fv[c]) {
+      o[c] = load_vec<VW>(out + row * ldo + fo[c]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) o[c].v[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VW; ++i) ties[c][i] = 0.f;
+  }
+  Vec<VW> q[CH];
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    for (IdxT base = start; base < end; base += kWave) {
+      const IdxT rem = end - base;
+      const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+      IdxT myc = 0;
+      if (lane < cnt) myc = col ? col[base + lane] : base + lane;
+      for (int j = 0; j < cnt; j += STEP) {
+        Vec<VW> v[U][CH];
+        bool ok[U];
+        int64_t src[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = j + u * EPI + sub;
+          ok[u] = k < cnt;
+          const int kk = ok[u] ? k : cnt - 1;
+          IdxT c;
+          if constexpr (EPI == 1) {
+            c = bcast_uniform(myc, kk);
+          } else {
+            c = bcast_lane(myc, kk);
+          }
+          src[u] = static_cast<int64_t>(c);
+          const float* __restrict__ xr = x + src[u] * ldx;
+#pragma unroll
+          for (int c2 = 0; c2 < CH; ++c2) {
+            if (fv[c2] && ok[u]) v[u][c2] = load_vec<VW>(xr + fo[c2]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int c2 = 0; c2 < CH; ++c2) {
+            if (fv[c2] && ok[u]) {
+#pragma unroll
+              for (int i = 0; i < VW; ++i) {
+                const bool hit = v[u][c2].v[i] == o[c2].v[i];
+                if (pass == 0) {
+                  ties[c2][i] += hit ? 1.f : 0.f;
+                } else if (hit) {
+                  atomicAdd(grad_x + src[u] * ldg + fo[c2] + i, q[c2].v[i]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    if (pass == 0) {
+      combine_subgroups<VW, LPR, CH>(ties);  // every sub-group now holds the row's tie counts
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        Vec<VW> g;
+        if (fv[c]) {
+          g = load_vec<VW>(grad_out + row * ldgo + fo[c]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < VW; ++i) g.v[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+          const float n = ties[c][i] + ((count_self && o[c].v[i] == 0.f) ? 1.f : 0.f);
+          q[c].v[i] = n > 0.f ? g.v[i] / n : 0.f;
+        }
+      }
+    }
+  }
+}
+
 // ---- SDDMM ----------------------------------------------------------------------------------
 // grad_w[e(k), h] = <grad_out[i, head h], x[col[k], head h]> for every slot k of row i.  Same
 // mapping as the SpMM: one wave per destination row, the row of grad_out stays in registers, slot
@@ -760,6 +872,47 @@ static int launch_sddmm(const Shape& s, const void* rowptr, const void* col, con
 #undef PYGAMD_SDDMM
 }
 
+template <typename IdxT>
+static int launch_minmax_bwd_dst(const Shape& s, const void* rowptr, const void* col,
+                                 const float* x, int64_t ldx, const float* out, int64_t ldo,
+                                 const float* grad_out, int64_t ldgo, int64_t n_rows, int64_t F,
+                                 int count_self, float* grad_x, int64_t ldg, hipStream_t st) {
+  dim3 grid(wave_grid(n_rows), s.tiles);
+#define PYGAMD_MMB(VW, LPR, CH)                                                                \
+  hipLaunchKernelGGL((spmm_minmax_bwd_dst<IdxT, VW, LPR, CH>), grid, dim3(kBlock), 0, st,      \
+                     static_cast<const IdxT*>(rowptr), static_cast<const IdxT*>(col), x, ldx,  \
+                     out, ldo, grad_out, ldgo, n_rows, F, count_self, grad_x, ldg);            \
+  break
+  if (s.vw == 4) {
+    switch (s.lpr) {
+      case 4: PYGAMD_MMB(4, 4, 1);
+      case 8: PYGAMD_MMB(4, 8, 1);
+      case 16: PYGAMD_MMB(4, 16, 1);
+      case 32: PYGAMD_MMB(4, 32, 1);
+      default:
+        if (s.ch == 2) {
+          PYGAMD_MMB(4, 64, 2);
+        }
+        PYGAMD_MMB(4, 64, 1);
+    }
+  } else {
+    switch (s.lpr) {
+      case 4: PYGAMD_MMB(1, 4, 1);
+      case 8: PYGAMD_MMB(1, 8, 1);
+      case 16: PYGAMD_MMB(1, 16, 1);
+      case 32: PYGAMD_MMB(1, 32, 1);
+      default:
+        if (s.ch == 2) {
+          PYGAMD_MMB(1, 64, 2);
+        }
+        PYGAMD_MMB(1, 64, 1);
+    }
+  }
+#undef PYGAMD_MMB
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
 static int validate(const pygamd_spmm_args* p) {
   if (!p) return PYGAMD_ERR_INVALID_ARG;
   if (p->n_rows < 0 || p->F < 0 || p->ldx < p->F || p->ldo < p->F) return PYGAMD_ERR_INVALID_ARG;
@@ -846,6 +999,34 @@ int pygamd_spmm_csr_minmax_backward(const void* rowptr_t, const void* col_t, int
                        F, grad_x, ldg);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
+  });
+}
+
+int pygamd_spmm_csr_minmax_backward_dst(const void* rowptr, const void* col, int idx_dtype,
+                                        const float* x, int64_t ldx, const float* out,
+                                        int64_t ldo, const float* grad_out, int64_t ldgo,
+                                        int64_t n_rows, int64_t n_src, int64_t F, int count_self,
+                                        float* grad_x, int64_t ldg, void* stream) {
+  if (n_rows < 0 || n_src < 0 || F < 0 || ldx < F || ldo < F || ldgo < F || ldg < F)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (n_src == 0 || F == 0) return PYGAMD_OK;
+  if (!grad_x) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  PYGAMD_HIP_CHECK(hipMemset2DAsync(grad_x, sizeof(float) * ldg, 0, sizeof(float) * F, n_src, st));
+  if (n_rows == 0) return PYGAMD_OK;
+  if (!rowptr || !x || !out || !grad_out) return PYGAMD_ERR_INVALID_ARG;
+  pygamd_spmm_args probe = {};
+  probe.F = F;
+  probe.ldx = (ldx % 4 == 0 && ldgo % 4 == 0 && ldg % 4 == 0 && aligned16(grad_out)) ? ldx : 1;
+  probe.ldo = ldo;
+  probe.x = x;
+  probe.out = const_cast<float*>(out);
+  probe.w_heads = 1;
+  probe.head_dim = static_cast<int>(F);
+  const Shape s = pick_shape(&probe);
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    return launch_minmax_bwd_dst<IdxT>(s, rowptr, col, x, ldx, out, ldo, grad_out, ldgo, n_rows,
+                                       F, count_self, grad_x, ldg, st);
   });
 }
 
