@@ -59,8 +59,14 @@ class SpmmFunction(Function):
             x2, out = ctx.saved_tensors
             if ctx.needs_input_grad[0]:
                 fwd = graph.by_dst()
-                grad_x = _native.spmm_minmax_backward_dst(fwd.ptr, fwd.idx, x2, out, g2,
-                                                          graph.num_src_nodes)
+                if torch.are_deterministic_algorithms_enabled():
+                    # source-driven, no atomics: fixed summation order, ~3.5x slower
+                    bwd = graph.by_src()
+                    ntie = _native.spmm_tie_count(fwd.ptr, fwd.idx, x2, out, count_self=True)
+                    grad_x = _native.spmm_minmax_backward(bwd.ptr, bwd.idx, x2, out, g2, ntie)
+                else:
+                    grad_x = _native.spmm_minmax_backward_dst(fwd.ptr, fwd.idx, x2, out, g2,
+                                                              graph.num_src_nodes)
                 grad_x = grad_x.view(ctx.x_shape)
             return grad_x, None, None, None, None
         x2, w = ctx.saved_tensors

@@ -246,6 +246,16 @@ def test_spmm_minmax_vs_oracle(dev, F):
         out, (gx, ) = run_grad(lambda t: pga.utils.spmm(h, t, red), [x.to(dev)], go)
         assert_close(out, ref, rtol=0, atol=0, what=f'spmm {red} F={F}')  # selection: exact
         assert_close(gx, rg, what=f'spmm {red} grad F={F}')
+        # deterministic mode: the source-driven backward (no atomics), bit-identical run to run
+        torch.use_deterministic_algorithms(True)
+        try:
+            xs = [x.to(dev).requires_grad_(True) for _ in range(2)]
+            for t in xs:
+                pga.utils.spmm(h, t, red).backward(go.to(dev))
+        finally:
+            torch.use_deterministic_algorithms(False)
+        assert torch.equal(xs[0].grad, xs[1].grad)
+        assert_close(xs[0].grad, rg, what=f'spmm {red} deterministic grad F={F}')
 
 
 @pytest.mark.parametrize('F,H', [(1, 1), (16, 1), (100, 1), (256, 1), (64, 8), (256, 8),
