@@ -50,9 +50,17 @@ for red in ('sum', 'mean', 'max', 'min'):
     tb = timeit(bwd)
     print(f'fused {red:4s}: fwd {tf:7.2f} ms ({GB / tf:5.2f} TB/s algorithmic)   bwd {tb:7.2f} ms')
 if os.environ.get('UNFUSED'):
-    for red in ('sum', 'max'):
+    GBu = E * 4 * F / 1e9
+    for red in ('sum', 'mean', 'max', 'mul'):
         def fwd():
             global out
             out = U.scatter(h[ei[0]], ei[1], 0, N, red)
-        tf = timeit(fwd, 1)
-        print(f'unfused gather+scatter {red}: fwd {tf:7.2f} ms')
+
+        def bwd():
+            h.grad = None
+            out.backward(go, retain_graph=True)
+
+        tf = timeit(fwd, 2)
+        tb = timeit(bwd, 2)
+        print(f'unfused index_select + scatter {red:4s}: fwd {tf:7.2f} ms   bwd {tb:7.2f} ms   '
+              f'([E, F] messages = {GBu:.1f} GB)')
