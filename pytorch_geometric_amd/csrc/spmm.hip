@@ -312,7 +312,7 @@ __device__ __forceinline__ bool better_val(float v, float best) {
 template <typename IdxT, int VW, int LPR, int CH, bool IS_MAX, bool IDENT>
 __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
   constexpr int EPI = kWave / LPR;
-  constexpr int U = 4;
+  constexpr int U = spmm_unroll<LPR, CH>();
   constexpr int STEP = EPI * U;
   const int lane = lane_id();
   const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(kBlock)
                         int64_t n_rows, int64_t F, int count_self, float* __restrict__ grad_x,
                         int64_t ldg) {
   constexpr int EPI = kWave / LPR;
-  constexpr int U = 4;
+  constexpr int U = spmm_unroll<LPR, CH>();
   constexpr int STEP = EPI * U;
   const int lane = lane_id();
   const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
