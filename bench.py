@@ -232,7 +232,7 @@ def main():
 
     if args.mode == 'minibatch':
         run_minibatch(args, rank, local_rank, world, dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -339,7 +339,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(args.cpu_scale)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
