@@ -430,23 +430,17 @@ def test_training_step_is_hipgraph_capturable(dev):
         out.square().mean().backward()
         return out
 
+    from pytorch_geometric_amd.hipgraph import CapturedStep
     for p in model.parameters():
         p.grad = torch.zeros_like(p)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):  # eager warm-up: builds and caches the sorted handles
-            ref_out = step()
-    torch.cuda.current_stream().wait_stream(side)
-    ref_out = ref_out.detach().clone()
+    ref_out = step().detach().clone()  # eager reference (also builds and caches the handles)
     ref_grads = [p.grad.clone() for p in model.parameters()]
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        cap_out = step()
+    replay = CapturedStep(step, warmup=2)
+    cap_out = replay.output
     static_x.copy_(x * 2)       # new input through the static buffer
-    graph.replay()
+    replay()
     static_x.copy_(x)           # and back: must reproduce the eager numbers
-    graph.replay()
+    assert replay() is cap_out
     torch.cuda.synchronize()
     assert_close(cap_out, ref_out.cpu(), atol=1e-6, rtol=1e-6)
     for p, r in zip(model.parameters(), ref_grads):
