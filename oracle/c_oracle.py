@@ -48,6 +48,24 @@ def index_sort(keys, max_value):
     return torch.from_numpy(s), torch.from_numpy(p)
 
 
+def sort_edges(edge_index, num_nodes, by_row=True, dedup=False):
+    """(edge_index_out, perm, group): sort_edge_index (dedup=False) / coalesce (dedup=True)."""
+    r, rp = _i(edge_index[0])
+    c, cp = _i(edge_index[1])
+    E = r.size
+    orow, orp = _out((E, ), np.int64)
+    ocol, ocp = _out((E, ), np.int64)
+    perm, pp = _out((E, ), np.int64)
+    group, gp = _out((E, ), np.int64)
+    n_out = I64(0)
+    rc = load().oracle_sort_edges(rp, cp, I64(E), I64(num_nodes), int(by_row), int(dedup), orp,
+                                  ocp, pp, gp, ctypes.byref(n_out))
+    assert rc == 0, rc
+    k = n_out.value
+    out = torch.stack([torch.from_numpy(orow[:k].copy()), torch.from_numpy(ocol[:k].copy())])
+    return out, torch.from_numpy(perm), torch.from_numpy(group)
+
+
 def index2ptr(index, size):
     k, kp = _i(index)
     o, op = _out((size + 1, ), np.int64)

@@ -8,7 +8,8 @@
  * order, exactly like a single-threaded scatter_add_.
  *
  * Parity status: pinned.  tests/test_oracle_c.py checks every function against
- * oracle/pyg_oracle.py and against tests/golden/golden_v1.pt (outputs of the real reference).
+ * oracle/pyg_oracle.py and against tests/golden/golden_v1.pt / golden_preproc_v1.pt (outputs of
+ * the real reference).
  */
 #include <math.h>
 #include <stdint.h>
@@ -42,6 +43,51 @@ void oracle_index2ptr(const int64_t* index, int64_t n, int64_t size, int64_t* pt
   for (int64_t v = 0; v <= size; ++v) ptr[v] = 0;
   for (int64_t i = 0; i < n; ++i) ptr[index[i] + 1]++;
   for (int64_t v = 0; v < size; ++v) ptr[v + 1] += ptr[v];
+}
+
+/* utils/_sort_edge_index.py:105-113 / utils/_coalesce.py:131-176, integer part: stable sort of
+ * the compound key major * n + minor (major = row when by_row), then — for coalesce — keep the
+ * first edge of every run of equal keys.  out_row / out_col hold E entries (the first *n_out are
+ * valid), perm[i] = original position of the i-th sorted edge, group[e] = output slot of the
+ * ORIGINAL edge e (what the attribute scatter uses).  dedup == 0: plain sort_edge_index. */
+int oracle_sort_edges(const int64_t* row, const int64_t* col, int64_t E, int64_t n, int by_row,
+                      int dedup, int64_t* out_row, int64_t* out_col, int64_t* perm,
+                      int64_t* group, int64_t* n_out) {
+  /* two stable counting-sort passes (minor digit first) == one stable sort of the compound key */
+  int64_t* tmp = (int64_t*)malloc((size_t)(E > 0 ? E : 1) * sizeof(int64_t));
+  int64_t* count = (int64_t*)malloc((size_t)(n + 2) * sizeof(int64_t));
+  if (!tmp || !count) { free(tmp); free(count); return 1; }
+  const int64_t* major = by_row ? row : col;
+  const int64_t* minor = by_row ? col : row;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int64_t* digit = pass == 0 ? minor : major;
+    memset(count, 0, (size_t)(n + 2) * sizeof(int64_t));
+    for (int64_t e = 0; e < E; ++e) {
+      if (digit[e] < 0 || digit[e] >= n) { free(tmp); free(count); return 2; }
+      count[digit[e] + 1]++;
+    }
+    for (int64_t v = 0; v < n; ++v) count[v + 1] += count[v];
+    if (pass == 0) {
+      for (int64_t e = 0; e < E; ++e) tmp[count[digit[e]]++] = e;
+    } else {
+      for (int64_t i = 0; i < E; ++i) perm[count[digit[tmp[i]]]++] = tmp[i];
+    }
+  }
+  int64_t k = 0;
+  for (int64_t i = 0; i < E; ++i) {
+    const int64_t e = perm[i];
+    const int first = !dedup || i == 0 || row[e] != row[perm[i - 1]] || col[e] != col[perm[i - 1]];
+    if (first) {
+      out_row[k] = row[e];
+      out_col[k] = col[e];
+      ++k;
+    }
+    group[e] = k - 1;
+  }
+  *n_out = k;
+  free(tmp);
+  free(count);
+  return 0;
 }
 
 /* index.py:27-29 ptr2index == arange(size).repeat_interleave(ptr.diff()). */

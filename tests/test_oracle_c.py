@@ -51,3 +51,22 @@ def test_propagate_and_sage_conv(golden):
     st = L['sage_sum_noroot']['state']
     close(C.sage_conv(x, ei, st['lin_l.weight'], None, None, 'sum'),
           L['sage_sum_noroot']['out'], 2e-5)
+
+
+def test_sort_edges_and_coalesce(golden_preproc):
+    """C restatement of the integer part of sort_edge_index / coalesce vs the real reference."""
+    S, Cg = golden_preproc['sort_edge_index'], golden_preproc['coalesce']
+    n = S['num_nodes']
+    for by_row in (True, False):
+        want = S[f'simple_by_row={by_row}']
+        ei, perm, _ = C.sort_edges(S['simple'], n, by_row)
+        assert torch.equal(ei, want['edge_index'])
+        assert torch.equal(S['attr_i'][perm], want['attr_i'])       # attributes follow the edges
+        ei, _, _ = C.sort_edges(S['dup'], n, by_row)
+        assert torch.equal(ei, S[f'dup_by_row={by_row}'])
+    ei, _, group = C.sort_edges(Cg['dup'], n, True, dedup=True)
+    assert torch.equal(ei, Cg['sum']['edge_index'])
+    merged = torch.zeros(ei.size(1), Cg['attr'].size(1)).index_add_(0, group, Cg['attr'])
+    assert torch.allclose(merged, Cg['sum']['attr'], atol=1e-5)
+    ei, _, _ = C.sort_edges(Cg['dup'], n, False, dedup=True)
+    assert torch.equal(ei, Cg['list_by_col']['edge_index'])
