@@ -224,6 +224,8 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:  # the ranks build their synthetic graphs on the host at the same time
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     pga.load_library()  # fail loudly if the HIP library is missing
     tuned = False
     if not args.no_tuned_gemm:
