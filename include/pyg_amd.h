@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 1
+#define PYGAMD_ABI_VERSION 2
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -293,8 +293,21 @@ PYGAMD_API int pygamd_scatter_minmax_tie_count(const float* src, int64_t lds, co
 PYGAMD_API int pygamd_scatter_minmax_backward(const float* src, int64_t lds, const void* index,
                                               int idx_dtype, int64_t n, int64_t F,
                                               const float* out, const float* grad_out,
-                                              const float* ntie, int64_t ldo, float* grad_src,
-                                              int64_t ldg, void* stream);
+                                              const float* ntie, int64_t ldo, int64_t dim_size,
+                                              float* grad_src, int64_t ldg, void* stream);
+
+/* Backward of scatter(reduce='mul'), i.e. of ones.scatter_reduce_('prod', include_self=True)
+ * (utils/_scatter.py:119-133; ATen scatter_reduce_backward): with z zeros scattered into
+ * (group, f):  z == 0: g * out / src_e;  z == 1: the zero element gets g * prod(others), all
+ * other elements 0;  z >= 2: 0.  Rows with an out-of-range index get 0.  Workspace =
+ * dim_size * F * 8 bytes.                                                                      */
+PYGAMD_API int pygamd_scatter_mul_backward_workspace_bytes(int64_t dim_size, int64_t F,
+                                                           size_t* bytes /*[host]*/);
+PYGAMD_API int pygamd_scatter_mul_backward(const float* src, int64_t lds, const void* index,
+                                           int idx_dtype, int64_t n, int64_t F, const float* out,
+                                           const float* grad_out, int64_t ldo, int64_t dim_size,
+                                           float* grad_src, int64_t ldg, void* workspace,
+                                           size_t workspace_bytes, void* stream);
 
 /* ---- a6: scatter_argmax (1-D) ---------------------------------------------------------------
  * utils/_scatter.py:147-184: out[g] = the LAST e (largest e) with src[e] == max of group g,

@@ -154,10 +154,11 @@ class ScatterFunction(Function):
             index, s2, out = ctx.saved_tensors
             grad = _native.scatter_minmax_backward(s2, index, out, g2)
         elif reduce == 'mul':
-            # d(prod)/d(src_e) = prod / src_e (the reference's scatter_reduce 'prod' backward for
-            # non-zero inputs)
+            # ATen's scatter_reduce 'prod' backward incl. its zero-count rule (one zero in the
+            # group: that element gets g * prod(others); two or more: all 0) — g * out / src alone
+            # would be NaN there
             index, s2, out = ctx.saved_tensors
-            grad = _native.gather_rows(g2 * out, index) / s2
+            grad = _native.scatter_mul_backward(s2, index, out, g2)
         else:
             raise NotImplementedError(f"backward of scatter(reduce='{reduce}') is undefined")
         return grad.view(ctx.src_shape), None, None, None

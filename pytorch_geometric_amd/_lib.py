@@ -10,6 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 from . import _build
 
+ABI_VERSION = 2  # PYGAMD_ABI_VERSION of include/pyg_amd.h
 IDX_I32, IDX_I64 = 0, 1
 SUM, MEAN, MIN, MAX, MUL, ANY = 0, 1, 2, 3, 4, 5
 REDUCE_IDS = {'sum': SUM, 'add': SUM, 'mean': MEAN, 'min': MIN, 'amin': MIN, 'max': MAX,
@@ -88,7 +89,10 @@ SIGNATURES = {
     'pygamd_scatter_minmax_tie_count': (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P,
                                                 c_int64, c_int64, _P, _P]),
     'pygamd_scatter_minmax_backward': (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P, _P,
-                                               _P, c_int64, _P, c_int64, _P]),
+                                               _P, c_int64, c_int64, _P, c_int64, _P]),
+    'pygamd_scatter_mul_backward_workspace_bytes': (c_int, [c_int64, c_int64, POINTER(c_size_t)]),
+    'pygamd_scatter_mul_backward': (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P, _P,
+                                            c_int64, c_int64, _P, c_int64, _P, c_size_t, _P]),
     'pygamd_scatter_argmax': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     'pygamd_segment_softmax_forward': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P]),
     'pygamd_segment_softmax_backward': (c_int, [_P, _P, _P, c_int, c_int64, c_int64, _P, _P]),
@@ -128,7 +132,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.pygamd_abi_version() != 1:
+    if lib.pygamd_abi_version() != ABI_VERSION:
         raise PygAmdError(f'ABI mismatch: library reports {lib.pygamd_abi_version()}')
     _lib = lib
     return lib

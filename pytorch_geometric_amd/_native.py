@@ -313,21 +313,21 @@ def sddmm_csr(rowptr, col, eid, grad_out, x, n_edges: int, w_heads: int) -> Tens
 
 
 # ---- unsorted gather / scatter ----------------------------------------------------------------
-_pending_err = []  # device flags set by kernels that met an out-of-range index
+class IndexOutOfRange(PygAmdError, IndexError):
+    """An index outside [0, size) reached a scatter/gather kernel (the reference's ATen CPU
+    kernels raise 'index ... is out of bounds' at the same place)."""
 
 
-def _err_flag(device):
-    flag = torch.zeros(1, dtype=torch.int32, device=device)
-    del _pending_err[:-7]  # bounded history
-    _pending_err.append(flag)
-    return flag
-
-
-def consume_index_error() -> bool:
-    """True if any scatter/gather since the last call met an out-of-range index (host sync)."""
-    bad = any(int(f.item()) != 0 for f in _pending_err)
-    _pending_err.clear()
-    return bad
+def _raise_if_flagged(err: Tensor, index: Tensor, size: int, what: str):
+    """One 4-byte host read of the kernel's error flag.  Skipped while the stream is being
+    captured into a hipGraph (no sync allowed there; the kernels still skip such rows)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    if int(err.item()) != 0:
+        lo, hi = index_minmax(index)
+        bad = hi if hi >= size else lo
+        raise IndexOutOfRange(f'{what}: index {bad} is out of bounds for dimension 0 with size '
+                              f'{size} (indices span [{lo}, {hi}])')
 
 
 def gather_rows(x: Tensor, index: Tensor, check_bounds: bool = False) -> Tensor:
@@ -362,9 +362,12 @@ def scatter_rows(src: Tensor, index: Tensor, dim_size: int, reduce: str,
     st = _stream(src)
     check(lib.pygamd_scatter_init(_p(out), _ld(out), dim_size, F, red, _p(count), st),
           'scatter_init')
-    err = _err_flag(src.device)
+    err = torch.zeros(1, dtype=torch.int32, device=src.device)
     check(lib.pygamd_scatter_rows(_p(s2), _ld(s2), _p(index), _idx_dtype(index), n, F, _p(out),
                                   _ld(out), dim_size, red, _p(count), _p(err), st), 'scatter_rows')
+    if n > 0 and F > 0:
+        # before anything is saved for a backward that would index with the same values
+        _raise_if_flagged(err, index, dim_size, 'scatter')
     check(lib.pygamd_scatter_finalize(_p(out), _ld(out), dim_size, F, red, _p(count), st),
           'scatter_finalize')
     return (out, count) if return_count else out
@@ -384,8 +387,28 @@ def scatter_minmax_backward(src, index, out, grad_out) -> Tensor:
           'scatter_minmax_tie_count')
     grad_src = torch.empty(n, F, dtype=torch.float32, device=src.device)
     check(lib.pygamd_scatter_minmax_backward(_p(s2), _ld(s2), _p(index), _idx_dtype(index), n, F,
-                                             _p(o2), _p(g2), _p(ntie), _ld(o2), _p(grad_src),
-                                             _ld(grad_src), st), 'scatter_minmax_backward')
+                                             _p(o2), _p(g2), _p(ntie), _ld(o2), dim_size,
+                                             _p(grad_src), _ld(grad_src), st),
+          'scatter_minmax_backward')
+    return grad_src
+
+
+def scatter_mul_backward(src, index, out, grad_out) -> Tensor:
+    """Gradient of scatter(reduce='mul') w.r.t. ``src`` with ATen's zero-count rule."""
+    _require_device(src, index, out, grad_out)
+    lib = _lib.load()
+    s2 = _f32_rows(src, 'src')
+    o2, g2 = out.contiguous(), grad_out.contiguous()
+    index = index.contiguous()
+    n, F, dim_size = index.numel(), s2.size(1), o2.size(0)
+    grad_src = torch.empty(n, F, dtype=torch.float32, device=src.device)
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_scatter_mul_backward_workspace_bytes(dim_size, F, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=src.device)
+    check(lib.pygamd_scatter_mul_backward(_p(s2), _ld(s2), _p(index), _idx_dtype(index), n, F,
+                                          _p(o2), _p(g2), _ld(o2) if dim_size else max(F, 1),
+                                          dim_size, _p(grad_src), _ld(grad_src), _p(ws),
+                                          nbytes.value, _stream(src)), 'scatter_mul_backward')
     return grad_src
 
 

@@ -15,7 +15,16 @@ modules.  ``install()`` therefore
 4. wraps ``propagate`` of the hot conv classes (SAGEConv, GCNConv, GraphConv, GATConv) so that a
    plain ``edge_index`` tensor is sorted once (cached handle) and gather -> message -> aggregate
    runs as ONE CSR SpMM — the fused route the reference only takes for sparse ``adj_t`` inputs
-   (nn/conv/message_passing.py:469-479).
+   (nn/conv/message_passing.py:469-479);
+5. memoises the per-forward graph rewrites of the reference's layers by INPUT IDENTITY —
+   ``gcn_norm`` inside ``GCNConv(cached=False)`` (nn/conv/gcn_conv.py:241-258) and the
+   ``remove_self_loops`` + ``add_self_loops`` pair of ``GATConv`` (nn/conv/gat_conv.py:334-347):
+   both build a NEW ``edge_index`` tensor every call, which would make the handle cache of step 4
+   miss and re-sort the graph per layer per step; the memo returns the SAME output tensors for
+   the same input tensors (no values are compared, no host sync);
+6. routes ``torch_geometric.nn.GraphSAGE.forward`` (models/basic_gnn.py:175-270) to the fused
+   whole-stack schedule (``nn/models/_fused_sage.py``) when that computes exactly the same thing
+   — plain mean/sum ``SAGEConv`` layers, ReLU, Identity norms, no dropout in effect.
 
 Every wrapper STEPS ASIDE to the original reference function for anything that is not a float32
 HIP tensor, under ``torch.compile`` / TorchScript, or when ``backend.use_mi355x`` is False —
@@ -28,7 +37,7 @@ from typing import Any, Callable, Dict, List, Tuple
 import torch
 from torch import Tensor
 
-_state: Dict[str, Any] = {'installed': False, 'rebinds': [], 'classes': []}
+_state: Dict[str, Any] = {'installed': False, 'rebinds': [], 'classes': [], 'forwards': []}
 
 
 def _enabled() -> bool:
@@ -77,7 +86,10 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
     def index_sort(inputs, max_value=None, stable=False):
         if (isinstance(inputs, Tensor) and inputs.is_cuda and inputs.dim() == 1
                 and inputs.dtype in (torch.int32, torch.int64) and _enabled()):
-            return U.index_sort(inputs, max_value, stable)
+            # the caller's `max_value` is a hint the reference's GPU path (torch.sort) never
+            # trusts; a too-small one would drop radix passes and mis-sort — so it is ignored
+            # here (all key bits are sorted), like torch.sort
+            return U.index_sort(inputs, None, stable)
         return orig['index_sort'](inputs, max_value, stable)
 
     def scatter_argmax(src, index, dim=0, dim_size=None):
@@ -225,6 +237,98 @@ def _make_edge_index_spmm(orig: Callable) -> Callable:
     return _spmm
 
 
+class _IdentityMemo:
+    """``fn(*tensors, *rest)`` memoised on the IDENTITY (id + in-place version) of its tensor
+    arguments; entries die with their inputs (weakref finalisers).  Holds at most 8 results."""
+
+    def __init__(self, fn: Callable):
+        self.fn, self.store = fn, {}
+
+    def __call__(self, tensors: Tuple[Any, ...], rest: Tuple[Any, ...]):
+        import weakref
+        key = tuple((id(t), t._version) if isinstance(t, Tensor) else None for t in tensors) + rest
+        hit = self.store.get(key)
+        if hit is not None and all(r() is t for r, t in zip(hit[0], tensors)
+                                   if isinstance(t, Tensor)):
+            return hit[1]
+        out = self.fn(*tensors, *rest)
+        if len(self.store) >= 8:
+            self.store.pop(next(iter(self.store)))
+
+        def _drop(_, key=key, store=self.store):
+            store.pop(key, None)
+
+        refs = tuple(weakref.ref(t, _drop) if isinstance(t, Tensor) else None for t in tensors)
+        self.store[key] = (refs, out)
+        return out
+
+
+def _memoisable(edge_index, edge_attr) -> bool:
+    return (_ours_index(edge_index) and _enabled()
+            and (edge_attr is None or (isinstance(edge_attr, Tensor) and edge_attr.is_cuda
+                                       and not edge_attr.requires_grad)))
+
+
+def _make_graph_rewrite_memos(gcn_mod, gat_mod) -> List[Tuple[Any, str, Callable]]:
+    """Step 5 of the module docstring.  Returns the (module, attribute, original) rebinds."""
+    from .nn.conv.gcn_conv import gcn_norm as our_gcn_norm
+    from .utils import loop as our_loop
+    orig_norm = gcn_mod.gcn_norm
+    orig_rm, orig_add = gat_mod.remove_self_loops, gat_mod.add_self_loops
+    memo_norm = _IdentityMemo(our_gcn_norm)
+    memo_rm = _IdentityMemo(lambda ei: our_loop.remove_self_loops(ei, None))
+    memo_add = _IdentityMemo(lambda ei, n: our_loop.add_self_loops(ei, None, None, n))
+
+    def gcn_norm(edge_index, edge_weight=None, num_nodes=None, improved=False,
+                 add_self_loops=True, flow='source_to_target', dtype=None):
+        if (_memoisable(edge_index, edge_weight) and dtype in (None, torch.float32)
+                and (edge_weight is None or (edge_weight.dtype == torch.float32
+                                             and edge_weight.dim() == 1))):
+            return memo_norm((edge_index, edge_weight),
+                             (num_nodes, bool(improved), bool(add_self_loops), flow, dtype))
+        return orig_norm(edge_index, edge_weight, num_nodes, improved, add_self_loops, flow, dtype)
+
+    def remove_self_loops(edge_index, edge_attr=None):
+        if edge_attr is None and _memoisable(edge_index, None):
+            return memo_rm((edge_index, ), ())
+        return orig_rm(edge_index, edge_attr)
+
+    def add_self_loops(edge_index, edge_attr=None, fill_value=None, num_nodes=None):
+        if edge_attr is None and _memoisable(edge_index, None) and isinstance(num_nodes, int):
+            return memo_add((edge_index, ), (num_nodes, ))
+        return orig_add(edge_index, edge_attr, fill_value, num_nodes)
+
+    for fn, o in ((gcn_norm, orig_norm), (remove_self_loops, orig_rm), (add_self_loops, orig_add)):
+        fn.__wrapped__ = o
+        fn.__doc__ = o.__doc__
+    gcn_mod.gcn_norm = gcn_norm
+    gat_mod.remove_self_loops = remove_self_loops
+    gat_mod.add_self_loops = add_self_loops
+    return [(gcn_mod, 'gcn_norm', orig_norm), (gat_mod, 'remove_self_loops', orig_rm),
+            (gat_mod, 'add_self_loops', orig_add)]
+
+
+def _wrap_graphsage_forward(cls) -> Callable:
+    """Step 6: the reference's ``GraphSAGE`` (a ``BasicGNN`` whose layers are the reference's
+    ``SAGEConv``) through the fused whole-stack schedule when it is eligible."""
+    orig = cls.forward
+
+    def forward(self, x, edge_index, edge_weight=None, edge_attr=None, batch=None,
+                batch_size=None, num_sampled_nodes_per_hop=None,
+                num_sampled_edges_per_hop=None):
+        from .nn.models import _fused_sage
+        if (_enabled() and edge_weight is None and edge_attr is None
+                and _fused_sage.eligible(self, x, edge_index,
+                                         num_sampled_nodes_per_hop is not None)):
+            return _fused_sage.run(self, x, edge_index)
+        return orig(self, x, edge_index, edge_weight, edge_attr, batch, batch_size,
+                    num_sampled_nodes_per_hop, num_sampled_edges_per_hop)
+
+    forward.__wrapped__ = orig
+    forward.__doc__ = orig.__doc__
+    return forward
+
+
 def _wrap_propagate(cls) -> Callable:
     orig = cls.propagate
 
@@ -271,6 +375,16 @@ def install() -> None:
         cls.propagate = _wrap_propagate(cls)
         _state['classes'].append((cls, had_own, prev))
 
+    import torch_geometric.nn.conv.gat_conv as pyg_gat_mod
+    import torch_geometric.nn.conv.gcn_conv as pyg_gcn_mod
+    _state['rebinds'] += _make_graph_rewrite_memos(pyg_gcn_mod, pyg_gat_mod)
+
+    from torch_geometric.nn.models import GraphSAGE
+    had_own = 'forward' in GraphSAGE.__dict__
+    prev = GraphSAGE.__dict__.get('forward')
+    GraphSAGE.forward = _wrap_graphsage_forward(GraphSAGE)
+    _state['forwards'].append((GraphSAGE, had_own, prev))
+
     pyg_backend.mi355x = sys.modules[__name__]
     if not hasattr(pyg_backend, 'use_mi355x'):
         pyg_backend.use_mi355x = None  # None = auto (on for float32 HIP tensors)
@@ -291,10 +405,18 @@ def uninstall() -> None:
                 delattr(cls, 'propagate')
             except AttributeError:  # pragma: no cover
                 pass
+    for cls, had_own, prev in _state['forwards']:
+        if had_own:
+            cls.forward = prev
+        else:
+            try:
+                delattr(cls, 'forward')
+            except AttributeError:  # pragma: no cover
+                pass
     for attr in ('mi355x', 'use_mi355x'):
         if hasattr(pyg_backend, attr):
             delattr(pyg_backend, attr)
-    _state.update(installed=False, rebinds=[], classes=[])
+    _state.update(installed=False, rebinds=[], classes=[], forwards=[])
 
 
 def is_installed() -> bool:

@@ -122,15 +122,91 @@ __global__ void __launch_bounds__(kBlock)
     scatter_minmax_bwd_kernel(const float* __restrict__ src, int64_t lds,
                               const IdxT* __restrict__ index, int64_t n, int64_t F,
                               const float* __restrict__ out, const float* __restrict__ grad_out,
-                              const float* __restrict__ ntie, int64_t ldo,
+                              const float* __restrict__ ntie, int64_t ldo, int64_t dim_size,
                               float* __restrict__ grad_src, int64_t ldg) {
   const int64_t total = n * F;
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
        t += static_cast<int64_t>(gridDim.x) * kBlock) {
     const int64_t e = t / F;
     const int64_t f = t - e * F;
-    const int64_t o = static_cast<int64_t>(index[e]) * ldo + f;
+    const int64_t g = index[e];
+    if (g < 0 || g >= dim_size) {  // the forward flagged it; never read out of bounds here
+      grad_src[e * ldg + f] = 0.f;
+      continue;
+    }
+    const int64_t o = g * ldo + f;
     grad_src[e * ldg + f] = (src[e * lds + f] == out[o]) ? grad_out[o] / ntie[o] : 0.f;
+  }
+}
+
+// ---- backward of scatter(reduce='mul') ---------------------------------------------------------
+// The reference's CPU path is ones.scatter_reduce_('prod', include_self=True)
+// (torch_geometric/utils/_scatter.py:119-133); its gradient (ATen scatter_reduce_backward, 'prod')
+// is NOT g * out / src when zeros are present: with z = number of zeros scattered into (group, f)
+//   z == 0 : grad_e = g * out / src_e
+//   z == 1 : the zero element gets g * prod(other elements of the group), every other element 0
+//   z >= 2 : every element 0.
+// Three flat passes: count the zeros (atomics only where src == 0), multiply the non-zero
+// elements of the groups that hold exactly one zero (atomics only there), then the gradient.
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    scatter_mul_zero_count_kernel(const float* __restrict__ src, int64_t lds,
+                                  const IdxT* __restrict__ index, int64_t n, int64_t F,
+                                  int64_t dim_size, int32_t* __restrict__ nzero) {
+  const int64_t total = n * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t e = t / F;
+    const int64_t f = t - e * F;
+    const int64_t g = index[e];
+    if (g < 0 || g >= dim_size) continue;
+    if (src[e * lds + f] == 0.f) atomicAdd(nzero + g * F + f, 1);
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    scatter_mul_others_kernel(const float* __restrict__ src, int64_t lds,
+                              const IdxT* __restrict__ index, int64_t n, int64_t F,
+                              int64_t dim_size, const int32_t* __restrict__ nzero,
+                              float* __restrict__ others) {
+  const int64_t total = n * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t e = t / F;
+    const int64_t f = t - e * F;
+    const int64_t g = index[e];
+    if (g < 0 || g >= dim_size) continue;
+    const float v = src[e * lds + f];
+    if (v != 0.f && nzero[g * F + f] == 1) atomic_mul_f32(others + g * F + f, v);
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    scatter_mul_bwd_kernel(const float* __restrict__ src, int64_t lds,
+                           const IdxT* __restrict__ index, int64_t n, int64_t F,
+                           const float* __restrict__ out, const float* __restrict__ grad_out,
+                           int64_t ldo, int64_t dim_size, const int32_t* __restrict__ nzero,
+                           const float* __restrict__ others, float* __restrict__ grad_src,
+                           int64_t ldg) {
+  const int64_t total = n * F;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t e = t / F;
+    const int64_t f = t - e * F;
+    const int64_t g = index[e];
+    float r = 0.f;
+    if (g >= 0 && g < dim_size) {
+      const float v = src[e * lds + f];
+      const float go = grad_out[g * ldo + f];
+      if (v != 0.f) {
+        r = (go * out[g * ldo + f]) / v;  // out == 0 as soon as the group holds a zero
+      } else if (nzero[g * F + f] == 1) {
+        r = go * others[g * F + f];
+      }
+    }
+    grad_src[e * ldg + f] = r;
   }
 }
 
@@ -458,14 +534,59 @@ int pygamd_scatter_minmax_tie_count(const float* src, int64_t lds, const void* i
 int pygamd_scatter_minmax_backward(const float* src, int64_t lds, const void* index,
                                    int idx_dtype, int64_t n, int64_t F, const float* out,
                                    const float* grad_out, const float* ntie, int64_t ldo,
-                                   float* grad_src, int64_t ldg, void* stream) {
-  if (n < 0 || F < 0) return PYGAMD_ERR_INVALID_ARG;
+                                   int64_t dim_size, float* grad_src, int64_t ldg,
+                                   void* stream) {
+  if (n < 0 || F < 0 || dim_size < 0) return PYGAMD_ERR_INVALID_ARG;
   if (n == 0 || F == 0) return PYGAMD_OK;
-  if (!src || !index || !out || !grad_out || !ntie || !grad_src) return PYGAMD_ERR_INVALID_ARG;
+  if (!src || !index || !grad_src) return PYGAMD_ERR_INVALID_ARG;
+  if (dim_size > 0 && (!out || !grad_out || !ntie)) return PYGAMD_ERR_INVALID_ARG;
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     hipLaunchKernelGGL((scatter_minmax_bwd_kernel<IdxT>), dim3(flat_grid(n * F)), dim3(kBlock),
                        0, as_stream(stream), src, lds, static_cast<const IdxT*>(index), n, F, out,
-                       grad_out, ntie, ldo, grad_src, ldg);
+                       grad_out, ntie, ldo, dim_size, grad_src, ldg);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_scatter_mul_backward_workspace_bytes(int64_t dim_size, int64_t F, size_t* bytes) {
+  if (!bytes || dim_size < 0 || F < 0) return PYGAMD_ERR_INVALID_ARG;
+  *bytes = static_cast<size_t>(dim_size) * static_cast<size_t>(F) * 8;  // int32 count + float
+  return PYGAMD_OK;
+}
+
+int pygamd_scatter_mul_backward(const float* src, int64_t lds, const void* index, int idx_dtype,
+                                int64_t n, int64_t F, const float* out, const float* grad_out,
+                                int64_t ldo, int64_t dim_size, float* grad_src, int64_t ldg,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (n < 0 || F < 0 || dim_size < 0 || lds < F || ldo < F || ldg < F)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0 || F == 0) return PYGAMD_OK;
+  if (!src || !index || !grad_src) return PYGAMD_ERR_INVALID_ARG;
+  if (dim_size > 0 && (!out || !grad_out)) return PYGAMD_ERR_INVALID_ARG;
+  size_t need = 0;
+  pygamd_scatter_mul_backward_workspace_bytes(dim_size, F, &need);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return PYGAMD_ERR_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  int32_t* nzero = static_cast<int32_t*>(workspace);
+  float* others = reinterpret_cast<float*>(nzero + dim_size * F);
+  if (dim_size > 0) {
+    PYGAMD_HIP_CHECK(hipMemsetAsync(nzero, 0, sizeof(int32_t) * dim_size * F, st));
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(flat_grid(dim_size * F)), dim3(kBlock), 0, st,
+                       others, F, dim_size, F, 1.f);
+    PYGAMD_LAUNCH_CHECK();
+  }
+  const dim3 grid(flat_grid(n * F));
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const IdxT* idx = static_cast<const IdxT*>(index);
+    hipLaunchKernelGGL((scatter_mul_zero_count_kernel<IdxT>), grid, dim3(kBlock), 0, st, src, lds,
+                       idx, n, F, dim_size, nzero);
+    PYGAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL((scatter_mul_others_kernel<IdxT>), grid, dim3(kBlock), 0, st, src, lds,
+                       idx, n, F, dim_size, nzero, others);
+    PYGAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL((scatter_mul_bwd_kernel<IdxT>), grid, dim3(kBlock), 0, st, src, lds, idx,
+                       n, F, out, grad_out, ldo, dim_size, nzero, others, grad_src, ldg);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });

@@ -35,13 +35,16 @@ class Aggregation(torch.nn.Module):
                                  f"'{ptr.numel() - 1}')")
         if index is not None and dim_size is None:
             dim_size = _native.index_minmax(index)[1] + 1 if index.numel() > 0 else 0
-        out = super().__call__(x, index=index, ptr=ptr, dim_size=dim_size, dim=dim, **kwargs)
-        if index is not None and _native.consume_index_error():
-            hi = _native.index_minmax(index)[1]
-            raise ValueError(f"Encountered invalid 'dim_size' (got "
-                             f"'{dim_size}' but expected "
-                             f">= '{hi + 1}')")
-        return out
+        try:
+            return super().__call__(x, index=index, ptr=ptr, dim_size=dim_size, dim=dim, **kwargs)
+        except (IndexError, RuntimeError) as e:  # same recovery as nn/aggr/base.py:131-141
+            if index is not None and index.numel() > 0:
+                hi = _native.index_minmax(index)[1]
+                if dim_size <= hi:
+                    raise ValueError(f"Encountered invalid 'dim_size' (got "
+                                     f"'{dim_size}' but expected "
+                                     f">= '{hi + 1}')")
+            raise e
 
     def __repr__(self) -> str:
         return f'{self.__class__.__name__}()'

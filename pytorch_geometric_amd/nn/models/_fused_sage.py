@@ -182,23 +182,37 @@ class FusedSageStack(Function):
 
 
 def eligible(model, x, edge_index, trim: bool) -> bool:
-    """Conditions under which the fused stack computes exactly what the layer loop does."""
-    from ..conv import SAGEConv
+    """Conditions under which the fused stack computes exactly what the layer loop does.  Duck-typed
+    on purpose: ``backend.install()`` routes the REFERENCE's ``GraphSAGE`` here too, whose layers
+    are ``torch_geometric.nn.SAGEConv`` (same attribute names, nn/conv/sage_conv.py:72-116)."""
     if trim or not getattr(model, 'fuse_stack', True):
         return False
     if not (isinstance(x, Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
         return False
-    if not isinstance(model.act, torch.nn.ReLU):
+    if not isinstance(model.act, torch.nn.ReLU):  # act_first is moot with Identity norms
         return False
     if model.dropout.p > 0 and model.training:
         return False
+    # the reference's BasicGNN extras (basic_gnn.py:99-160): norm layers, jumping knowledge and
+    # the trailing Linear are not part of the fused schedule
+    if getattr(model, 'jk_mode', None) is not None or hasattr(model, 'lin'):
+        return False
+    norms = getattr(model, 'norms', None)
+    if norms is not None and any(not isinstance(n, torch.nn.Identity) for n in norms):
+        return False
     aggr = None
     for conv in model.convs:
-        if not isinstance(conv, SAGEConv) or not conv.fuse:
+        if type(conv).__name__ != 'SAGEConv' or not getattr(conv, 'fuse', True):
             return False
         if conv.aggr not in ('mean', 'sum', 'add') or not conv.root_weight:
             return False
         if conv.normalize or conv.project or conv.flow != 'source_to_target':
+            return False
+        if getattr(conv, 'explain', False) or getattr(conv, 'decomposed_layers', 1) != 1:
+            return False
+        if (getattr(conv, '_propagate_forward_pre_hooks', None)
+                or getattr(conv, '_propagate_forward_hooks', None)
+                or conv._forward_hooks or conv._forward_pre_hooks):
             return False
         if aggr is not None and conv.aggr != aggr:
             return False
@@ -207,7 +221,9 @@ def eligible(model, x, edge_index, trim: bool) -> bool:
         if edge_index.atomic_backward:  # single-use batch handle: keep the no-sort layer path
             return False
         return edge_index.sparse_size == (x.size(0), x.size(0))
-    return isinstance(edge_index, Tensor) and edge_index.dim() == 2
+    return (isinstance(edge_index, Tensor) and type(edge_index) is Tensor and edge_index.is_cuda
+            and not edge_index.is_sparse and edge_index.dim() == 2 and edge_index.size(0) == 2
+            and edge_index.dtype in (torch.int32, torch.int64))
 
 
 def run(model, x: Tensor, edge_index) -> Tensor:

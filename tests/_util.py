@@ -9,11 +9,19 @@ def assert_close(got, ref, rtol=RTOL, atol=ATOL, what=''):
     ref = ref.detach().cpu()
     assert got.shape == ref.shape, f'{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}'
     if got.dtype.is_floating_point:
-        err = (got - ref).abs()
-        tol = atol + rtol * ref.abs()
-        bad = err > tol
-        assert not bad.any(), (f'{what}: {int(bad.sum())} / {got.numel()} elements off, '
-                               f'max abs err {float(err.max()):.3e}')
+        # isclose, not `err > tol`: a NaN/Inf in `got` where `ref` is finite must FAIL (NaN
+        # compares False with everything); non-finite reference entries must be reproduced
+        # exactly (same-signed inf, NaN for NaN)
+        ok = torch.isclose(got, ref.to(got.dtype), rtol=rtol, atol=atol, equal_nan=True)
+        if not bool(ok.all()):
+            bad = ~ok
+            err = (got - ref).abs()
+            finite = err[torch.isfinite(err)]
+            worst = float(finite.max()) if finite.numel() else float('nan')
+            nonfinite = int((~torch.isfinite(got) & torch.isfinite(ref)).sum())
+            raise AssertionError(f'{what}: {int(bad.sum())} / {got.numel()} elements off '
+                                 f'({nonfinite} non-finite where the reference is finite), '
+                                 f'max finite abs err {worst:.3e}')
     else:
         assert torch.equal(got, ref), f'{what}: integer mismatch'
 
@@ -47,9 +55,11 @@ def assert_sum_close(got, ref32, exact64, rtol=RTOL, atol=ATOL, what='', abs_sum
     if abs_sum is not None:
         # condition-aware bound for sums with cancellation: a few fp32 ulps of sum_i |x_i|
         tol = torch.maximum(tol, 1e-6 * abs_sum.detach().cpu().double())
-    bad = err > tol
+    assert bool(torch.isfinite(exact64).all()), f'{what}: the fp64 evaluation is not finite'
+    bad = ~(err <= tol)  # NaN-proof: a non-finite `got` is never <= tol
     assert not bad.any(), (f'{what}: {int(bad.sum())} / {got.numel()} elements off, max err vs '
-                           f'fp64 {float(err.max()):.3e} (reference fp32 err {ref_err:.3e})')
+                           f'fp64 {float(err.nan_to_num(nan=float("inf")).max()):.3e} '
+                           f'(reference fp32 err {ref_err:.3e})')
 
 
 def assert_close_scaled(got, ref, tol=2e-5, what=''):
@@ -57,8 +67,10 @@ def assert_close_scaled(got, ref, tol=2e-5, what=''):
     element rtol is meaningless where large terms cancel)."""
     got, ref = got.detach().cpu(), ref.detach().cpu()
     assert got.shape == ref.shape, f'{what}: shape'
-    err = float((got - ref).abs().max())
-    scale = max(float(ref.abs().max()), 1.0)
+    assert bool(torch.isfinite(got).all()) or not bool(torch.isfinite(ref).all()), \
+        f'{what}: non-finite values where the reference is finite'
+    err = float((got - ref).abs().max()) if got.numel() else 0.0
+    scale = max(float(ref.abs().max()), 1.0) if ref.numel() else 1.0
     assert err <= tol * scale, f'{what}: max abs err {err:.3e} vs scale {scale:.3e}'
 
 
@@ -69,8 +81,10 @@ def assert_close_outliers(got, ref, tol=2e-5, max_outlier_frac=2e-3, what=''):
     scale) and bound the number of such rows."""
     got, ref = got.detach().cpu(), ref.detach().cpu()
     assert got.shape == ref.shape, f'{what}: shape'
+    assert bool(torch.isfinite(got).all()) or not bool(torch.isfinite(ref).all()), \
+        f'{what}: non-finite values where the reference is finite'
     scale = max(float(ref.abs().max()), 1.0)
-    bad = (got - ref).abs() > tol * scale
+    bad = ~((got - ref).abs() <= tol * scale)  # NaN-proof
     frac = float(bad.float().mean())
     assert frac <= max_outlier_frac, f'{what}: {frac:.2e} of the elements differ by > {tol:g}'
     assert float((got - ref).abs().max()) <= 0.05 * scale, f'{what}: gross mismatch'

@@ -7,11 +7,15 @@ import sys
 import pytest
 import torch
 
-REF = os.environ.get('PYG_REFERENCE', '/root/reference')
-if os.path.isdir(os.path.join(REF, 'torch_geometric')) and REF not in sys.path:
-    sys.path.insert(0, REF)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from oracle import make_ref  # noqa: E402
 
-pyg = pytest.importorskip('torch_geometric')
+try:  # the mounted reference (build container) or the staged copy under oracle/_ref
+    pyg = make_ref.import_reference()
+except ImportError:
+    pytest.skip('no reference available', allow_module_level=True)
 
 
 @pytest.fixture()
@@ -64,6 +68,50 @@ def test_cpu_tensors_step_aside_to_the_reference(installed):
         assert torch.allclose(out, ref, atol=1e-6)
 
 
+def test_identity_memo_semantics():
+    """install() step 5: results are keyed on tensor identity + in-place version, never values."""
+    from pytorch_geometric_amd.backend import _IdentityMemo
+    calls = []
+
+    def fn(a, b, k):
+        calls.append(k)
+        return a + (0 if b is None else b) + k
+
+    memo = _IdentityMemo(fn)
+    a, b = torch.arange(4), torch.ones(4, dtype=torch.long)
+    r1 = memo((a, b), (1, ))
+    assert memo((a, b), (1, )) is r1 and calls == [1]
+    assert memo((a, None), (1, )) is not r1 and calls == [1, 1]
+    assert memo((a.clone(), b), (1, )) is not r1  # equal values, different tensor
+    a.add_(1)  # version bump -> recompute
+    r2 = memo((a, b), (1, ))
+    assert r2 is not r1 and torch.equal(r2, a + b + 1)
+    n = len(memo.store)
+    del a
+    import gc
+    gc.collect()
+    assert len(memo.store) < n  # entries die with their inputs
+    for i in range(20):
+        memo((b, None), (i, ))
+    assert len(memo.store) <= 8
+
+
+def test_reference_graphsage_forward_is_wrapped_and_cpu_steps_aside(installed):
+    from torch_geometric.nn import GraphSAGE
+    assert hasattr(GraphSAGE.forward, '__wrapped__')
+    g = torch.Generator().manual_seed(1)
+    x, ei = torch.randn(12, 6, generator=g), torch.randint(0, 12, (2, 40), generator=g)
+    model = GraphSAGE(6, 8, num_layers=2, out_channels=3)
+    out = model(x, ei)
+    installed.uninstall()
+    assert not hasattr(GraphSAGE.forward, '__wrapped__')
+    ref = model(x, ei)
+    installed.install()
+    assert torch.equal(out, ref)
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    assert not _fused_sage.eligible(model, x, ei, False)  # CPU tensors are never eligible
+
+
 def test_flag_disables_the_backend(installed):
     pyg.backend.use_mi355x = False
     from pytorch_geometric_amd.backend import _enabled
@@ -114,6 +162,9 @@ def oracle_kernels(monkeypatch, installed):
     monkeypatch.setattr(backend, '_ours_index',
                         lambda t: type(t) is torch.Tensor and t.dim() == 2 and t.size(0) == 2
                         and t.dtype in (torch.int32, torch.int64))
+    # the graph-rewrite memos call the device-side gcn_norm / self-loop helpers: covered on the
+    # GPU by tests/test_gpu_reference_install.py, bypassed here
+    monkeypatch.setattr(backend, '_memoisable', lambda ei, ea: False)
     monkeypatch.setattr(_functions, 'SpmmFunction', Spmm)
     monkeypatch.setattr(ei_mod, 'as_edge_index', as_edge_index)
     monkeypatch.setattr(U, 'scatter', counted('scatter', O.scatter))

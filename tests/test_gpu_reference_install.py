@@ -1,0 +1,240 @@
+"""The REAL reference on the GPU box: ``oracle/_ref`` (staged by ``oracle/make_ref.py``, test
+infrastructure) + ``pytorch_geometric_amd.backend.install()``.  The reference's OWN modules —
+``nn.conv.{SAGEConv, GCNConv, GraphConv, GATConv}``, ``nn.models.GraphSAGE``, ``nn.aggr.*``,
+``EdgeIndex.matmul``, ``utils.{scatter, segment, softmax, spmm, index_sort, sort_edge_index,
+coalesce}`` — run on HIP tensors through the installed backend and are compared with the SAME
+reference objects evaluated on the CPU (where the backend always steps aside).
+
+This is the first execution of ``backend.py``'s device branches against the real reference
+(round-1 VERDICT, weak #4): the CPU-side glue test (tests/test_backend_install.py) swaps the
+kernels for the oracle."""
+import copy
+
+import pytest
+import torch
+
+from tests._util import assert_close, assert_close_scaled, gen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pyg():
+    from oracle import make_ref
+    return make_ref.import_reference()  # ImportError = the staged reference did not travel
+
+
+@pytest.fixture()
+def installed(pyg):
+    from pytorch_geometric_amd import backend, edge_index
+    backend.install()
+    edge_index.clear_cache()
+    yield backend
+    backend.uninstall()
+
+
+@pytest.fixture()
+def launches(monkeypatch):
+    """Counts what reaches the HIP library: SpMM launches (with their widths) and radix sorts."""
+    from pytorch_geometric_amd import _native
+    rec = {'spmm': [], 'sorts': 0}
+    sink = []
+    monkeypatch.setattr(_native, 'timing_sink', sink)
+    real_sort = _native.index_sort
+
+    def counted_sort(*a, **k):
+        rec['sorts'] += 1
+        return real_sort(*a, **k)
+
+    monkeypatch.setattr(_native, 'index_sort', counted_sort)
+    rec['sink'] = sink
+    return rec
+
+
+def _fwd_bwd(module, args, grad_out, kwargs=None):
+    for p in module.parameters():
+        p.grad = None
+    leaves = [a.clone().requires_grad_(True) if isinstance(a, torch.Tensor)
+              and a.is_floating_point() else a for a in args]
+    out = module(*leaves, **(kwargs or {}))
+    out.backward(grad_out.to(out.device))
+    grads = [a.grad for a in leaves if isinstance(a, torch.Tensor) and a.is_floating_point()]
+    return out.detach(), grads, [p.grad.clone() for p in module.parameters()]
+
+
+def _to(dev, args):
+    return [a.to(dev) if isinstance(a, torch.Tensor) else a for a in args]
+
+
+def test_reference_convs_take_the_hip_path_and_match_their_cpu_results(pyg, installed, launches,
+                                                                       dev):
+    from torch_geometric.nn import GATConv, GCNConv, GraphConv, SAGEConv
+    g = gen(5)
+    n, e = 300, 4000
+    x = torch.randn(n, 16, generator=g)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = torch.rand(e, generator=g)
+    torch.manual_seed(0)
+    cases = [
+        ('sage-mean', SAGEConv(16, 12), (x, ei)),
+        ('sage-max', SAGEConv(16, 12, aggr='max'), (x, ei)),
+        ('sage-sum-t2s', SAGEConv(16, 12, aggr='sum', flow='target_to_source'), (x, ei)),
+        ('gcn', GCNConv(16, 12), (x, ei)),
+        ('gcn-weighted', GCNConv(16, 12, improved=True), (x, ei, w)),
+        ('graphconv', GraphConv(16, 12, aggr='mean'), (x, ei, w)),
+        ('gat', GATConv(16, 4, heads=3), (x, ei)),
+        ('gat-mean-heads', GATConv(16, 6, heads=2, concat=False), (x, ei)),
+    ]
+    for name, conv, args in cases:
+        go = torch.randn(n, conv(*args).size(1), generator=g)
+        ref_out, ref_gin, ref_gp = _fwd_bwd(conv, args, go)  # CPU: the reference's own path
+        dconv = copy.deepcopy(conv).to(dev)
+        before = len(launches['sink'])
+        out, gin, gp = _fwd_bwd(dconv, _to(dev, args), go)
+        assert len(launches['sink']) > before, f'{name}: no SpMM launch — reference path taken'
+        assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what=f'{name} out')
+        for a, b in zip(gin, ref_gin):
+            assert_close(a, b, rtol=1e-5, atol=2e-5, what=f'{name} grad input')
+        for a, b in zip(gp, ref_gp):
+            assert_close_scaled(a, b, tol=2e-5, what=f'{name} grad param')
+
+
+def test_reference_layers_do_not_resort_the_graph_every_forward(pyg, installed, launches, dev):
+    """GCNConv(cached=False) and GATConv rebuild ``edge_index`` (self-loops) on every forward; the
+    identity memos of install() hand the handle cache the same tensor again: the radix sorts
+    happen once (by destination in the forward, by source in the first backward), not per step."""
+    from torch_geometric.nn import GATConv, GCNConv
+    g = gen(9)
+    n = 500
+    x = torch.randn(n, 8, generator=g).to(dev)
+    ei = torch.randint(0, n, (2, 6000), generator=g).to(dev)
+    torch.manual_seed(1)
+    for conv in (GCNConv(8, 8).to(dev), GATConv(8, 4, heads=2).to(dev)):
+        conv(x, ei).sum().backward()
+        first = launches['sorts']
+        assert first >= 1
+        outs = []
+        for _ in range(3):
+            out = conv(x, ei)
+            out.sum().backward()
+            outs.append(out.detach())
+        assert launches['sorts'] == first, (type(conv).__name__, launches['sorts'] - first)
+        assert torch.equal(outs[0], outs[2])
+    # an in-place edit of the input must invalidate the memo (tensor version counter)
+    conv = GCNConv(8, 8).to(dev)
+    a = conv(x, ei).detach()
+    ei[0, :50] = (ei[0, :50] + 1) % n
+    b = conv(x, ei).detach()
+    ref = copy.deepcopy(conv).cpu()(x.cpu(), ei.cpu()).detach()
+    assert not torch.equal(a, b)
+    assert_close(b, ref, rtol=1e-5, atol=2e-5, what='gcn after in-place edit')
+
+
+def test_reference_graphsage_model_runs_the_fused_stack(pyg, installed, launches, dev):
+    """torch_geometric.nn.GraphSAGE + install() reaches the schedule of the headline number: one
+    SpMM per layer and direction, the 64 -> 10 output layer aggregated at width 12 (narrow-layer
+    re-order), not the per-layer propagate route."""
+    from torch_geometric.nn import GraphSAGE
+    g = gen(12)
+    n = 400
+    x = torch.randn(n, 20, generator=g)
+    ei = torch.randint(0, n, (2, 5000), generator=g)
+    torch.manual_seed(2)
+    model = GraphSAGE(20, 64, num_layers=3, out_channels=10)
+    go = torch.randn(n, 10, generator=g)
+    ref_out, ref_gin, ref_gp = _fwd_bwd(model, (x, ei), go)
+    dmodel = copy.deepcopy(model).to(dev)
+    out, gin, gp = _fwd_bwd(dmodel, _to(dev, (x, ei)), go)
+    widths = [info['F'] for info, _, _ in launches['sink']]
+    assert sorted(widths) == [12, 12, 20, 20, 64, 64], widths  # fwd 20,64,12; bwd 12,64,20
+    assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what='GraphSAGE out')
+    assert_close_scaled(gin[0], ref_gin[0], tol=2e-5, what='GraphSAGE grad x')
+    for a, b in zip(gp, ref_gp):
+        assert_close_scaled(a, b, tol=2e-5, what='GraphSAGE grad param')
+    # switched off: the reference's own layer loop runs (one fused propagate per layer at the
+    # layer's INPUT width), same numbers
+    dmodel.fuse_stack = False
+    del launches['sink'][:]
+    out2, _, _ = _fwd_bwd(dmodel, _to(dev, (x, ei)), go)
+    assert sorted(i['F'] for i, _, _ in launches['sink']) == [20, 20, 64, 64, 64, 64]
+    assert_close(out2, ref_out, rtol=1e-5, atol=2e-5, what='GraphSAGE layer loop')
+
+
+def test_reference_edge_index_matmul_on_device(pyg, installed, launches, dev):
+    from torch_geometric import EdgeIndex
+    g = gen(4)
+    n_row, n_col = 90, 140
+    raw = torch.stack([torch.randint(0, n_row, (900, ), generator=g),
+                       torch.randint(0, n_col, (900, ), generator=g)])
+    value = torch.rand(900, generator=g)
+    for order, transpose, other_rows in (('row', False, n_col), ('col', True, n_row)):
+        srt = EdgeIndex(raw, sparse_size=(n_row, n_col)).sort_by(order)
+        adj, val = srt.values, value[srt.indices]
+        other = torch.randn(other_rows, 24, generator=g)
+        for reduce in ('sum', 'mean', 'max', 'min'):
+            for v in (None, val):
+                if v is not None and reduce in ('max', 'min'):
+                    continue
+                o_cpu = other.clone().requires_grad_(True)
+                ref = adj.matmul(o_cpu, v, reduce=reduce, transpose=transpose)
+                ref.sum().backward()
+                o_dev = other.to(dev).requires_grad_(True)
+                before = len(launches['sink'])
+                out = adj.to(dev).matmul(o_dev, None if v is None else v.to(dev), reduce=reduce,
+                                         transpose=transpose)
+                out.sum().backward()
+                assert len(launches['sink']) > before, (order, reduce)
+                assert_close(out, ref, rtol=1e-5, atol=2e-5, what=f'matmul {order} {reduce}')
+                assert_close(o_dev.grad, o_cpu.grad, rtol=1e-5, atol=2e-5,
+                             what=f'matmul grad {order} {reduce}')
+
+
+def test_reference_utils_and_aggregations_on_device(pyg, installed, dev):
+    import torch_geometric.utils as U
+    from torch_geometric.nn import aggr
+    g = gen(6)
+    src = torch.randn(2000, 9, generator=g)
+    index = torch.randint(0, 150, (2000, ), generator=g)
+    for red in ('sum', 'mean', 'min', 'max', 'mul'):
+        s = src if red != 'mul' else src.abs().add(0.5)
+        ref = U.scatter(s, index, 0, 160, red)
+        out = U.scatter(s.to(dev), index.to(dev), 0, 160, red)
+        assert out.is_cuda
+        assert_close(out, ref, rtol=2e-5, atol=2e-5, what=f'scatter {red}')
+    sidx, _ = index.sort()
+    ptr = torch._convert_indices_from_coo_to_csr(sidx, 160)
+    for red in ('sum', 'mean', 'min', 'max'):
+        assert_close(U.segment(src.to(dev), ptr.to(dev), red), U.segment(src, ptr, red),
+                     rtol=1e-5, atol=2e-5, what=f'segment {red}')
+    assert_close(U.softmax(src.to(dev), index.to(dev), num_nodes=160),
+                 U.softmax(src, index, num_nodes=160), what='softmax index')
+    assert_close(U.softmax(src.to(dev), ptr=ptr.to(dev)), U.softmax(src, ptr=ptr),
+                 what='softmax ptr')
+    keys = torch.randint(0, 1000, (5000, ), generator=g)
+    v_ref, p_ref = U.index_sort(keys, stable=True)
+    v, p = U.index_sort(keys.to(dev), max_value=3, stable=True)  # a WRONG hint must not matter
+    assert torch.equal(v.cpu(), v_ref) and torch.equal(p.cpu(), p_ref)
+    ei = torch.randint(0, 60, (2, 3000), generator=g)
+    attr = torch.randn(3000, 3, generator=g)
+    r_ei, r_at = U.sort_edge_index(ei, attr, num_nodes=60)
+    d_ei, d_at = U.sort_edge_index(ei.to(dev), attr.to(dev), num_nodes=60)
+    assert torch.equal(d_ei.cpu(), r_ei)
+    assert_close(d_at, r_at, rtol=0, atol=0, what='sort_edge_index attr')
+    r_ei, r_at = U.coalesce(ei, attr, num_nodes=60, reduce='mean')
+    d_ei, d_at = U.coalesce(ei.to(dev), attr.to(dev), num_nodes=60, reduce='mean')
+    assert torch.equal(d_ei.cpu(), r_ei)
+    assert_close(d_at, r_at, rtol=1e-5, atol=1e-5, what='coalesce attr')
+    adj = torch.sparse_coo_tensor(ei, torch.rand(3000, generator=g), (60, 60)).coalesce()
+    dense = torch.randn(60, 7, generator=g)
+    for red in ('sum', 'mean'):
+        assert_close(U.spmm(adj.to_sparse_csr().to(dev), dense.to(dev), red),
+                     U.spmm(adj.to_sparse_csr(), dense, red), rtol=1e-5, atol=2e-5,
+                     what=f'spmm {red}')
+    for mod in (aggr.MeanAggregation(), aggr.MaxAggregation(), aggr.SumAggregation(),
+                aggr.StdAggregation(), aggr.MultiAggregation(['mean', 'max', 'std']),
+                aggr.SoftmaxAggregation(t=0.5)):
+        ref = mod(src, index, dim_size=160)
+        out = mod(src.to(dev), index.to(dev), dim_size=160)
+        assert_close(out, ref, rtol=2e-5, atol=2e-5, what=type(mod).__name__)
+    with pytest.raises(ValueError, match="invalid 'dim_size'"):
+        aggr.MeanAggregation()(src.to(dev), index.to(dev), dim_size=3)
