@@ -2,7 +2,8 @@
 """bench.py — aggregated edges/sec, forward+backward, 3-layer GraphSAGE on a synthetic
 ogbn-products-shaped graph (BASELINE.json `metric`, `configs[1]`), 1..N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: re-executes itself under
+                                                          torch.distributed.run with N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = zero grads, full-batch forward of GraphSAGE(100, 256, 3 layers, 47 classes),
@@ -63,35 +64,86 @@ def pmc_traffic(args, N, E, F_dom):
     return d['traffic_bytes_per_launch'] if same else None
 
 
-def cpu_baseline(scale: float, steps: int = 2):
-    """The reference's CPU scatter path (index_select -> scatter_add_ -> divide; oracle port,
-    torch ATen CPU kernels on all host cores) on a `scale` x products-shaped sample."""
-    from oracle import pyg_oracle as O
+def _time_steps(step_fn, steps: int, warmup: int = 1):
+    """Median (fwd, bwd) wall seconds of `steps` calls after `warmup`."""
+    rec = []
+    for it in range(warmup + steps):
+        tf, tb = step_fn()
+        if it >= warmup:
+            rec.append((tf + tb, tf, tb))
+    rec.sort()
+    return rec[len(rec) // 2]
+
+
+def cpu_baseline(scale: float, steps: int = 3):
+    """PyG's CPU paths timed on this box's host cores, on a `scale` x products-shaped sample of the
+    bench workload: the UNMODIFIED reference (oracle/_ref, staged by
+    oracle/make_ref.py; kind "reference") — primary line = the scatter path (plain `edge_index`
+    tensor: index_select + scatter_add_), second line = its fast path (`adj_t` as a torch CSR
+    tensor -> torch.sparse.mm).  Falls back to the oracle port (kind "port") only when no staged
+    reference travelled with the snapshot."""
     from pytorch_geometric_amd.datasets import products_like
-    from pytorch_geometric_amd.nn import GraphSAGE
     x, y, ei, c = products_like(seed=1, scale=scale)
-    torch.manual_seed(0)
-    model = GraphSAGE(100, 256, num_layers=3, out_channels=c)
-    params = [(cv.lin_l.weight, cv.lin_l.bias, cv.lin_r.weight) for cv in model.convs]
+    E = ei.size(1)
     g = torch.Generator().manual_seed(7)
     train_idx = torch.randperm(x.size(0), generator=g)[:max(int(0.0803 * x.size(0)), 1)]
-    times = []
-    for it in range(steps + 1):
-        t0 = time.perf_counter()
-        for p in model.parameters():
-            p.grad = None
-        out = O.graphsage(x, ei, params)
-        loss = F.cross_entropy(out[train_idx], y[train_idx])
-        loss.backward()
-        times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    return {
-        'value': 3 * ei.size(1) / t, 'unit': 'edges/s', 'cores': torch.get_num_threads(),
-        'kind': 'port',
-        'sample': (f'oracle/pyg_oracle.py graphsage fwd+bwd (index_select + scatter_add_ mean), '
-                   f'{scale:g} x ogbn-products shape: N={x.size(0)}, E={ei.size(1)}, '
-                   f'median of {steps} steps after 1 warm-up, {t * 1e3:.0f} ms/step'),
-    }
+    threads = torch.get_num_threads()
+    base = {'unit': 'edges/s', 'cores': threads, 'host_cpus': os.cpu_count()}
+    shape = f'{scale:g} x ogbn-products shape: N={x.size(0)}, E={E}'
+    try:
+        from oracle import make_ref
+        make_ref.import_reference()
+        from torch_geometric.nn import GraphSAGE as RefSAGE
+        from torch_geometric.utils import to_torch_csc_tensor
+    except ImportError:
+        RefSAGE = None
+    if RefSAGE is None:
+        from oracle import pyg_oracle as O
+        from pytorch_geometric_amd.nn import GraphSAGE
+        torch.manual_seed(0)
+        model = GraphSAGE(100, 256, num_layers=3, out_channels=c)
+        params = [(cv.lin_l.weight, cv.lin_l.bias, cv.lin_r.weight) for cv in model.convs]
+
+        def step():
+            t0 = time.perf_counter()
+            for p in model.parameters():
+                p.grad = None
+            loss = F.cross_entropy(O.graphsage(x, ei, params)[train_idx], y[train_idx])
+            t1 = time.perf_counter()
+            loss.backward()
+            return t1 - t0, time.perf_counter() - t1
+
+        t, tf, tb = _time_steps(step, steps)
+        return dict(base, value=3 * E / t, kind='port',
+                    sample=(f'oracle/pyg_oracle.py graphsage fwd+bwd (index_select + scatter_add_ '
+                            f'mean), {shape}, median of {steps} steps after 1 warm-up, '
+                            f'{t * 1e3:.0f} ms/step'))
+    torch.manual_seed(0)
+    model = RefSAGE(100, 256, num_layers=3, out_channels=c)
+
+    def make_step(graph):
+        def step():
+            t0 = time.perf_counter()
+            model.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(model(x, graph)[train_idx], y[train_idx])
+            t1 = time.perf_counter()
+            loss.backward()
+            return t1 - t0, time.perf_counter() - t1
+        return step
+
+    t, tf, tb = _time_steps(make_step(ei), steps)
+    adj_t = to_torch_csc_tensor(ei, size=(x.size(0), x.size(0))).t()  # CSR (BASELINE.md 3.3)
+    t2, tf2, tb2 = _time_steps(make_step(adj_t), steps)
+    return dict(
+        base, value=3 * E / t, kind='reference',
+        sample=(f'unmodified torch_geometric 2.9.0 (oracle/_ref) GraphSAGE(100,256,3,{c}) fwd + '
+                f'CE(8% split) + bwd, plain edge_index -> index_select + scatter_add_ (the CPU '
+                f'scatter path), {shape}, median of {steps} steps after 1 warm-up: '
+                f'fwd {tf:.2f} s + bwd {tb:.2f} s; torch threads {threads} of '
+                f'{os.cpu_count()} host CPUs'),
+        csr_fast_path={'value': 3 * E / t2, 'unit': 'edges/s',
+                       'sample': f'same model and sample, adj_t = torch.sparse_csr -> '
+                                 f'torch.sparse.mm: fwd {tf2:.2f} s + bwd {tb2:.2f} s'})
 
 
 def run_minibatch(args, rank, local_rank, world, dev):
@@ -186,27 +238,137 @@ def run_minibatch(args, rank, local_rank, world, dev):
                                       f'all-reduce/step)'}}), flush=True)
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no rendezvous in the environment: start N ranks of this
+    script under torch.distributed.run (one process per GPU) and pass everything through; rank 0
+    of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={n}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_ranks(args):
+    """(rank, local_rank, world, device).  Backend 'nccl' (= RCCL) on GPUs; 'gloo' only for the
+    CPU launcher check (--dry-run), which runs no kernel of this repo."""
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    has_gpu = torch.cuda.is_available()
+    if not has_gpu and not args.dry_run:
+        raise RuntimeError('bench.py needs a GPU (there is no CPU fallback); --dry-run only '
+                           'checks the multi-rank launcher')
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if has_gpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl' if has_gpu else 'gloo', rank=rank, world_size=world)
+        assert dist.get_world_size() == world
+    if world != args.gpus:
+        raise RuntimeError(f'--gpus {args.gpus} but the process group has {world} rank(s): '
+                           f'launch with --nproc-per-node {args.gpus} (or let bench.py spawn the '
+                           f'ranks itself by not setting WORLD_SIZE)')
+    dev = torch.device('cuda', local_rank) if has_gpu else torch.device('cpu')
+    if has_gpu:
+        torch.cuda.set_device(dev)
+    return rank, local_rank, world, dev
+
+
+def run_dry(args, rank, world, dev):
+    """Launcher / collective plumbing only (used by tests/test_bench_launcher.py on CPU with gloo
+    and usable on GPUs): rendezvous, parameter broadcast, K flat-bucket all-reduces of a toy
+    module, barrier + max-over-ranks timing, ONE JSON line on rank 0.  No kernel of this repo
+    runs and nothing here is a measurement of the hot path."""
+    import torch.distributed as dist
+
+    from pytorch_geometric_amd.data_parallel import FlatGradBucket, broadcast_parameters
+    torch.manual_seed(100 + rank)
+    model = torch.nn.Linear(64, 32).to(dev)
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        if dev.type == 'cuda':
+            torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        bucket.flat.fill_(float(rank + 1))
+        bucket.all_reduce_mean()
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    expect = sum(range(1, world + 1)) / world
+    ok = bool(torch.allclose(bucket.flat, torch.full_like(bucket.flat, expect)))
+    w0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    same = w0.clone()
+    if world > 1:
+        dist.broadcast(same, src=0)
+    ok = ok and bool(torch.equal(same, w0))
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        n_pg = dist.get_world_size() if dist.is_initialized() else 1
+        print(json.dumps({
+            'metric': 'launcher dry run (no kernels)', 'value': None, 'unit': None,
+            'n_gpus': n_pg, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': float(t.item()) / max(args.steps, 1) * 1e3, 'dry_run': True,
+            'backend': dist.get_backend() if dist.is_initialized() else None,
+            'collectives_ok': bool(flag.item() == 1.0)}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    if flag.item() != 1.0:
+        raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', choices=['fullbatch', 'minibatch'], default='fullbatch',
                     help="'fullbatch' = BASELINE config 2 (the metric's configuration); "
                          "'minibatch' = config 4, informational")
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--dry-run', action='store_true',
+                    help='only exercise the N-rank launcher and the collectives (no kernels)')
     ap.add_argument('--scale', type=float, default=1.0, help='fraction of the products shape')
     ap.add_argument('--prefetch', type=int, default=2,
                     help='mini-batch mode: batches sampled ahead on a side stream (0 = inline)')
     ap.add_argument('--index-dtype', choices=['int64', 'int32'], default='int64')
     ap.add_argument('--uniform', action='store_true', help='uniform instead of power-law graph')
-    ap.add_argument('--cpu-scale', type=float, default=1 / 64)
+    ap.add_argument('--cpu-scale', type=float, default=1 / 16,
+                    help='fraction of the products shape the CPU baseline is timed on '
+                         '(BASELINE.md 3.5: s in {1 .. 1/16})')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-tuned-gemm', action='store_true',
                     help='use the default rocBLAS/hipBLASLt heuristics instead of the shipped '
                          'TunableOp table')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch.distributed as dist
+
+    rank, local_rank, world, dev = init_ranks(args)
+    if args.dry_run:
+        return run_dry(args, rank, world, dev)
 
     import pytorch_geometric_amd as pga
     from pytorch_geometric_amd import _native
@@ -214,16 +376,6 @@ def main():
     from pytorch_geometric_amd.datasets import products_like
     from pytorch_geometric_amd.nn import GraphSAGE
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus > 1 or world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
     if world > 1:  # the ranks build their synthetic graphs on the host at the same time
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     pga.load_library()  # fail loudly if the HIP library is missing
@@ -259,12 +411,19 @@ def main():
     train_idx = torch.randperm(N, generator=g)[:max(int(0.0803 * N), 1)].to(dev)
     y_train = y[train_idx]
 
+    ar_events = []  # (start, end) HIP events around the gradient all-reduce, timed steps only
+
     def step():
         bucket.zero_()
         out = model(x, ei)
         loss = F.cross_entropy(out[train_idx], y_train)
         loss.backward()
-        bucket.all_reduce_mean()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.all_reduce_mean()  # the current stream waits for RCCL's stream before e1
+            e1.record()
+            ar_events.append((e0, e1))
         opt.step()
         return loss
 
@@ -276,6 +435,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    del ar_events[:]
     sink = []
     _native.timing_sink = sink
     t0 = time.perf_counter()
@@ -294,7 +454,12 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = 3.0 * E * world / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel: CSR SpMM at F = 256 (4 of the 5 launches per step) ----
+    allreduce_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1)
+                    if world > 1 else 0.0)
+    n_pg = dist.get_world_size() if dist.is_initialized() else 1
+
+    # ---- roofline of the dominant kernel: the CSR SpMM at F = 256 (2 of the 5 SpMM launches per
+    # step — layer 2 forward and its transposed backward; layer 3 is re-ordered to width 48) ----
     groups = {}
     for info, ev0, ev1 in sink:
         groups.setdefault(info['F'], []).append((info, ev0.elapsed_time(ev1)))
@@ -307,6 +472,8 @@ def main():
     roofline = {
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(args, N, E, dom_F),
+        'traffic_source': 'profiles/ PMC passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE per '
+                          'launch, collected by scripts/gpu_pmc_script.sh), not a live counter',
         'kernel': f'spmm_sum_rows<F={dom_F}> (pygamd_spmm_csr, fwd mean + transposed bwd)',
         'launches_timed': len(dom), 'avg_launch_ms': round(avg_ms, 4),
         'algorithmic_bytes_per_launch': alg_bytes,
@@ -318,7 +485,7 @@ def main():
     if rank == 0:
         result = {
             'metric': 'edges/sec (fwd+bwd) 3-layer SAGE, ogbn-products shape',
-            'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
+            'value': value, 'unit': 'edges/s', 'n_gpus': n_pg, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
@@ -328,6 +495,7 @@ def main():
                              f'degrees, {args.index_dtype} edge_index, fp32 features)'),
                 'edges_per_step_per_gpu': 3 * E, 'scale': args.scale,
                 'parallelism': f'dp{world} (graph replicas, one flat-bucket all-reduce/step)',
+                'allreduce_ms_per_step': round(allreduce_ms, 4),
                 'graph_gen_s': round(t_gen, 1),
                 'gemm': ('rocBLAS/hipBLASLt via torch.mm, solution per shape from '
                          'pytorch_geometric_amd/tuning (TunableOp, read-only)' if tuned else

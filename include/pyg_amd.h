@@ -388,6 +388,32 @@ PYGAMD_API int pygamd_relabel(int phase, const void* src, int idx_dtype, int64_t
                               void* local_map, int64_t* flag_or_scan, int64_t base, void* out,
                               void* stream);
 
+/* ---- a17 / f3: the dense feature transform on the fp32 matrix cores ---------------------------
+ * `F.linear(x, weight, bias)` of nn/dense/linear.py:121-127 — what SAGEConv's `lin_l(agg) +
+ * lin_r(x)` (sage_conv.py:134-139), GCNConv's `lin(x)` (gcn_conv.py:260) etc. end in — and its
+ * two gradients, written for v_mfma_f32_32x32x2_f32 (exact fp32).  Row-major, explicit leading
+ * dimensions in elements, so halves of wider `[agg | x]` buffers are read / written in place.
+ *   forward : out[M, N] = act(x[M, K] @ w[N, K]^T + bias[N]);  relu != 0 fuses the activation
+ *             (basic_gnn.py:258-266), accumulate != 0 adds onto `out`.
+ *   dgrad   : out[M, K] = g[M, N] @ w[N, K], the weight handed over TRANSPOSED (w_t[K, N],
+ *             contiguous rows); columns [0, n_scaled) are multiplied by row_scale[row] in the
+ *             epilogue (the 1/deg of a mean aggregation that follows, utils/_scatter.py:72-80).
+ *   wgrad   : out[N, K] = g[M, N]^T @ x[M, K]; deterministic (split over M, slabs summed in
+ *             order); workspace from the _workspace_bytes query.                               */
+PYGAMD_API int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
+                                     const float* bias, int64_t M, int64_t K, int64_t N, int relu,
+                                     int accumulate, float* out, int64_t ldo, void* stream);
+PYGAMD_API int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
+                                   const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
+                                   int64_t K, int accumulate, float* out, int64_t ldo,
+                                   void* stream);
+PYGAMD_API int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K,
+                                                   size_t* bytes /*[host]*/);
+PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx,
+                                   int64_t M, int64_t N, int64_t K, int accumulate, float* out,
+                                   int64_t ldo, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

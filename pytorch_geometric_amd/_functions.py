@@ -12,6 +12,17 @@ from . import _native
 from .edge_index import EdgeIndex
 
 
+def _shaped(out2d: Tensor, shape) -> Tensor:
+    """The freshly allocated 2-D kernel output under its public shape WITHOUT making it a view:
+    autograd forbids in-place edits of views returned by a custom Function, and the reference does
+    edit such outputs in place (``deg.pow_(-0.5)`` on a ``scatter`` result, gcn_conv.py:109)."""
+    shape = tuple(shape)
+    if tuple(out2d.shape) == shape:
+        return out2d
+    assert out2d.is_contiguous() and out2d._base is None
+    return out2d.new_empty(0).set_(out2d.untyped_storage(), out2d.storage_offset(), shape)
+
+
 def _rows(t: Tensor) -> Tensor:
     """[n, ...] -> [n, prod(...)] (also for empty tensors, where reshape(n, -1) is ambiguous)."""
     return t.reshape(t.size(0), math.prod(t.shape[1:]))
@@ -48,7 +59,7 @@ class SpmmFunction(Function):
                                    hub=fwd.hub)
             need_x = w is not None and ctx.needs_input_grad[1]
             ctx.save_for_backward(x2 if need_x else None, w)
-        return out.view(fwd.n_rows, *x.shape[1:])
+        return _shaped(out, (fwd.n_rows, *x.shape[1:]))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
@@ -109,7 +120,7 @@ class GatherFunction(Function):
         ctx.save_for_backward(index)
         ctx.x_shape = x.shape
         out = _native.gather_rows(_rows(x), index, check_bounds)
-        return out.view(index.numel(), *x.shape[1:])
+        return _shaped(out, (index.numel(), *x.shape[1:]))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
@@ -138,7 +149,7 @@ class ScatterFunction(Function):
         else:
             out = _native.scatter_rows(s2, index, dim_size, reduce)
             ctx.save_for_backward(index)
-        return out.view(dim_size, *src.shape[1:])
+        return _shaped(out, (dim_size, *src.shape[1:]))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
@@ -177,7 +188,7 @@ class SegmentFunction(Function):
             ctx.save_for_backward(ptr, s2, out)
         else:
             ctx.save_for_backward(ptr)
-        return out.view(n_seg, *src.shape[1:])
+        return _shaped(out, (n_seg, *src.shape[1:]))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
@@ -212,7 +223,7 @@ class SegmentSoftmaxFunction(Function):
         out = _native.segment_softmax_forward(s2, ptr)
         ctx.save_for_backward(out, ptr)
         ctx.src_shape = src.shape
-        return out.view(src.shape)
+        return _shaped(out, src.shape)
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):

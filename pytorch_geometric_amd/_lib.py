@@ -65,6 +65,14 @@ SIGNATURES = {
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'pygamd_relu_backward_colsum': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P,
                                             c_int64, _P, _P]),
+    'pygamd_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
+                                      c_int, c_int, _P, c_int64, _P]),
+    'pygamd_linear_dgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
+                                    c_int64, c_int, _P, c_int64, _P]),
+    'pygamd_linear_wgrad_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
+                                                    POINTER(c_size_t)]),
+    'pygamd_linear_wgrad': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int,
+                                    _P, c_int64, _P, c_size_t, _P]),
     'pygamd_segment_matmul_tile_rows': (c_int, []),
     'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64,
                                       c_int64, c_int64, c_int64, _P, c_int64, _P]),

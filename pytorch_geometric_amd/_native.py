@@ -474,6 +474,72 @@ def gat_edge_softmax_backward(rowptr, col, alpha_src, alpha_dst, alpha, grad_alp
     return g_src, g_dst
 
 
+# ---- dense feature transform (fp32 MFMA GEMM, csrc/gemm.hip) -------------------------------------
+def linear_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
+                   out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """``act(x @ w.T + bias)`` for row-strided fp32 ``x [M, K]``, ``w [N, K]``; ``out`` may be a
+    row-strided view (e.g. one half of an ``[agg | x]`` buffer)."""
+    _require_device(x, w, bias, out)
+    lib = _lib.load()
+    x2, w2 = _f32_rows(x, 'x'), _f32_rows(w, 'weight')
+    M, K = x2.shape
+    N = w2.size(0)
+    if w2.size(1) != K:
+        raise ValueError(f"'x' has {K} columns but 'weight' expects {w2.size(1)}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    elif out.shape != (M, N) or out.dtype != torch.float32 or (N > 1 and out.stride(1) != 1):
+        raise ValueError("'out' must be a float32 [M, N] tensor with unit inner stride")
+    if bias is not None:
+        bias = bias.contiguous()
+    check(lib.pygamd_linear_forward(_p(x2), _ld(x2), _p(w2), _ld(w2), _p(bias), M, K, N,
+                                    int(relu), int(accumulate), _p(out), _ld(out), _stream(x)),
+          'linear_forward')
+    return out
+
+
+def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_scaled: int = 0,
+                 out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """``g [M, N] @ w [N, K]`` with the weight handed over transposed (``w_t [K, N]``); columns
+    ``[0, n_scaled)`` of the result are multiplied by ``row_scale[row]``."""
+    _require_device(g, w_t, row_scale, out)
+    lib = _lib.load()
+    g2, w2 = _f32_rows(g, 'grad'), _f32_rows(w_t, 'weight_t')
+    M, N = g2.shape
+    K = w2.size(0)
+    if w2.size(1) != N:
+        raise ValueError(f"'grad' has {N} columns but 'weight_t' expects {w2.size(1)}")
+    if out is None:
+        out = torch.empty(M, K, dtype=torch.float32, device=g.device)
+    if row_scale is not None:
+        row_scale = row_scale.contiguous()
+    check(lib.pygamd_linear_dgrad(_p(g2), _ld(g2), _p(w2), _ld(w2), _p(row_scale),
+                                  n_scaled if row_scale is not None else 0, M, N, K,
+                                  int(accumulate), _p(out), _ld(out), _stream(g)), 'linear_dgrad')
+    return out
+
+
+def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
+                 accumulate: bool = False) -> Tensor:
+    """``g [M, N].T @ x [M, K]`` -> ``[N, K]`` (deterministic split reduction over M)."""
+    _require_device(g, x, out)
+    lib = _lib.load()
+    g2, x2 = _f32_rows(g, 'grad'), _f32_rows(x, 'x')
+    M, N = g2.shape
+    K = x2.size(1)
+    if x2.size(0) != M:
+        raise ValueError(f"'grad' has {M} rows but 'x' has {x2.size(0)}")
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.float32, device=g.device)
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_linear_wgrad_workspace_bytes(M, N, K, ctypes.byref(nbytes)))
+    ws = torch.empty(max(nbytes.value, 4), dtype=torch.uint8, device=g.device)
+    check(lib.pygamd_linear_wgrad(_p(g2), _ld(g2), _p(x2), _ld(x2), M, N, K, int(accumulate),
+                                  _p(out), _ld(out), _p(ws), nbytes.value, _stream(g)),
+          'linear_wgrad')
+    return out
+
+
 # ---- segment_matmul (grouped GEMM, fp32 MFMA) ---------------------------------------------------
 _segmm_plans = {}
 

@@ -1,0 +1,567 @@
+// gemm.hip — the dense feature transform of the layers (nn/dense/linear.py:121-127 `F.linear`,
+// sage_conv.py:134-139 `lin_l(agg) + lin_r(x)`) on the fp32 matrix cores of gfx950.
+//
+// MFMA-bound: v_mfma_f32_32x32x2_f32 (exact fp32 — bitwise an fmaf chain — 64 cycles per
+// instruction per SIMD, 157 TFLOP/s chip peak).  Three entry points, all row-major with explicit
+// leading dimensions so they read / write halves of the `[agg | x]` buffers in place:
+//
+//   linear_forward : out[M, N]  = act(x[M, K] @ w[N, K]^T + bias)          ("NT")
+//   linear_dgrad   : out[M, K]  = g[M, N] @ w[N, K]   (w passed transposed -> the same NT kernel),
+//                    optionally out[:, :n_scaled] *= row_scale[row]  (the 1/deg of the mean that
+//                    the transposed SpMM would otherwise gather once per edge)
+//   linear_wgrad   : out[N, K]  = g[M, N]^T @ x[M, K]                      ("TN", split over M)
+//
+// NT kernel.  A workgroup (4 waves) owns a (WM*TM*32) x (WN*TN*32) output tile, a wave TM x TN
+// accumulator blocks of 32 x 32.  K is walked in chunks of 32 through a double-buffered LDS ring
+// (one barrier per chunk): global -> registers (16-byte loads, issued one chunk ahead) ->
+// ds_write_b128 -> fragments.  The k index consumed by MFMA step s of a chunk is (s + 16 h) for
+// lane half h = lane >> 5 — any assignment of the 32 k values to (step, half) is legal as long as
+// A and B agree — so a lane's sixteen A (or B) operands of a chunk are 16 CONSECUTIVE floats of
+// one row: four ds_read_b128 per 32 x 32 block per chunk instead of sixteen ds_read_b32, from a
+// row stride of 36 floats that is conflict-free for both the 16-byte writes and reads.
+// Workgroups are numbered so that the column tiles of one row block run back to back on one XCD
+// (x rows are fetched from HBM once and served to the sibling tiles by that XCD's L2).
+//
+// TN kernel.  out tile 128 x 128 (2 x 2 waves, 2 x 2 blocks each); the reduction runs over the
+// rows of a split of M in chunks of 32 rows staged row-major in LDS ([32][132]); the two operands
+// of an MFMA step are rows (2 s + h) of the staged g and x blocks (conflict-free ds_read_b32).
+// Splits write their partial tiles to a slab; a second kernel adds the slabs in split order
+// (deterministic, no atomics).  Workgroups of one split are adjacent on one XCD: each row of g and
+// x leaves HBM once.
+#include "common.h"
+
+namespace pygamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGK = 32;        // k chunk
+constexpr int kGLD = kGK + 4;  // LDS row stride (floats) of the NT kernel's tiles
+
+struct GemmNT {
+  const float* __restrict__ a;  // [M, K]
+  const float* __restrict__ b;  // [N, K]
+  const float* __restrict__ bias;       // [N] or null
+  const float* __restrict__ row_scale;  // [M] or null
+  float* __restrict__ c;                // [M, N]
+  int64_t M, lda, ldb, ldc;
+  int N, K;
+  int relu;
+  int n_scaled;   // columns [0, n_scaled) are multiplied by row_scale[row]
+  int accumulate; // c += result
+  int tiles_m, tiles_n;
+};
+
+// Tile numbering: hardware block b runs on XCD b % 8.  Logical order inside an XCD: for each row
+// block, all of its column tiles consecutively.
+__device__ __forceinline__ void nt_tile_of_block(const GemmNT& p, int& tm, int& tn) {
+  const int64_t b = blockIdx.x;
+  const int64_t per_xcd = gridDim.x >> 3;
+  const int64_t q = (b & 7) * per_xcd + (b >> 3);  // logical id, contiguous per XCD
+  tm = static_cast<int>(q / p.tiles_n);
+  tn = static_cast<int>(q - static_cast<int64_t>(tm) * p.tiles_n);
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC>
+__global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_LD4 = BM * (kGK / 4) / kBlock;  // 16-byte loads per thread per chunk
+  constexpr int B_LD4 = (BN * (kGK / 4) + kBlock - 1) / kBlock;
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;                       // [2][BM][kGLD]
+  float* Bs = smem + 2 * BM * kGLD;       // [2][BN][kGLD]
+  int tile_m, tile_n;
+  nt_tile_of_block(p, tile_m, tile_n);
+  if (tile_m >= p.tiles_m) return;
+  const int64_t m0 = static_cast<int64_t>(tile_m) * BM;
+  const int n0 = tile_n * BN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- global -> register staging map: thread -> (row r0 + 32 q, 16-byte column kq).  Row
+  // pointers are fixed for the whole K walk; rows past M / N are clamped (never stored / zeroed).
+  const int kq = threadIdx.x & 7;
+  const int r0 = threadIdx.x >> 3;
+  const float* pa[A_LD4];
+  const float* pb[B_LD4];
+  bool okb[B_LD4];
+#pragma unroll
+  for (int q = 0; q < A_LD4; ++q) {
+    int64_t row = m0 + r0 + 32 * q;
+    row = row < p.M ? row : p.M - 1;
+    pa[q] = p.a + row * p.lda;
+  }
+#pragma unroll
+  for (int q = 0; q < B_LD4; ++q) {
+    int row = n0 + r0 + 32 * q;
+    okb[q] = row < p.N && (BN % 32 == 0 || r0 + 32 * q < BN);
+    row = row < p.N ? row : p.N - 1;
+    pb[q] = p.b + static_cast<int64_t>(row) * p.ldb;
+  }
+  f32x4 ra[A_LD4], rb[B_LD4];
+  // Loads only ISSUE here (clamped to a valid, aligned column); the zeroing of the K tail and of
+  // the rows past N happens when the registers move to LDS one iteration later — a select next to
+  // the load would make the wave wait for the data right away.
+  auto load_chunk = [&](int k0) {
+    const int k = k0 + 4 * kq;
+    if (VEC) {
+      const int kc = k < p.K ? k : 0;  // column 0 exists whenever a chunk is loaded (K > 0)
+#pragma unroll
+      for (int q = 0; q < A_LD4; ++q) ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + kc);
+#pragma unroll
+      for (int q = 0; q < B_LD4; ++q) rb[q] = *reinterpret_cast<const f32x4*>(pb[q] + kc);
+    } else {
+#pragma unroll
+      for (int q = 0; q < A_LD4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[q][e] = pa[q][k + e < p.K ? k + e : 0];
+#pragma unroll
+      for (int q = 0; q < B_LD4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[q][e] = pb[q][k + e < p.K ? k + e : 0];
+    }
+  };
+  auto store_chunk = [&](int buf, int k0) {
+    float* as = As + buf * BM * kGLD + r0 * kGLD + 4 * kq;
+    float* bs = Bs + buf * BN * kGLD + r0 * kGLD + 4 * kq;
+    const int k = k0 + 4 * kq;
+    // both operands are zeroed past K (a clamped A value could be Inf/NaN: Inf * 0 = NaN)
+#pragma unroll
+    for (int q = 0; q < A_LD4; ++q) {
+      f32x4 v = ra[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (k + e < p.K) ? v[e] : 0.f;
+      *reinterpret_cast<f32x4*>(as + 32 * q * kGLD) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < B_LD4; ++q) {
+      if (BN % 32 == 0 || r0 + 32 * q < BN) {
+        f32x4 v = rb[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (okb[q] && k + e < p.K) ? v[e] : 0.f;
+        *reinterpret_cast<f32x4*>(bs + 32 * q * kGLD) = v;
+      }
+    }
+  };
+  // fragments of half a chunk (8 MFMA steps): 8 consecutive floats per 32 x 32 block
+  struct Frag {
+    f32x4 a[TM][2], b[TN][2];
+  };
+  const int a_off = (wm * TM * 32 + li) * kGLD + 16 * lh;
+  const int b_off = (wn * TN * 32 + li) * kGLD + 16 * lh;
+  auto read_frag = [&](Frag& f, int buf, int hf) {
+    const float* as = As + buf * BM * kGLD + a_off + 8 * hf;
+    const float* bs = Bs + buf * BN * kGLD + b_off + 8 * hf;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+        f.a[i][v] = *reinterpret_cast<const f32x4*>(as + i * 32 * kGLD + 4 * v);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+        f.b[j][v] = *reinterpret_cast<const f32x4*>(bs + j * 32 * kGLD + 4 * v);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto mma_steps = [&](const Frag& f, int s_begin, int s_end) {
+#pragma unroll
+    for (int s = s_begin; s < s_end; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s >> 2][s & 3],
+                                                            f.b[j][s >> 2][s & 3], acc[i][j], 0, 0,
+                                                            0);
+  };
+
+  // Pipeline (ONE barrier per chunk, every LDS read issued at least 16 MFMAs before its use):
+  //   iteration c:  LDS[c+1] <- registers;  registers <- global chunk c+2;
+  //                 f1 <- LDS[c] upper half;  MFMA(f0 = lower half of chunk c, steps 0-3);
+  //                 barrier;  MFMA(f0, steps 4-7);  f0 <- LDS[c+1] lower half;  MFMA(f1).
+  // The barrier orders (a) the stores of chunk c+1 before anybody's reads of it and (b) every
+  // wave's reads of LDS[c] before the stores of chunk c+2 into the same buffer next iteration.
+  const int n_chunks = (p.K + kGK - 1) / kGK;
+  Frag f0, f1;
+  if (n_chunks > 0) {
+    load_chunk(0);
+    store_chunk(0, 0);
+  }
+  if (n_chunks > 1) load_chunk(kGK);
+  __syncthreads();
+  if (n_chunks > 0) read_frag(f0, 0, 0);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < n_chunks) store_chunk(buf ^ 1, (c + 1) * kGK);
+    if (c + 2 < n_chunks) load_chunk((c + 2) * kGK);
+    read_frag(f1, buf, 1);
+    mma_steps(f0, 0, 4);
+    // keep the barrier in the MIDDLE of the MFMA stream (hipcc hoists it to the top otherwise:
+    // the wave would then sit in lgkmcnt(0) + s_barrier with one MFMA in flight)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    mma_steps(f0, 4, 8);
+    if (c + 1 < n_chunks) read_frag(f0, buf ^ 1, 0);
+    // a K tail of <= 8 leaves the upper 8 steps all zero in both lane halves: skip them
+    if (p.K - c * kGK > 8) mma_steps(f1, 0, 8);
+  }
+
+  // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const float floor_v = p.relu ? 0.f : -INFINITY;  // branch-free ReLU switch
+  const bool wave_scaled = p.n_scaled > n0 + wn * TN * 32;  // wave-uniform
+  if (full && !p.accumulate) {
+    // interior tile (all but the last row block): no bounds checks, no read-modify-write
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+      f32x4 sc[4];
+      if (wave_scaled) {  // rows rbase + 8 g + {0..3}: four aligned 16-byte loads
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sc[g4][e] = p.row_scale[rbase + 8 * g4 + e];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + li;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        const bool scaled = wave_scaled && col < p.n_scaled;
+        float* cp = p.c + rbase * p.ldc + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][j][e] + bv;
+          if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
+          cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = fmaxf(v, floor_v);
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + li;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+      const bool scaled = col < p.n_scaled;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
+        if (row < p.M) {
+          float v = acc[i][j][e] + bv;
+          if (scaled) v *= p.row_scale[row];
+          v = fmaxf(v, floor_v);
+          float* dst = p.c + row * p.ldc + col;
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- TN: out[N, K] = g[M, N]^T @ x[M, K], split over M -------------------------------------------
+constexpr int kWRows = 32;          // rows of M per staged block
+constexpr int kWTile = 128;         // output tile edge
+constexpr int kWLD = kWTile + 4;    // LDS row stride
+
+struct GemmTN {
+  const float* __restrict__ g;  // [M, N]
+  const float* __restrict__ x;  // [M, K]
+  float* __restrict__ partial;  // [splits][N][K]
+  int64_t M, ldg, ldx;
+  int N, K;
+  int tiles_n, tiles_k, splits;
+  int64_t rows_per_split;       // multiple of kWRows
+};
+
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
+  extern __shared__ __align__(16) float smem[];
+  float (*Gs)[kWRows][kWLD] = reinterpret_cast<float (*)[kWRows][kWLD]>(smem);
+  float (*Xs)[kWRows][kWLD] =
+      reinterpret_cast<float (*)[kWRows][kWLD]>(smem + 2 * kWRows * kWLD);
+  // logical id: per XCD, all tiles of one split consecutively
+  const int64_t b = blockIdx.x;
+  const int64_t per_xcd = gridDim.x >> 3;
+  const int64_t q = (b & 7) * per_xcd + (b >> 3);
+  const int tiles = p.tiles_n * p.tiles_k;
+  const int64_t split = q / tiles;
+  if (split >= p.splits) return;
+  const int t = static_cast<int>(q - split * tiles);
+  const int tn = t / p.tiles_k, tk = t - tn * p.tiles_k;
+  const int n0 = tn * kWTile, k0 = tk * kWTile;
+  const int64_t ra = split * p.rows_per_split;
+  int64_t rb = ra + p.rows_per_split;
+  rb = rb < p.M ? rb : p.M;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // staging: thread -> (row sr + 8 j, 16-byte column sc): a wave covers two 512-byte rows
+  const int sc = threadIdx.x & 31;
+  const int sr = threadIdx.x >> 5;
+  const int gcol = n0 + 4 * sc, xcol = k0 + 4 * sc;
+  f32x4 rg[4], rx[4];
+  auto load_rows = [&](int64_t r) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = r + sr + 8 * j;
+      const bool ok = row < rb;
+      const int64_t rs = ok ? row : ra;
+      const float* gp = p.g + rs * p.ldg + gcol;
+      const float* xp = p.x + rs * p.ldx + xcol;
+      if (VEC) {
+        rg[j] = (ok && gcol < p.N) ? *reinterpret_cast<const f32x4*>(gp)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+        rx[j] = (ok && xcol < p.K) ? *reinterpret_cast<const f32x4*>(xp)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rg[j][e] = (ok && gcol + e < p.N) ? gp[e] : 0.f;
+          rx[j][e] = (ok && xcol + e < p.K) ? xp[e] : 0.f;
+        }
+      }
+    }
+  };
+  auto store_rows = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<f32x4*>(&Gs[buf][sr + 8 * j][4 * sc]) = rg[j];
+      *reinterpret_cast<f32x4*>(&Xs[buf][sr + 8 * j][4 * sc]) = rx[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // wave-uniform: which 32-wide blocks of this wave's range exist
+  const bool nb0 = n0 + wn * 64 < p.N, nb1 = n0 + wn * 64 + 32 < p.N;
+  const bool kb0 = k0 + wk * 64 < p.K, kb1 = k0 + wk * 64 + 32 < p.K;
+
+  const int64_t n_blocks = (rb - ra + kWRows - 1) / kWRows;
+  if (n_blocks > 0) {
+    load_rows(ra);
+    store_rows(0);
+    if (n_blocks > 1) load_rows(ra + kWRows);
+  }
+  __syncthreads();
+  for (int64_t c = 0; c < n_blocks; ++c) {
+    const int buf = static_cast<int>(c & 1);
+    if (c + 1 < n_blocks) store_rows(buf ^ 1);
+    if (c + 2 < n_blocks) load_rows(ra + (c + 2) * kWRows);
+    if (nb0 && kb0) {
+      const float* gs = &Gs[buf][lh][wn * 64 + li];
+      const float* xs = &Xs[buf][lh][wk * 64 + li];
+#pragma unroll
+      for (int s = 0; s < kWRows / 2; ++s) {
+        const float a0 = gs[2 * s * kWLD];
+        const float b0 = xs[2 * s * kWLD];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        float b1 = 0.f;
+        if (kb1) {
+          b1 = xs[2 * s * kWLD + 32];
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        }
+        if (nb1) {
+          const float a1 = gs[2 * s * kWLD + 32];
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+          if (kb1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* __restrict__ slab = p.partial + split * static_cast<int64_t>(p.N) * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = k0 + wk * 64 + j * 32 + li;
+      if (col >= p.K) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row < p.N) slab[static_cast<int64_t>(row) * p.K + col] = acc[i][j][e];
+      }
+    }
+  }
+}
+
+// out[n, k] (+)= sum over splits, in split order (deterministic)
+__global__ void __launch_bounds__(kBlock)
+    gemm_tn_reduce_kernel(const float* __restrict__ partial, int splits, int64_t NK, int K,
+                          float* __restrict__ out, int64_t ldo, int accumulate) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= NK) return;
+  float s = 0.f;
+  for (int sp = 0; sp < splits; ++sp) s += partial[sp * NK + t];
+  const int64_t r = t / K;
+  float* dst = out + r * ldo + (t - r * K);
+  *dst = accumulate ? *dst + s : s;
+}
+
+static bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int WM, int WN, int TM, int TN>
+static int launch_nt(GemmNT p, bool vec, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  p.tiles_m = static_cast<int>(ceil_div(p.M, BM));
+  p.tiles_n = static_cast<int>(ceil_div(p.N, BN));
+  const int64_t blocks = round_up(static_cast<int64_t>(p.tiles_m) * p.tiles_n, 8);
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * kGLD;
+  // (the opt-in to > 64 KiB of dynamic LDS is per kernel and per device: set it on every launch,
+  // it is a host-side attribute write)
+  if (vec) {
+    auto k = gemm_nt_kernel<WM, WN, TM, TN, true>;
+    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds)));
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, st, p);
+  } else {
+    auto k = gemm_nt_kernel<WM, WN, TM, TN, false>;
+    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds)));
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, st, p);
+  }
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+static int run_nt(GemmNT p, hipStream_t st) {
+  if (p.M == 0 || p.N == 0) return PYGAMD_OK;
+  const bool vec = (p.K % 4 == 0) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) && aligned16p(p.a) &&
+                   aligned16p(p.b);
+  // tile shape by output width: wide outputs 128 x 128; 65..96 columns one 128 x 96 tile row;
+  // narrow outputs 128 x 64 / 128 x 32 tiles (all four waves stacked along M)
+  if (p.N > 96) return launch_nt<2, 2, 2, 2>(p, vec, st);
+  if (p.N > 64) return launch_nt<4, 1, 1, 3>(p, vec, st);
+  if (p.N > 32) return launch_nt<4, 1, 1, 2>(p, vec, st);
+  return launch_nt<4, 1, 1, 1>(p, vec, st);
+}
+
+}  // namespace pygamd
+
+using namespace pygamd;
+
+extern "C" {
+
+int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
+                          const float* bias, int64_t M, int64_t K, int64_t N, int relu,
+                          int accumulate, float* out, int64_t ldo, void* stream) {
+  if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldx < K || ldw < K ||
+      ldo < N)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return PYGAMD_OK;
+  if (!out || (K > 0 && (!x || !w))) return PYGAMD_ERR_INVALID_ARG;
+  GemmNT p = {};
+  p.a = x; p.b = w; p.bias = bias; p.row_scale = nullptr; p.c = out;
+  p.M = M; p.lda = ldx; p.ldb = ldw; p.ldc = ldo;
+  p.N = static_cast<int>(N); p.K = static_cast<int>(K);
+  p.relu = relu ? 1 : 0; p.n_scaled = 0; p.accumulate = accumulate ? 1 : 0;
+  return run_nt(p, as_stream(stream));
+}
+
+int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
+                        const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
+                        int64_t K, int accumulate, float* out, int64_t ldo, void* stream) {
+  // out[M, K] = g[M, N] @ w[N, K], with w given TRANSPOSED as w_t[K, N]: the same NT kernel
+  if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldwt < N ||
+      ldo < K || n_scaled < 0 || n_scaled > K)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (M == 0 || K == 0) return PYGAMD_OK;
+  if (!out || (N > 0 && (!g || !w_t)) || (n_scaled > 0 && !row_scale))
+    return PYGAMD_ERR_INVALID_ARG;
+  GemmNT p = {};
+  p.a = g; p.b = w_t; p.bias = nullptr; p.row_scale = row_scale; p.c = out;
+  p.M = M; p.lda = ldg; p.ldb = ldwt; p.ldc = ldo;
+  p.N = static_cast<int>(K); p.K = static_cast<int>(N);
+  p.relu = 0; p.n_scaled = static_cast<int>(n_scaled); p.accumulate = accumulate ? 1 : 0;
+  return run_nt(p, as_stream(stream));
+}
+
+static int64_t wgrad_splits(int64_t M, int64_t tiles) {
+  // two workgroups per CU (the LDS ring allows no more) = one full wave of workgroups, every
+  // split a multiple of 32 rows and at least 2048 rows
+  int64_t s = ceil_div(256 * 2, tiles < 1 ? 1 : tiles);
+  const int64_t max_s = ceil_div(M, 2048);
+  s = s > max_s ? max_s : s;
+  return s < 1 ? 1 : s;
+}
+
+int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t* bytes) {
+  if (!bytes || M < 0 || N < 0 || K < 0) return PYGAMD_ERR_INVALID_ARG;
+  const int64_t tiles = ceil_div(N, kWTile) * ceil_div(K, kWTile);
+  *bytes = static_cast<size_t>(wgrad_splits(M, tiles)) * static_cast<size_t>(N) *
+           static_cast<size_t>(K) * sizeof(float);
+  return PYGAMD_OK;
+}
+
+int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t M,
+                        int64_t N, int64_t K, int accumulate, float* out, int64_t ldo,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldx < K ||
+      ldo < K)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (N == 0 || K == 0) return PYGAMD_OK;
+  if (!out || (M > 0 && (!g || !x))) return PYGAMD_ERR_INVALID_ARG;
+  size_t need = 0;
+  pygamd_linear_wgrad_workspace_bytes(M, N, K, &need);
+  if (!workspace || workspace_bytes < need) return PYGAMD_ERR_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  GemmTN p = {};
+  p.g = g; p.x = x; p.partial = static_cast<float*>(workspace);
+  p.M = M; p.ldg = ldg; p.ldx = ldx;
+  p.N = static_cast<int>(N); p.K = static_cast<int>(K);
+  p.tiles_n = static_cast<int>(ceil_div(N, kWTile));
+  p.tiles_k = static_cast<int>(ceil_div(K, kWTile));
+  const int64_t tiles = static_cast<int64_t>(p.tiles_n) * p.tiles_k;
+  p.splits = static_cast<int>(wgrad_splits(M, tiles));
+  p.rows_per_split = round_up(ceil_div(M > 0 ? M : 1, p.splits), kWRows);
+  const bool vec = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) &&
+                   aligned16p(g) && aligned16p(x);
+  const int64_t blocks = round_up(tiles * p.splits, 8);
+  const size_t lds = sizeof(float) * 4 * kWRows * kWLD;
+  if (vec) {
+    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds)));
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock),
+                       lds, st, p);
+  } else {
+    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds)));
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock),
+                       lds, st, p);
+  }
+  PYGAMD_LAUNCH_CHECK();
+  const int64_t NK = N * K;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(static_cast<unsigned>(ceil_div(NK, kBlock))),
+                     dim3(kBlock), 0, st, p.partial, p.splits, NK, p.K, out, ldo,
+                     accumulate ? 1 : 0);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+}  // extern "C"

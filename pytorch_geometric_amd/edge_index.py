@@ -119,6 +119,7 @@ class EdgeIndex:
         self._csc: Optional[CSR] = None   # sorted by source (transposed / backward)
         self._slot_map = None
         self._flipped: Optional['EdgeIndex'] = None
+        self._derived = {}
         # True: the backward of an aggregation runs the edge-parallel atomic kernel on the COO
         # list instead of building the source-sorted form (graphs used once: sampled batches)
         self.atomic_backward = False
@@ -262,6 +263,17 @@ class EdgeIndex:
             flipped._csr, flipped._csc = self._csc, self._csr  # the sorted forms swap roles
             self._flipped = flipped
         return SpmmFunction.apply(other, input_value, self._flipped, reduce, 'coo')
+
+    def derived(self, key, build):
+        """Per-handle cache of graphs DERIVED from this one by a layer (``gcn_norm``'s
+        self-looped, normalised edge list; GAT's re-self-looped edge list): ``build()`` runs once
+        per ``key``; the derived handle keeps its own sorted forms."""
+        hit = self._derived.get(key)
+        if hit is None:
+            if len(self._derived) >= 4:
+                self._derived.pop(next(iter(self._derived)))
+            hit = self._derived[key] = build()
+        return hit
 
     def fill_cache_(self) -> 'EdgeIndex':
         self.by_dst().hub

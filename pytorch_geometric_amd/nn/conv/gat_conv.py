@@ -120,6 +120,21 @@ class GATConv(MessagePassing):
             n = x_src.size(0) if x_dst is None else min(x_src.size(0), x_dst.size(0))
             n = min(size) if size is not None else n
             edge_index, edge_attr = self._with_self_loops(edge_index, edge_attr, n)
+        elif self.add_self_loops and isinstance(edge_index, EdgeIndex):
+            # handles get the same remove + add self-loops treatment as tensors (the reference's
+            # EdgeIndex is a Tensor and takes that branch, gat_conv.py:334-347)
+            handle = edge_index
+            n = min(handle.sparse_size) if size is None else min(size)
+
+            def build():
+                ei, ea = remove_self_loops(handle.edge_index, edge_attr)
+                ei, ea = add_self_loops(ei, ea, fill_value=self.fill_value, num_nodes=n)
+                return EdgeIndex(ei, handle.sparse_size, validate=False), ea
+
+            if edge_attr is None:
+                edge_index, edge_attr = handle.derived(('self_loops', n), build)
+            else:
+                edge_index, edge_attr = build()
 
         use_fused = (self.fuse and edge_attr is None and a_dst is not None
                      and self.flow == 'source_to_target')
@@ -133,9 +148,11 @@ class GATConv(MessagePassing):
             out = SpmmFunction.apply(x_src.reshape(n_src, H * C), weights, graph, 'sum', 'slot')
             out = out.view(-1, H, C)
             alpha = None
-            if return_attention_weights is not None:  # back to the caller's edge order
-                alpha = torch.empty_like(alpha_slot)
-                alpha[graph.by_dst().perm.long()] = alpha_slot
+            if return_attention_weights is not None:
+                # the POST-dropout coefficients (what edge_update returns in the reference,
+                # gat_conv.py:404-406), back in the caller's edge order
+                alpha = torch.empty_like(weights)
+                alpha[graph.by_dst().perm.long()] = weights
         else:
             alpha = self.edge_updater(edge_index, alpha=(a_src, a_dst), edge_attr=edge_attr,
                                       size=size)

@@ -75,6 +75,21 @@ class GCNConv(MessagePassing):
             self._cached_edge_index = out
         return out
 
+    def _normalized_handle(self, x: Tensor, handle: EdgeIndex, edge_weight: Optional[Tensor]):
+        n = x.size(self.node_dim)
+        if handle.sparse_size != (n, n):
+            raise ValueError(f"'{type(self).__name__}' needs a square graph over the {n} rows "
+                             f"of 'x' (got sparse_size={handle.sparse_size})")
+
+        def build():
+            ei, w = gcn_norm(handle.edge_index, edge_weight, n, self.improved,
+                             self.add_self_loops, self.flow, x.dtype)
+            return EdgeIndex(ei, (n, n), validate=False), w
+
+        if edge_weight is not None:  # values (and maybe a graph of gradients) differ per call
+            return build()
+        return handle.derived(('gcn_norm', self.improved, self.add_self_loops, self.flow), build)
+
     def forward(self, x: Tensor, edge_index, edge_weight: Optional[Tensor] = None) -> Tensor:
         if isinstance(x, (tuple, list)):
             raise ValueError(f"'{type(self).__name__}' received a tuple of node features as "
@@ -83,6 +98,10 @@ class GCNConv(MessagePassing):
                              f"'GraphConv' instead")
         if self.normalize and isinstance(edge_index, Tensor):
             edge_index, edge_weight = self._normalized(x, edge_index, edge_weight)
+        elif self.normalize and isinstance(edge_index, EdgeIndex):
+            # the reference normalises its EdgeIndex inputs too (gcn_conv.py:241-258, EdgeIndex
+            # IS a Tensor there): never aggregate an un-normalised handle silently
+            edge_index, edge_weight = self._normalized_handle(x, edge_index, edge_weight)
         out = self.propagate(edge_index, x=self.lin(x), edge_weight=edge_weight)
         return out if self.bias is None else out + self.bias
 

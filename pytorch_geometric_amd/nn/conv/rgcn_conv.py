@@ -30,6 +30,18 @@ class RelationalHandle:
                  num_relations: int):
         dev = edge_index.device
         src, dst = edge_index[0], edge_index[1]
+        if edge_type.numel() > 0:
+            # the radix sort below only looks at the bits `max_value` needs: a relation id outside
+            # [0, num_relations) would be mis-sorted silently (the reference fails with an index
+            # error in its per-relation loop).  Once per handle (handles are cached).
+            lo, hi = _native.index_minmax(edge_type)
+            if lo < 0 or hi >= num_relations:
+                raise IndexError(f"'edge_type' must lie in [0, {num_relations}) "
+                                 f"(got values in [{lo}, {hi}])")
+            lo, hi = _native.index_minmax(dst)
+            if lo < 0 or hi >= num_dst:
+                raise IndexError(f"Found indices in 'edge_index' outside the valid range "
+                                 f"[0, {num_dst - 1}] (got interval [{lo}, {hi}])")
         key = edge_type.to(torch.int64) * num_dst + dst.to(torch.int64)
         skey, perm = _native.index_sort(key, max_value=num_relations * num_dst)
         # pair boundaries: positions where the sorted key changes

@@ -111,6 +111,12 @@ class HeteroLinear(torch.nn.Module):
         from ..._functions import GatherFunction
         from ...utils import segment_matmul
         perm = None
+        if type_vec.numel() > 0:
+            # (the grouped GEMM reads the segment pointer on the host anyway: one more tiny sync)
+            lo, hi = _native.index_minmax(type_vec)
+            if lo < 0 or hi >= self.num_types:
+                raise IndexError(f"'type_vec' must lie in [0, {self.num_types}) "
+                                 f"(got values in [{lo}, {hi}])")
         if not self.is_sorted:
             type_vec, perm = _native.index_sort(type_vec, max_value=self.num_types)
             x = GatherFunction.apply(x, perm, False)

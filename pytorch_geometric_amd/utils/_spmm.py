@@ -67,7 +67,14 @@ def spmm(src: Union[EdgeIndex, Tensor], other: Tensor, reduce: str = 'sum',
         if vals.dim() != 1:
             raise ValueError("only scalar sparse values are supported")
         if reduce in ('min', 'max'):
-            # values multiply the gathered rows only for sum/mean (like torch.sparse.mm)
+            # torch.sparse.mm(A, B, 'amax') — the reference's CPU route — multiplies by the
+            # stored values; the extremum kernels take no weights, so only unit values are
+            # accepted (the reference's CUDA route refuses min/max altogether,
+            # utils/_spmm.py:92-99)
+            if not bool((vals == 1).all()):
+                raise NotImplementedError(
+                    f"`{reduce}` reduction over a sparse matrix with non-unit values is not "
+                    f"supported on the MI355X path")
             return SpmmFunction.apply(other, None, handle, reduce, 'coo')
         return SpmmFunction.apply(other, vals.to(torch.float32), handle, reduce, 'coo')
     raise ValueError("'src' must be an EdgeIndex handle or a torch.sparse CSR/COO/CSC tensor")

@@ -1,0 +1,107 @@
+"""The fp32-MFMA dense transform (csrc/gemm.hip) against torch's CPU GEMM: exact-fp32 MFMA is an
+fmaf chain, so the 1e-5 contract holds relative to the size of the dot product's terms
+(`assert_sum_close` with the |a|.|b| bound — K up to thousands of terms, wgrad sums over M rows)."""
+import pytest
+import torch
+
+from tests._util import assert_close, assert_sum_close, gen
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (M, K, N)
+    (1, 1, 1), (5, 3, 2), (33, 7, 31), (64, 32, 32), (130, 200, 256), (257, 512, 256),
+    (300, 256, 96), (129, 100, 47), (1000, 36, 130), (70, 16, 7), (513, 1433, 16), (40, 0, 8),
+    (0, 16, 8),
+]
+
+
+def _fwd_ref(x, w, b, relu):
+    out = x.double() @ w.double().t()
+    if b is not None:
+        out = out + b.double()
+    return out.relu() if relu else out
+
+
+@pytest.mark.parametrize('M,K,N', SHAPES)
+def test_linear_forward(dev, M, K, N):
+    from pytorch_geometric_amd import _native
+    g = gen(M * 31 + K * 7 + N)
+    x, w, b = (torch.randn(M, K, generator=g), torch.randn(N, K, generator=g),
+               torch.randn(N, generator=g))
+    for bias, relu in ((None, False), (b, False), (b, True)):
+        ex = _fwd_ref(x, w, bias, relu)
+        ref32 = torch.nn.functional.linear(x, w, bias)
+        ref32 = ref32.relu() if relu else ref32
+        bound = x.abs().double() @ w.abs().double().t() + (0 if bias is None else bias.abs())
+        out = _native.linear_forward(x.to(dev), w.to(dev), None if bias is None else bias.to(dev),
+                                     relu=relu)
+        assert out.shape == (M, N)
+        assert_sum_close(out, ref32, ex, abs_sum=bound, what=f'fwd {M}x{K}x{N} relu={relu}')
+
+
+def test_linear_forward_strided_views_and_accumulate(dev):
+    """Operands and outputs as halves of wider buffers (the `[agg | x]` layout), unaligned
+    (scalar-load) fallbacks, accumulate."""
+    from pytorch_geometric_amd import _native
+    g = gen(5)
+    big = torch.randn(300, 520, generator=g).to(dev)
+    w = torch.randn(96, 256, generator=g).to(dev)
+    b = torch.randn(96, generator=g).to(dev)
+    outbuf = torch.zeros(300, 200, device=dev)
+    for off in (0, 256, 3):  # 3: rows no longer 16-byte aligned -> scalar loads
+        xv = big[:, off:off + 256]
+        ov = outbuf[:, 100:196]
+        _native.linear_forward(xv, w, b, relu=True, out=ov)
+        ref = torch.nn.functional.linear(xv.cpu(), w.cpu(), b.cpu()).relu()
+        assert_close(ov, ref, rtol=1e-5, atol=2e-4, what=f'strided off={off}')
+        assert bool((outbuf[:, :100] == 0).all()) and bool((outbuf[:, 196:] == 0).all())
+    base = torch.randn(300, 96, generator=g).to(dev)
+    acc = base.clone()
+    _native.linear_forward(big[:, :256], w, None, out=acc, accumulate=True)
+    ref = base.cpu() + big[:, :256].cpu() @ w.cpu().t()
+    assert_close(acc, ref, rtol=1e-5, atol=2e-4, what='accumulate')
+
+
+@pytest.mark.parametrize('M,K,N', SHAPES)
+def test_linear_dgrad_and_wgrad(dev, M, K, N):
+    from pytorch_geometric_amd import _native
+    g = gen(M + K * 13 + N * 101)
+    x, w, go = (torch.randn(M, K, generator=g), torch.randn(N, K, generator=g),
+                torch.randn(M, N, generator=g))
+    scale = torch.rand(M, generator=g) + 0.5
+    # dgrad: go @ w, left `ns` columns scaled per row
+    ns = K // 2
+    ex = go.double() @ w.double()
+    ex[:, :ns] *= scale.double().view(-1, 1)
+    ref32 = go @ w
+    ref32[:, :ns] *= scale.view(-1, 1)
+    bound = go.abs().double() @ w.abs().double()
+    bound[:, :ns] *= scale.double().view(-1, 1)
+    out = _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev), scale.to(dev), ns)
+    assert out.shape == (M, K)
+    assert_sum_close(out, ref32, ex, abs_sum=bound, what=f'dgrad {M}x{K}x{N}')
+    # wgrad: go^T @ x
+    ex = go.double().t() @ x.double()
+    ref32 = go.t() @ x
+    bound = go.abs().double().t() @ x.abs().double()
+    out = _native.linear_wgrad(go.to(dev), x.to(dev))
+    assert out.shape == (N, K)
+    assert_sum_close(out, ref32, ex, abs_sum=bound, what=f'wgrad {M}x{K}x{N}')
+
+
+def test_wgrad_long_reduction_is_deterministic_and_accurate(dev):
+    """M = 200k rows split over many workgroups: slabs are summed in split order (no atomics), so
+    two runs are bitwise equal; accuracy judged against fp64."""
+    from pytorch_geometric_amd import _native
+    g = gen(9)
+    M, N, K = 200_003, 96, 200
+    go, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+    a = _native.linear_wgrad(go.to(dev), x.to(dev))
+    b = _native.linear_wgrad(go.to(dev), x.to(dev))
+    assert torch.equal(a, b)
+    ex = go.double().t() @ x.double()
+    bound = go.abs().double().t() @ x.abs().double()
+    assert_sum_close(a, go.t() @ x, ex, abs_sum=bound, what='wgrad M=200003')
+    acc = torch.ones(N, K, device=dev)
+    _native.linear_wgrad(go.to(dev), x.to(dev), out=acc, accumulate=True)
+    assert_sum_close(acc - 1, go.t() @ x, ex, abs_sum=bound + 1, what='wgrad accumulate')

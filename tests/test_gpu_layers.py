@@ -445,3 +445,84 @@ def test_training_step_is_hipgraph_capturable(dev):
     assert_close(cap_out, ref_out.cpu(), atol=1e-6, rtol=1e-6)
     for p, r in zip(model.parameters(), ref_grads):
         assert_close(p.grad, r.cpu(), atol=1e-6, rtol=1e-6)
+
+
+def test_handles_are_normalised_and_self_looped_like_tensors(dev):
+    """Round-1 ADVICE: GCNConv(normalize=True) / GATConv(add_self_loops=True) must treat an
+    EdgeIndex handle exactly like the raw tensor (the reference's EdgeIndex IS a Tensor and takes
+    the gcn_norm / self-loop branches, gcn_conv.py:241-258, gat_conv.py:334-347) — and the derived
+    graph is built once per handle."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd.nn import GATConv, GCNConv
+    g = gen(41)
+    n = 120
+    x = torch.randn(n, 10, generator=g).to(dev)
+    ei = torch.randint(0, n, (2, 900), generator=g).to(dev)
+    ew = torch.rand(900, generator=g).to(dev)
+    torch.manual_seed(5)
+    for conv, extra in ((GCNConv(10, 6).to(dev), ()), (GCNConv(10, 6, improved=True).to(dev),
+                                                        (ew, )),
+                        (GATConv(10, 4, heads=2).to(dev), ())):
+        handle = pga.EdgeIndex(ei, (n, n))
+        want = conv(x, ei, *extra)
+        got = conv(x, handle, *extra)
+        # (degrees come from an atomic scatter-add: last-ulp differences between two evaluations)
+        assert_close(got, want, rtol=1e-6, atol=1e-6, what=type(conv).__name__)
+        if not extra:
+            assert len(handle._derived) == 1
+            first = next(iter(handle._derived.values()))[0]
+            conv(x, handle)
+            assert next(iter(handle._derived.values()))[0] is first  # no rebuild, no re-sort
+    with pytest.raises(ValueError, match='square graph'):
+        GCNConv(10, 6).to(dev)(x, pga.EdgeIndex(ei, (n, n + 3)))
+
+
+def test_gat_returns_post_dropout_attention(dev):
+    """return_attention_weights gives what edge_update returns in the reference: the coefficients
+    AFTER dropout, on the fused and on the unfused path alike."""
+    from pytorch_geometric_amd.nn import GATConv
+    g = gen(43)
+    n = 200
+    x = torch.randn(n, 8, generator=g).to(dev)
+    ei = torch.randint(0, n, (2, 3000), generator=g).to(dev)
+    for fuse in (True, False):
+        conv = GATConv(8, 4, heads=2, dropout=0.5).to(dev).train()
+        conv.fuse = fuse
+        _, (coo, alpha) = conv(x, ei, return_attention_weights=True)
+        frac = float((alpha == 0).float().mean())
+        assert 0.4 < frac < 0.6, (fuse, frac)       # half of the coefficients were dropped
+        kept = alpha[alpha != 0]
+        assert float(kept.min()) > 0 and coo.size(1) == alpha.size(0)
+        conv.eval()
+        _, (_, alpha) = conv(x, ei, return_attention_weights=True)
+        assert float((alpha == 0).float().mean()) < 0.01
+
+
+def test_key_range_is_validated_before_limited_bit_sorts(dev):
+    """Round-1 ADVICE: index_sort only sorts the bits `max_value` needs; layers that derive
+    max_value from a constructor argument must reject keys beyond it instead of mis-sorting."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd.nn import HeteroLinear, RGCNConv
+    g = gen(44)
+    x = torch.randn(30, 6, generator=g).to(dev)
+    ei = torch.randint(0, 30, (2, 100), generator=g).to(dev)
+    et = torch.randint(0, 4, (100, ), generator=g).to(dev)
+    conv = RGCNConv(6, 5, num_relations=4).to(dev)
+    conv(x, ei, et)
+    et_bad = et.clone()
+    et_bad[7] = 4
+    with pytest.raises(IndexError, match=r"'edge_type' must lie in \[0, 4\)"):
+        conv(x, ei, et_bad)
+    lin = HeteroLinear(6, 5, num_types=3).to(dev)
+    tv = torch.randint(0, 3, (30, ), generator=g).to(dev)
+    lin(x, tv)
+    tv[3] = 3
+    with pytest.raises(IndexError, match=r"'type_vec' must lie in \[0, 3\)"):
+        lin(x, tv)
+    # sparse min/max with non-unit values: refused, not silently un-weighted
+    adj = torch.sparse_coo_tensor(ei, torch.rand(100, generator=g).to(dev), (30, 30)).coalesce()
+    with pytest.raises(NotImplementedError, match='non-unit values'):
+        pga.utils.spmm(adj.to_sparse_csr(), x, 'max')
+    ones = torch.sparse_coo_tensor(adj.indices(), torch.ones_like(adj.values()), (30, 30))
+    out = pga.utils.spmm(ones.coalesce().to_sparse_csr(), x, 'max')
+    assert out.shape == (30, 6)

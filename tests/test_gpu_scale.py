@@ -92,3 +92,79 @@ def test_max_aggregation_full_size(products):
         s, e = int(fwd.ptr[r]), int(fwd.ptr[r + 1])
         if e > s:
             assert torch.equal(mx[r], a[fwd.idx[s:e]].max(0).values)
+
+
+# ---- the headline config against the CPU paths AT ITS OWN SIZE -----------
+def _csr_cpu(key, other, n):
+    """(ptr, idx, perm) of the COO list stably sorted by `key`, on the host with torch's own ops:
+    torch.sort(stable=True) + torch._convert_indices_from_coo_to_csr (what the reference's
+    EdgeIndex cache is made of, edge_index.py:605-663)."""
+    skey, perm = torch.sort(key, stable=True)
+    return torch._convert_indices_from_coo_to_csr(skey, n), other[perm], perm, skey
+
+
+@pytest.mark.timeout(900)
+def test_headline_config_against_the_cpu_paths_full_size(products):
+    """One F = 256 `mean` aggregation of the full ogbn-products-shaped graph and its transposed
+    backward, VALUE-checked on every row (hub rows of ~16 k neighbours included) against
+      * the reference's CPU scatter path in fp32 (oracle.spmm = index_select + scatter_add_ +
+        divide, 63 GB of messages on the host: affordable once on the GPU box) and
+      * an fp64 evaluation (torch.sparse.mm on the CSR form, the reference's fast path),
+    plus the integer side (ptr / idx / perm / sorted keys of both orientations) BIT-exact against
+    torch.sort(stable=True) + _convert_indices_from_coo_to_csr at E = 61,859,140."""
+    import pytorch_geometric_amd as pga
+    from oracle import pyg_oracle as O
+    from tests._util import assert_close, assert_sum_close
+    x, ei, h = products
+    dev = x.device
+    N, E = x.size(0), ei.size(1)
+    ei_c = ei.cpu()
+
+    # integer outputs, bit-exact at full size
+    for csr, key, other in ((h.by_dst(), ei_c[1], ei_c[0]), (h.by_src(), ei_c[0], ei_c[1])):
+        ptr, idx, perm, skey = _csr_cpu(key, other, N)
+        assert torch.equal(csr.ptr.cpu(), ptr), 'ptr'
+        assert torch.equal(csr.perm.cpu(), perm), 'perm'
+        assert torch.equal(csr.idx.cpu(), idx), 'idx'
+        s2, p2 = pga.utils.index_sort(key.to(dev), max_value=N - 1)
+        assert torch.equal(s2.cpu(), skey) and torch.equal(p2.cpu(), perm), 'index_sort'
+        del ptr, idx, perm, skey, s2, p2
+
+    F = 256
+    g = torch.Generator().manual_seed(2024)
+    a = torch.randn(N, F, generator=g)
+    go = torch.randn(N, F, generator=g)
+
+    # HIP: forward + input gradient through the autograd pair the model uses
+    av = a.to(dev).requires_grad_(True)
+    out = pga.utils.spmm(h, av, 'mean')
+    out.backward(go.to(dev))
+    out, grad = out.detach().cpu(), av.grad.cpu()
+    del av
+
+    # fp64 on the host: CSR of the by-destination form, torch.sparse.mm
+    ptr, idx, _, _ = _csr_cpu(ei_c[1], ei_c[0], N)
+    deg = (ptr[1:] - ptr[:-1]).clamp(min=1)
+    A64 = torch.sparse_csr_tensor(ptr, idx, torch.ones(E, dtype=torch.float64), size=(N, N))
+    ex_out = torch.sparse.mm(A64, a.double()) / deg.double().view(-1, 1)
+    abs_sum = torch.sparse.mm(A64, a.abs().double()) / deg.double().view(-1, 1)
+    # fp32: the reference's CPU scatter path
+    ref_out = O.spmm(ei_c, a, N, 'mean')
+    assert_sum_close(out, ref_out, ex_out, abs_sum=abs_sum, what='mean aggregation at P')
+    # rows of ordinary degree must meet the plain 1e-5 contract against the scatter path
+    small = (ptr[1:] - ptr[:-1]) <= 64
+    assert_close(out[small], ref_out[small], rtol=1e-5, atol=1e-5, what='rows with deg <= 64')
+    del A64, ex_out, abs_sum, ref_out
+
+    # input gradient: grad_x = A^T (go / deg)
+    tptr, tidx, _, _ = _csr_cpu(ei_c[0], ei_c[1], N)
+    gs = go / deg.to(torch.float32).view(-1, 1)
+    At64 = torch.sparse_csr_tensor(tptr, tidx, torch.ones(E, dtype=torch.float64), size=(N, N))
+    ex_grad = torch.sparse.mm(At64, gs.double())
+    abs_g = torch.sparse.mm(At64, gs.abs().double())
+    At32 = torch.sparse_csr_tensor(tptr, tidx, torch.ones(E), size=(N, N))
+    ref_grad = torch.sparse.mm(At32, gs)
+    assert_sum_close(grad, ref_grad, ex_grad, abs_sum=abs_g, what='input gradient at P')
+    small_t = (tptr[1:] - tptr[:-1]) <= 64
+    assert_close(grad[small_t], ref_grad[small_t], rtol=1e-5, atol=1e-5,
+                 what='grad rows with out-degree <= 64')
