@@ -238,6 +238,17 @@ def run_minibatch(args, rank, local_rank, world, dev):
                                       f'all-reduce/step)'}}), flush=True)
 
 
+def gemm_desc(tuned: bool) -> str:
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    if _fused_sage.GEMM_BACKEND == 'own':
+        return ('pytorch_geometric_amd/csrc/gemm.hip: hand-written fp32 MFMA '
+                '(v_mfma_f32_32x32x2_f32) forward (+bias+ReLU epilogue), dgrad (+1/deg row '
+                'scale epilogue) and split-reduction wgrad kernels')
+    return ('rocBLAS/hipBLASLt via torch.mm (PYGAMD_GEMM=lib), ' +
+            ('solution per shape from pytorch_geometric_amd/tuning (TunableOp, read-only)'
+             if tuned else 'default heuristics'))
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` with no rendezvous in the environment: start N ranks of this
     script under torch.distributed.run (one process per GPU) and pass everything through; rank 0
@@ -497,12 +508,11 @@ def main():
                 'parallelism': f'dp{world} (graph replicas, one flat-bucket all-reduce/step)',
                 'allreduce_ms_per_step': round(allreduce_ms, 4),
                 'graph_gen_s': round(t_gen, 1),
-                'gemm': ('rocBLAS/hipBLASLt via torch.mm, solution per shape from '
-                         'pytorch_geometric_amd/tuning (TunableOp, read-only)' if tuned else
-                         'rocBLAS/hipBLASLt via torch.mm, default heuristics'),
+                'gemm': gemm_desc(tuned),
                 'schedule': 'fused stack: [agg|x] single GEMM per layer; 256->47 layer '
                             'transforms first and aggregates at width 48; ReLU backward '
-                            'fused with the bias column sum',
+                            'fused with the bias column sum; the mean\'s 1/deg of the backward '
+                            'applied in the dgrad GEMM epilogue',
             },
             'roofline': roofline,
         }

@@ -282,3 +282,31 @@ class HeadDotFunction(Function):
             grad_a, grad_b if ctx.has_b else None, H, C, ctx.needs_input_grad[0])
         return (None if gx is None else gx.view(N, H, C), ga.view(att_a.shape),
                 None if gb is None else gb.view(att_b.shape))
+
+
+class LinearFunction(Function):
+    """``x @ weight.T + bias`` (nn/dense/linear.py:121-127 ``F.linear``) on the fp32-MFMA kernels
+    of csrc/gemm.hip: forward with the bias epilogue, input gradient with the same kernel on the
+    transposed weight, weight gradient as a deterministic split reduction, bias gradient as a
+    column sum."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor]):
+        x2 = x.reshape(-1, x.size(-1))
+        ctx.save_for_backward(x2, weight)
+        ctx.x_shape, ctx.has_bias = x.shape, bias is not None
+        out = _native.linear_forward(x2, weight, bias)
+        return _shaped(out, (*x.shape[:-1], weight.size(0)))
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        x2, weight = ctx.saved_tensors
+        g2 = grad_out.reshape(-1, grad_out.size(-1))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _native.linear_dgrad(g2, weight.t().contiguous()).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            gw = _native.linear_wgrad(g2, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _native.colsum(g2)
+        return gx, gw, gb

@@ -13,8 +13,10 @@ class Linear(torch.nn.Module):
     r"""``x @ W.T + b`` with the reference's initialisers
     (torch_geometric/nn/dense/linear.py:59-127: ``weight_initializer`` in ``glorot | uniform |
     kaiming_uniform | None``, ``bias_initializer`` in ``zeros | None``; ``None`` matches
-    :class:`torch.nn.Linear`).  The GEMM is a plain library call (rocBLAS / hipBLASLt through
-    ``F.linear``) — MFMA-bound, not part of the HBM-bound aggregation path."""
+    :class:`torch.nn.Linear`).  float32 HIP inputs run on this repo's fp32-MFMA GEMM
+    (csrc/gemm.hip through :class:`~pytorch_geometric_amd._functions.LinearFunction`: exact fp32,
+    an ``fmaf`` chain per output); anything else (other dtypes, CPU tensors during module
+    construction / ``state_dict`` round trips in the tests) is ``F.linear``."""
 
     def __init__(self, in_channels: int, out_channels: int, bias: bool = True,
                  weight_initializer: Optional[str] = None,
@@ -54,6 +56,10 @@ class Linear(torch.nn.Module):
                                    f"'{self.bias_initializer}' is not supported")
 
     def forward(self, x: Tensor) -> Tensor:
+        if (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32
+                and x.dim() >= 2 and not torch.jit.is_scripting()):
+            from ..._functions import LinearFunction
+            return LinearFunction.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
 
     def __repr__(self) -> str:

@@ -20,7 +20,11 @@ Two per-layer schedules, chosen by width (both compute ``lin_l(aggr_j x_j) + lin
 Numerics: identical operations up to fp32 summation order; tests/test_gpu_layers.py pins both
 schedules against the oracle and the layer-by-layer path at 1e-5.
 
-GEMMs are plain library calls (rocBLAS / hipBLASLt through ``torch.mm``) on strided views."""
+GEMMs run on this repo's fp32-MFMA kernels (csrc/gemm.hip: ``linear_forward`` with the bias + ReLU
+epilogue writing straight into the next ``[agg | x]`` buffer, ``linear_dgrad`` whose epilogue
+applies the mean's ``1/deg`` to the ``grad_agg`` half so that the transposed SpMM needs no
+per-edge scale gather, ``linear_wgrad`` as a deterministic split reduction).
+``PYGAMD_GEMM=lib`` switches back to rocBLAS / hipBLASLt through ``torch.mm`` for comparison."""
 import os
 from typing import List, Optional
 
@@ -36,6 +40,8 @@ from ...edge_index import EdgeIndex
 # available) instead of a separate in-place pass over the layer output: -1 ms per products step.
 # PYGAMD_RELU_EPILOGUE=0 restores the separate pass.
 RELU_EPILOGUE = os.environ.get('PYGAMD_RELU_EPILOGUE', '1') != '0'
+# 'own' = csrc/gemm.hip (default), 'lib' = torch.mm (rocBLAS / hipBLASLt)
+GEMM_BACKEND = os.environ.get('PYGAMD_GEMM', 'own')
 
 
 def _pad4(n: int) -> int:
@@ -92,7 +98,10 @@ class FusedSageStack(Function):
                                  out=buf[:, :Fi])
                 wmat = torch.cat([W_l, W_r], dim=1)  # [Fo, 2 Fi]
                 relu_done = False
-                if b is not None and not last and RELU_EPILOGUE:
+                if GEMM_BACKEND == 'own':
+                    _native.linear_forward(buf, wmat, b, relu=not last, out=dst)
+                    relu_done = True
+                elif b is not None and not last and RELU_EPILOGUE:
                     torch._addmm_activation(b, buf, wmat.t(), use_gelu=False, out=dst)
                     relu_done = True
                 elif b is not None:
@@ -105,9 +114,13 @@ class FusedSageStack(Function):
                 wmat = torch.zeros(2 * Fp, Fi, dtype=torch.float32, device=dev)  # [W_l ; W_r]
                 wmat[:Fo] = W_l
                 wmat[Fp:Fp + Fo] = W_r
+                bias = None
                 if b is not None:
                     bias = torch.zeros(2 * Fp, dtype=torch.float32, device=dev)
                     bias[Fp:Fp + Fo] = b
+                if GEMM_BACKEND == 'own':
+                    y = _native.linear_forward(inp, wmat, bias)
+                elif bias is not None:
                     y = torch.addmm(bias, inp, wmat.t())
                 else:
                     y = torch.mm(inp, wmat.t())
@@ -151,15 +164,24 @@ class FusedSageStack(Function):
             elif ctx.has_bias[layer]:
                 grads[3 * layer + 1] = _native.colsum(g)
             need_input_grad = layer > 0 or ctx.needs_input_grad[0]
+            own = GEMM_BACKEND == 'own'
             if ctx.modes[layer] == 'post':
-                gw = torch.mm(g.t(), buf)  # [Fo, 2 Fi] = [grad W_l | grad W_r]
+                # [Fo, 2 Fi] = [grad W_l | grad W_r]
+                gw = _native.linear_wgrad(g, buf) if own else torch.mm(g.t(), buf)
                 grads[3 * layer] = gw[:, :Fi]
                 grads[3 * layer + 2] = gw[:, Fi:]
                 if need_input_grad:
-                    gcat = torch.mm(g, wmat)  # [N, 2 Fi] = [grad_agg | grad_root]
+                    # [N, 2 Fi] = [grad_agg | grad_root]
+                    if own:  # grad_agg rows leave the GEMM already divided by their degree
+                        gcat = _native.linear_dgrad(g, wmat.t().contiguous(), scale,
+                                                    Fi if scale is not None else 0)
+                        pre_scaled = True
+                    else:
+                        gcat = torch.mm(g, wmat)
+                        pre_scaled = False
                     _native.spmm_csr(bwd.ptr, bwd.idx, gcat[:, :Fi], 'sum', n_rows=N,
-                                     src_scale=scale, hub=bwd.hub, out=gcat[:, Fi:],
-                                     accumulate=True)
+                                     src_scale=None if pre_scaled else scale, hub=bwd.hub,
+                                     out=gcat[:, Fi:], accumulate=True)
                     g = gcat[:, Fi:]
             else:
                 Fp = _pad4(Fo)
@@ -181,11 +203,13 @@ class FusedSageStack(Function):
                 _native.spmm_csr(bwd.ptr, bwd.idx, gsrc, 'sum', n_rows=N, hub=bwd.hub,
                                  out=gy[:, :Fp])
                 x_in = buf
-                gw = torch.mm(gy.t(), x_in)  # [2 Fp, Fi]
+                # [2 Fp, Fi]
+                gw = _native.linear_wgrad(gy, x_in) if own else torch.mm(gy.t(), x_in)
                 grads[3 * layer] = gw[:Fo]
                 grads[3 * layer + 2] = gw[Fp:Fp + Fo]
-                if need_input_grad:
-                    g = torch.mm(gy, wmat)  # [N, Fi]
+                if need_input_grad:  # [N, Fi]
+                    g = (_native.linear_dgrad(gy, wmat.t().contiguous()) if own
+                         else torch.mm(gy, wmat))
             if layer == 0 and need_input_grad:
                 grad_x = g.contiguous()
         return (grad_x, None, None, None, *grads)

@@ -57,7 +57,9 @@ class FusedSageHopStack(Function):
             else:
                 nxt = torch.empty(m, 2 * Fo, dtype=torch.float32, device=dev)
                 dst = nxt[:, Fo:]
-            if b is not None and not last and _fused_sage.RELU_EPILOGUE:
+            if _fused_sage.GEMM_BACKEND == 'own':
+                _native.linear_forward(cat[:m], wmat, b, relu=not last, out=dst)
+            elif b is not None and not last and _fused_sage.RELU_EPILOGUE:
                 torch._addmm_activation(b, cat[:m], wmat.t(), use_gelu=False, out=dst)
             else:
                 if b is not None:
@@ -94,10 +96,13 @@ class FusedSageHopStack(Function):
                 g, grads[3 * l + 1] = _native.relu_backward_colsum(g, h_next, ctx.has_bias[l])
             elif ctx.has_bias[l]:
                 grads[3 * l + 1] = _native.colsum(g)
-            gw = torch.mm(g.t(), cat[:m])
+            own = _fused_sage.GEMM_BACKEND == 'own'
+            gw = _native.linear_wgrad(g, cat[:m]) if own else torch.mm(g.t(), cat[:m])
             grads[3 * l], grads[3 * l + 2] = gw[:, :Fi], gw[:, Fi:]
             if l > 0 or ctx.needs_input_grad[0]:
-                gcat = torch.mm(g, wmat)  # [m, 2 Fi] = [grad_agg | grad_root]
+                # [m, 2 Fi] = [grad_agg | grad_root]
+                gcat = (_native.linear_dgrad(g, wmat.t().contiguous()) if own
+                        else torch.mm(g, wmat))
                 g_in = torch.zeros(ctx.in_rows[l], Fi, dtype=torch.float32, device=g.device)
                 g_in[:m].copy_(gcat[:, Fi:])
                 scale = None

@@ -73,6 +73,12 @@ def test_reference_convs_take_the_hip_path_and_match_their_cpu_results(pyg, inst
     n, e = 300, 4000
     x = torch.randn(n, 16, generator=g)
     ei = torch.randint(0, n, (2, e), generator=g)
+    # at most ONE self-loop per node: with duplicates the reference's add_remaining_self_loops
+    # (`loop_attr[index] = edge_attr[...]`, utils/loop.py:640-644) keeps an unspecified one — its
+    # own CPU and GPU results then differ (checked: 16 of 300 rows by up to 9e-2 on this graph)
+    loops = (ei[0] == ei[1]).nonzero().view(-1)
+    ei[1, loops] = (ei[1, loops] + 1) % n
+    ei[:, :20] = torch.arange(20).repeat(2, 1) * 7
     w = torch.rand(e, generator=g)
     torch.manual_seed(0)
     cases = [
