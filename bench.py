@@ -159,10 +159,14 @@ def run_minibatch(args, rank, local_rank, world, dev):
     from pytorch_geometric_amd.datasets import powerlaw_undirected
     from pytorch_geometric_amd.loader import NeighborLoader
     from pytorch_geometric_amd.nn import GraphSAGE
-    scale = args.scale if args.scale != 1.0 else 1 / 16
+    # the FULL ogbn-papers100M shape by default: x (56.9 GB) + edge_index (25.9 GB) + the CSC form
+    # (26.7 GB) are resident in the 288 GB of one MI355X, replicated per rank;
+    # the graph is generated ON the device (1.6 G edges are too many to draw on the host)
+    scale = args.scale
     N = int(111_059_956 * scale)
     E = int(1_615_685_872 * scale) // 2 * 2
-    ei = powerlaw_undirected(N, E, seed=3).to(dev)  # same graph on every rank (replicated)
+    t_gen = time.perf_counter()
+    ei = powerlaw_undirected(N, E, seed=3, device=dev)  # same graph on every rank (replicated)
     g = torch.Generator(device=dev).manual_seed(5)
     x = torch.randn(N, 128, device=dev, generator=g)
     y = torch.randint(0, 172, (N, ), device=dev, generator=g)
@@ -171,6 +175,9 @@ def run_minibatch(args, rank, local_rank, world, dev):
     fan = [15, 10, 5]
     loader = NeighborLoader(x, ei, fan, batch_size=1024, y=y, input_nodes=seeds, shuffle=True,
                             drop_last=True, seed=17 + rank, prefetch=args.prefetch)
+    torch.cuda.synchronize(dev)
+    t_gen = time.perf_counter() - t_gen
+    torch.cuda.empty_cache()  # the radix sort's scratch
     torch.manual_seed(0)
     model = GraphSAGE(128, 256, num_layers=3, out_channels=172).to(dev)
     broadcast_parameters(model)
@@ -184,6 +191,7 @@ def run_minibatch(args, rank, local_rank, world, dev):
 
     it = batches()
     edges = 0
+    ar_events = []
 
     def step():
         nonlocal edges
@@ -193,7 +201,12 @@ def run_minibatch(args, rank, local_rank, world, dev):
                     num_sampled_edges_per_hop=b.num_sampled_edges)[:b.batch_size]
         loss = F.cross_entropy(out, b.y[:b.batch_size])
         loss.backward()
-        bucket.all_reduce_mean()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.all_reduce_mean()
+            e1.record()
+            ar_events.append((e0, e1))
         opt.step()
         ne = b.num_sampled_edges  # layer l aggregates the edges of hops 0 .. L-1-l
         edges += sum(sum(ne[:len(ne) - l]) for l in range(len(ne)))
@@ -208,6 +221,7 @@ def run_minibatch(args, rank, local_rank, world, dev):
         step()
     fence()
     edges = 0
+    del ar_events[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -226,7 +240,8 @@ def run_minibatch(args, rank, local_rank, world, dev):
         print(json.dumps({
             'metric': 'edges/sec (fwd+bwd) 3-layer SAGE + NeighborLoader [15,10,5], '
                       'papers100M shape (BASELINE config 4, informational)',
-            'value': total_edges / elapsed, 'unit': 'edges/s', 'n_gpus': world,
+            'value': total_edges / elapsed, 'unit': 'edges/s',
+            'n_gpus': dist.get_world_size() if dist.is_initialized() else 1,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -235,7 +250,13 @@ def run_minibatch(args, rank, local_rank, world, dev):
                                    f'papers100M shape x {scale:g} (N={N}, E={E}) replicated per '
                                    f'GPU, GPU sampler + gather, {args.prefetch} batch(es) prefetched on a side stream',
                        'parallelism': f'dp{world} (seed sharding, one flat-bucket '
-                                      f'all-reduce/step)'}}), flush=True)
+                                      f'all-reduce/step)',
+                       'allreduce_ms_per_step': round(
+                           sum(a.elapsed_time(b) for a, b in ar_events)
+                           / max(len(ar_events), 1), 4) if world > 1 else 0.0,
+                       'graph_build_s': round(t_gen, 1),
+                       'hbm_gb_allocated': round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                       'gemm': gemm_desc(False)}}), flush=True)
 
 
 def gemm_desc(tuned: bool) -> str:

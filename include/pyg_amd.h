@@ -327,6 +327,17 @@ PYGAMD_API int pygamd_segment_softmax_backward(const float* out, const float* gr
                                                const void* ptr, int idx_dtype, int64_t n_seg,
                                                int64_t H, float* grad_src, void* stream);
 
+/* segment_logsumexp (utils/_segment.py:53-80): out[s,h] = log(sum_{k in s} exp(src[k,h])),
+ * evaluated with the segment maximum subtracted; an empty segment gives 0.  src is [n, H]
+ * contiguous, out [n_seg, H].  Backward: grad_src[k,h] = exp(src[k,h] - out[s,h]) * grad_out[s,h]. */
+PYGAMD_API int pygamd_segment_logsumexp_forward(const float* src, const void* ptr, int idx_dtype,
+                                                int64_t n_seg, int64_t H, float* out,
+                                                void* stream);
+PYGAMD_API int pygamd_segment_logsumexp_backward(const float* src, const float* out,
+                                                 const float* grad_out, const void* ptr,
+                                                 int idx_dtype, int64_t n_seg, int64_t H,
+                                                 float* grad_src, void* stream);
+
 /* ---- a15: GAT node terms ----------------------------------------------------------------------
  * out_a[n,h] = sum_c x[n, h*C + c] * att_a[h*C + c]  (and out_b with att_b when given) — the
  * `(x * att).sum(-1)` pair of nn/conv/gat_conv.py:330-332 in one pass over x.  Backward:
@@ -374,19 +385,38 @@ PYGAMD_API int pygamd_sample_neighbors(const void* colptr, const void* row, int 
                                        void* src_out, void* dstpos_out, void* slot_out,
                                        void* stream);
 
-/* cnt[f] = min(deg(frontier[f]), k) (k < 0: deg) — the per-node sample counts of one hop.        */
+/* cnt[f] = min(deg(frontier[f]), k) (k < 0: deg) — the per-node sample counts of one hop.
+ * `n_valid` (device int64, may be NULL): only the first *n_valid entries of the fixed-capacity
+ * `frontier` are real; the rest (which must hold valid node ids, e.g. 0) get count 0.  With it a
+ * hop can be sized by the static bound frontier x fan-out and run WITHOUT a host sync.           */
 PYGAMD_API int pygamd_sample_counts(const void* colptr, int idx_dtype, const void* frontier,
-                                    int64_t n, int64_t k, void* cnt_out, void* stream);
+                                    int64_t n, int64_t k, const int64_t* n_valid, void* cnt_out,
+                                    void* stream);
 /* Relabelling of the sampled sources (global -> local ids, new nodes in order of first
  * appearance, deterministic).  `local_map` has one entry per graph node; entries
  * not in the batch hold a value below -(m+1) (the host side uses the type's minimum).
  * phase 0 "claim":  local[src[e]] = max(local[src[e]], -(e+2));
  * phase 1 "flag":   flag_or_scan[e] = (local[src[e]] == -(e+2));        (caller scans inclusively)
  * phase 2 "assign": claimants write local[s] = base + rank and out[rank] = s (out = new nodes);
- * phase 3 "lookup": out[e] = local[src[e]].                                                      */
+ * phase 3 "lookup": out[e] = local[src[e]].
+ * `m_dev` / `base_dev` (device int64, may be NULL) override min(m, *m_dev) / *base_dev: the
+ * number of sampled edges and of batch nodes so far stay on the device, `m` is then the static
+ * capacity of the hop (entries past *m_dev flag 0 / look up 0).                                  */
 PYGAMD_API int pygamd_relabel(int phase, const void* src, int idx_dtype, int64_t m,
-                              void* local_map, int64_t* flag_or_scan, int64_t base, void* out,
-                              void* stream);
+                              const int64_t* m_dev, void* local_map, int64_t* flag_or_scan,
+                              int64_t base, const int64_t* base_dev, void* out, void* stream);
+
+/* ---- a18: one-pass multi-reduce (FusedAggregation) ---------------------------------------------
+ * nn/aggr/fused.py:191-336 shares the group count, the sum and the sum of squares between
+ * sum / mean / var / std / min / max.  Here ONE read of the rows produces all requested statistics
+ * of every group: rows of group g are x[perm[k]] for k in [rowptr[g], rowptr[g+1]) (`perm` =
+ * the stable sort permutation of the aggregation index, or NULL when the rows are already
+ * grouped, i.e. the `ptr` form).  Null outputs are skipped; empty groups give 0.  Outputs are
+ * [n_rows, F] with leading dimension ldo.                                                      */
+PYGAMD_API int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int idx_dtype,
+                                       const float* x, int64_t ldx, int64_t n_rows, int64_t F,
+                                       float* out_sum, float* out_sq, float* out_min,
+                                       float* out_max, int64_t ldo, void* stream);
 
 /* ---- a17 / f3: the dense feature transform on the fp32 matrix cores ---------------------------
  * `F.linear(x, weight, bias)` of nn/dense/linear.py:121-127 — what SAGEConv's `lin_l(agg) +

@@ -119,6 +119,17 @@ def segment(src: Tensor, ptr: Tensor, reduce: str = 'sum') -> Tensor:
 
 
 # ---- utils/_softmax.py ---------------------------------------------------------------------------
+def segment_logsumexp(src: Tensor, ptr: Tensor, dim: int) -> Tensor:
+    """utils/_segment.py:53-80: scatter-max over ptr2index, exp of the shifted values, segment sum,
+    log with -inf mapped to 0, plus the maximum."""
+    src = src.transpose(0, dim)
+    index = ptr2index(ptr, src.size(0))
+    max_src = scatter(src, index, 0, ptr.numel() - 1, 'max')
+    out = segment((src - max_src[index]).exp(), ptr, 'sum')
+    out = out.log().nan_to_num(neginf=0.0) + max_src
+    return out.transpose(0, dim)
+
+
 def softmax(src: Tensor, index: Optional[Tensor] = None, ptr: Optional[Tensor] = None,
             num_nodes: Optional[int] = None, dim: int = 0) -> Tensor:
     """utils/_softmax.py:60-92 (ptr branch for 1-D ptr, else index branch)."""

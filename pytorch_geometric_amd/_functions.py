@@ -175,6 +175,44 @@ class ScatterFunction(Function):
         return grad.view(ctx.src_shape), None, None, None
 
 
+class MultiReduceFunction(Function):
+    """Several reductions of the same grouped rows in ONE read (``pygamd_multi_reduce_csr``; the
+    shared work of nn/aggr/fused.py:191-336): returns one ``[dim_size, F]`` tensor per name in
+    ``want`` (names from ``sum | pow_sum | min | max``).  ``perm`` is the stable sort permutation
+    of ``index`` (``None`` when the rows are already grouped).  Backward composes the existing
+    kernels: a gather for ``sum``, ``2 x`` times a gather for ``pow_sum`` (skipped with
+    ``semi_grad``), the tie-splitting min / max gradient of the reference."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, index: Tensor, ptr: Tensor, perm: Optional[Tensor], want: tuple,
+                semi_grad: bool):
+        outs = _native.multi_reduce_csr(ptr, perm, x, want)
+        ctx.want, ctx.semi_grad = want, semi_grad
+        ctx.save_for_backward(x, index, *[outs[k] for k in want if k in ('min', 'max')])
+        return tuple(outs[k] for k in want)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, index, *extrema = ctx.saved_tensors
+        extrema = iter(extrema)
+        total = None
+        for name, g in zip(ctx.want, grads):
+            out = next(extrema) if name in ('min', 'max') else None
+            if g is None:
+                continue
+            g = g.contiguous()
+            if name == 'sum':
+                term = _native.gather_rows(g, index)
+            elif name == 'pow_sum':
+                if ctx.semi_grad:
+                    continue
+                term = _native.gather_rows(g, index).mul_(x).mul_(2.0)
+            else:
+                term = _native.scatter_minmax_backward(x, index, out, g)
+            total = term if total is None else total.add_(term)
+        return total, None, None, None, None, None
+
+
 class SegmentFunction(Function):
     """``segment(src, ptr, reduce)`` over contiguous row ranges (utils/_segment.py:11-50)."""
 
@@ -229,6 +267,25 @@ class SegmentSoftmaxFunction(Function):
     def backward(ctx, grad_out: Tensor):
         out, ptr = ctx.saved_tensors
         g = _native.segment_softmax_backward(out, grad_out.reshape(out.shape), ptr)
+        return g.view(ctx.src_shape), None
+
+
+class SegmentLogSumExpFunction(Function):
+    """``segment_logsumexp(src, ptr, dim=0)`` (utils/_segment.py:53-80) for 2-D ``src``; the total
+    derivative through the subtracted maximum is the in-segment softmax."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, ptr: Tensor):
+        s2 = _rows(src)
+        out = _native.segment_logsumexp_forward(s2, ptr)
+        ctx.save_for_backward(s2, out, ptr)
+        ctx.src_shape = src.shape
+        return _shaped(out, (ptr.numel() - 1, *src.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        s2, out, ptr = ctx.saved_tensors
+        g = _native.segment_logsumexp_backward(s2, out, _rows(grad_out), ptr)
         return g.view(ctx.src_shape), None
 
 

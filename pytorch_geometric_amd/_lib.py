@@ -60,6 +60,8 @@ SIGNATURES = {
     'pygamd_spmm_csr_minmax_backward_dst': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, _P,
                                                     c_int64, c_int64, c_int64, c_int64, c_int, _P,
                                                     c_int64, _P]),
+    'pygamd_multi_reduce_csr': (c_int, [_P, _P, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P,
+                                        _P, c_int64, _P]),
     'pygamd_sddmm_csr': (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                  c_int32, c_int32, _P, _P]),
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
@@ -84,8 +86,8 @@ SIGNATURES = {
     'pygamd_edge_key': (c_int, [_P, _P, c_int, c_int64, c_int64, c_int, _P, _P]),
     'pygamd_run_flags': (c_int, [_P, c_int64, _P, _P]),
     'pygamd_edge_unkey': (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P]),
-    'pygamd_sample_counts': (c_int, [_P, c_int, _P, c_int64, c_int64, _P, _P]),
-    'pygamd_relabel': (c_int, [c_int, _P, c_int, c_int64, _P, _P, c_int64, _P, _P]),
+    'pygamd_sample_counts': (c_int, [_P, c_int, _P, c_int64, c_int64, _P, _P, _P]),
+    'pygamd_relabel': (c_int, [c_int, _P, c_int, c_int64, _P, _P, _P, c_int64, _P, _P, _P]),
     'pygamd_gather_rows': (c_int, [_P, c_int64, c_int64, _P, c_int, c_int64, c_int64, _P,
                                    c_int64, _P, _P]),
     'pygamd_gather_scatter_add': (c_int, [_P, c_int64, _P, _P, c_int, _P, _P, c_int64, c_int64,
@@ -104,6 +106,9 @@ SIGNATURES = {
     'pygamd_scatter_argmax': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     'pygamd_segment_softmax_forward': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P]),
     'pygamd_segment_softmax_backward': (c_int, [_P, _P, _P, c_int, c_int64, c_int64, _P, _P]),
+    'pygamd_segment_logsumexp_forward': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P]),
+    'pygamd_segment_logsumexp_backward': (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, _P,
+                                                  _P]),
     'pygamd_head_dot_forward': (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int64, _P, _P,
                                         _P]),
     'pygamd_head_dot_backward': (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int64,

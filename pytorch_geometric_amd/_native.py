@@ -231,6 +231,27 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     return (out, arg) if return_arg else out
 
 
+def multi_reduce_csr(rowptr: Tensor, perm: Optional[Tensor], x: Tensor, want):
+    """{'sum' | 'pow_sum' | 'min' | 'max': [n_groups, F]} for the requested names in ONE read of the
+    rows (group g = rows x[perm[k]], k in [rowptr[g], rowptr[g+1]); ``perm=None``: rows are already
+    grouped)."""
+    _require_device(rowptr, perm, x)
+    lib = _lib.load()
+    x2 = _f32_rows(x, 'x')
+    n_rows, F = rowptr.numel() - 1, x2.size(1)
+    names = ('sum', 'pow_sum', 'min', 'max')
+    outs = {k: torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
+            for k in names if k in want}
+    if perm is not None:
+        perm = perm.contiguous()
+        if perm.dtype != rowptr.dtype:
+            perm = perm.to(rowptr.dtype)
+    check(lib.pygamd_multi_reduce_csr(_p(rowptr), _p(perm), _idx_dtype(rowptr), _p(x2), _ld(x2),
+                                      n_rows, F, *[_p(outs.get(k)) for k in names], max(F, 1),
+                                      _stream(x)), 'multi_reduce_csr')
+    return outs
+
+
 def colsum(x: Tensor) -> Tensor:
     """x.sum(0) for a 2-D fp32 tensor (bias gradient)."""
     _require_device(x)
@@ -447,6 +468,28 @@ def segment_softmax_backward(out: Tensor, grad_out: Tensor, ptr: Tensor) -> Tens
     return grad_src
 
 
+def segment_logsumexp_forward(src: Tensor, ptr: Tensor) -> Tensor:
+    _require_device(src, ptr)
+    lib = _lib.load()
+    s2 = src.contiguous()
+    out = torch.empty(ptr.numel() - 1, s2.size(1), dtype=torch.float32, device=src.device)
+    check(lib.pygamd_segment_logsumexp_forward(_p(s2), _p(ptr), _idx_dtype(ptr), ptr.numel() - 1,
+                                               s2.size(1), _p(out), _stream(src)),
+          'segment_logsumexp_forward')
+    return out
+
+
+def segment_logsumexp_backward(src: Tensor, out: Tensor, grad_out: Tensor, ptr: Tensor) -> Tensor:
+    _require_device(src, out, grad_out, ptr)
+    lib = _lib.load()
+    s2, o2, g2 = src.contiguous(), out.contiguous(), grad_out.contiguous()
+    grad_src = torch.empty_like(s2)
+    check(lib.pygamd_segment_logsumexp_backward(_p(s2), _p(o2), _p(g2), _p(ptr), _idx_dtype(ptr),
+                                                ptr.numel() - 1, s2.size(1), _p(grad_src),
+                                                _stream(src)), 'segment_logsumexp_backward')
+    return grad_src
+
+
 def gat_edge_softmax_forward(rowptr, col, alpha_src, alpha_dst, slope: float) -> Tensor:
     _require_device(rowptr, col, alpha_src, alpha_dst)
     lib = _lib.load()
@@ -616,13 +659,16 @@ def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int, blocks: int = 1
 
 # ---- neighbour sampling (one hop) ---------------------------------------------------------------
 def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Tensor, total: int,
-                     max_per_node: int, seed: int):
-    """(src_global, dst_pos_in_frontier, csc_slot) for the sampled in-edges of `frontier`."""
+                     max_per_node: int, seed: int, zero_fill: bool = False):
+    """(src_global, dst_pos_in_frontier, csc_slot) for the sampled in-edges of `frontier`.
+    ``total`` sizes the outputs; ``zero_fill`` for a static capacity larger than what the hop
+    really samples (the tail then holds 0 = a valid node / slot id)."""
     _require_device(colptr, row, frontier, offsets)
     lib = _lib.load()
-    src = torch.empty(total, dtype=colptr.dtype, device=colptr.device)
-    dstpos = torch.empty_like(src)
-    slot = torch.empty_like(src)
+    alloc = torch.zeros if zero_fill else torch.empty
+    src = alloc(total, dtype=colptr.dtype, device=colptr.device)
+    dstpos = alloc(total, dtype=colptr.dtype, device=colptr.device)
+    slot = alloc(total, dtype=colptr.dtype, device=colptr.device)
     if total > 0:
         check(lib.pygamd_sample_neighbors(_p(colptr), _p(row), _idx_dtype(colptr), _p(frontier),
                                           frontier.numel(), _p(offsets), max_per_node,
@@ -691,12 +737,15 @@ def head_dot_backward(x: Tensor, att_a: Tensor, att_b: Optional[Tensor], grad_a:
     return grad_x, g_att_a, g_att_b
 
 
-def sample_counts(colptr: Tensor, frontier: Tensor, k: int) -> Tensor:
-    _require_device(colptr, frontier)
+def sample_counts(colptr: Tensor, frontier: Tensor, k: int,
+                  n_valid: Optional[Tensor] = None) -> Tensor:
+    """min(deg, k) per frontier entry; entries past the device-side count ``n_valid`` (int64
+    [1]) of a fixed-capacity frontier get 0."""
+    _require_device(colptr, frontier, n_valid)
     lib = _lib.load()
     cnt = torch.empty_like(frontier)
     check(lib.pygamd_sample_counts(_p(colptr), _idx_dtype(colptr), _p(frontier),
-                                   frontier.numel(), k, _p(cnt), _stream(colptr)),
+                                   frontier.numel(), k, _p(n_valid), _p(cnt), _stream(colptr)),
           'sample_counts')
     return cnt
 
@@ -711,17 +760,48 @@ def relabel_new_nodes(src_global: Tensor, local_map: Tensor, base: int):
     st = _stream(src_global)
     if m == 0:
         return src_global.new_empty(0), src_global.new_empty(0)
-    check(lib.pygamd_relabel(0, _p(src_global), dt, m, _p(local_map), None, 0, None, st))
+    check(lib.pygamd_relabel(0, _p(src_global), dt, m, None, _p(local_map), None, 0, None, None,
+                             st))
     flag = torch.empty(m, dtype=torch.int64, device=src_global.device)
-    check(lib.pygamd_relabel(1, _p(src_global), dt, m, _p(local_map), _p(flag), 0, None, st))
+    check(lib.pygamd_relabel(1, _p(src_global), dt, m, None, _p(local_map), _p(flag), 0, None,
+                             None, st))
     scan = torch.cumsum(flag, 0)
     n_new = int(scan[-1])  # host sync: sizes the next hop (the frontier)
     new_nodes = torch.empty(n_new, dtype=src_global.dtype, device=src_global.device)
-    check(lib.pygamd_relabel(2, _p(src_global), dt, m, _p(local_map), _p(scan), base,
+    check(lib.pygamd_relabel(2, _p(src_global), dt, m, None, _p(local_map), _p(scan), base, None,
                              _p(new_nodes) if n_new > 0 else _p(flag), st))
     rows = torch.empty_like(src_global)
-    check(lib.pygamd_relabel(3, _p(src_global), dt, m, _p(local_map), None, 0, _p(rows), st))
+    check(lib.pygamd_relabel(3, _p(src_global), dt, m, None, _p(local_map), None, 0, None,
+                             _p(rows), st))
     return new_nodes, rows
+
+
+def relabel_new_nodes_padded(src_global: Tensor, total: Tensor, local_map: Tensor, base: Tensor):
+    """The same WITHOUT a host sync: ``src_global`` has the hop's static capacity, ``total`` (int64
+    [1], device) of its entries are real, ``base`` (int64 [1], device) nodes are in the batch so
+    far.  Returns (new_nodes [capacity] zero-padded, row_local [capacity] zero-padded, n_new int64
+    [1] on the device)."""
+    _require_device(src_global, total, local_map, base)
+    lib = _lib.load()
+    m = src_global.numel()
+    dt = _idx_dtype(src_global)
+    st = _stream(src_global)
+    dev = src_global.device
+    new_nodes = torch.zeros(m, dtype=src_global.dtype, device=dev)
+    rows = torch.empty_like(src_global)
+    if m == 0:
+        return new_nodes, rows, torch.zeros(1, dtype=torch.int64, device=dev)
+    check(lib.pygamd_relabel(0, _p(src_global), dt, m, _p(total), _p(local_map), None, 0, None,
+                             None, st))
+    flag = torch.empty(m, dtype=torch.int64, device=dev)
+    check(lib.pygamd_relabel(1, _p(src_global), dt, m, _p(total), _p(local_map), _p(flag), 0,
+                             None, None, st))
+    scan = torch.cumsum(flag, 0)
+    check(lib.pygamd_relabel(2, _p(src_global), dt, m, _p(total), _p(local_map), _p(scan), 0,
+                             _p(base), _p(new_nodes), st))
+    check(lib.pygamd_relabel(3, _p(src_global), dt, m, _p(total), _p(local_map), None, 0, None,
+                             _p(rows), st))
+    return new_nodes, rows, scan[-1:]
 
 
 def edge_key(row: Tensor, col: Tensor, num_nodes: int, by_row: bool) -> Tensor:

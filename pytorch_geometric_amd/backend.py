@@ -7,7 +7,7 @@ modules.  ``install()`` therefore
 
 1. publishes itself on ``torch_geometric.backend`` (``backend.mi355x`` = this module,
    ``backend.use_mi355x`` flag, ``None`` = auto like ``use_segment_matmul``) — seam S5;
-2. rebinds the dispatcher functions ``scatter``, ``segment``, ``softmax``, ``spmm``,
+2. rebinds the dispatcher functions ``scatter``, ``segment``, ``segment_logsumexp``, ``softmax``, ``spmm``,
    ``index_sort``, ``scatter_argmax``, ``sort_edge_index``, ``coalesce`` in EVERY loaded ``torch_geometric*`` module whose attribute ``is`` the
    original function — seam S3 (utils/__init__.py:5-10,36);
 3. replaces ``torch_geometric.edge_index._spmm`` (what ``EdgeIndex.matmul`` and therefore the
@@ -78,6 +78,11 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
             return U.segment(src, ptr, reduce)
         return orig['segment'](src, ptr, reduce)
 
+    def segment_logsumexp(src, ptr, dim):
+        if _ours(src) and ptr.dim() == 1 and _enabled():
+            return U.segment_logsumexp(src, ptr, dim)
+        return orig['segment_logsumexp'](src, ptr, dim)
+
     def softmax(src, index=None, ptr=None, num_nodes=None, dim=0):
         if _ours(src) and _enabled():
             return U.softmax(src, index, ptr, num_nodes, dim)
@@ -121,7 +126,8 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
             return U.coalesce(edge_index, edge_attr, num_nodes, reduce, is_sorted, sort_by_row)
         return orig['coalesce'](edge_index, edge_attr, num_nodes, reduce, is_sorted, sort_by_row)
 
-    new = dict(scatter=scatter, segment=segment, softmax=softmax, index_sort=index_sort,
+    new = dict(scatter=scatter, segment=segment, segment_logsumexp=segment_logsumexp,
+               softmax=softmax, index_sort=index_sort,
                scatter_argmax=scatter_argmax, spmm=spmm, sort_edge_index=sort_edge_index,
                coalesce=coalesce)
     for name, fn in new.items():
@@ -343,6 +349,48 @@ def _wrap_propagate(cls) -> Callable:
     return propagate
 
 
+_sampler_cls = None
+
+
+def neighbor_sampler(data, num_neighbors: List[int], seed: int = 0):
+    """A ``torch_geometric.sampler.BaseSampler`` (sampler/base.py:932-998) whose
+    ``sample_from_nodes(NodeSamplerInput) -> SamplerOutput`` runs on the GPU
+    (:class:`pytorch_geometric_amd.sampler.NeighborSampler`), so that the reference's
+    ``NodeLoader(data, node_sampler=...)`` (loader/node_loader.py:90-152) drives it unchanged and
+    joins the features with its own ``filter_data``.  ``data``: a ``torch_geometric.data.Data`` on
+    the device (``edge_index``, ``num_nodes``) or a ``(edge_index, num_nodes)`` pair."""
+    global _sampler_cls
+    import torch_geometric.sampler as pyg_sampler
+    from .sampler import NeighborSampler
+    if _sampler_cls is None:
+
+        class MI355XNeighborSampler(pyg_sampler.BaseSampler):
+            def __init__(self, edge_index, num_nodes, num_neighbors, seed=0):
+                self.impl = NeighborSampler(edge_index, num_nodes, num_neighbors, seed=seed,
+                                            output_cls=pyg_sampler.SamplerOutput)
+                self.num_neighbors = list(num_neighbors)
+
+            def sample_from_nodes(self, index, **kwargs):
+                return self.impl.sample_from_nodes(index, **kwargs)
+
+            def sample_from_edges(self, index, neg_sampling=None):
+                raise NotImplementedError('link-level sampling is out of scope (SURVEY.md §8)')
+
+            @property
+            def edge_permutation(self):
+                return None  # `edge` already indexes the caller's edge_index
+
+        _sampler_cls = MI355XNeighborSampler
+    if isinstance(data, (tuple, list)):
+        edge_index, num_nodes = data
+    else:
+        edge_index, num_nodes = data.edge_index, data.num_nodes
+    if not (isinstance(edge_index, Tensor) and edge_index.is_cuda):
+        raise ValueError("the sampler needs 'edge_index' on the HIP device (there is no CPU "
+                         "fallback): move the data with `.to('cuda')` first")
+    return _sampler_cls(edge_index, int(num_nodes), num_neighbors, seed)
+
+
 def install() -> None:
     """Idempotent.  Needs ``torch_geometric`` importable; raises ImportError otherwise."""
     if _state['installed']:
@@ -355,6 +403,7 @@ def install() -> None:
 
     orig = {
         'scatter': pyg_utils.scatter, 'segment': pyg_utils.segment,
+        'segment_logsumexp': pyg_utils.segment_logsumexp,
         'softmax': pyg_utils.softmax, 'index_sort': pyg_utils.index_sort,
         'scatter_argmax': pyg_scatter.scatter_argmax, 'spmm': pyg_utils.spmm,
         'sort_edge_index': pyg_utils.sort_edge_index, 'coalesce': pyg_utils.coalesce,

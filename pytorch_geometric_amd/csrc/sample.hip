@@ -3,10 +3,10 @@
 // (torch_geometric/sampler/neighbor_sampler.py:550-577: colptr, row, seed nodes, fan-out k).
 //
 // One wavefront per frontier node v.  If deg(v) <= k every in-neighbour is taken (lanes copy the
-// slot range, coalesced).  Otherwise lane 0 draws a uniform k-subset of the deg(v) slots with
-// Floyd's algorithm (k <= 64 draws, O(k^2) membership checks in LDS) from a counter-based hash
-// of (seed, v, draw), so a batch is reproducible from its seed regardless of scheduling; lanes
-// 0..k-1 then emit one edge each.  HBM-bound integer work: 3 index reads + 3 index writes per
+// slot range, coalesced).  Otherwise the wave draws a uniform k-subset of the deg(v) slots with
+// Floyd's algorithm (k <= 64: lane c makes draw c from a counter-based hash of (seed, v, c), the
+// k insertions are k wave-wide membership tests), so a batch is reproducible from its seed
+// regardless of scheduling; lanes 0..k-1 then emit one edge each.  HBM-bound integer work: 3 index reads + 3 index writes per
 // sampled edge.
 #include "common.h"
 
@@ -28,10 +28,8 @@ __global__ void __launch_bounds__(kBlock)
                             const IdxT* __restrict__ offsets, uint64_t seed,
                             IdxT* __restrict__ src_out, IdxT* __restrict__ dstpos_out,
                             IdxT* __restrict__ slot_out) {
-  __shared__ int chosen[kWavesPerBlock][kMaxFanout];
   const int lane = lane_id();
-  const int w = wave_in_block();
-  const int64_t f = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + w;
+  const int64_t f = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   if (f >= n_frontier) return;
   const int64_t v = frontier[f];
   const int64_t s = colptr[v];
@@ -47,25 +45,27 @@ __global__ void __launch_bounds__(kBlock)
     }
     return;
   }
-  // Floyd: for j = deg-k .. deg-1: t = U{0..j}; insert t, or j if t is already chosen
-  if (lane == 0) {
-    int c = 0;
+  // Floyd: for j = deg-k .. deg-1: t = U{0..j}; insert t, or j if t is already chosen.  Lane c
+  // draws t_c; the k dependent insertions then run as k wave-wide steps (one 64-lane membership
+  // test each) instead of an O(k^2) loop on lane 0 — same draws, same result, bit for bit.
+  const int k = static_cast<int>(cnt);
+  const int64_t jl = deg - cnt + lane;  // Floyd's j of this lane's draw
+  int64_t t = 0;
+  if (lane < k) {
     const uint64_t key = mix64(seed ^ mix64(static_cast<uint64_t>(v)));
-    for (int64_t j = deg - cnt; j < deg; ++j) {
-      const uint64_t r = mix64(key + static_cast<uint64_t>(c));
-      int t = static_cast<int>(__umul64hi(r, static_cast<uint64_t>(j + 1)));
-      bool dup = false;
-      for (int q = 0; q < c; ++q) dup |= (chosen[w][q] == t);
-      chosen[w][c++] = dup ? static_cast<int>(j) : t;
-    }
+    const uint64_t r = mix64(key + static_cast<uint64_t>(lane));
+    t = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(jl + 1)));
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (lane < cnt) {
-    const int64_t t = chosen[w][lane];
-    src_out[o + lane] = row[s + t];
+  int64_t mine = -1;  // final choice of lane c (only lanes < k end up with one)
+  for (int c = 0; c < k; ++c) {
+    const int64_t tc = bcast_uniform(t, c);
+    const bool dup = __ballot(lane < c && mine == tc) != 0;
+    if (lane == c) mine = dup ? jl : tc;
+  }
+  if (lane < k) {
+    src_out[o + lane] = row[s + mine];
     dstpos_out[o + lane] = static_cast<IdxT>(f);
-    slot_out[o + lane] = static_cast<IdxT>(s + t);
+    slot_out[o + lane] = static_cast<IdxT>(s + mine);
   }
 }
 
@@ -73,9 +73,14 @@ __global__ void __launch_bounds__(kBlock)
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
     sample_counts_kernel(const IdxT* __restrict__ colptr, const IdxT* __restrict__ frontier,
-                         int64_t n, int64_t k, IdxT* __restrict__ cnt) {
+                         int64_t n, int64_t k, const int64_t* __restrict__ n_valid,
+                         IdxT* __restrict__ cnt) {
   const int64_t f = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (f >= n) return;
+  if (n_valid && f >= *n_valid) {  // padding of a fixed-capacity frontier
+    cnt[f] = 0;
+    return;
+  }
   const int64_t v = frontier[f];
   const int64_t deg = static_cast<int64_t>(colptr[v + 1]) - static_cast<int64_t>(colptr[v]);
   cnt[f] = static_cast<IdxT>((k >= 0 && deg > k) ? k : deg);
@@ -102,26 +107,34 @@ __device__ __forceinline__ void atomic_max_idx<int64_t>(int64_t* p, int64_t v) {
 
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
-    relabel_claim_kernel(const IdxT* __restrict__ src, int64_t m, IdxT* __restrict__ local) {
+    relabel_claim_kernel(const IdxT* __restrict__ src, int64_t m,
+                         const int64_t* __restrict__ m_dev, IdxT* __restrict__ local) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (m_dev && *m_dev < m) m = *m_dev;
   if (e < m) atomic_max_idx<IdxT>(local + src[e], static_cast<IdxT>(-(e + 2)));
 }
 
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
-    relabel_flag_kernel(const IdxT* __restrict__ src, int64_t m, const IdxT* __restrict__ local,
+    relabel_flag_kernel(const IdxT* __restrict__ src, int64_t m,
+                        const int64_t* __restrict__ m_dev, const IdxT* __restrict__ local,
                         int64_t* __restrict__ flag) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (e < m) flag[e] = (static_cast<int64_t>(local[src[e]]) == -(e + 2)) ? 1 : 0;
+  if (e >= m) return;
+  const bool valid = !m_dev || e < *m_dev;  // the padding flags 0: the scan stays fixed-size
+  flag[e] = (valid && static_cast<int64_t>(local[src[e]]) == -(e + 2)) ? 1 : 0;
 }
 
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
     relabel_assign_kernel(const IdxT* __restrict__ src, int64_t m,
-                          const int64_t* __restrict__ scan, int64_t base,
+                          const int64_t* __restrict__ m_dev, const int64_t* __restrict__ scan,
+                          int64_t base, const int64_t* __restrict__ base_dev,
                           IdxT* __restrict__ local, IdxT* __restrict__ new_nodes) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (m_dev && *m_dev < m) m = *m_dev;
   if (e >= m) return;
+  if (base_dev) base = *base_dev;
   const int64_t prev = (e == 0) ? 0 : scan[e - 1];
   if (scan[e] != prev) {  // this entry claimed its source
     const IdxT s = src[e];
@@ -132,10 +145,12 @@ __global__ void __launch_bounds__(kBlock)
 
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
-    relabel_lookup_kernel(const IdxT* __restrict__ src, int64_t m, const IdxT* __restrict__ local,
+    relabel_lookup_kernel(const IdxT* __restrict__ src, int64_t m,
+                          const int64_t* __restrict__ m_dev, const IdxT* __restrict__ local,
                           IdxT* __restrict__ out) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (e < m) out[e] = local[src[e]];
+  if (e >= m) return;
+  out[e] = (!m_dev || e < *m_dev) ? local[src[e]] : static_cast<IdxT>(0);
 }
 
 }  // namespace pygamd
@@ -170,7 +185,7 @@ int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
 }
 
 int pygamd_sample_counts(const void* colptr, int idx_dtype, const void* frontier, int64_t n,
-                         int64_t k, void* cnt_out, void* stream) {
+                         int64_t k, const int64_t* n_valid, void* cnt_out, void* stream) {
   if (n < 0) return PYGAMD_ERR_INVALID_ARG;
   if (n == 0) return PYGAMD_OK;
   if (!colptr || !frontier || !cnt_out) return PYGAMD_ERR_INVALID_ARG;
@@ -178,14 +193,16 @@ int pygamd_sample_counts(const void* colptr, int idx_dtype, const void* frontier
     hipLaunchKernelGGL((sample_counts_kernel<IdxT>),
                        dim3(static_cast<unsigned>(ceil_div(n, kBlock))), dim3(kBlock), 0,
                        as_stream(stream), static_cast<const IdxT*>(colptr),
-                       static_cast<const IdxT*>(frontier), n, k, static_cast<IdxT*>(cnt_out));
+                       static_cast<const IdxT*>(frontier), n, k, n_valid,
+                       static_cast<IdxT*>(cnt_out));
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });
 }
 
-int pygamd_relabel(int phase, const void* src, int idx_dtype, int64_t m, void* local_map,
-                   int64_t* flag_or_scan, int64_t base, void* out, void* stream) {
+int pygamd_relabel(int phase, const void* src, int idx_dtype, int64_t m, const int64_t* m_dev,
+                   void* local_map, int64_t* flag_or_scan, int64_t base,
+                   const int64_t* base_dev, void* out, void* stream) {
   if (m < 0 || phase < 0 || phase > 3) return PYGAMD_ERR_INVALID_ARG;
   if (m == 0) return PYGAMD_OK;
   if (!src || !local_map) return PYGAMD_ERR_INVALID_ARG;
@@ -198,19 +215,20 @@ int pygamd_relabel(int phase, const void* src, int idx_dtype, int64_t m, void* l
     IdxT* local = static_cast<IdxT*>(local_map);
     switch (phase) {
       case 0:
-        hipLaunchKernelGGL((relabel_claim_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, local);
+        hipLaunchKernelGGL((relabel_claim_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, m_dev,
+                           local);
         break;
       case 1:
-        hipLaunchKernelGGL((relabel_flag_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, local,
-                           flag_or_scan);
+        hipLaunchKernelGGL((relabel_flag_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, m_dev,
+                           local, flag_or_scan);
         break;
       case 2:
-        hipLaunchKernelGGL((relabel_assign_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m,
-                           flag_or_scan, base, local, static_cast<IdxT*>(out));
+        hipLaunchKernelGGL((relabel_assign_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, m_dev,
+                           flag_or_scan, base, base_dev, local, static_cast<IdxT*>(out));
         break;
       default:
-        hipLaunchKernelGGL((relabel_lookup_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, local,
-                           static_cast<IdxT*>(out));
+        hipLaunchKernelGGL((relabel_lookup_kernel<IdxT>), grid, dim3(kBlock), 0, st, s, m, m_dev,
+                           local, static_cast<IdxT*>(out));
     }
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;

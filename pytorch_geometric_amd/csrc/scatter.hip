@@ -37,36 +37,42 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-template <typename IdxT, int REDUCE>
+// Work item = (row e, VW-float chunk): one 16-byte source load and ONE index load per item (the
+// scalar version re-read index[e] for every float), then VW device-scope atomics.
+template <typename IdxT, int REDUCE, int VW>
 __global__ void __launch_bounds__(kBlock)
     scatter_rows_kernel(const float* __restrict__ src, int64_t lds,
-                        const IdxT* __restrict__ index, int64_t n, int64_t F,
+                        const IdxT* __restrict__ index, int64_t n, int64_t units, int64_t F,
                         float* __restrict__ out, int64_t ldo, int64_t dim_size,
                         float* __restrict__ count, int32_t* __restrict__ err) {
-  const int64_t total = n * F;
+  const int64_t total = n * units;
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
        t += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int64_t e = t / F;
-    const int64_t f = t - e * F;
+    const int64_t e = t / units;
+    const int64_t u = t - e * units;
+    const int64_t f = u * VW;
     const int64_t g = index[e];
     if (g < 0 || g >= dim_size) {
       if (err) *err = 1;
       continue;
     }
-    const float v = src[e * lds + f];
+    const Vec<VW> v = load_vec<VW>(src + e * lds + f);
     float* dst = out + g * ldo + f;
-    if (REDUCE == PYGAMD_SUM || REDUCE == PYGAMD_MEAN) {
-      atomicAdd(dst, v);
-    } else if (REDUCE == PYGAMD_MAX) {
-      atomic_max_f32(dst, v);
-    } else if (REDUCE == PYGAMD_MIN) {
-      atomic_min_f32(dst, v);
-    } else if (REDUCE == PYGAMD_MUL) {
-      atomic_mul_f32(dst, v);
-    } else {
-      *dst = v;  // 'any': some contributing row wins
+#pragma unroll
+    for (int q = 0; q < VW; ++q) {
+      if (REDUCE == PYGAMD_SUM || REDUCE == PYGAMD_MEAN) {
+        atomicAdd(dst + q, v.v[q]);
+      } else if (REDUCE == PYGAMD_MAX) {
+        atomic_max_f32(dst + q, v.v[q]);
+      } else if (REDUCE == PYGAMD_MIN) {
+        atomic_min_f32(dst + q, v.v[q]);
+      } else if (REDUCE == PYGAMD_MUL) {
+        atomic_mul_f32(dst + q, v.v[q]);
+      } else {
+        dst[q] = v.v[q];  // 'any': some contributing row wins
+      }
     }
-    if (count && f == 0) atomicAdd(count + g, 1.f);
+    if (count && u == 0) atomicAdd(count + g, 1.f);
   }
 }
 
@@ -334,14 +340,16 @@ static unsigned flat_grid(int64_t total) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <typename IdxT>
+template <typename IdxT, int VW>
 static int launch_scatter(const float* src, int64_t lds, const IdxT* idx, int64_t n, int64_t F,
                           float* out, int64_t ldo, int64_t dim_size, int reduce, float* count,
-                          int32_t* err_flag, dim3 grid, hipStream_t st) {
-#define PYGAMD_SCATTER_CASE(R)                                                              \
-  case R:                                                                                   \
-    hipLaunchKernelGGL((scatter_rows_kernel<IdxT, R>), grid, dim3(kBlock), 0, st, src, lds, \
-                       idx, n, F, out, ldo, dim_size, count, err_flag);                     \
+                          int32_t* err_flag, hipStream_t st) {
+  const int64_t units = F / VW;
+  const dim3 grid(flat_grid(n * units));
+#define PYGAMD_SCATTER_CASE(R)                                                                  \
+  case R:                                                                                       \
+    hipLaunchKernelGGL((scatter_rows_kernel<IdxT, R, VW>), grid, dim3(kBlock), 0, st, src, lds, \
+                       idx, n, units, F, out, ldo, dim_size, count, err_flag);                  \
     break;
   switch (reduce) {
     PYGAMD_SCATTER_CASE(PYGAMD_SUM)
@@ -484,10 +492,13 @@ int pygamd_scatter_rows(const float* src, int64_t lds, const void* index, int id
   if (n == 0 || F == 0) return PYGAMD_OK;
   if (!src || !index || !out) return PYGAMD_ERR_INVALID_ARG;
   hipStream_t st = as_stream(stream);
-  const dim3 grid(flat_grid(n * F));
+  const bool v4 = (F % 4 == 0) && (lds % 4 == 0) && aligned16(src);
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
-    return launch_scatter<IdxT>(src, lds, static_cast<const IdxT*>(index), n, F, out, ldo,
-                                dim_size, reduce, count, err_flag, grid, st);
+    const IdxT* idx = static_cast<const IdxT*>(index);
+    return v4 ? launch_scatter<IdxT, 4>(src, lds, idx, n, F, out, ldo, dim_size, reduce, count,
+                                        err_flag, st)
+              : launch_scatter<IdxT, 1>(src, lds, idx, n, F, out, ldo, dim_size, reduce, count,
+                                        err_flag, st);
   });
 }
 

@@ -84,6 +84,45 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- segment_logsumexp (utils/_segment.py:53-80) -------------------------------------------------
+// out[seg, h] = log(sum_{k in seg} exp(src[k, h] - m)) + m with m = the segment maximum (0 for an
+// empty segment, whose result is 0: log(0) = -inf is mapped to 0 by the reference's
+// nan_to_num(neginf=0)).  Same lane mapping as the softmax: for narrow power-of-two H the wave
+// covers 64 / H rows per pass.  BWD: grad_src[k, h] = exp(src[k, h] - out[seg, h]) * g[seg, h].
+template <typename IdxT, bool BWD>
+__global__ void __launch_bounds__(kBlock)
+    segment_logsumexp_kernel(const float* __restrict__ src, const IdxT* __restrict__ ptr,
+                             int64_t n_seg, int64_t H, float* __restrict__ out,
+                             const float* __restrict__ grad_out, float* __restrict__ grad_src) {
+  const int lane = lane_id();
+  const int64_t seg = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (seg >= n_seg) return;
+  const int64_t s = ptr[seg];
+  const int64_t e = ptr[seg + 1];
+  const bool narrow = H <= kWave && is_pow2(H);
+  const int64_t hstep = narrow ? H : kWave;
+  const int64_t kstep = narrow ? kWave / H : 1;
+  const int64_t koff = narrow ? lane / H : 0;
+  for (int64_t h = narrow ? lane % H : lane; h < H; h += hstep) {
+    if (BWD) {
+      const float lse = out[seg * H + h];
+      const float g = grad_out[seg * H + h];
+      for (int64_t k = s + koff; k < e; k += kstep)
+        grad_src[k * H + h] = expf(src[k * H + h] - lse) * g;
+    } else {
+      float m = -INFINITY;
+      for (int64_t k = s + koff; k < e; k += kstep) m = fmaxf(m, src[k * H + h]);
+      if (narrow) m = column_reduce<true>(m, static_cast<int>(H));
+      if (e <= s) m = 0.f;
+      float sum = 0.f;
+      for (int64_t k = s + koff; k < e; k += kstep) sum += expf(src[k * H + h] - m);
+      if (narrow) sum = column_reduce<false>(sum, static_cast<int>(H));
+      const float l = logf(sum);
+      if (koff == 0) out[seg * H + h] = (l == -INFINITY ? 0.f : l) + m;
+    }
+  }
+}
+
 // grad_src[k,h] = out[k,h] * (g[k,h] - sum_seg(out*g)[h]);  GAT: additionally through the
 // leaky-relu and into grad_alpha_dst (row-owned, plain store) / grad_alpha_src (atomics).
 template <typename IdxT, bool GAT>
@@ -273,6 +312,36 @@ int pygamd_segment_softmax_backward(const float* out, const float* grad_out, con
                        dim3(kBlock), 0, as_stream(stream), out, grad_out,
                        static_cast<const IdxT*>(ptr), n_seg, H, grad_src, none,
                        static_cast<float*>(nullptr), static_cast<float*>(nullptr));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_segment_logsumexp_forward(const float* src, const void* ptr, int idx_dtype,
+                                     int64_t n_seg, int64_t H, float* out, void* stream) {
+  if (n_seg < 0 || H < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n_seg == 0 || H == 0) return PYGAMD_OK;
+  if (!ptr || !out) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((segment_logsumexp_kernel<IdxT, false>), dim3(wave_grid(n_seg)),
+                       dim3(kBlock), 0, as_stream(stream), src, static_cast<const IdxT*>(ptr),
+                       n_seg, H, out, static_cast<const float*>(nullptr),
+                       static_cast<float*>(nullptr));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_segment_logsumexp_backward(const float* src, const float* out, const float* grad_out,
+                                      const void* ptr, int idx_dtype, int64_t n_seg, int64_t H,
+                                      float* grad_src, void* stream) {
+  if (n_seg < 0 || H < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n_seg == 0 || H == 0) return PYGAMD_OK;
+  if (!ptr || !out || !grad_out) return PYGAMD_ERR_INVALID_ARG;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    hipLaunchKernelGGL((segment_logsumexp_kernel<IdxT, true>), dim3(wave_grid(n_seg)),
+                       dim3(kBlock), 0, as_stream(stream), src, static_cast<const IdxT*>(ptr),
+                       n_seg, H, const_cast<float*>(out), grad_out, grad_src);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });

@@ -426,6 +426,133 @@ __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
   }
 }
 
+// ---- one-pass multi-reduce (FusedAggregation, nn/aggr/fused.py:191-336) ----------------------
+// sum, sum of squares, min and max of the rows of a group in ONE read of the rows: the SpMM's lane
+// mapping with four accumulators per feature.  Outputs that are not requested are null; empty
+// groups give 0 everywhere (utils/_scatter.py semantics).
+template <typename IdxT, int VW, int LPR, int CH, bool IDENT>
+__global__ void __launch_bounds__(kBlock)
+    spmm_multi_rows(SpmmDev<IdxT> a, float* __restrict__ out_sum, float* __restrict__ out_sq,
+                    float* __restrict__ out_min, float* __restrict__ out_max) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = CH == 1 ? (LPR < 4 ? LPR : 4) : 2;
+  constexpr int STEP = EPI * U;
+  const int lane = lane_id();
+  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (row >= a.n_rows) return;
+  const IdxT start = a.rowptr[row];
+  const IdxT end = a.rowptr[row + 1];
+  int fo[CH], head[CH];
+  bool fv[CH];
+  feature_slots<VW, LPR, CH>(lane, a.F, 1, fo, fv, head);
+  const int sub = lane / LPR;
+  float s1[CH][VW], s2[CH][VW], mn[CH][VW], mx[CH][VW];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      s1[c][i] = 0.f;
+      s2[c][i] = 0.f;
+      mn[c][i] = INFINITY;
+      mx[c][i] = -INFINITY;
+    }
+  }
+  for (IdxT base = start; base < end; base += kWave) {
+    const IdxT rem = end - base;
+    const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+    IdxT myc = 0;
+    if (lane < cnt) {
+      if constexpr (IDENT) {
+        myc = base + lane;
+      } else {
+        myc = __builtin_nontemporal_load(&a.col[base + lane]);
+      }
+    }
+    for (int j = 0; j < cnt; j += STEP) {
+      Vec<VW> v[U][CH];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = j + u * EPI + sub;
+        ok[u] = k < cnt;
+        const int kk = ok[u] ? k : cnt - 1;
+        IdxT c;
+        if constexpr (EPI == 1) {
+          c = bcast_uniform(myc, kk);
+        } else {
+          c = bcast_lane(myc, kk);
+        }
+        const float* __restrict__ xr = a.x + static_cast<int64_t>(c) * a.ldx;
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+          if (fv[c2] && ok[u]) v[u][c2] = load_vec<VW>(xr + fo[c2]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+          if (fv[c2] && ok[u]) {
+#pragma unroll
+            for (int i = 0; i < VW; ++i) {
+              const float val = v[u][c2].v[i];
+              s1[c2][i] += val;
+              s2[c2][i] = fmaf(val, val, s2[c2][i]);
+              // NaN propagates like torch's amin / amax
+              mn[c2][i] = better_val<false>(val, mn[c2][i]) ? val : mn[c2][i];
+              mx[c2][i] = better_val<true>(val, mx[c2][i]) ? val : mx[c2][i];
+            }
+          }
+        }
+      }
+    }
+  }
+  combine_subgroups<VW, LPR, CH>(s1);
+  combine_subgroups<VW, LPR, CH>(s2);
+#pragma unroll
+  for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) {
+        const float on = __shfl_xor(mn[c][i], off, kWave);
+        const float ox = __shfl_xor(mx[c][i], off, kWave);
+        mn[c][i] = better_val<false>(on, mn[c][i]) ? on : mn[c][i];
+        mx[c][i] = better_val<true>(ox, mx[c][i]) ? ox : mx[c][i];
+      }
+    }
+  }
+  if (lane < LPR) {
+    const bool empty = end <= start;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (!fv[c]) continue;
+      Vec<VW> o;
+      const int64_t off = row * a.ldo + fo[c];
+      if (out_sum) {
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = s1[c][i];
+        store_vec<VW>(out_sum + off, o);
+      }
+      if (out_sq) {
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = s2[c][i];
+        store_vec<VW>(out_sq + off, o);
+      }
+      if (out_min) {
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = empty ? 0.f : mn[c][i];
+        store_vec<VW>(out_min + off, o);
+      }
+      if (out_max) {
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = empty ? 0.f : mx[c][i];
+        store_vec<VW>(out_max + off, o);
+      }
+    }
+  }
+}
+
 // ---- min/max backward helpers (reference tie rule, see pyg_amd.h) --------------------------
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
@@ -913,6 +1040,54 @@ static int launch_minmax_bwd_dst(const Shape& s, const void* rowptr, const void*
   return PYGAMD_OK;
 }
 
+template <typename IdxT>
+static int launch_multi(const pygamd_spmm_args* p, const Shape& s, bool has_perm, float* out_sum,
+                        float* out_sq, float* out_min, float* out_max, hipStream_t st) {
+  SpmmDev<IdxT> a = make_dev<IdxT>(p);
+  a.hub_threshold = 0;
+  dim3 grid(wave_grid(p->n_rows), s.tiles);
+#define PYGAMD_MULTI(VW, LPR, CH)                                                                \
+  do {                                                                                           \
+    if (has_perm) {                                                                              \
+      hipLaunchKernelGGL((spmm_multi_rows<IdxT, VW, LPR, CH, false>), grid, dim3(kBlock), 0, st, \
+                         a, out_sum, out_sq, out_min, out_max);                                  \
+    } else {                                                                                     \
+      hipLaunchKernelGGL((spmm_multi_rows<IdxT, VW, LPR, CH, true>), grid, dim3(kBlock), 0, st,  \
+                         a, out_sum, out_sq, out_min, out_max);                                  \
+    }                                                                                            \
+  } while (0)
+  if (s.vw == 4) {
+    switch (s.lpr) {
+      case 4: PYGAMD_MULTI(4, 4, 1); break;
+      case 8: PYGAMD_MULTI(4, 8, 1); break;
+      case 16: PYGAMD_MULTI(4, 16, 1); break;
+      case 32: PYGAMD_MULTI(4, 32, 1); break;
+      default:
+        if (s.ch == 2) {
+          PYGAMD_MULTI(4, 64, 2);
+        } else {
+          PYGAMD_MULTI(4, 64, 1);
+        }
+    }
+  } else {
+    switch (s.lpr) {
+      case 4: PYGAMD_MULTI(1, 4, 1); break;
+      case 8: PYGAMD_MULTI(1, 8, 1); break;
+      case 16: PYGAMD_MULTI(1, 16, 1); break;
+      case 32: PYGAMD_MULTI(1, 32, 1); break;
+      default:
+        if (s.ch == 2) {
+          PYGAMD_MULTI(1, 64, 2);
+        } else {
+          PYGAMD_MULTI(1, 64, 1);
+        }
+    }
+  }
+#undef PYGAMD_MULTI
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
 static int validate(const pygamd_spmm_args* p) {
   if (!p) return PYGAMD_ERR_INVALID_ARG;
   if (p->n_rows < 0 || p->F < 0 || p->ldx < p->F || p->ldo < p->F) return PYGAMD_ERR_INVALID_ARG;
@@ -1027,6 +1202,42 @@ int pygamd_spmm_csr_minmax_backward_dst(const void* rowptr, const void* col, int
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     return launch_minmax_bwd_dst<IdxT>(s, rowptr, col, x, ldx, out, ldo, grad_out, ldgo, n_rows,
                                        F, count_self, grad_x, ldg, st);
+  });
+}
+
+int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int idx_dtype, const float* x,
+                            int64_t ldx, int64_t n_rows, int64_t F, float* out_sum,
+                            float* out_sq, float* out_min, float* out_max, int64_t ldo,
+                            void* stream) {
+  if (n_rows < 0 || F < 0 || ldx < F || ldo < F) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows == 0 || F == 0) return PYGAMD_OK;
+  if (!rowptr || !x || !(out_sum || out_sq || out_min || out_max)) return PYGAMD_ERR_INVALID_ARG;
+  pygamd_spmm_args args = {};
+  args.rowptr = rowptr;
+  args.col = perm;
+  args.x = x;
+  // every requested output must allow the vector width the probe picks
+  float* outs[4] = {out_sum, out_sq, out_min, out_max};
+  args.out = nullptr;
+  bool all_aligned = true;
+  for (float* o : outs) {
+    if (o) {
+      if (!args.out) args.out = o;
+      all_aligned = all_aligned && aligned16(o);
+    }
+  }
+  args.n_rows = n_rows;
+  args.F = F;
+  args.ldx = all_aligned ? ldx : 1;  // ldx % 4 != 0 forces the scalar shape in pick_shape
+  args.ldo = ldo;
+  args.idx_dtype = idx_dtype;
+  args.w_heads = 1;
+  args.head_dim = static_cast<int>(F);
+  const Shape s = pick_shape(&args);
+  args.ldx = ldx;
+  hipStream_t st = as_stream(stream);
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    return launch_multi<IdxT>(&args, s, perm != nullptr, out_sum, out_sq, out_min, out_max, st);
   });
 }
 

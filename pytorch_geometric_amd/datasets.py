@@ -16,25 +16,32 @@ SHAPES = {
 
 
 def powerlaw_undirected(num_nodes: int, num_edges: int, seed: int, alpha: float = 0.54,
-                        dtype: torch.dtype = torch.int64) -> Tensor:
+                        dtype: torch.dtype = torch.int64, device=None) -> Tensor:
     r"""``[2, num_edges]`` edge list of an undirected graph stored in both directions (like
     ogbn-products): ``num_edges / 2`` pairs ``(u, v)`` with ``u`` drawn from a Zipf-like popularity
     ``p(rank) ~ rank^-alpha`` over randomly permuted node ids and ``v`` uniform, then mirrored.
-    ``alpha = 0.54`` gives a maximum degree of about 17 k at the ogbn-products shape."""
-    g = torch.Generator().manual_seed(seed)
+    ``alpha = 0.54`` gives a maximum degree of about 17 k at the ogbn-products shape.
+    ``device``: generate there (a device generator has its own stream of numbers — the same
+    distribution, not the same bits; for graphs too large to build on the host, e.g. the
+    ogbn-papers100M shape with 1.6 G edges)."""
+    device = torch.device('cpu') if device is None else torch.device(device)
+    g = torch.Generator(device=device).manual_seed(seed)
     half = num_edges // 2
-    w = torch.arange(1, num_nodes + 1, dtype=torch.float64).pow_(-alpha)
+    w = torch.arange(1, num_nodes + 1, dtype=torch.float64, device=device).pow_(-alpha)
     cdf = w.cumsum(0)
     cdf /= cdf[-1].clone()
-    r = torch.rand(half, generator=g, dtype=torch.float64)
+    del w
+    edge_index = torch.empty(2, num_edges, dtype=dtype, device=device)
+    r = torch.rand(half, generator=g, dtype=torch.float64, device=device)
     u = torch.searchsorted(cdf, r).clamp_(max=num_nodes - 1)
-    u = torch.randperm(num_nodes, generator=g)[u]
-    v = torch.randint(0, num_nodes, (half, ), generator=g)
-    edge_index = torch.stack([torch.cat([u, v]), torch.cat([v, u])])
+    del r, cdf
+    u = torch.randperm(num_nodes, generator=g, device=device)[u]
+    v = torch.randint(0, num_nodes, (half, ), generator=g, device=device)
+    edge_index[0, :half], edge_index[0, half:2 * half] = u, v
+    edge_index[1, :half], edge_index[1, half:2 * half] = v, u
     if num_edges % 2 == 1:  # one extra directed edge to hit an odd count exactly
-        extra = torch.randint(0, num_nodes, (2, 1), generator=g)
-        edge_index = torch.cat([edge_index, extra], dim=1)
-    return edge_index.to(dtype)
+        edge_index[:, -1] = torch.randint(0, num_nodes, (2, ), generator=g, device=device)
+    return edge_index
 
 
 def uniform_directed(num_nodes: int, num_edges: int, seed: int,

@@ -81,6 +81,37 @@ class FusedAggregation(Aggregation):
                              for m in mods)
         self.need_degree = any(isinstance(m, _DEGREE_BASED) for m in mods)
 
+    def _one_pass(self, x: Tensor, index: Tensor, dim_size: Optional[int]) -> Dict[str, Tensor]:
+        """sum / sum of squares / min / max / count of every group from ONE read of the rows: the
+        index is sorted once (stable radix sort; skipped when it already is), then a single
+        multi-reduce kernel walks the groups (csrc/spmm.hip ``spmm_multi_rows``)."""
+        from ... import _native
+        from ..._functions import MultiReduceFunction
+        need = {'SumAggregation': ('sum', ), 'MeanAggregation': ('sum', ),
+                'MinAggregation': ('min', ), 'MaxAggregation': ('max', ),
+                'VarAggregation': ('sum', 'pow_sum'), 'StdAggregation': ('sum', 'pow_sum')}
+        want = tuple(k for k in ('sum', 'pow_sum', 'min', 'max')
+                     if any(k in need.get(n, ()) for n in self.aggr_names))
+        if not want:
+            return {}
+        n = index.numel()
+        lo, hi = _native.index_minmax(index) if n > 0 else (0, -1)
+        if dim_size is None:
+            dim_size = hi + 1
+        if lo < 0 or hi >= dim_size:
+            raise IndexError(f'index {hi if hi >= dim_size else lo} is out of bounds for '
+                             f'dimension 0 with size {dim_size}')
+        index = index.contiguous()
+        if n > 1 and bool((index[1:] >= index[:-1]).all()):
+            key, perm = index, None
+        else:
+            key, perm = _native.index_sort(index, max_value=max(dim_size - 1, 0))
+        ptr = _native.index2ptr(key, dim_size)
+        outs = MultiReduceFunction.apply(x.contiguous(), index, ptr, perm, want, self.semi_grad)
+        cache = dict(zip(want, outs))
+        cache['count'] = (ptr[1:] - ptr[:-1]).clamp(min=1).to(torch.float32).view(-1, 1)
+        return cache
+
     def forward(self, x: Tensor, index: Optional[Tensor] = None, ptr: Optional[Tensor] = None,
                 dim_size: Optional[int] = None, dim: int = -2) -> List[Tensor]:
         if index is None:
@@ -91,6 +122,8 @@ class FusedAggregation(Aggregation):
             raise ValueError(f"Aggregation needs to perform aggregation in first dimension "
                              f"(got '{dim}')")
         cache: Dict[str, Tensor] = {}
+        if x.is_cuda and x.dtype == torch.float32:
+            cache.update(self._one_pass(x, index, dim_size))
 
         def get(reduce: str) -> Tensor:
             if reduce not in cache:

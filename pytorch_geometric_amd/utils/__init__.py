@@ -1,5 +1,5 @@
 from ._scatter import scatter, scatter_argmax
-from ._segment import segment
+from ._segment import segment, segment_logsumexp
 from ._softmax import softmax
 from ._spmm import spmm
 from ._index_sort import index_sort
@@ -12,7 +12,7 @@ from .loop import (add_remaining_self_loops, add_self_loops, contains_self_loops
                    remove_self_loops)
 
 __all__ = [
-    'scatter', 'scatter_argmax', 'segment', 'softmax', 'spmm', 'index_sort', 'degree',
+    'scatter', 'scatter_argmax', 'segment', 'segment_logsumexp', 'softmax', 'spmm', 'index_sort', 'degree',
     'maybe_num_nodes', 'trim_to_layer', 'segment_matmul', 'add_remaining_self_loops', 'add_self_loops', 'contains_self_loops',
     'remove_self_loops', 'sort_edge_index', 'coalesce', 'to_undirected', 'is_undirected',
 ]

@@ -1,6 +1,6 @@
 from torch import Tensor
 
-from .._functions import SegmentFunction
+from .._functions import SegmentFunction, SegmentLogSumExpFunction
 from ._scatter import _require_fp32
 
 
@@ -17,3 +17,17 @@ def segment(src: Tensor, ptr: Tensor, reduce: str = 'sum') -> Tensor:
     _require_fp32(src, 'segment')
     reduce = 'sum' if reduce == 'add' else reduce
     return SegmentFunction.apply(src, ptr, reduce)
+
+
+def segment_logsumexp(src: Tensor, ptr: Tensor, dim: int) -> Tensor:
+    r"""Log of the summed exponentials of the slices of :obj:`src` along :obj:`dim` that lie in the
+    same :obj:`ptr` range — drop-in for ``torch_geometric.utils.segment_logsumexp``
+    (torch_geometric/utils/_segment.py:53-80): evaluated with the segment maximum subtracted, an
+    empty segment gives 0.  One HIP kernel forward, one backward (the in-segment softmax)."""
+    if ptr.dim() != 1:
+        raise ValueError("'ptr' must be one-dimensional")
+    _require_fp32(src, 'segment_logsumexp')
+    dim = dim + src.dim() if dim < 0 else dim
+    if dim != 0:
+        return segment_logsumexp(src.transpose(0, dim).contiguous(), ptr, 0).transpose(0, dim)
+    return SegmentLogSumExpFunction.apply(src, ptr)

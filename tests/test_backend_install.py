@@ -248,3 +248,21 @@ def test_edge_index_matmul_glue_matches_the_reference(installed, oracle_kernels)
     unsorted = EdgeIndex(raw, sparse_size=(n_row, n_col))
     with pytest.raises(ValueError, match='sorted'):
         unsorted.matmul(torch.randn(n_col, 3))
+
+
+def test_oracle_segment_logsumexp_matches_the_reference():
+    """Pins oracle.segment_logsumexp (the checker of tests/test_gpu_ops.py::test_segment_logsumexp)
+    against the real utils/_segment.py:53-80 on the CPU: dim 0 / dim 1, empty segments, grads."""
+    from oracle import pyg_oracle as O
+    from torch_geometric.utils import segment_logsumexp
+    g = torch.Generator().manual_seed(0)
+    ptr = torch.tensor([0, 0, 5, 10, 10, 15, 20])
+    for shape, dim in (((20, 16), 0), ((16, 20), 1), ((20, ), 0)):
+        a = torch.randn(*shape, generator=g, requires_grad=True)
+        b = a.detach().clone().requires_grad_(True)
+        ref, got = segment_logsumexp(a, ptr, dim), O.segment_logsumexp(b, ptr, dim)
+        assert torch.allclose(got, ref, atol=1e-6)
+        w = torch.randn(ref.shape, generator=g)
+        (ref * w).sum().backward()
+        (got * w).sum().backward()
+        assert torch.allclose(b.grad, a.grad, atol=1e-6)

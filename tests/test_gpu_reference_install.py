@@ -263,3 +263,53 @@ def test_reference_utils_and_aggregations_on_device(pyg, installed, dev):
     ref = U.scatter(w_c, index, 0, 160, 'sum').pow(-0.5)
     ref.sum().backward()
     assert_close(w.grad, w_c.grad, rtol=2e-5, atol=2e-5, what='in-place edit of a scatter result')
+
+
+def test_reference_node_loader_drives_the_gpu_sampler(pyg, installed, dev):
+    """backend.neighbor_sampler(...) IS a torch_geometric.sampler.BaseSampler: the reference's
+    NodeLoader (loader/node_loader.py:90-207) calls sample_from_nodes(NodeSamplerInput) and joins
+    features with its own filter_data; the batch has the reference's fields."""
+    from torch_geometric.data import Data
+    from torch_geometric.loader import NodeLoader
+    from torch_geometric.sampler import BaseSampler, SamplerOutput
+    g = gen(21)
+    N = 1500
+    ei = torch.randint(0, N, (2, 20000), generator=g)
+    x = torch.randn(N, 12, generator=g)
+    y = torch.randint(0, 5, (N, ), generator=g)
+    data = Data(x=x, y=y, edge_index=ei, num_nodes=N).to(dev)
+    sampler = installed.neighbor_sampler(data, [6, 3], seed=5)
+    assert isinstance(sampler, BaseSampler)
+    train_idx = torch.randperm(N, generator=g)[:200]
+    loader = NodeLoader(data, node_sampler=sampler, input_nodes=train_idx, batch_size=64,
+                        shuffle=False)
+    seen = 0
+    for i, batch in enumerate(loader):
+        seeds = train_idx[i * 64:(i + 1) * 64]
+        bs = seeds.numel()
+        assert batch.batch_size == bs and torch.equal(batch.input_id.cpu(),
+                                                      torch.arange(i * 64, i * 64 + bs))
+        n_id, e_id = batch.n_id.cpu(), batch.e_id.cpu()
+        assert torch.equal(n_id[:bs], seeds)
+        assert torch.equal(batch.x.cpu(), x[n_id]) and torch.equal(batch.y.cpu(), y[n_id])
+        loc = batch.edge_index.cpu()
+        assert torch.equal(n_id[loc[0]], ei[0][e_id]) and torch.equal(n_id[loc[1]], ei[1][e_id])
+        assert len(batch.num_sampled_nodes) == 3 and len(batch.num_sampled_edges) == 2
+        assert sum(batch.num_sampled_nodes) == n_id.numel()
+        assert sum(batch.num_sampled_edges) == e_id.numel()
+        # per-destination counts: min(in-degree, fan-out) for the seeds
+        deg = torch.bincount(ei[1], minlength=N)
+        first_hop = loc[1][:batch.num_sampled_edges[0]]
+        got = torch.bincount(first_hop, minlength=bs)[:bs]
+        assert torch.equal(got, deg[seeds].clamp(max=6))
+        seen += bs
+    assert seen == 200
+    out = sampler.sample_from_nodes(loader.input_data[[0, 1, 2]])
+    assert isinstance(out, SamplerOutput) and out.metadata[0].tolist() == [0, 1, 2]
+    # the reference's model consumes the batch (trim_to_layer path included)
+    from torch_geometric.nn import GraphSAGE
+    torch.manual_seed(0)
+    model = GraphSAGE(12, 16, num_layers=2, out_channels=5).to(dev)
+    out = model(batch.x, batch.edge_index, num_sampled_nodes_per_hop=batch.num_sampled_nodes,
+                num_sampled_edges_per_hop=batch.num_sampled_edges)
+    assert out.shape[1] == 5 and bool(torch.isfinite(out).all())

@@ -189,3 +189,82 @@ def test_prefetching_loader_yields_the_same_batches(dev):
     it = iter(NeighborLoader(x, ei, [6, 4], batch_size=256, prefetch=2))
     next(it)
     it.close()
+
+
+def test_full_fanout_equals_the_reference_k_hop_subgraph(dev):
+    """num_neighbors = [-1] * k: node set and edge set equal the reference's
+    k_hop_subgraph(directed=True) exactly (golden generated by tests/golden/make_golden_khop.py
+    from utils/_subgraph.py:249-370); local row / col decode to the original edges."""
+    import os
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_khop_v1.pt')
+    G = torch.load(path, map_location='cpu', weights_only=False)
+    ei, seeds = G['edge_index'], G['seeds']
+    for dtype in (torch.int64, torch.int32):
+        for k, want in G['hops'].items():
+            s = NeighborSampler(ei.to(dtype).to(dev), G['N'], [-1] * k)
+            out = s.sample_from_nodes(seeds.to(dev))
+            node, edge = out.node.cpu().long(), out.edge.cpu().long()
+            assert torch.equal(node[:seeds.numel()], seeds)            # seeds first, in order
+            assert node.unique().numel() == node.numel()               # no node twice
+            assert torch.equal(node.sort().values, want['subset'])     # same node set
+            assert torch.equal(edge.sort().values, want['edge_ids'])   # same edges, each once
+            # local indices decode to the original endpoints
+            assert torch.equal(node[out.row.cpu().long()], ei[0][edge])
+            assert torch.equal(node[out.col.cpu().long()], ei[1][edge])
+            assert sum(out.num_sampled_nodes) == node.numel()
+            assert sum(out.num_sampled_edges) == edge.numel()
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_sync_free_hops_equal_the_synced_hops(dev, dtype):
+    """Bounded fan-outs run with static capacities and device-side counts (one host read per
+    batch).  Same seed -> exactly the batch of the per-hop-synchronised algorithm."""
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    g = gen(91)
+    N = 3000
+    ei = torch.randint(0, N, (2, 40000), generator=g)
+    ei[1, :3000] = 5  # a hub: deg >> fan-out
+    s = NeighborSampler(ei.to(dtype).to(dev), N, [7, 4, 3], seed=11)
+    seeds = torch.randperm(N, generator=g)[:64].to(dev)
+    for call in range(3):
+        a = s.sample_from_nodes(seeds, seed=100 + call)
+        b = s._hops_synced(seeds.to(dtype), 100 + call)
+        for f in ('node', 'row', 'col', 'edge'):
+            assert torch.equal(getattr(a, f), getattr(b, f)), f
+        assert a.num_sampled_nodes == b.num_sampled_nodes
+        assert a.num_sampled_edges == b.num_sampled_edges
+        assert bool((s._local == s._unset).all())  # the id map is clean again
+    # zero-capacity corner: a fan-out of 0 stops the expansion
+    z = NeighborSampler(ei.to(dtype).to(dev), N, [3, 0, 2]).sample_from_nodes(seeds)
+    assert z.num_sampled_edges[1:] == [0, 0] and z.num_sampled_nodes[2:] == [0, 0]
+
+
+def test_padded_sampling_is_hipgraph_capturable(dev):
+    """sample_padded: no host read at all -> one batch = one captured HIP graph; replaying it with
+    other seeds written into the static input gives that batch."""
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    g = gen(92)
+    N = 2000
+    ei = torch.randint(0, N, (2, 30000), generator=g).to(dev)
+    s = NeighborSampler(ei, N, [5, 3], seed=3)
+    static_seeds = torch.randperm(N, generator=g)[:32].to(dev)
+    s.sample_padded(static_seeds, seed=9)  # warm-up (allocations, library load)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        p = s.sample_padded(static_seeds, seed=9)
+    for trial in range(2):
+        seeds = torch.randperm(N, generator=g)[:32].to(dev)
+        static_seeds.copy_(seeds)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = s.sample_from_nodes(seeds, seed=9)
+        n_new = [int(t) for t in p.n_nodes]
+        n_edge = [int(t) for t in p.n_edges]
+        assert [32] + n_new == want.num_sampled_nodes and n_edge == want.num_sampled_edges
+        node = torch.cat([p.seeds] + [t[:n] for t, n in zip(p.new_nodes, n_new)])
+        assert torch.equal(node, want.node)
+        for name, parts in (('row', p.rows), ('col', p.cols), ('edge', p.edges)):
+            got = torch.cat([t[:n] for t, n in zip(parts, n_edge)])
+            assert torch.equal(got, getattr(want, name)), name
