@@ -40,19 +40,30 @@ from torch import Tensor
 _state: Dict[str, Any] = {'installed': False, 'rebinds': [], 'classes': [], 'forwards': []}
 
 
-def _enabled() -> bool:
+def _flag_on() -> bool:
     import torch_geometric
     flag = getattr(torch_geometric.backend, 'use_mi355x', None)
-    if flag is False:
-        return False
-    if torch.jit.is_scripting():
-        return False
+    return flag is not False and not torch.jit.is_scripting()
+
+
+def _compiling() -> bool:
+    import torch_geometric
     try:
-        if torch_geometric.is_compiling():
-            return False
+        return bool(torch_geometric.is_compiling())
     except Exception:  # pragma: no cover
-        pass
-    return True
+        return False
+
+
+def _enabled() -> bool:
+    """The eager route (autograd Functions over ctypes) — not traceable, so it is only taken
+    outside ``torch.compile``; while compiling, the dispatchers below hand the same kernels over
+    as registered operators (``torch.ops.pyg_amd.*``, :mod:`.ops`) where the call maps onto one,
+    and step aside to the reference otherwise."""
+    return _flag_on() and not _compiling()
+
+
+def _traced() -> bool:
+    return _flag_on() and _compiling()
 
 
 def _ours(t: Any) -> bool:
@@ -68,14 +79,25 @@ def _ours_index(t: Any) -> bool:
 def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
     from . import utils as U
 
+    norm = {'add': 'sum', 'amin': 'min', 'amax': 'max'}
+
     def scatter(src, index, dim=0, dim_size=None, reduce='sum'):
         if _ours(src) and _enabled():
             return U.scatter(src, index, dim, dim_size, reduce)
+        r = norm.get(reduce, reduce)
+        if (_ours(src) and _traced() and dim in (0, -src.dim()) and isinstance(dim_size, int)
+                and index.dim() == 1 and r in ('sum', 'mean', 'min', 'max', 'mul')):
+            from . import ops  # noqa: F401  (registers torch.ops.pyg_amd.*)
+            return torch.ops.pyg_amd.scatter(src, index, dim_size, r)
         return orig['scatter'](src, index, dim, dim_size, reduce)
 
     def segment(src, ptr, reduce='sum'):
         if _ours(src) and ptr.dim() == 1 and _enabled():
             return U.segment(src, ptr, reduce)
+        if (_ours(src) and ptr.dim() == 1 and _traced()
+                and norm.get(reduce, reduce) in ('sum', 'mean', 'min', 'max')):
+            from . import ops  # noqa: F401
+            return torch.ops.pyg_amd.segment_csr(src, ptr, norm.get(reduce, reduce))
         return orig['segment'](src, ptr, reduce)
 
     def segment_logsumexp(src, ptr, dim):
@@ -86,6 +108,10 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
     def softmax(src, index=None, ptr=None, num_nodes=None, dim=0):
         if _ours(src) and _enabled():
             return U.softmax(src, index, ptr, num_nodes, dim)
+        if (_ours(src) and _traced() and ptr is not None and ptr.dim() == 1
+                and dim in (0, -src.dim())):
+            from . import ops  # noqa: F401
+            return torch.ops.pyg_amd.softmax_csr(src, ptr)
         return orig['softmax'](src, index, ptr, num_nodes, dim)
 
     def index_sort(inputs, max_value=None, stable=False):
@@ -95,6 +121,10 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
             # trusts; a too-small one would drop radix passes and mis-sort — so it is ignored
             # here (all key bits are sorted), like torch.sort
             return U.index_sort(inputs, None, stable)
+        if (isinstance(inputs, Tensor) and inputs.is_cuda and inputs.dim() == 1
+                and inputs.dtype in (torch.int32, torch.int64) and _traced()):
+            from . import ops  # noqa: F401
+            return torch.ops.pyg_amd.index_sort(inputs, None)
         return orig['index_sort'](inputs, max_value, stable)
 
     def scatter_argmax(src, index, dim=0, dim_size=None):

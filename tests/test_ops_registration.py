@@ -1,0 +1,55 @@
+"""torch.ops.pyg_amd.* (pytorch_geometric_amd/ops.py, seam S2): the schemas are registered and every
+operator has a FAKE kernel that propagates shapes / dtypes / devices without touching the HIP
+library — checked here under FakeTensorMode with fake 'cuda' tensors, no GPU needed.  The device
+side (opcheck, torch.compile) is tests/test_gpu_compile.py."""
+import pytest
+import torch
+from torch._subclasses.fake_tensor import FakeTensorMode
+
+import pytorch_geometric_amd.ops as ops
+
+
+def test_every_operator_is_registered_with_a_schema():
+    for name in ops.OPS:
+        packet = getattr(torch.ops.pyg_amd, name)
+        schema = str(packet.default._schema)
+        assert schema.startswith(f'pyg_amd::{name}('), schema
+    assert str(torch.ops.pyg_amd.spmm.default._schema) == (
+        'pyg_amd::spmm(Tensor rowptr, Tensor col, Tensor? value, Tensor other, str reduce) '
+        '-> Tensor')
+    assert str(torch.ops.pyg_amd.index_sort.default._schema) == (
+        'pyg_amd::index_sort(Tensor inputs, SymInt? max_value=None) -> (Tensor, Tensor)')
+
+
+def test_fake_kernels_propagate_shapes_without_the_library():
+    with FakeTensorMode():
+        dev = 'cuda'
+        x = torch.empty(50, 3, 8, device=dev, requires_grad=True)
+        idx = torch.empty(50, dtype=torch.int32, device=dev)
+        ptr = torch.empty(13, dtype=torch.int64, device=dev)
+        col = torch.empty(400, dtype=torch.int64, device=dev)
+        val = torch.empty(400, device=dev)
+        w, b = torch.empty(5, 8, device=dev), torch.empty(5, device=dev)
+        O = torch.ops.pyg_amd
+        s, p = O.index_sort(idx, 40)
+        assert s.shape == (50, ) and s.dtype == torch.int32 and p.dtype == torch.int64
+        assert O.index2ptr(idx, 12).shape == (13, ) and O.ptr2index(ptr, 50).shape == (50, )
+        assert O.gather(x, idx).shape == (50, 3, 8)
+        for red in ('sum', 'mean', 'min', 'max', 'mul'):
+            out = O.scatter(x, idx, 12, red)
+            assert out.shape == (12, 3, 8) and out.device.type == 'cuda' and out.requires_grad
+        assert O.segment_csr(x, ptr, 'max').shape == (12, 3, 8)
+        assert O.softmax_csr(x, ptr).shape == x.shape
+        assert O.spmm(ptr, col, val, x[:, 0], 'sum').shape == (12, 8)
+        assert O.spmm(ptr, col, None, x, 'max').shape == (12, 3, 8)
+        assert O.linear(x, w, b).shape == (50, 3, 5)
+        g1, g2, g3 = O.linear_backward(torch.empty(50, 3, 5, device=dev), x, w, True, True, False)
+        assert g1.shape == x.shape and g2.shape == w.shape and g3.numel() == 0
+        go, gv = O.spmm_backward(torch.empty(12, 8, device=dev), ptr, col, val, x[:, 0],
+                                 torch.empty(12, 8, device=dev), 'sum', True, True)
+        assert go.shape == (50, 8) and gv.shape == (400, )
+
+
+def test_there_is_no_cpu_kernel():
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.pyg_amd.scatter(torch.randn(4, 2), torch.tensor([0, 1, 0, 1]), 2, 'sum')
