@@ -239,7 +239,11 @@ class SegmentFunction(Function):
             index = _native.ptr2index(ptr, n)
             # each row belongs to exactly one segment: grad = [src == out[seg]] * g[seg] / ntie[seg]
             o_e = _native.gather_rows(out, index)
-            g_e = _native.gather_rows(g2 / ntie.clamp(min=1), index)
+            # ATen's _segment_reduce backward (the reference's CPU path, utils/_segment.py:48)
+            # averages over the tied extrema ONLY where the incoming gradient is positive
+            # (SegmentReduce.cpp: `if (grad_input > 0) grad_input /= counter`); a negative
+            # gradient reaches every tied element undivided.  Matched as is.
+            g_e = _native.gather_rows(torch.where(g2 > 0, g2 / ntie.clamp(min=1), g2), index)
             grad = torch.where(s2 == o_e, g_e, torch.zeros_like(g_e))
         else:
             (ptr,) = ctx.saved_tensors

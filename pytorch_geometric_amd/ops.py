@@ -180,7 +180,8 @@ def segment_csr_backward(grad: Tensor, src: Tensor, ptr: Tensor, out: Tensor,
         s2, o2 = src.reshape(n, -1), _rows(out)
         ntie = _native.spmm_tie_count(ptr, None, s2, o2, count_self=False)
         o_e = _native.gather_rows(o2, index)
-        g_e = _native.gather_rows(g2 / ntie.clamp(min=1), index)
+        # (ATen averages over ties only where the gradient is positive — see SegmentFunction)
+        g_e = _native.gather_rows(torch.where(g2 > 0, g2 / ntie.clamp(min=1), g2), index)
         res = torch.where(s2 == o_e, g_e, torch.zeros_like(g_e))
     else:
         if reduce == 'mean':

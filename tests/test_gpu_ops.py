@@ -187,6 +187,23 @@ def test_segment_vs_oracle(dev, F):
         assert_close(out32, out.cpu(), rtol=0, atol=0)
 
 
+def test_segment_gradients_with_ties_and_mixed_sign_grads(dev):
+    """min / max over tied extrema: the reference's CPU path (torch._segment_reduce) averages the
+    gradient over the ties ONLY where it is positive (ATen SegmentReduce.cpp), negative gradients
+    reach every tied element undivided — matched as is (found with the torch.ops.pyg_amd tests)."""
+    import pytorch_geometric_amd as pga
+    g = gen(314)
+    lens = torch.randint(0, 25, (120, ), generator=g)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    src = torch.randint(-2, 3, (int(ptr[-1]), 9), generator=g).float()  # many ties
+    go = torch.randn(120, 9, generator=g)                               # both signs
+    for red in ['sum', 'mean', 'min', 'max']:
+        ref, (rg, ) = run_grad(lambda s: O.segment(s, ptr, red), [src], go)
+        out, (gs, ) = run_grad(lambda s: pga.utils.segment(s, ptr.to(dev), red), [src.to(dev)], go)
+        assert_close(out, ref, what=f'segment {red}')
+        assert_close(gs, rg, what=f'segment {red} grad')
+
+
 # ---- softmax ---------------------------------------------------------------------------------------
 def test_softmax_golden(dev, golden):
     import pytorch_geometric_amd as pga
