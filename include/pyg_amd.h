@@ -444,6 +444,23 @@ PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, 
                                    int64_t ldo, void* workspace, size_t workspace_bytes,
                                    void* stream);
 
+/* ---- f3: SAGEConv layer forward in one kernel ----------------------------------------------------
+ * y[i, :] = act([aggr_{j->i} x[j] | x_root[i]] @ w[Fo, 2F]^T + bias) — `propagate` + `lin_l(agg)
+ * + lin_r(x)` of nn/conv/sage_conv.py:134-139 with the aggregated 32-row tile handed from the
+ * gather phase to the MFMA loop through LDS.  `graph` describes the aggregation exactly as for
+ * pygamd_spmm_csr (reduce SUM or MEAN, no edge weights; x / ldx = the rows that are gathered;
+ * out / ldo = the global agg buffer, always required: hub rows are aggregated there first by the
+ * two-stage hub kernels, and with save_agg != 0 every row is stored there once for the weight
+ * gradient).  Supported: F % 4 == 0, F <= 256, Fo <= 256, 16-byte aligned operands (query below);
+ * otherwise PYGAMD_ERR_UNSUPPORTED and the caller runs pygamd_spmm_csr + pygamd_linear_forward.
+ * Workspace: pygamd_spmm_csr_workspace_bytes(graph).                                              */
+PYGAMD_API int pygamd_sage_layer_forward_supported(int64_t F, int64_t Fo, int reduce);
+PYGAMD_API int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root,
+                                         int64_t ld_root, const float* w, int64_t ldw,
+                                         const float* bias, int64_t Fo, int relu, int save_agg,
+                                         float* y, int64_t ldy, void* workspace,
+                                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

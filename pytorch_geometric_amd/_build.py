@@ -16,7 +16,7 @@ LIB_DIR = os.path.join(PKG_DIR, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpyg_amd.so')
 BUILD_DIR = os.path.join(os.path.dirname(PKG_DIR), 'build', 'pyg_amd')
 SOURCES = ['capi.hip', 'graph.hip', 'spmm.hip', 'scatter.hip', 'softmax.hip', 'segmm.hip',
-           'sample.hip', 'gemm.hip']
+           'sample.hip', 'gemm.hip', 'sage_fused.hip']
 ARCH = 'gfx950'
 FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
@@ -61,9 +61,9 @@ def build_library(force=False, verbose=True):
         raise RuntimeError('hipcc not found: cannot build libpyg_amd.so')
     os.makedirs(BUILD_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers_mtime = max(
-        os.path.getmtime(os.path.join(CSRC_DIR, 'common.h')),
-        os.path.getmtime(os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h')))
+    headers = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith('.h')]
+    headers.append(os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h'))
+    headers_mtime = max(os.path.getmtime(h) for h in headers)
 
     def compile_one(src):
         src_path = os.path.join(CSRC_DIR, src)

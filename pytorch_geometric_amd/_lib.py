@@ -67,6 +67,9 @@ SIGNATURES = {
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'pygamd_relu_backward_colsum': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P,
                                             c_int64, _P, _P]),
+    'pygamd_sage_layer_forward_supported': (c_int, [c_int64, c_int64, c_int]),
+    'pygamd_sage_layer_forward': (c_int, [POINTER(SpmmArgs), _P, c_int64, _P, c_int64, _P, c_int64,
+                                          c_int, c_int, _P, c_int64, _P, c_size_t, _P]),
     'pygamd_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                       c_int, c_int, _P, c_int64, _P]),
     'pygamd_linear_dgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,

@@ -541,6 +541,59 @@ def linear_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, relu: bo
     return out
 
 
+def sage_layer_forward_supported(F: int, Fo: int, reduce: str) -> bool:
+    return bool(_lib.load().pygamd_sage_layer_forward_supported(F, Fo, REDUCE_IDS[reduce]))
+
+
+def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Tensor, w: Tensor,
+                       bias: Optional[Tensor], reduce: str, relu: bool, agg: Tensor, out: Tensor,
+                       hub=None, save_agg: bool = True, hub_threshold: int = None,
+                       hub_chunk: int = None) -> Tensor:
+    """``out = act([aggr(x_gather) | x_root] @ w.T + bias)`` in ONE kernel (csrc/sage_fused.hip);
+    ``agg`` ([n_rows, F] view, may be a half of a wider buffer) receives the aggregated rows when
+    ``save_agg`` (hub rows always)."""
+    _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out)
+    lib = _lib.load()
+    xg, xr, w2 = _f32_rows(x_gather, 'x'), _f32_rows(x_root, 'x_root'), _f32_rows(w, 'weight')
+    n_rows, F, Fo = rowptr.numel() - 1, xg.size(1), w2.size(0)
+    if xr.shape != (n_rows, F) or w2.size(1) != 2 * F or agg.shape != (n_rows, F) \
+            or out.shape != (n_rows, Fo):
+        raise ValueError('shape mismatch in sage_layer_forward')
+    a = SpmmArgs()
+    a.rowptr, a.col = rowptr.data_ptr(), col.data_ptr()
+    a.x, a.out = xg.data_ptr(), agg.data_ptr()
+    a.n_rows, a.n_src, a.F = n_rows, xg.size(0), F
+    a.ldx, a.ldo = _ld(xg), _ld(agg)
+    a.idx_dtype, a.reduce = _idx_dtype(rowptr), REDUCE_IDS[reduce]
+    a.w_heads, a.head_dim = 1, F
+    ws, ws_bytes = None, 0
+    if hub is not None and hub[2] > 0:
+        hub_rows, hub_cptr, n_hub, n_chunks = hub
+        a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), hub_cptr.data_ptr()
+        a.n_hub, a.n_chunks = n_hub, n_chunks
+        a.hub_threshold = HUB_THRESHOLD if hub_threshold is None else hub_threshold
+        a.hub_chunk = HUB_CHUNK if hub_chunk is None else hub_chunk
+        ws_bytes = n_chunks * F * 4
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xg.device)
+    if bias is not None:
+        bias = bias.contiguous()
+    sink = timing_sink
+    if sink is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(xg.device))
+    check(lib.pygamd_sage_layer_forward(ctypes.byref(a), _p(xr), _ld(xr), _p(w2), _ld(w2),
+                                        _p(bias), Fo, int(relu), int(save_agg), _p(out),
+                                        _ld(out), _p(ws), ws_bytes, _stream(xg)),
+          'sage_layer_forward')
+    if sink is not None:
+        ev1.record(torch.cuda.current_stream(xg.device))
+        sink.append(({'n_rows': n_rows, 'n_src': xg.size(0), 'nnz': col.numel(), 'F': F,
+                      'reduce': reduce, 'idx_bytes': rowptr.element_size(), 'weighted': False,
+                      'src_scale': False, 'accumulate': False, 'n_hub': a.n_hub,
+                      'fused_gemm': {'Fo': Fo, 'K': 2 * F}}, ev0, ev1))
+    return out
+
+
 def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_scaled: int = 0,
                  out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     """``g [M, N] @ w [N, K]`` with the weight handed over transposed (``w_t [K, N]``); columns

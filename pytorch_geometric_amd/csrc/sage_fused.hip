@@ -1,0 +1,327 @@
+// sage_fused.hip — one SAGEConv layer forward in ONE kernel:
+//
+//   out[i, :] = act( [ aggr_{j -> i} x[j]  |  x_root[i] ] @ [W_l | W_r]^T + b )
+//
+// i.e. `propagate` (gather -> mean/sum) and `lin_l(agg) + lin_r(x)` + bias (+ ReLU) of
+// torch_geometric/nn/conv/sage_conv.py:134-139.  The aggregated tile never makes the HBM round
+// trip between an SpMM launch and a GEMM launch: it is produced into LDS by the gather phase and
+// consumed from there by the MFMA loop (it is additionally stored once, write-only, when the
+// caller needs it for the weight gradient).  And because the gather phase is HBM-bound while the
+// transform is MFMA-bound, two workgroups per CU in different phases overlap the two.
+//
+// Workgroup = 512 threads (8 waves), one tile of 32 destination rows, two workgroups per CU:
+//   phase 1  the tile's own (root) rows are copied to LDS; every wave then takes the next row of
+//            the tile from an LDS counter and aggregates it with the SpMM's row loop (slot indices
+//            staged 64 at a time, LPR lanes x 16 bytes per source row, 8 row loads in flight),
+//            leaving the (mean-scaled) row in the LDS tile `agg[32][F_pad + 4]`.  Rows longer than
+//            the hub threshold are NOT gathered here: the host runs the two-stage hub kernels
+//            first and this kernel copies their result from the global `agg` buffer.
+//   phase 2  out tile [32 x Fo] = A [32 x 2F] @ B^T with A = [agg | root rows] (both in LDS), B =
+//            the concatenated weight [Fo x 2F]; wave w owns output columns [32 w, 32 w + 32)
+//            (Fo <= 256) and one 32 x 32 accumulator; K is walked in chunks of 32 with the
+//            fragment layout "16 consecutive floats per lane" (k = s + 16 h, see gemm.hip), which
+//            doubles as a coalesced global access: the weight fragments go global -> registers
+//            one chunk ahead (every weight byte once per workgroup, L2-resident); no staging and
+//            no barrier after the one that closes phase 1; v_mfma_f32_32x32x2_f32.
+//   epilogue bias, optional ReLU, 128-byte row segments to `out` (leading dimension given).
+// LDS: 2 x 33.3 KB (aggregated + root tile, F = 256) -> 2 workgroups per CU: while one gathers
+// (HBM-bound) the other transforms (MFMA-bound).
+// Measured at the products shape (scripts/fused_probe.py; SpMM + GEMM as two launches: 17.3 ms at
+// F = 256, 7.4 ms at F = 100): this kernel 14.7 / 7.2 ms; weight chunks staged through LDS with
+// two barriers per chunk 14.3 / 7.7 ms; root-half fragments fetched from global memory by every
+// wave 15.7 ms (L1-bound); ONE persistent 1024-thread workgroup per CU with 12 gather waves
+// feeding 4 MFMA waves through two LDS buffers 16.0 / 9.6 ms (a barrier per tile drains the memory
+// pipeline; lowering the hub threshold to 128 changed nothing) — not adopted.
+#include "spmm_device.h"
+
+namespace pygamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFTile = 32;    // destination rows per workgroup
+constexpr int kFBlock = 512;  // threads per workgroup
+constexpr int kFWaves = kFBlock / kWave;
+constexpr int kFK = 32;       // k chunk
+constexpr int kFLD = kFK + 4; // row stride of the staged chunks
+constexpr int kFMaxFo = 256;  // one 32-column block per wave
+
+template <typename IdxT>
+struct SageFusedArgs {
+  SpmmDev<IdxT> g;              // graph + gather source (x, ldx) + global agg buffer (out, ldo)
+  const float* __restrict__ x_root;  // [n_rows, F]
+  int64_t ld_root;
+  const float* __restrict__ w;       // [Fo, 2F]
+  int64_t ldw;
+  const float* __restrict__ bias;    // [Fo] or null
+  float* __restrict__ y;             // [n_rows, Fo]
+  int64_t ldy;
+  int Fo, relu, save_agg;
+  int f_pad;                         // F rounded up to a multiple of 32
+};
+
+// aggregated row -> LDS tile (+ global agg buffer); lanes < LPR hold VW features per CH
+template <typename IdxT, int VW, int LPR>
+__device__ __forceinline__ void fused_gather_row(const SageFusedArgs<IdxT>& a, int64_t row,
+                                                 float* __restrict__ agg_row, int lane) {
+  constexpr int CH = 1;
+  int fo[CH], head[CH];
+  bool fv[CH];
+  const int lir = lane % LPR;
+  fo[0] = lir * VW;
+  fv[0] = fo[0] < a.g.F;
+  head[0] = 0;
+  float acc[CH][VW];
+#pragma unroll
+  for (int i = 0; i < VW; ++i) acc[0][i] = 0.f;
+  IdxT start = 0, end = 0;
+  if (row < a.g.n_rows) {
+    start = a.g.rowptr[row];
+    end = a.g.rowptr[row + 1];
+  }
+  const IdxT deg = end - start;
+  const bool hub = a.g.hub_threshold > 0 && deg > a.g.hub_threshold;
+  if (hub) {  // aggregated by the two-stage hub kernels before this launch
+    if (lane < LPR && fv[0]) {
+      const Vec<VW> v = load_vec<VW>(a.g.out + row * a.g.ldo + fo[0]);
+      store_vec<VW>(agg_row + fo[0], v);
+    }
+    return;
+  }
+  spmm_accumulate<IdxT, VW, LPR, CH, 0, false>(a.g, start, end, lane, fo, fv, head, acc);
+  combine_subgroups<VW, LPR, CH>(acc);
+  if (lane < LPR && fv[0]) {
+    const float cntf = static_cast<float>(deg > 0 ? deg : 1);
+    Vec<VW> o;
+#pragma unroll
+    for (int i = 0; i < VW; ++i) o.v[i] = a.g.mean ? acc[0][i] / cntf : acc[0][i];
+    store_vec<VW>(agg_row + fo[0], o);
+    if (a.save_agg && row < a.g.n_rows) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i)
+        __builtin_nontemporal_store(o.v[i], a.g.out + row * a.g.ldo + fo[0] + i);
+    }
+  }
+}
+
+template <typename IdxT, int LPR>
+__global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArgs<IdxT> a) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ int next_row;
+  const int agg_ld = a.f_pad + 4;
+  float* agg = smem;                    // [32][f_pad + 4]  aggregated rows
+  float* xr = smem + kFTile * agg_ld;   // [32][f_pad + 4]  root rows of the tile
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t tile = xcd_logical_block();
+  const int64_t row0 = tile * kFTile;
+  if (row0 >= a.g.n_rows) return;
+  const int F = static_cast<int>(a.g.F);
+
+  // ---- phase 1: the aggregated tile and the tile's own (root) rows -> LDS.  Padding columns
+  // [F, f_pad) are zeroed once.
+  if (threadIdx.x == 0) next_row = 0;
+  if (a.f_pad > F) {
+    const int padw = a.f_pad - F;
+    for (int t = threadIdx.x; t < 2 * kFTile * padw; t += kFBlock) {
+      const int r = t / padw;
+      smem[r * agg_ld + F + (t - r * padw)] = 0.f;
+    }
+  }
+  {
+    const int units = F / 4;  // 16-byte pieces per row
+    for (int t = threadIdx.x; t < kFTile * units; t += kFBlock) {
+      const int r = t / units;
+      const int u = t - r * units;
+      int64_t rr = row0 + r;
+      rr = rr < a.g.n_rows ? rr : a.g.n_rows - 1;
+      *reinterpret_cast<f32x4*>(xr + r * agg_ld + 4 * u) =
+          *reinterpret_cast<const f32x4*>(a.x_root + rr * a.ld_root + 4 * u);
+    }
+  }
+  __syncthreads();  // next_row armed
+  for (;;) {  // rows are handed out one by one: long and short rows balance over the 8 waves
+    int r = 0;
+    if (lane == 0) r = atomicAdd(&next_row, 1);
+    r = __builtin_amdgcn_readfirstlane(r);
+    if (r >= kFTile) break;
+    fused_gather_row<IdxT, 4, LPR>(a, row0 + r, agg + r * agg_ld, lane);
+  }
+
+  // ---- phase 2: [32 x Fo] = [agg | x_root] @ w^T.  No staging and no barrier: wave w owns the
+  // output columns [32 w, 32 w + 32), so of every weight chunk it needs exactly its own 32 rows x
+  // 32 k — and the MFMA operand layout (lane (j, h): 16 consecutive k of row j) IS a coalesced
+  // global access pattern (a wave reads 32 full 128-byte lines).  The weight fragments therefore
+  // go global -> registers directly, one chunk ahead of the MFMAs (every weight byte once per
+  // workgroup); both halves of A come from the LDS tiles.
+  __syncthreads();  // phase 1 complete: both tiles visible to every wave
+  const int wave_col0 = wave * 32;
+  if (wave_col0 >= a.Fo) return;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n_half = a.f_pad / kFK;  // chunks per half (aggregated / root)
+  const int n_chunks = 2 * n_half;
+  const int col = wave_col0 + li;
+  const bool col_ok = col < a.Fo;
+  const float* __restrict__ wrow = a.w + static_cast<int64_t>(col_ok ? col : a.Fo - 1) * a.ldw;
+  const float* agg_row = agg + li * agg_ld + 16 * lh;
+  const float* xr_row = xr + li * agg_ld + 16 * lh;
+  f32x4 fb[4], fa[4], nb[4];
+  // weight fragments of chunk c: k = (chunk base) + 16 lh + 4 v + e; columns past F are clamped
+  // to a valid address here and zeroed right before use
+  auto load_b = [&](int c, f32x4 (&dst)[4]) {
+    const bool root = c >= n_half;
+    const int kl = (root ? c - n_half : c) * kFK + 16 * lh;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = kl + 4 * v;
+      dst[v] = *reinterpret_cast<const f32x4*>(wrow + (root ? F : 0) + (k < F ? k : 0));
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  load_b(0, nb);
+  for (int c = 0; c < n_chunks; ++c) {
+    const bool root = c >= n_half;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) fb[v] = nb[v];
+    if (c + 1 < n_chunks) load_b(c + 1, nb);
+    const int base = (root ? c - n_half : c) * kFK;
+    const float* ap = (root ? xr_row : agg_row) + base;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) fa[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
+    const int rem = F - base;  // > 0: valid k of this chunk (multiple of 4)
+    if (rem < kFK || !col_ok) {  // boundary chunk / padding column: zero B past F (the LDS
+      const int kl = base + 16 * lh;  // tiles are zero there already)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          fb[v][e] = (col_ok && (kl + 4 * v + e < F)) ? fb[v][e] : 0.f;
+    }
+    // a tail shorter than 16 leaves the upper lane half all zero: only `rem` steps carry data
+    const int groups = rem >= 16 ? 4 : rem / 4;  // wave-uniform
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (v < groups) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[v][e], fb[v][e], acc, 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
+  if (!col_ok) return;
+  const float bv = a.bias ? a.bias[col] : 0.f;
+  const float floor_v = a.relu ? 0.f : -INFINITY;
+  float* yp = a.y + (row0 + 4 * lh) * a.ldy + col;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int roff = (e & 3) + 8 * (e >> 2);
+    if (row0 + 4 * lh + roff < a.g.n_rows) yp[roff * a.ldy] = fmaxf(acc[e] + bv, floor_v);
+  }
+}
+
+static bool aligned16f(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename IdxT, int LPR>
+static int launch_fused(const SageFusedArgs<IdxT>& a, hipStream_t st) {
+  const size_t lds = sizeof(float) * 2 * kFTile * (a.f_pad + 4);
+  auto k = sage_fused_fwd_kernel<IdxT, LPR>;
+  PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+  const int64_t tiles = ceil_div(a.g.n_rows, kFTile);
+  const unsigned grid = static_cast<unsigned>(round_up(tiles, 8));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kFBlock), lds, st, a);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
+}  // namespace pygamd
+
+using namespace pygamd;
+
+extern "C" {
+
+int pygamd_sage_layer_forward_supported(int64_t F, int64_t Fo, int reduce) {
+  return (F > 0 && F % 4 == 0 && F <= 256 && Fo > 0 && Fo <= kFMaxFo &&
+          (reduce == PYGAMD_SUM || reduce == PYGAMD_MEAN))
+             ? 1
+             : 0;
+}
+
+int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root,
+                              int64_t ld_root, const float* w, int64_t ldw, const float* bias,
+                              int64_t Fo, int relu, int save_agg, float* y, int64_t ldy,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (!graph) return PYGAMD_ERR_INVALID_ARG;
+  const int64_t F = graph->F;
+  if (graph->n_rows < 0 || F < 0 || Fo < 0 || graph->ldx < F || graph->ldo < F ||
+      ld_root < F || ldw < 2 * F || ldy < Fo)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (!pygamd_sage_layer_forward_supported(F, Fo, graph->reduce) || graph->w ||
+      graph->src_scale || graph->eid || graph->accumulate || !graph->col)
+    return PYGAMD_ERR_UNSUPPORTED;
+  if (graph->n_rows == 0) return PYGAMD_OK;
+  if (!graph->rowptr || !graph->x || !graph->out || !x_root || !w || !y)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (graph->idx_dtype != PYGAMD_IDX_I32 && graph->idx_dtype != PYGAMD_IDX_I64)
+    return PYGAMD_ERR_INVALID_ARG;
+  // 16-byte accesses everywhere
+  if ((graph->ldx % 4) || (graph->ldo % 4) || (ld_root % 4) || (ldw % 4) ||
+      !aligned16f(graph->x) || !aligned16f(graph->out) || !aligned16f(x_root) || !aligned16f(w))
+    return PYGAMD_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  // hub rows first (two-stage, deterministic) into the global agg buffer; the fused kernel copies
+  // them from there
+  if (graph->n_hub > 0) {
+    pygamd_spmm_args hubs = *graph;
+    hubs.hub_phase = 2;
+    const int rc = pygamd_spmm_csr(&hubs, workspace, workspace_bytes, stream);
+    if (rc != PYGAMD_OK) return rc;
+  }
+  int lpr = 4;
+  while (lpr < 64 && lpr * 4 < F) lpr <<= 1;
+  return PYGAMD_DISPATCH_IDX(graph->idx_dtype, [&]() -> int {
+    SageFusedArgs<IdxT> a;
+    a.g.rowptr = static_cast<const IdxT*>(graph->rowptr);
+    a.g.col = static_cast<const IdxT*>(graph->col);
+    a.g.eid = nullptr;
+    a.g.w = nullptr;
+    a.g.src_scale = nullptr;
+    a.g.x = graph->x;
+    a.g.out = graph->out;
+    a.g.arg_out = nullptr;
+    a.g.n_rows = graph->n_rows;
+    a.g.F = F;
+    a.g.ldx = graph->ldx;
+    a.g.ldo = graph->ldo;
+    a.g.w_heads = 1;
+    a.g.head_dim = static_cast<int>(F);
+    a.g.mean = (graph->reduce == PYGAMD_MEAN);
+    a.g.accumulate = 0;
+    a.g.hub_threshold = graph->n_hub > 0 ? graph->hub_threshold : 0;
+    a.x_root = x_root;
+    a.ld_root = ld_root;
+    a.w = w;
+    a.ldw = ldw;
+    a.bias = bias;
+    a.y = y;
+    a.ldy = ldy;
+    a.Fo = static_cast<int>(Fo);
+    a.relu = relu ? 1 : 0;
+    a.save_agg = save_agg ? 1 : 0;
+    a.f_pad = static_cast<int>(round_up(F, kFK));
+    switch (lpr) {
+      case 4: return launch_fused<IdxT, 4>(a, st);
+      case 8: return launch_fused<IdxT, 8>(a, st);
+      case 16: return launch_fused<IdxT, 16>(a, st);
+      case 32: return launch_fused<IdxT, 32>(a, st);
+      default: return launch_fused<IdxT, 64>(a, st);
+    }
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// spmm_device.h — device-side building blocks of the CSR aggregation shared by spmm.hip (the
+// stand-alone SpMM family) and sage_fused.hip (aggregation fused with the feature transform):
+// the argument block, the per-lane feature slots, and the slot-staged, U-loads-in-flight row
+// accumulation loop.  See spmm.hip for the mapping.
+#pragma once
+#include "common.h"
+
+namespace pygamd {
+
+template <typename IdxT>
+struct SpmmDev {
+  const IdxT* __restrict__ rowptr;
+  const IdxT* __restrict__ col;
+  const IdxT* __restrict__ eid;
+  const float* __restrict__ w;
+  const float* __restrict__ src_scale;
+  const float* __restrict__ x;
+  float* __restrict__ out;
+  IdxT* __restrict__ arg_out;
+  int64_t n_rows, F, ldx, ldo;
+  int w_heads, head_dim;
+  int mean;
+  int accumulate;  // out[i] += result instead of out[i] = result
+  int64_t hub_threshold;
+};
+
+// Independent row loads issued per lane before the first add.  A staged index chunk holds 64
+// slots, so EPI * U never needs to exceed 64 (U <= LPR).
+template <int LPR, int CH>
+constexpr int spmm_unroll() {
+  return CH == 1 ? (LPR < 8 ? LPR : 8) : 4;
+}
+
+// WMODE: 0 = plain sum; 1 = one staged multiplier per slot (w with one head and/or src_scale);
+//        2 = per-head weights fetched per slot (+ optional staged src_scale).
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, bool FULL>
+__device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cnt, int sub,
+                                           IdxT myc, IdxT mye, float mym, const int (&fo)[CH],
+                                           const bool (&fv)[CH], const int (&head)[CH],
+                                           float (&acc)[CH][VW]) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = spmm_unroll<LPR, CH>();
+  Vec<VW> v[U][CH];
+  float m[U];
+  float wv[U][CH];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = j + u * EPI + sub;
+    const bool valid = FULL || (k < cnt);
+    const int kk = FULL ? k : (k < cnt ? k : cnt - 1);
+    IdxT c;
+    if constexpr (EPI == 1) {
+      c = bcast_uniform(myc, kk);
+    } else {
+      c = bcast_lane(myc, kk);
+    }
+    if constexpr (WMODE != 0) {
+      float mm;
+      if constexpr (EPI == 1) {
+        mm = bcast_uniform(mym, kk);
+      } else {
+        mm = bcast_lane(mym, kk);
+      }
+      m[u] = valid ? mm : 0.f;
+    } else {
+      m[u] = 1.f;
+    }
+    const float* __restrict__ xr = a.x + static_cast<int64_t>(c) * a.ldx;
+    if constexpr (WMODE == 2) {
+      IdxT e;
+      if constexpr (EPI == 1) {
+        e = bcast_uniform(mye, kk);
+      } else {
+        e = bcast_lane(mye, kk);
+      }
+      const float* __restrict__ wr = a.w + static_cast<int64_t>(e) * a.w_heads;
+#pragma unroll
+      for (int c2 = 0; c2 < CH; ++c2) wv[u][c2] = fv[c2] ? wr[head[c2]] : 0.f;
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < CH; ++c2) {
+      if (fv[c2] && valid) {
+        v[u][c2] = load_vec<VW>(xr + fo[c2]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VW; ++i) v[u][c2].v[i] = 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int c2 = 0; c2 < CH; ++c2) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) {
+        if constexpr (WMODE == 0) {
+          acc[c2][i] += v[u][c2].v[i];
+        } else if constexpr (WMODE == 1) {
+          acc[c2][i] = fmaf(v[u][c2].v[i], m[u], acc[c2][i]);
+        } else {
+          acc[c2][i] = fmaf(v[u][c2].v[i], m[u] * wv[u][c2], acc[c2][i]);
+        }
+      }
+    }
+  }
+}
+
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
+__device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT start, IdxT end,
+                                                int lane, const int (&fo)[CH],
+                                                const bool (&fv)[CH], const int (&head)[CH],
+                                                float (&acc)[CH][VW]) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = spmm_unroll<LPR, CH>();
+  constexpr int STEP = EPI * U;
+  const int sub = lane / LPR;
+  for (IdxT base = start; base < end; base += kWave) {
+    const IdxT rem = end - base;
+    const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+    IdxT myc = 0, mye = 0;
+    float mym = 1.f;
+    if (lane < cnt) {
+      const IdxT k = base + lane;
+      if constexpr (IDENT) {
+        myc = k;
+      } else {
+        myc = __builtin_nontemporal_load(&a.col[k]);  // streamed once: keep L2 for feature rows
+      }
+      if constexpr (WMODE != 0) {
+        mye = a.eid ? a.eid[k] : k;
+        if (a.src_scale) mym = a.src_scale[myc];
+        if constexpr (WMODE == 1) {
+          if (a.w) mym *= a.w[mye];
+        }
+      }
+    }
+    int j = 0;
+    for (; j + STEP <= cnt; j += STEP) {
+      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, true>(a, j, cnt, sub, myc, mye, mym, fo, fv,
+                                                        head, acc);
+    }
+    if (j < cnt) {
+      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, false>(a, j, cnt, sub, myc, mye, mym, fo, fv,
+                                                         head, acc);
+    }
+  }
+}
+
+template <int VW, int LPR, int CH>
+__device__ __forceinline__ void feature_slots(int lane, int64_t F, int head_dim, int (&fo)[CH],
+                                              bool (&fv)[CH], int (&head)[CH]) {
+  const int lir = lane % LPR;
+  const int f0 = blockIdx.y * (LPR * CH * VW);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    fo[c] = f0 + (lir + LPR * c) * VW;
+    fv[c] = fo[c] < F;
+    head[c] = fv[c] ? fo[c] / head_dim : 0;
+  }
+}
+
+template <int VW, int LPR, int CH>
+__device__ __forceinline__ void combine_subgroups(float (&acc)[CH][VW]) {
+#pragma unroll
+  for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) acc[c][i] += __shfl_xor(acc[c][i], off, kWave);
+    }
+  }
+}
+
+}  // namespace pygamd

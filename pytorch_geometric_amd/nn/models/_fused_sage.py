@@ -42,6 +42,10 @@ from ...edge_index import EdgeIndex
 RELU_EPILOGUE = os.environ.get('PYGAMD_RELU_EPILOGUE', '1') != '0'
 # 'own' = csrc/gemm.hip (default), 'lib' = torch.mm (rocBLAS / hipBLASLt)
 GEMM_BACKEND = os.environ.get('PYGAMD_GEMM', 'own')
+# aggregation and transform of a 'post' layer in ONE kernel (csrc/sage_fused.hip: the aggregated
+# tile goes from the gather phase to the MFMA loop through LDS); PYGAMD_FUSE_LAYER=0 runs the SpMM
+# and the GEMM as two launches
+FUSE_LAYER = os.environ.get('PYGAMD_FUSE_LAYER', '1') != '0'
 
 
 def _pad4(n: int) -> int:
@@ -94,11 +98,23 @@ class FusedSageStack(Function):
                 nbuf, dst = new_input(layer + 1)
             if modes[layer] == 'post':
                 src = agg_src0 if (layer == 0 and agg_src0 is not None) else inp
-                _native.spmm_csr(fwd.ptr, fwd.idx, src, aggr, n_rows=N, hub=fwd.hub,
-                                 out=buf[:, :Fi])
                 wmat = torch.cat([W_l, W_r], dim=1)  # [Fo, 2 Fi]
                 relu_done = False
-                if GEMM_BACKEND == 'own':
+                one_kernel = (FUSE_LAYER and GEMM_BACKEND == 'own'
+                              and _native.sage_layer_forward_supported(Fi, Fo, aggr)
+                              and src.stride(0) % 4 == 0 and buf.stride(0) % 4 == 0)
+                if one_kernel:
+                    # the aggregated rows are stored once (write-only) for the weight gradient
+                    _native.sage_layer_forward(fwd.ptr, fwd.idx, src, buf[:, Fi:], wmat, b, aggr,
+                                               not last, buf[:, :Fi], dst, hub=fwd.hub,
+                                               save_agg=True)
+                    relu_done = True
+                else:
+                    _native.spmm_csr(fwd.ptr, fwd.idx, src, aggr, n_rows=N, hub=fwd.hub,
+                                     out=buf[:, :Fi])
+                if one_kernel:
+                    pass
+                elif GEMM_BACKEND == 'own':
                     _native.linear_forward(buf, wmat, b, relu=not last, out=dst)
                     relu_done = True
                 elif b is not None and not last and RELU_EPILOGUE:

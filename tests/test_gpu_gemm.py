@@ -105,3 +105,51 @@ def test_wgrad_long_reduction_is_deterministic_and_accurate(dev):
     acc = torch.ones(N, K, device=dev)
     _native.linear_wgrad(go.to(dev), x.to(dev), out=acc, accumulate=True)
     assert_sum_close(acc - 1, go.t() @ x, ex, abs_sum=bound + 1, what='wgrad accumulate')
+
+
+@pytest.mark.parametrize('F,Fo,reduce', [(256, 256, 'mean'), (100, 256, 'mean'), (64, 200, 'sum'),
+                                         (8, 47, 'mean'), (128, 32, 'sum')])
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_sage_layer_forward_one_kernel(dev, F, Fo, reduce, dtype):
+    """csrc/sage_fused.hip: aggregation + transform + bias + ReLU of a SAGEConv layer in one
+    kernel against the oracle's sage_conv (index_select + scatter + two matmuls), with hub rows,
+    empty rows, a row count that is no multiple of the 32-row tile, and strided operands (the
+    `[agg | x]` buffer layout); the saved aggregated rows are checked too."""
+    import pytorch_geometric_amd as pga
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd import _native
+    from tests._util import random_graph
+    n = 1037
+    g = gen(F * 3 + Fo)
+    ei = random_graph(n, n, 30000, seed=F + Fo, skew=True)   # a few hub destinations
+    ei[1][ei[1] == 5] = 6                                      # row 5 has no in-edges
+    x = torch.randn(n, F, generator=g)
+    wl, wr = torch.randn(Fo, F, generator=g) * 0.1, torch.randn(Fo, F, generator=g) * 0.1
+    b = torch.randn(Fo, generator=g)
+    aggr_ref = O.spmm(ei, x, n, reduce)
+    ref = (aggr_ref @ wl.t() + x @ wr.t() + b).relu()
+    ex = (aggr_ref.double() @ wl.double().t() + x.double() @ wr.double().t() + b.double()).relu()
+    # rounding scales with the sum of |terms|: hub rows aggregate thousands of |x_j|
+    aggr_abs = O.spmm(ei, x.abs(), n, reduce).double()
+    bound = aggr_abs @ wl.abs().double().t() + x.abs().double() @ wr.abs().double().t()
+    h = pga.EdgeIndex(ei.to(dtype).to(dev), (n, n))
+    fwd = h.by_dst()
+    assert fwd.hub[2] > 0
+    buf = torch.full((n, 2 * F), float('nan'), device=dev)
+    buf[:, F:] = x.to(dev)
+    out = torch.full((n, Fo + 8), float('nan'), device=dev)
+    wcat = torch.cat([wl, wr], 1).to(dev)
+    assert _native.sage_layer_forward_supported(F, Fo, reduce)
+    _native.sage_layer_forward(fwd.ptr, fwd.idx, x.to(dev), buf[:, F:], wcat, b.to(dev), reduce,
+                               True, buf[:, :F], out[:, :Fo], hub=fwd.hub, save_agg=True)
+    assert_sum_close(out[:, :Fo], ref, ex, abs_sum=bound + 1, what=f'fused layer F={F} Fo={Fo}')
+    assert bool(torch.isnan(out[:, Fo:]).all())               # nothing written past Fo
+    assert_sum_close(buf[:, :F], aggr_ref, O.spmm(ei, x.double(), n, reduce),
+                     what='saved aggregated rows')
+    # without ReLU / bias, gathering from the strided half of the buffer itself
+    out2 = torch.empty(n, Fo, device=dev)
+    _native.sage_layer_forward(fwd.ptr, fwd.idx, buf[:, F:], buf[:, F:], wcat, None, reduce, False,
+                               buf[:, :F], out2, hub=fwd.hub, save_agg=False)
+    ref2 = aggr_ref @ wl.t() + x @ wr.t()
+    ex2 = aggr_ref.double() @ wl.double().t() + x.double() @ wr.double().t()
+    assert_sum_close(out2, ref2, ex2, abs_sum=bound + 1, what='fused layer, no bias / relu')
