@@ -492,9 +492,10 @@ def main():
 
     # ---- roofline of the dominant kernel: the CSR SpMM at F = 256 (2 of the 5 SpMM launches per
     # step — layer 2 forward and its transposed backward; layer 3 is re-ordered to width 48) ----
-    groups = {}
+    groups, fused = {}, {}
     for info, ev0, ev1 in sink:
-        groups.setdefault(info['F'], []).append((info, ev0.elapsed_time(ev1)))
+        dst = fused if info.get('fused_gemm') else groups
+        dst.setdefault(info['F'], []).append((info, ev0.elapsed_time(ev1)))
     dom_F = 256 if 256 in groups else max(groups)
     dom = groups[dom_F]
     avg_ms = sum(ms for _, ms in dom) / len(dom)
@@ -506,13 +507,35 @@ def main():
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(args, N, E, dom_F),
         'traffic_source': 'profiles/ PMC passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE per '
                           'launch, collected by scripts/gpu_pmc_script.sh), not a live counter',
-        'kernel': f'spmm_sum_rows<F={dom_F}> (pygamd_spmm_csr, fwd mean + transposed bwd)',
+        'kernel': f'spmm_sum_rows<F={dom_F}> (pygamd_spmm_csr: the stand-alone CSR aggregation; '
+                  f'with the layer forward fused into one kernel these launches are the '
+                  f'transposed, accumulating backward)',
         'launches_timed': len(dom), 'avg_launch_ms': round(avg_ms, 4),
         'algorithmic_bytes_per_launch': alg_bytes,
         'all_spmm_ms_per_step': round(spmm_ms_per_step, 3),
         'per_width_avg_ms': {str(k): round(sum(ms for _, ms in v) / len(v), 4)
                              for k, v in sorted(groups.items())},
     }
+    if fused:
+        # the one-kernel layer forward (csrc/sage_fused.hip) is bound by BOTH rooflines at once:
+        # its gather phase by HBM, its transform phase by the fp32 matrix cores
+        fl = {}
+        for Fw, items in sorted(fused.items()):
+            ms = sum(t for _, t in items) / len(items)
+            i0 = items[0][0]
+            Fo, K = i0['fused_gemm']['Fo'], i0['fused_gemm']['K']
+            # gather + rowptr/col + root rows read + aggregated rows written once + output written
+            byts = (spmm_algorithmic_bytes(i0) + i0['n_rows'] * 4 * Fw + i0['n_rows'] * 4 * Fo)
+            flops = 2.0 * i0['n_rows'] * K * Fo
+            fl[str(Fw)] = {'avg_launch_ms': round(ms, 4), 'launches_timed': len(items),
+                           'hbm_algorithmic_bytes': byts,
+                           'hbm_GBps': round(byts / (ms * 1e-3) / 1e9, 1),
+                           'hbm_frac': round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           'mfma_TFLOPs': round(flops / (ms * 1e-3) / 1e12, 1),
+                           'mfma_frac_of_157.3': round(flops / (ms * 1e-3) / 1e12 / 157.3, 4)}
+        roofline['fused_layer_forward'] = {
+            'kernel': 'sage_fused_fwd_kernel (pygamd_sage_layer_forward: aggregation + '
+                      '[agg|x] @ W^T + bias + ReLU)', 'per_width': fl}
 
     if rank == 0:
         result = {
@@ -531,7 +554,8 @@ def main():
                 'graph_gen_s': round(t_gen, 1),
                 'gemm': gemm_desc(tuned),
                 'schedule': 'fused stack: [agg|x] single GEMM per layer; 256->47 layer '
-                            'transforms first and aggregates at width 48; ReLU backward '
+                            'transforms first and aggregates at width 48; layers 1-2 forward '
+                            'as ONE kernel each (aggregation -> LDS -> MFMA); ReLU backward '
                             'fused with the bias column sum; the mean\'s 1/deg of the backward '
                             'applied in the dgrad GEMM epilogue',
             },

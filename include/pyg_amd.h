@@ -169,6 +169,13 @@ typedef struct {
   int32_t accumulate;        /* SUM/MEAN only: out += result (fused "x_root + aggregate") */
   int32_t hub_phase;         /* 0: rows + hubs; 1: non-hub rows only; 2: hub rows only (lets a
                                 caller run row ranges as separate launches and the hubs once)  */
+  int32_t* arg32_out;        /* MIN/MAX only, [n_rows, F] contiguous or NULL: per output the slot
+                                OFFSET inside its row of the attaining neighbour (>= 0) when it
+                                is the unique extremum; -1 for an empty row; -2 when the
+                                gradient must be split (ties, or an extremum of exactly 0, which
+                                ties with the zero-initialised output of the reference's
+                                scatter_reduce_).  What pygamd_spmm_csr_minmax_backward_arg
+                                consumes.                                                       */
 } pygamd_spmm_args;
 
 PYGAMD_API int pygamd_spmm_csr_workspace_bytes(const pygamd_spmm_args* args, size_t* bytes);
@@ -207,6 +214,19 @@ PYGAMD_API int pygamd_spmm_csr_minmax_backward_dst(const void* rowptr, const voi
                                                    int64_t n_rows, int64_t n_src, int64_t F,
                                                    int count_self, float* grad_x, int64_t ldg,
                                                    void* stream);
+/* The fast path of the same gradient with the forward's saved `arg32` (pygamd_spmm_args.arg32_out):
+ * every output whose extremum is unique sends its whole gradient to ONE source row with one fp32
+ * atomic (no edge pass at all: arg32 and grad_out are read once, col is looked up inside the
+ * row's slot range); outputs marked -2 are left to the two-pass kernel, which then only visits
+ * rows that contain such an output.  grad_x is zeroed internally.  x / out are only read for the
+ * marked outputs.                                                                                */
+PYGAMD_API int pygamd_spmm_csr_minmax_backward_arg(const void* rowptr, const void* col,
+                                                   int idx_dtype, const int32_t* arg32,
+                                                   const float* x, int64_t ldx, const float* out,
+                                                   int64_t ldo, const float* grad_out,
+                                                   int64_t ldgo, int64_t n_rows, int64_t n_src,
+                                                   int64_t F, int count_self, float* grad_x,
+                                                   int64_t ldg, void* stream);
 
 /* ---- SDDMM: gradient w.r.t. edge weights ----------------------------------------------------
  * grad_w[e(k), h] = sum_{f in head h} grad_out[i, f] * x[col[k], f] * (src_scale? ...)  for k in

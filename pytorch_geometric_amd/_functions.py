@@ -51,8 +51,16 @@ class SpmmFunction(Function):
         if reduce in ('min', 'max'):
             if w is not None:
                 raise NotImplementedError("edge weights are not supported for min/max")
-            out = _native.spmm_csr(fwd.ptr, fwd.idx, x2, reduce, n_rows=fwd.n_rows)
-            ctx.save_for_backward(x2, out)
+            # the forward also leaves, per output, WHICH slot attained the extremum (int32) or a
+            # "split" mark: the backward then needs no edge pass for the unique extrema
+            save = ctx.needs_input_grad[0] and not torch.are_deterministic_algorithms_enabled()
+            if save:
+                out, arg32 = _native.spmm_csr(fwd.ptr, fwd.idx, x2, reduce, n_rows=fwd.n_rows,
+                                              hub=fwd.hub, save_arg32=True)
+            else:
+                out, arg32 = _native.spmm_csr(fwd.ptr, fwd.idx, x2, reduce, n_rows=fwd.n_rows,
+                                              hub=fwd.hub), None
+            ctx.save_for_backward(x2, out, arg32)
         else:
             eid = fwd.perm if (w is not None and w_order == 'coo') else None
             out = _native.spmm_csr(fwd.ptr, fwd.idx, x2, reduce, n_rows=fwd.n_rows, eid=eid, w=w,
@@ -67,7 +75,7 @@ class SpmmFunction(Function):
         g2 = _rows(grad_out)
         grad_x = grad_w = None
         if reduce in ('min', 'max'):
-            x2, out = ctx.saved_tensors
+            x2, out, arg32 = ctx.saved_tensors
             if ctx.needs_input_grad[0]:
                 fwd = graph.by_dst()
                 if torch.are_deterministic_algorithms_enabled():
@@ -77,7 +85,7 @@ class SpmmFunction(Function):
                     grad_x = _native.spmm_minmax_backward(bwd.ptr, bwd.idx, x2, out, g2, ntie)
                 else:
                     grad_x = _native.spmm_minmax_backward_dst(fwd.ptr, fwd.idx, x2, out, g2,
-                                                              graph.num_src_nodes)
+                                                              graph.num_src_nodes, arg32=arg32)
                 grad_x = grad_x.view(ctx.x_shape)
             return grad_x, None, None, None, None
         x2, w = ctx.saved_tensors

@@ -31,6 +31,7 @@ class SpmmArgs(Structure):
         ('head_dim', c_int32), ('hub_rows', c_void_p), ('hub_chunk_ptr', c_void_p),
         ('n_hub', c_int64), ('n_chunks', c_int64), ('hub_threshold', c_int64),
         ('hub_chunk', c_int64), ('accumulate', c_int32), ('hub_phase', c_int32),
+        ('arg32_out', c_void_p),
     ]
 
 
@@ -62,6 +63,9 @@ SIGNATURES = {
                                                     c_int64, _P]),
     'pygamd_multi_reduce_csr': (c_int, [_P, _P, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P,
                                         _P, c_int64, _P]),
+    'pygamd_spmm_csr_minmax_backward_arg': (c_int, [_P, _P, c_int, _P, _P, c_int64, _P, c_int64, _P,
+                                                    c_int64, c_int64, c_int64, c_int64, c_int, _P,
+                                                    c_int64, _P]),
     'pygamd_sddmm_csr': (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                  c_int32, c_int32, _P, _P]),
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),

@@ -166,7 +166,7 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
              n_rows: Optional[int] = None, eid: Optional[Tensor] = None,
              w: Optional[Tensor] = None, src_scale: Optional[Tensor] = None,
              hub=None, out: Optional[Tensor] = None, return_arg: bool = False,
-             accumulate: bool = False, hub_phase: int = 0):
+             accumulate: bool = False, hub_phase: int = 0, save_arg32: bool = False):
     """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h."""
     _require_device(rowptr, col, x, eid, w, src_scale)
     lib = _lib.load()
@@ -200,6 +200,10 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     if return_arg:
         arg = torch.empty(n_rows, F, dtype=rowptr.dtype, device=x.device)
         a.arg_out = arg.data_ptr()
+    arg32 = None
+    if save_arg32 and red in (_lib.MIN, _lib.MAX):
+        arg32 = torch.empty(n_rows, F, dtype=torch.int32, device=x.device)
+        a.arg32_out = arg32.data_ptr()
     a.n_rows, a.n_src, a.F = n_rows, x2.size(0), F
     a.ldx, a.ldo = _ld(x2), _ld(out)
     a.idx_dtype, a.reduce = _idx_dtype(rowptr), red
@@ -207,12 +211,13 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     a.accumulate = 1 if accumulate else 0
     a.hub_phase = hub_phase
     ws, ws_bytes = None, 0
-    if hub is not None and hub[2] > 0 and red in (_lib.SUM, _lib.MEAN):
+    if hub is not None and hub[2] > 0:
         hub_rows, hub_cptr, n_hub, n_chunks = hub
         a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), hub_cptr.data_ptr()
         a.n_hub, a.n_chunks = n_hub, n_chunks
         a.hub_threshold, a.hub_chunk = HUB_THRESHOLD, HUB_CHUNK
-        if hub_phase != 1:
+        # (min / max take the hub list only to schedule those rows first: no workspace)
+        if hub_phase != 1 and red in (_lib.SUM, _lib.MEAN):
             ws_bytes = n_chunks * F * 4
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     sink = timing_sink
@@ -228,6 +233,8 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
                       'reduce': reduce, 'idx_bytes': rowptr.element_size(),
                       'weighted': w is not None, 'src_scale': src_scale is not None,
                       'accumulate': bool(accumulate), 'n_hub': a.n_hub}, ev0, ev1))
+    if save_arg32:
+        return out, arg32
     return (out, arg) if return_arg else out
 
 
@@ -264,18 +271,26 @@ def colsum(x: Tensor) -> Tensor:
 
 
 def spmm_minmax_backward_dst(rowptr: Tensor, col: Optional[Tensor], x: Tensor, out: Tensor,
-                             grad_out: Tensor, n_src: int, count_self: bool = True) -> Tensor:
+                             grad_out: Tensor, n_src: int, count_self: bool = True,
+                             arg32: Optional[Tensor] = None) -> Tensor:
     """Gradient of the min/max aggregation w.r.t. ``x`` (reference tie rule) from the forward's
-    destination-sorted handle, one launch."""
-    _require_device(rowptr, col, x, out, grad_out)
+    destination-sorted handle.  With the forward's ``arg32`` the outputs with a unique extremum
+    take the one-atomic fast path and only the marked ones the two-pass kernel."""
+    _require_device(rowptr, col, x, out, grad_out, arg32)
     lib = _lib.load()
     x2, o2, g2 = _f32_rows(x, 'x'), _f32_rows(out, 'out'), _f32_rows(grad_out, 'grad_out')
     F = x2.size(1)
     grad_x = torch.empty(n_src, F, dtype=torch.float32, device=x.device)
-    check(lib.pygamd_spmm_csr_minmax_backward_dst(
-        _p(rowptr), _p(col), _idx_dtype(rowptr), _p(x2), _ld(x2), _p(o2), _ld(o2), _p(g2),
-        _ld(g2), rowptr.numel() - 1, n_src, F, int(count_self), _p(grad_x), _ld(grad_x),
-        _stream(x)), 'spmm_minmax_backward_dst')
+    if arg32 is None:
+        check(lib.pygamd_spmm_csr_minmax_backward_dst(
+            _p(rowptr), _p(col), _idx_dtype(rowptr), _p(x2), _ld(x2), _p(o2), _ld(o2), _p(g2),
+            _ld(g2), rowptr.numel() - 1, n_src, F, int(count_self), _p(grad_x), _ld(grad_x),
+            _stream(x)), 'spmm_minmax_backward_dst')
+    else:
+        check(lib.pygamd_spmm_csr_minmax_backward_arg(
+            _p(rowptr), _p(col), _idx_dtype(rowptr), _p(arg32.contiguous()), _p(x2), _ld(x2),
+            _p(o2), _ld(o2), _p(g2), _ld(g2), rowptr.numel() - 1, n_src, F, int(count_self),
+            _p(grad_x), _ld(grad_x), _stream(x)), 'spmm_minmax_backward_arg')
     return grad_x
 
 

@@ -294,6 +294,7 @@ int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root
     a.g.x = graph->x;
     a.g.out = graph->out;
     a.g.arg_out = nullptr;
+    a.g.arg32_out = nullptr;
     a.g.n_rows = graph->n_rows;
     a.g.F = F;
     a.g.ldx = graph->ldx;

@@ -147,29 +147,44 @@ __device__ __forceinline__ bool better_val(float v, float best) {
   return (!bn) & (vn | cmp);
 }
 
+// Hub rows (longer than hub_threshold) are not split here — an extremum needs no two-stage sum —
+// but they go FIRST: the lowest wave ids take the rows of the hub list, so the 16 k-slot rows
+// start at time 0 and run under the rest of the launch instead of forming its tail.
 template <typename IdxT, int VW, int LPR, int CH, bool IS_MAX, bool IDENT>
-__global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
+__global__ void __launch_bounds__(kBlock)
+    spmm_minmax_rows(SpmmDev<IdxT> a, const IdxT* __restrict__ hub_rows, int64_t n_hub) {
   constexpr int EPI = kWave / LPR;
   constexpr int U = spmm_unroll<LPR, CH>();
   constexpr int STEP = EPI * U;
   const int lane = lane_id();
-  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
-  if (row >= a.n_rows) return;
+  const int64_t wid = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  int64_t row;
+  if (wid < n_hub) {
+    row = hub_rows[wid];
+  } else {
+    row = wid - n_hub;
+    if (row >= a.n_rows) return;
+  }
   const IdxT start = a.rowptr[row];
   const IdxT end = a.rowptr[row + 1];
+  if (wid >= n_hub && n_hub > 0 && end - start > a.hub_threshold) return;  // done by a hub wave
   int fo[CH], head[CH];
   bool fv[CH];
   feature_slots<VW, LPR, CH>(lane, a.F, 1, fo, fv, head);
   const int sub = lane / LPR;
   const float init = IS_MAX ? -INFINITY : INFINITY;
+  // per feature: the extremum, the slot OFFSET inside the row of its first occurrence (32 bits: a
+  // row holds < 2^31 slots) and whether it was met more than once
   float best[CH][VW];
-  IdxT barg[CH][VW];
+  int32_t barg[CH][VW];
+  bool tie[CH][VW];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
       best[c][i] = init;
       barg[c][i] = -1;
+      tie[c][i] = false;
     }
   }
   for (IdxT base = start; base < end; base += kWave) {
@@ -180,9 +195,10 @@ __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
       if constexpr (IDENT) {
         myc = base + lane;
       } else {
-        myc = a.col[base + lane];
+        myc = __builtin_nontemporal_load(&a.col[base + lane]);  // streamed once
       }
     }
+    const int32_t off0 = static_cast<int32_t>(base - start);
     for (int j = 0; j < cnt; j += STEP) {
       Vec<VW> v[U][CH];
       bool ok[U];
@@ -210,14 +226,18 @@ __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const IdxT slot = base + static_cast<IdxT>(j + u * EPI + sub);
+        const int32_t slot = off0 + (j + u * EPI + sub);
 #pragma unroll
         for (int c2 = 0; c2 < CH; ++c2) {
 #pragma unroll
           for (int i = 0; i < VW; ++i) {
             const float val = v[u][c2].v[i];
+            const bool empty = barg[c2][i] < 0;
+            const bool gt = better_val<IS_MAX>(val, best[c2][i]);
+            const bool lt = better_val<IS_MAX>(best[c2][i], val);
             // the first valid slot always wins over the (arg == -1) initial state
-            const bool take = ok[u] & ((barg[c2][i] < 0) | better_val<IS_MAX>(val, best[c2][i]));
+            const bool take = ok[u] & (empty | gt);
+            tie[c2][i] = take ? false : (tie[c2][i] | (ok[u] & !empty & !lt));
             best[c2][i] = take ? val : best[c2][i];
             barg[c2][i] = take ? slot : barg[c2][i];
           }
@@ -225,7 +245,7 @@ __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
       }
     }
   }
-  // merge the EPI sub-groups: better value wins, equal values keep the smaller slot
+  // merge the EPI sub-groups: better value wins, equal values keep the smaller slot (and tie)
 #pragma unroll
   for (int off = LPR; off < kWave; off <<= 1) {
 #pragma unroll
@@ -233,15 +253,19 @@ __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
         const float ov = bcast_lane(best[c][i], lane ^ off);
-        const IdxT oa = bcast_lane(barg[c][i], lane ^ off);
+        const int32_t oa = bcast_lane(barg[c][i], lane ^ off);
+        const bool ot = bcast_lane(static_cast<int32_t>(tie[c][i]), lane ^ off) != 0;
         // Branch-free on purpose: hipcc 7.2 drops the guarded assignment of the nested-if form
         // of this update for VW = 4 (found by tests/test_gpu_ops.py::test_spmm_minmax_vs_oracle).
         const bool other_valid = oa >= 0;
         const bool mine_empty = barg[c][i] < 0;
         const bool other_better = better_val<IS_MAX>(ov, best[c][i]);
         const bool mine_better = better_val<IS_MAX>(best[c][i], ov);
-        const bool tie_earlier = (!other_better) & (!mine_better) & (oa < barg[c][i]);
+        const bool equal = other_valid & !mine_empty & !other_better & !mine_better;
+        const bool tie_earlier = equal & (oa < barg[c][i]);
         const bool take = other_valid & (mine_empty | other_better | tie_earlier);
+        const bool take_tie = other_valid & (mine_empty | other_better);
+        tie[c][i] = equal ? true : (take_tie ? ot : tie[c][i]);
         best[c][i] = take ? ov : best[c][i];
         barg[c][i] = take ? oa : barg[c][i];
       }
@@ -257,8 +281,54 @@ __global__ void __launch_bounds__(kBlock) spmm_minmax_rows(SpmmDev<IdxT> a) {
         store_vec<VW>(a.out + row * a.ldo + fo[c], o);
         if (a.arg_out) {
 #pragma unroll
-          for (int i = 0; i < VW; ++i) a.arg_out[row * a.ldo + fo[c] + i] = barg[c][i];
+          for (int i = 0; i < VW; ++i)
+            a.arg_out[row * a.ldo + fo[c] + i] =
+                barg[c][i] < 0 ? static_cast<IdxT>(-1) : start + static_cast<IdxT>(barg[c][i]);
         }
+        if (a.arg32_out) {
+          // -2: the gradient is split (several attaining neighbours, or an extremum of exactly 0,
+          // which ties with the zero-initialised output of scatter_reduce_(include_self=False))
+#pragma unroll
+          for (int i = 0; i < VW; ++i) {
+            const bool split = tie[c][i] | (best[c][i] == 0.f);
+            a.arg32_out[row * a.F + fo[c] + i] = barg[c][i] < 0 ? -1 : (split ? -2 : barg[c][i]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Fast half of the min/max backward: outputs with a unique extremum.  Thread = (row, VW features):
+// one read of arg32 and grad_out, a col lookup inside the row's own slot range, one fp32 atomic
+// into the single attaining source row.  No edge pass.
+template <typename IdxT, int VW>
+__global__ void __launch_bounds__(kBlock)
+    spmm_minmax_bwd_arg_kernel(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ col,
+                               const int32_t* __restrict__ arg32,
+                               const float* __restrict__ grad_out, int64_t ldgo, int64_t n_rows,
+                               int64_t units, int64_t F, float* __restrict__ grad_x,
+                               int64_t ldg) {
+  const int64_t total = n_rows * units;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t row = t / units;
+    const int64_t f = (t - row * units) * VW;
+    const IdxT start = rowptr[row];
+    int32_t a4[VW];
+    if constexpr (VW == 4) {
+      const int4 v = *reinterpret_cast<const int4*>(arg32 + row * F + f);
+      a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w;
+    } else {
+      a4[0] = arg32[row * F + f];
+    }
+    const Vec<VW> g = load_vec<VW>(grad_out + row * ldgo + f);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      if (a4[i] >= 0) {
+        const IdxT k = start + static_cast<IdxT>(a4[i]);
+        const int64_t src = col ? static_cast<int64_t>(col[k]) : static_cast<int64_t>(k);
+        atomicAdd(grad_x + src * ldg + f + i, g.v[i]);
       }
     }
   }
@@ -452,7 +522,8 @@ __global__ void __launch_bounds__(kBlock)
     spmm_minmax_bwd_dst(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ col,
                         const float* __restrict__ x, int64_t ldx, const float* __restrict__ out,
                         int64_t ldo, const float* __restrict__ grad_out, int64_t ldgo,
-                        int64_t n_rows, int64_t F, int count_self, float* __restrict__ grad_x,
+                        int64_t n_rows, int64_t F, int count_self,
+                        const int32_t* __restrict__ arg32, float* __restrict__ grad_x,
                         int64_t ldg) {
   constexpr int EPI = kWave / LPR;
   constexpr int U = spmm_unroll<LPR, CH>();
@@ -466,6 +537,19 @@ __global__ void __launch_bounds__(kBlock)
   bool fv[CH];
   feature_slots<VW, LPR, CH>(lane, F, 1, fo, fv, head);
   const int sub = lane / LPR;
+  // with the forward's arg32: only the outputs marked -2 (split gradient) are handled here, and
+  // a row without any is left after one read of its arg32 row
+  bool mine[CH][VW];
+  bool any = arg32 == nullptr;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      mine[c][i] = fv[c] && (arg32 == nullptr || arg32[row * F + fo[c] + i] == -2);
+      any |= mine[c][i];
+    }
+  }
+  if (__ballot(any) == 0) return;
   Vec<VW> o[CH];
   float ties[CH][VW];
 #pragma unroll
@@ -519,7 +603,7 @@ __global__ void __launch_bounds__(kBlock)
                 const bool hit = v[u][c2].v[i] == o[c2].v[i];
                 if (pass == 0) {
                   ties[c2][i] += hit ? 1.f : 0.f;
-                } else if (hit) {
+                } else if (hit && mine[c2][i]) {
                   atomicAdd(grad_x + src[u] * ldg + fo[c2] + i, q[c2].v[i]);
                 }
               }
@@ -673,6 +757,7 @@ static SpmmDev<IdxT> make_dev(const pygamd_spmm_args* p) {
   a.x = p->x;
   a.out = p->out;
   a.arg_out = static_cast<IdxT*>(p->arg_out);
+  a.arg32_out = p->arg32_out;
   a.n_rows = p->n_rows;
   a.F = p->F;
   a.ldx = p->ldx;
@@ -748,14 +833,15 @@ static int launch_sum_w(const pygamd_spmm_args* p, const Shape& s, float* partia
 template <typename IdxT, int VW, int LPR, int CH, bool IDENT>
 static int launch_minmax(const pygamd_spmm_args* p, const Shape& s, hipStream_t st) {
   SpmmDev<IdxT> a = make_dev<IdxT>(p);
-  a.hub_threshold = 0;
-  dim3 grid(wave_grid(p->n_rows), s.tiles);
+  const int64_t n_hub = p->n_hub > 0 ? p->n_hub : 0;
+  const IdxT* hub_rows = static_cast<const IdxT*>(p->hub_rows);
+  dim3 grid(wave_grid(p->n_rows + n_hub), s.tiles);
   if (p->reduce == PYGAMD_MAX) {
     hipLaunchKernelGGL((spmm_minmax_rows<IdxT, VW, LPR, CH, true, IDENT>), grid, dim3(kBlock), 0,
-                       st, a);
+                       st, a, hub_rows, n_hub);
   } else {
     hipLaunchKernelGGL((spmm_minmax_rows<IdxT, VW, LPR, CH, false, IDENT>), grid, dim3(kBlock),
-                       0, st, a);
+                       0, st, a, hub_rows, n_hub);
   }
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
@@ -841,12 +927,13 @@ template <typename IdxT>
 static int launch_minmax_bwd_dst(const Shape& s, const void* rowptr, const void* col,
                                  const float* x, int64_t ldx, const float* out, int64_t ldo,
                                  const float* grad_out, int64_t ldgo, int64_t n_rows, int64_t F,
-                                 int count_self, float* grad_x, int64_t ldg, hipStream_t st) {
+                                 int count_self, const int32_t* arg32, float* grad_x, int64_t ldg,
+                                 hipStream_t st) {
   dim3 grid(wave_grid(n_rows), s.tiles);
 #define PYGAMD_MMB(VW, LPR, CH)                                                                \
   hipLaunchKernelGGL((spmm_minmax_bwd_dst<IdxT, VW, LPR, CH>), grid, dim3(kBlock), 0, st,      \
                      static_cast<const IdxT*>(rowptr), static_cast<const IdxT*>(col), x, ldx,  \
-                     out, ldo, grad_out, ldgo, n_rows, F, count_self, grad_x, ldg);            \
+                     out, ldo, grad_out, ldgo, n_rows, F, count_self, arg32, grad_x, ldg);     \
   break
   if (s.vw == 4) {
     switch (s.lpr) {
@@ -1015,11 +1102,11 @@ int pygamd_spmm_csr_minmax_backward(const void* rowptr_t, const void* col_t, int
   });
 }
 
-int pygamd_spmm_csr_minmax_backward_dst(const void* rowptr, const void* col, int idx_dtype,
-                                        const float* x, int64_t ldx, const float* out,
-                                        int64_t ldo, const float* grad_out, int64_t ldgo,
-                                        int64_t n_rows, int64_t n_src, int64_t F, int count_self,
-                                        float* grad_x, int64_t ldg, void* stream) {
+static int minmax_backward_common(const void* rowptr, const void* col, int idx_dtype,
+                                  const int32_t* arg32, const float* x, int64_t ldx,
+                                  const float* out, int64_t ldo, const float* grad_out,
+                                  int64_t ldgo, int64_t n_rows, int64_t n_src, int64_t F,
+                                  int count_self, float* grad_x, int64_t ldg, void* stream) {
   if (n_rows < 0 || n_src < 0 || F < 0 || ldx < F || ldo < F || ldgo < F || ldg < F)
     return PYGAMD_ERR_INVALID_ARG;
   if (n_src == 0 || F == 0) return PYGAMD_OK;
@@ -1028,6 +1115,30 @@ int pygamd_spmm_csr_minmax_backward_dst(const void* rowptr, const void* col, int
   PYGAMD_HIP_CHECK(hipMemset2DAsync(grad_x, sizeof(float) * ldg, 0, sizeof(float) * F, n_src, st));
   if (n_rows == 0) return PYGAMD_OK;
   if (!rowptr || !x || !out || !grad_out) return PYGAMD_ERR_INVALID_ARG;
+  if (arg32) {  // unique extrema: one atomic per output, no edge pass
+    const bool v4 = (F % 4 == 0) && (ldgo % 4 == 0) && aligned16(grad_out) && aligned16(arg32);
+    const int rc = PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+      const IdxT* rp = static_cast<const IdxT*>(rowptr);
+      const IdxT* cp = static_cast<const IdxT*>(col);
+      if (v4) {
+        const int64_t units = F / 4;
+        int64_t blocks = ceil_div(n_rows * units, kBlock);
+        blocks = blocks > 256 * 64 ? 256 * 64 : blocks;
+        hipLaunchKernelGGL((spmm_minmax_bwd_arg_kernel<IdxT, 4>),
+                           dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, rp, cp, arg32,
+                           grad_out, ldgo, n_rows, units, F, grad_x, ldg);
+      } else {
+        int64_t blocks = ceil_div(n_rows * F, kBlock);
+        blocks = blocks > 256 * 64 ? 256 * 64 : blocks;
+        hipLaunchKernelGGL((spmm_minmax_bwd_arg_kernel<IdxT, 1>),
+                           dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, rp, cp, arg32,
+                           grad_out, ldgo, n_rows, F, F, grad_x, ldg);
+      }
+      PYGAMD_LAUNCH_CHECK();
+      return PYGAMD_OK;
+    });
+    if (rc != PYGAMD_OK) return rc;
+  }
   pygamd_spmm_args probe = {};
   probe.F = F;
   probe.ldx = (ldx % 4 == 0 && ldgo % 4 == 0 && ldg % 4 == 0 && aligned16(grad_out)) ? ldx : 1;
@@ -1039,8 +1150,28 @@ int pygamd_spmm_csr_minmax_backward_dst(const void* rowptr, const void* col, int
   const Shape s = pick_shape(&probe);
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     return launch_minmax_bwd_dst<IdxT>(s, rowptr, col, x, ldx, out, ldo, grad_out, ldgo, n_rows,
-                                       F, count_self, grad_x, ldg, st);
+                                       F, count_self, arg32, grad_x, ldg, st);
   });
+}
+
+int pygamd_spmm_csr_minmax_backward_dst(const void* rowptr, const void* col, int idx_dtype,
+                                        const float* x, int64_t ldx, const float* out,
+                                        int64_t ldo, const float* grad_out, int64_t ldgo,
+                                        int64_t n_rows, int64_t n_src, int64_t F, int count_self,
+                                        float* grad_x, int64_t ldg, void* stream) {
+  return minmax_backward_common(rowptr, col, idx_dtype, nullptr, x, ldx, out, ldo, grad_out, ldgo,
+                                n_rows, n_src, F, count_self, grad_x, ldg, stream);
+}
+
+int pygamd_spmm_csr_minmax_backward_arg(const void* rowptr, const void* col, int idx_dtype,
+                                        const int32_t* arg32, const float* x, int64_t ldx,
+                                        const float* out, int64_t ldo, const float* grad_out,
+                                        int64_t ldgo, int64_t n_rows, int64_t n_src, int64_t F,
+                                        int count_self, float* grad_x, int64_t ldg,
+                                        void* stream) {
+  if (!arg32 && n_rows > 0 && F > 0) return PYGAMD_ERR_INVALID_ARG;
+  return minmax_backward_common(rowptr, col, idx_dtype, arg32, x, ldx, out, ldo, grad_out, ldgo,
+                                n_rows, n_src, F, count_self, grad_x, ldg, stream);
 }
 
 int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int idx_dtype, const float* x,

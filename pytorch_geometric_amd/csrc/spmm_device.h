@@ -17,6 +17,7 @@ struct SpmmDev {
   const float* __restrict__ x;
   float* __restrict__ out;
   IdxT* __restrict__ arg_out;
+  int32_t* __restrict__ arg32_out;  // MIN/MAX: saved for the backward (see pyg_amd.h)
   int64_t n_rows, F, ldx, ldo;
   int w_heads, head_dim;
   int mean;

@@ -320,6 +320,48 @@ def test_spmm_minmax_vs_oracle(dev, F):
         assert_close(xs[0].grad, rg, what=f'spmm {red} deterministic grad F={F}')
 
 
+@pytest.mark.parametrize('F', [5, 64, 256])
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_spmm_minmax_saved_arg(dev, F, dtype):
+    """The forward's arg32 (what the one-atomic backward consumes): >= 0 = slot offset of the
+    UNIQUE attaining neighbour, -1 = empty row, -2 = split gradient (ties or an extremum of 0);
+    and the fast + marked-rows backward equals the reference on data without any ties, where every
+    output takes the fast path."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    ei = random_graph(300, 260, 6000, seed=F, skew=True)
+    ei[1][ei[1] == 9] = 10  # row 9 is empty
+    g = gen(F + 77)
+    x = torch.randn(300, F, generator=g)
+    x[::3] = torch.randint(-1, 2, (100, F), generator=g).float()  # ties and zeros
+    h = pga.EdgeIndex(ei.to(dtype).to(dev), (300, 260))
+    fwd = h.by_dst()
+    ptr, idx = fwd.ptr.cpu().long(), fwd.idx.cpu().long()
+    for red in ('max', 'min'):
+        out, arg = _native.spmm_csr(fwd.ptr, fwd.idx, x.to(dev), red, n_rows=260, save_arg32=True)
+        out, arg = out.cpu(), arg.cpu()
+        assert_close(out, O.spmm(ei, x, 260, red), rtol=0, atol=0)
+        for i in range(260):
+            rows = x[idx[ptr[i]:ptr[i + 1]]]
+            if rows.size(0) == 0:
+                assert bool((arg[i] == -1).all())
+                continue
+            hits = (rows == out[i]).sum(0)
+            split = (hits > 1) | (out[i] == 0)
+            assert bool((arg[i][split] == -2).all()), (red, i)
+            uniq = ~split
+            a = arg[i][uniq].long()
+            assert bool((a >= 0).all())
+            assert torch.equal(rows[a, uniq.nonzero().view(-1)], out[i][uniq])
+    # tie-free, zero-free data: the whole gradient goes through the fast path
+    xr = torch.randn(300, F, generator=g)
+    go = torch.randn(260, F, generator=g)
+    for red in ('max', 'min'):
+        ref, (rg, ) = run_grad(lambda t: O.spmm(ei, t, 260, red), [xr], go)
+        out, (gx, ) = run_grad(lambda t: pga.utils.spmm(h, t, red), [xr.to(dev)], go)
+        assert_close(gx, rg, what=f'{red} grad (fast path)')
+
+
 @pytest.mark.parametrize('F,H', [(1, 1), (16, 1), (100, 1), (256, 1), (64, 8), (256, 8),
                                  (320, 8), (6, 2), (21, 3)])
 def test_spmm_weighted_vs_oracle(dev, F, H):
