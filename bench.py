@@ -49,10 +49,11 @@ def spmm_algorithmic_bytes(info) -> float:
 
 def pmc_traffic(args, N, E, F_dom):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_spmm_f256.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE).  Counters
-    cannot be read from inside this process, so the number is only reported when this run is the
-    workload the counters were collected on; otherwise null."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_spmm_f256.json')
+    (profiles/r02_pmc_spmm_f256.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, collected by
+    scripts/gpu_r02_profile.sh over this very command).  Counters cannot be read from inside this
+    process, so the number is only reported when this run is the workload the counters were
+    collected on; otherwise null."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_spmm_f256.json')
     try:
         with open(path) as f:
             d = json.load(f)
@@ -506,7 +507,7 @@ def main():
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(args, N, E, dom_F),
         'traffic_source': 'profiles/ PMC passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE per '
-                          'launch, collected by scripts/gpu_pmc_script.sh), not a live counter',
+                          'launch, collected by scripts/gpu_r02_profile.sh), not a live counter',
         'kernel': f'spmm_sum_rows<F={dom_F}> (pygamd_spmm_csr: the stand-alone CSR aggregation; '
                   f'with the layer forward fused into one kernel these launches are the '
                   f'transposed, accumulating backward)',

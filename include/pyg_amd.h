@@ -460,9 +460,11 @@ PYGAMD_API int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t
 PYGAMD_API int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K,
                                                    size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx,
-                                   int64_t M, int64_t N, int64_t K, int accumulate, float* out,
-                                   int64_t ldo, void* workspace, size_t workspace_bytes,
-                                   void* stream);
+                                   int64_t M, int64_t N, int64_t K, int accumulate,
+                                   int wgs_per_cu /* 0 / 2: fill the chip; 1: leave room for a
+                                   bandwidth-bound kernel running on another stream */,
+                                   float* out, int64_t ldo, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* ---- f3: SAGEConv layer forward in one kernel ----------------------------------------------------
  * y[i, :] = act([aggr_{j->i} x[j] | x_root[i]] @ w[Fo, 2F]^T + bias) — `propagate` + `lin_l(agg)

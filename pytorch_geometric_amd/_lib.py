@@ -81,7 +81,7 @@ SIGNATURES = {
     'pygamd_linear_wgrad_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
                                                     POINTER(c_size_t)]),
     'pygamd_linear_wgrad': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int,
-                                    _P, c_int64, _P, c_size_t, _P]),
+                                    c_int, _P, c_int64, _P, c_size_t, _P]),
     'pygamd_segment_matmul_tile_rows': (c_int, []),
     'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64,
                                       c_int64, c_int64, c_int64, _P, c_int64, _P]),

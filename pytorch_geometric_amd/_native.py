@@ -631,8 +631,10 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
 
 
 def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
-                 accumulate: bool = False) -> Tensor:
-    """``g [M, N].T @ x [M, K]`` -> ``[N, K]`` (deterministic split reduction over M)."""
+                 accumulate: bool = False, wgs_per_cu: int = 0) -> Tensor:
+    """``g [M, N].T @ x [M, K]`` -> ``[N, K]`` (deterministic split reduction over M).
+    ``wgs_per_cu=1`` halves the launch's footprint (for running under a bandwidth-bound kernel
+    on another stream)."""
     _require_device(g, x, out)
     lib = _lib.load()
     g2, x2 = _f32_rows(g, 'grad'), _f32_rows(x, 'x')
@@ -646,7 +648,8 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
     check(lib.pygamd_linear_wgrad_workspace_bytes(M, N, K, ctypes.byref(nbytes)))
     ws = torch.empty(max(nbytes.value, 4), dtype=torch.uint8, device=g.device)
     check(lib.pygamd_linear_wgrad(_p(g2), _ld(g2), _p(x2), _ld(x2), M, N, K, int(accumulate),
-                                  _p(out), _ld(out), _p(ws), nbytes.value, _stream(g)),
+                                  int(wgs_per_cu), _p(out), _ld(out), _p(ws), nbytes.value,
+                                  _stream(g)),
           'linear_wgrad')
     return out
 

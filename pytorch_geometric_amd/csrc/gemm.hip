@@ -500,10 +500,12 @@ int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t l
   return run_nt(p, as_stream(stream));
 }
 
-static int64_t wgrad_splits(int64_t M, int64_t tiles) {
+static int64_t wgrad_splits(int64_t M, int64_t tiles, int wgs_per_cu = 2) {
   // two workgroups per CU (the LDS ring allows no more) = one full wave of workgroups, every
-  // split a multiple of 32 rows and at least 2048 rows
-  int64_t s = ceil_div(256 * 2, tiles < 1 ? 1 : tiles);
+  // split a multiple of 32 rows and at least 2048 rows.  wgs_per_cu = 1: half the footprint — the
+  // launch then shares the chip with a bandwidth-bound kernel on another stream (the matrix cores
+  // are idle under an SpMM) instead of taking every wave slot.
+  int64_t s = ceil_div(256 * (wgs_per_cu == 1 ? 1 : 2), tiles < 1 ? 1 : tiles);
   const int64_t max_s = ceil_div(M, 2048);
   s = s > max_s ? max_s : s;
   return s < 1 ? 1 : s;
@@ -518,8 +520,8 @@ int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t*
 }
 
 int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t M,
-                        int64_t N, int64_t K, int accumulate, float* out, int64_t ldo,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        int64_t N, int64_t K, int accumulate, int wgs_per_cu, float* out,
+                        int64_t ldo, void* workspace, size_t workspace_bytes, void* stream) {
   if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldx < K ||
       ldo < K)
     return PYGAMD_ERR_INVALID_ARG;
@@ -536,7 +538,7 @@ int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
   p.tiles_n = static_cast<int>(ceil_div(N, kWTile));
   p.tiles_k = static_cast<int>(ceil_div(K, kWTile));
   const int64_t tiles = static_cast<int64_t>(p.tiles_n) * p.tiles_k;
-  p.splits = static_cast<int>(wgrad_splits(M, tiles));
+  p.splits = static_cast<int>(wgrad_splits(M, tiles, wgs_per_cu));
   p.rows_per_split = round_up(ceil_div(M > 0 ? M : 1, p.splits), kWRows);
   const bool vec = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) &&
                    aligned16p(g) && aligned16p(x);

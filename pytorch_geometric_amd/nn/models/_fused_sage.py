@@ -46,6 +46,19 @@ GEMM_BACKEND = os.environ.get('PYGAMD_GEMM', 'own')
 # tile goes from the gather phase to the MFMA loop through LDS); PYGAMD_FUSE_LAYER=0 runs the SpMM
 # and the GEMM as two launches
 FUSE_LAYER = os.environ.get('PYGAMD_FUSE_LAYER', '1') != '0'
+# backward: weight-gradient GEMMs (MFMA-bound, needed only by the optimizer) on a side stream with
+# HALF the usual workgroups (one per CU), under the transposed SpMM of the same layer (HBM-bound,
+# matrix cores idle).  0 = everything on one stream.  (Round 1 measured the same idea with a
+# library GEMM that takes every wave slot: slower.  The own kernel's footprint is a parameter.)
+OVERLAP_WGRAD = os.environ.get('PYGAMD_OVERLAP_WGRAD', '0') != '0'
+_side_streams = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device)
+    return st
 
 
 def _pad4(n: int) -> int:
@@ -170,6 +183,7 @@ class FusedSageStack(Function):
         grads: List[Optional[Tensor]] = [None] * (3 * L)
         g = grad_out if grad_out.stride(1) == 1 else grad_out.contiguous()
         grad_x = None
+        pending = []  # side streams with weight-gradient launches in flight
         for layer in reversed(range(L)):
             buf, wmat = bufs[layer], wmats[layer]
             Fi, Fo = ctx.dims[layer]
@@ -183,9 +197,10 @@ class FusedSageStack(Function):
             own = GEMM_BACKEND == 'own'
             if ctx.modes[layer] == 'post':
                 # [Fo, 2 Fi] = [grad W_l | grad W_r]
-                gw = _native.linear_wgrad(g, buf) if own else torch.mm(g.t(), buf)
-                grads[3 * layer] = gw[:, :Fi]
-                grads[3 * layer + 2] = gw[:, Fi:]
+                overlap = (own and OVERLAP_WGRAD and need_input_grad
+                           and not torch.cuda.is_current_stream_capturing())
+                if not overlap:
+                    gw = _native.linear_wgrad(g, buf) if own else torch.mm(g.t(), buf)
                 if need_input_grad:
                     # [N, 2 Fi] = [grad_agg | grad_root]
                     if own:  # grad_agg rows leave the GEMM already divided by their degree
@@ -195,9 +210,23 @@ class FusedSageStack(Function):
                     else:
                         gcat = torch.mm(g, wmat)
                         pre_scaled = False
+                    if overlap:
+                        # the weight gradient starts together with the transposed SpMM: behind the
+                        # dgrad GEMM in program order (both want the matrix cores), on its own
+                        # stream, one workgroup per CU
+                        cur = torch.cuda.current_stream(g.device)
+                        side = _side_stream(g.device)
+                        side.wait_stream(cur)
+                        with torch.cuda.stream(side):
+                            gw = _native.linear_wgrad(g, buf, wgs_per_cu=1)
+                        g.record_stream(side)
+                        pending.append(side)
                     _native.spmm_csr(bwd.ptr, bwd.idx, gcat[:, :Fi], 'sum', n_rows=N,
                                      src_scale=None if pre_scaled else scale, hub=bwd.hub,
                                      out=gcat[:, Fi:], accumulate=True)
+                grads[3 * layer] = gw[:, :Fi]
+                grads[3 * layer + 2] = gw[:, Fi:]
+                if need_input_grad:
                     g = gcat[:, Fi:]
             else:
                 Fp = _pad4(Fo)
@@ -220,7 +249,16 @@ class FusedSageStack(Function):
                                  out=gy[:, :Fp])
                 x_in = buf
                 # [2 Fp, Fi]
-                gw = _native.linear_wgrad(gy, x_in) if own else torch.mm(gy.t(), x_in)
+                if own and OVERLAP_WGRAD and not torch.cuda.is_current_stream_capturing():
+                    cur = torch.cuda.current_stream(g.device)
+                    side = _side_stream(g.device)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        gw = _native.linear_wgrad(gy, x_in, wgs_per_cu=1)
+                    gy.record_stream(side)
+                    pending.append(side)
+                else:
+                    gw = _native.linear_wgrad(gy, x_in) if own else torch.mm(gy.t(), x_in)
                 grads[3 * layer] = gw[:Fo]
                 grads[3 * layer + 2] = gw[Fp:Fp + Fo]
                 if need_input_grad:  # [N, Fi]
@@ -228,6 +266,8 @@ class FusedSageStack(Function):
                          else torch.mm(gy, wmat))
             if layer == 0 and need_input_grad:
                 grad_x = g.contiguous()
+        for side in pending:  # the optimizer (main stream) consumes the weight gradients
+            torch.cuda.current_stream(grad_out.device).wait_stream(side)
         return (grad_x, None, None, None, *grads)
 
 
