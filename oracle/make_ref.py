@@ -1,14 +1,15 @@
 """Recipe for ``oracle/_ref/`` — the REAL reference as test infrastructure on the GPU box.
 
 TEST INFRASTRUCTURE ONLY.  The reference (PyG 2.9.0) is pure Python on this path, so "building"
-it is staging its importable package: this script mirrors ``<reference>/torch_geometric``
-(``*.py`` and the ``*.jinja`` templates ``MessagePassing`` renders at class creation) into
-``oracle/_ref/torch_geometric``.  ``oracle/_ref/`` is listed in ``.gitignore`` (no reference source
-ever enters the history) but not in ``.gpurunignore``: like ``lib/libpyg_amd.so`` it travels with
-the snapshot to the GPU box, where ``/root/reference`` does not exist.
+it is packing its importable package: this script packs ``<reference>/torch_geometric``
+(``*.py`` and the ``*.jinja`` templates ``MessagePassing`` renders at class creation) into ONE
+archive, ``oracle/_ref/torch_geometric.tar.gz``.  ``oracle/_ref/`` is listed in ``.gitignore`` (no
+reference source ever enters the history or sits loose in the tree) but not in ``.gpurunignore``:
+like ``lib/libpyg_amd.so`` the archive travels with the snapshot to the GPU box, where
+``/root/reference`` does not exist and ``import_reference()`` unpacks it under the temp directory.
 
-Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may put
-``oracle/_ref`` on ``sys.path``:
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may call
+``import_reference()``:
 
 * ``tests/test_gpu_reference_install.py`` runs the reference's OWN ``nn.conv.*`` / ``EdgeIndex`` /
   ``utils.*`` on HIP tensors through ``pytorch_geometric_amd.backend.install()`` and compares with
@@ -22,25 +23,30 @@ on the GPU box the staged copy is used as it arrived.
 import hashlib
 import json
 import os
-import shutil
 import sys
+import tarfile
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_ROOT = os.environ.get('PYG_REFERENCE', '/root/reference')
 DST = os.path.join(HERE, '_ref')
+ARCHIVE = os.path.join(DST, 'torch_geometric.tar.gz')
+MANIFEST = os.path.join(DST, 'MANIFEST.json')
 KEEP = ('.py', '.jinja', '.typed')
 
 
 def staged_path():
-    """``oracle/_ref`` if a staged reference is there, else None."""
-    return DST if os.path.isfile(os.path.join(DST, 'torch_geometric', '__init__.py')) else None
+    """The staged archive if it is there, else None."""
+    return ARCHIVE if os.path.isfile(ARCHIVE) else None
 
 
 def stage(force: bool = False):
+    """Build container only: pack ``<reference>/torch_geometric`` (``*.py`` + templates) into ONE
+    archive under the git-ignored ``oracle/_ref/`` — a built artefact like ``libpyg_amd.so``, not
+    loose sources in the tree."""
     src = os.path.join(REF_ROOT, 'torch_geometric')
     if not os.path.isdir(src):
         return staged_path()
-    manifest_path = os.path.join(DST, 'MANIFEST.json')
     files = []
     for base, dirs, names in os.walk(src):
         dirs[:] = sorted(d for d in dirs if d != '__pycache__')
@@ -53,28 +59,50 @@ def stage(force: bool = False):
         with open(os.path.join(src, rel), 'rb') as f:
             h.update(f.read())
     digest = h.hexdigest()
-    if not force and os.path.exists(manifest_path):
-        with open(manifest_path) as f:
-            if json.load(f).get('sha1') == digest and staged_path():
-                return DST
-    out = os.path.join(DST, 'torch_geometric')
-    shutil.rmtree(out, ignore_errors=True)
-    for rel in files:
-        dst = os.path.join(out, rel)
-        os.makedirs(os.path.dirname(dst), exist_ok=True)
-        shutil.copyfile(os.path.join(src, rel), dst)
-    with open(manifest_path, 'w') as f:
+    if not force and os.path.exists(MANIFEST) and staged_path():
+        with open(MANIFEST) as f:
+            if json.load(f).get('sha1') == digest:
+                return ARCHIVE
+    os.makedirs(DST, exist_ok=True)
+    for stale in os.listdir(DST):  # loose files of an earlier layout
+        path = os.path.join(DST, stale)
+        if os.path.isdir(path):
+            import shutil
+            shutil.rmtree(path, ignore_errors=True)
+    tmp = ARCHIVE + '.tmp'
+    with tarfile.open(tmp, 'w:gz') as tar:
+        for rel in files:
+            tar.add(os.path.join(src, rel), arcname=os.path.join('torch_geometric', rel))
+    os.replace(tmp, ARCHIVE)
+    with open(MANIFEST, 'w') as f:
         json.dump({'source': src, 'files': len(files), 'sha1': digest}, f)
-    return DST
+    return ARCHIVE
+
+
+def _unpacked_dir():
+    """Extract the staged archive once per content hash into the temp directory."""
+    with open(MANIFEST) as f:
+        digest = json.load(f)['sha1']
+    root = os.path.join(tempfile.gettempdir(), f'pyg_reference_{digest[:16]}')
+    marker = os.path.join(root, '.complete')
+    if not os.path.exists(marker):
+        os.makedirs(root, exist_ok=True)
+        with tarfile.open(ARCHIVE, 'r:gz') as tar:
+            tar.extractall(root)
+        with open(marker, 'w') as f:
+            f.write(digest)
+    return root
 
 
 def import_reference():
-    """Put the staged reference (or the mounted one) first on ``sys.path`` and import it."""
-    path = staged_path()
-    if path is None and os.path.isdir(os.path.join(REF_ROOT, 'torch_geometric')):
+    """Put the reference first on ``sys.path`` and import it: the mounted one in the build
+    container, else the staged archive (unpacked under the temp directory)."""
+    if os.path.isdir(os.path.join(REF_ROOT, 'torch_geometric')):
         path = REF_ROOT
-    if path is None:
-        raise ImportError('no staged reference under oracle/_ref and no /root/reference: run '
+    elif staged_path() and os.path.exists(MANIFEST):
+        path = _unpacked_dir()
+    else:
+        raise ImportError('no /root/reference and no staged archive under oracle/_ref: run '
                           '`python oracle/make_ref.py` in the build container')
     if path not in sys.path:
         sys.path.insert(0, path)
