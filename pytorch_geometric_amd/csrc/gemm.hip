@@ -365,31 +365,67 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
     if (n_blocks > 1) load_rows(ra + kWRows);
   }
   __syncthreads();
+  // One barrier per 32-row block, in the MIDDLE of the block's MFMAs (cf. the NT kernel): the
+  // operands of the block's second half (8 steps) are read into registers before the barrier, so
+  // that after it nobody touches buffer `buf` any more and the next iteration may overwrite it.
+  const bool whole = nb0 && nb1 && kb0 && kb1;  // wave-uniform: all four 32 x 32 blocks exist
+  auto mma_step = [&](float a0, float a1, float b0, float b1) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    if (kb1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    if (nb1) {
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      if (kb1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
   for (int64_t c = 0; c < n_blocks; ++c) {
     const int buf = static_cast<int>(c & 1);
     if (c + 1 < n_blocks) store_rows(buf ^ 1);
     if (c + 2 < n_blocks) load_rows(ra + (c + 2) * kWRows);
+    const float* gs = &Gs[buf][lh][wn * 64 + li];
+    const float* xs = &Xs[buf][lh][wk * 64 + li];
+    float ha0[8], ha1[8], hb0[8], hb1[8];  // second half of the block, steps 8..15
     if (nb0 && kb0) {
-      const float* gs = &Gs[buf][lh][wn * 64 + li];
-      const float* xs = &Xs[buf][lh][wk * 64 + li];
 #pragma unroll
-      for (int s = 0; s < kWRows / 2; ++s) {
-        const float a0 = gs[2 * s * kWLD];
-        const float b0 = xs[2 * s * kWLD];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        float b1 = 0.f;
-        if (kb1) {
-          b1 = xs[2 * s * kWLD + 32];
+      for (int s = 0; s < 8; ++s) {
+        ha0[s] = gs[2 * (s + 8) * kWLD];
+        ha1[s] = gs[2 * (s + 8) * kWLD + 32];
+        hb0[s] = xs[2 * (s + 8) * kWLD];
+        hb1[s] = xs[2 * (s + 8) * kWLD + 32];
+      }
+      if (whole) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float a0 = gs[2 * s * kWLD], a1 = gs[2 * s * kWLD + 32];
+          const float b0 = xs[2 * s * kWLD], b1 = xs[2 * s * kWLD + 32];
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
           acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        }
-        if (nb1) {
-          const float a1 = gs[2 * s * kWLD + 32];
           acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-          if (kb1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          mma_step(gs[2 * s * kWLD], gs[2 * s * kWLD + 32], xs[2 * s * kWLD],
+                   xs[2 * s * kWLD + 32]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (nb0 && kb0) {
+      if (whole) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ha0[s], hb0[s], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ha0[s], hb1[s], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ha1[s], hb0[s], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ha1[s], hb1[s], acc[1][1], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) mma_step(ha0[s], ha1[s], hb0[s], hb1[s]);
+      }
+    }
   }
   float* __restrict__ slab = p.partial + split * static_cast<int64_t>(p.N) * p.K;
 #pragma unroll

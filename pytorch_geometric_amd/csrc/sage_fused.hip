@@ -88,6 +88,7 @@ __device__ __forceinline__ void fused_gather_row(const SageFusedArgs<IdxT>& a, i
     }
     return;
   }
+  // (16 instead of 8 row loads in flight per lane was measured slower here: 14.4 / 7.5 ms)
   spmm_accumulate<IdxT, VW, LPR, CH, 0, false>(a.g, start, end, lane, fo, fv, head, acc);
   combine_subgroups<VW, LPR, CH>(acc);
   if (lane < LPR && fv[0]) {

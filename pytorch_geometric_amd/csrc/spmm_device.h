@@ -34,13 +34,13 @@ constexpr int spmm_unroll() {
 
 // WMODE: 0 = plain sum; 1 = one staged multiplier per slot (w with one head and/or src_scale);
 //        2 = per-head weights fetched per slot (+ optional staged src_scale).
-template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, bool FULL>
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, bool FULL, int UF = 0>
 __device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cnt, int sub,
                                            IdxT myc, IdxT mye, float mym, const int (&fo)[CH],
                                            const bool (&fv)[CH], const int (&head)[CH],
                                            float (&acc)[CH][VW]) {
   constexpr int EPI = kWave / LPR;
-  constexpr int U = spmm_unroll<LPR, CH>();
+  constexpr int U = UF > 0 ? UF : spmm_unroll<LPR, CH>();
   Vec<VW> v[U][CH];
   float m[U];
   float wv[U][CH];
@@ -106,13 +106,15 @@ __device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cn
   }
 }
 
-template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
+// UF > 0 overrides the number of row loads in flight per lane (a kernel with few resident waves
+// needs more memory-level parallelism per wave)
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, int UF = 0>
 __device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT start, IdxT end,
                                                 int lane, const int (&fo)[CH],
                                                 const bool (&fv)[CH], const int (&head)[CH],
                                                 float (&acc)[CH][VW]) {
   constexpr int EPI = kWave / LPR;
-  constexpr int U = spmm_unroll<LPR, CH>();
+  constexpr int U = UF > 0 ? UF : spmm_unroll<LPR, CH>();
   constexpr int STEP = EPI * U;
   const int sub = lane / LPR;
   for (IdxT base = start; base < end; base += kWave) {
@@ -137,11 +139,12 @@ __device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT sta
     }
     int j = 0;
     for (; j + STEP <= cnt; j += STEP) {
-      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, true>(a, j, cnt, sub, myc, mye, mym, fo, fv,
+      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, true, UF>(a, j, cnt, sub, myc, mye, mym, fo, fv,
                                                         head, acc);
     }
     if (j < cnt) {
-      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, false>(a, j, cnt, sub, myc, mye, mym, fo, fv,
+      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, false, UF>(a, j, cnt, sub, myc, mye, mym, fo,
+                                                             fv,
                                                          head, acc);
     }
   }
