@@ -31,7 +31,9 @@
 // two barriers per chunk 14.3 / 7.7 ms; root-half fragments fetched from global memory by every
 // wave 15.7 ms (L1-bound); ONE persistent 1024-thread workgroup per CU with 12 gather waves
 // feeding 4 MFMA waves through two LDS buffers 16.0 / 9.6 ms (a barrier per tile drains the memory
-// pipeline; lowering the hub threshold to 128 changed nothing) — not adopted.
+// pipeline; lowering the hub threshold to 128 changed nothing); ONE LDS tile used twice (root half
+// of the transform first, then the gather into the same tile, then the aggregated half), which
+// fits three workgroups per CU: 14.3 / 7.9 ms — not adopted.
 #include "spmm_device.h"
 
 namespace pygamd {
