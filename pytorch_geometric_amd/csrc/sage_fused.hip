@@ -264,8 +264,9 @@ int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root
   if (graph->n_rows < 0 || F < 0 || Fo < 0 || graph->ldx < F || graph->ldo < F ||
       ld_root < F || ldw < 2 * F || ldy < Fo)
     return PYGAMD_ERR_INVALID_ARG;
+  // (col may be NULL only for a graph without edges: it is never dereferenced then)
   if (!pygamd_sage_layer_forward_supported(F, Fo, graph->reduce) || graph->w ||
-      graph->src_scale || graph->eid || graph->accumulate || !graph->col)
+      graph->src_scale || graph->eid || graph->accumulate)
     return PYGAMD_ERR_UNSUPPORTED;
   if (graph->n_rows == 0) return PYGAMD_OK;
   if (!graph->rowptr || !graph->x || !graph->out || !x_root || !w || !y)

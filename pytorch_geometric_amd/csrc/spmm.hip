@@ -1180,7 +1180,8 @@ int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int idx_dtype,
                             void* stream) {
   if (n_rows < 0 || F < 0 || ldx < F || ldo < F) return PYGAMD_ERR_INVALID_ARG;
   if (n_rows == 0 || F == 0) return PYGAMD_OK;
-  if (!rowptr || !x || !(out_sum || out_sq || out_min || out_max)) return PYGAMD_ERR_INVALID_ARG;
+  // (x may be NULL: a zero-row source with only empty groups is legal and never dereferenced)
+  if (!rowptr || !(out_sum || out_sq || out_min || out_max)) return PYGAMD_ERR_INVALID_ARG;
   pygamd_spmm_args args = {};
   args.rowptr = rowptr;
   args.col = perm;

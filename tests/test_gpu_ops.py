@@ -765,3 +765,58 @@ def test_one_pass_multi_reduce(dev, F, sorted_index):
     assert_sum_close(xg.grad, xr.grad, x64.grad, rtol=2e-5, atol=2e-5, what='grad')
     with pytest.raises(ValueError, match="invalid 'dim_size'"):
         fused(xg, index.to(dev), dim_size=3)
+
+
+def test_round2_entry_points_on_empty_and_degenerate_inputs(dev):
+    """Empty / single-element inputs of the entry points added in round 2 (the reference accepts
+    them everywhere: zero edges, zero groups, zero features, one row)."""
+    import pytorch_geometric_amd as pga
+    import pytorch_geometric_amd.nn as nn
+    from pytorch_geometric_amd import _native
+    e = torch.empty
+    # segment_logsumexp: no rows at all, and only empty segments
+    out = pga.utils.segment_logsumexp(e(0, 4, device=dev), torch.zeros(3, dtype=torch.long,
+                                                                       device=dev), 0)
+    assert out.shape == (2, 4) and bool((out == 0).all())
+    # FusedAggregation: zero rows -> zeros; one row -> itself (std 0)
+    fused = nn.FusedAggregation(['sum', 'mean', 'max', 'std'])
+    outs = fused(e(0, 3, device=dev), e(0, dtype=torch.long, device=dev), dim_size=4)
+    assert all(o.shape == (4, 3) and bool((o == 0).all()) for o in outs)
+    x1 = torch.tensor([[1.0, -2.0, 3.0]], device=dev, requires_grad=True)
+    outs = fused(x1, torch.tensor([2], device=dev), dim_size=3)
+    assert_close(outs[0][2], x1[0].detach())
+    assert_close(outs[2][2], x1[0].detach())
+    assert bool((outs[3] == 0).all())
+    sum(o.sum() for o in outs).backward()
+    assert bool(torch.isfinite(x1.grad).all())
+    # scatter(mul) backward on an empty source
+    s0 = e(0, 2, device=dev, requires_grad=True)
+    pga.utils.scatter(s0, e(0, dtype=torch.long, device=dev), 0, 3, 'mul').sum().backward()
+    assert s0.grad.shape == (0, 2)
+    # dense transform: zero rows, zero input features
+    w = torch.randn(5, 7, device=dev)
+    assert _native.linear_forward(e(0, 7, device=dev), w).shape == (0, 5)
+    assert _native.linear_wgrad(e(0, 5, device=dev), e(0, 7, device=dev)).abs().sum() == 0
+    assert _native.linear_dgrad(e(0, 5, device=dev), w.t().contiguous()).shape == (0, 7)
+    b = torch.randn(5, device=dev)
+    assert_close(_native.linear_forward(e(3, 0, device=dev), e(5, 0, device=dev), b),
+                 b.cpu().expand(3, 5))
+    # min / max aggregation of a graph without edges: zeros, zero gradient, arg32 = -1
+    h = pga.EdgeIndex(e(2, 0, dtype=torch.long, device=dev), (6, 4))
+    xm = torch.randn(6, 8, device=dev, requires_grad=True)
+    om = pga.utils.spmm(h, xm, 'max')
+    om.sum().backward()
+    assert bool((om == 0).all()) and bool((xm.grad == 0).all())
+    _, arg = _native.spmm_csr(h.by_dst().ptr, h.by_dst().idx, xm.detach(), 'max', n_rows=4,
+                              save_arg32=True)
+    assert bool((arg == -1).all())
+    # one-kernel SAGE layer on a graph without edges: lin_r(x) + b
+    wc = torch.randn(6, 16, device=dev)
+    buf = torch.zeros(4, 16, device=dev)
+    xs = torch.randn(4, 8, device=dev)
+    buf[:, 8:] = xs
+    y = torch.empty(4, 6, device=dev)
+    h2 = pga.EdgeIndex(e(2, 0, dtype=torch.long, device=dev), (4, 4))
+    _native.sage_layer_forward(h2.by_dst().ptr, h2.by_dst().idx, xs, buf[:, 8:], wc, None, 'mean',
+                               False, buf[:, :8], y, hub=h2.by_dst().hub)
+    assert_close(y, (xs @ wc[:, 8:].t()).cpu(), rtol=1e-5, atol=1e-5)
