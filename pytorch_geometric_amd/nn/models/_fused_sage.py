@@ -52,6 +52,14 @@ FUSE_LAYER = os.environ.get('PYGAMD_FUSE_LAYER', '1') != '0'
 # library GEMM that takes every wave slot: slower.  The own kernel's footprint is a parameter.)
 OVERLAP_WGRAD = os.environ.get('PYGAMD_OVERLAP_WGRAD', '0') != '0'
 _side_streams = {}
+# below this many rows a launch of the own row-tiled kernels has fewer tiles than the chip has CUs
+# (cf. nn/dense/linear.py): small sampled batches keep the library GEMM
+OWN_GEMM_MIN_ROWS = 16384
+
+
+def own_gemm(rows: int) -> bool:
+    return GEMM_BACKEND == 'own' and rows >= OWN_GEMM_MIN_ROWS
+
 
 
 def _side_stream(device):

@@ -57,7 +57,7 @@ class FusedSageHopStack(Function):
             else:
                 nxt = torch.empty(m, 2 * Fo, dtype=torch.float32, device=dev)
                 dst = nxt[:, Fo:]
-            if _fused_sage.GEMM_BACKEND == 'own':
+            if _fused_sage.own_gemm(m):
                 _native.linear_forward(cat[:m], wmat, b, relu=not last, out=dst)
             elif b is not None and not last and _fused_sage.RELU_EPILOGUE:
                 torch._addmm_activation(b, cat[:m], wmat.t(), use_gelu=False, out=dst)
@@ -96,7 +96,7 @@ class FusedSageHopStack(Function):
                 g, grads[3 * l + 1] = _native.relu_backward_colsum(g, h_next, ctx.has_bias[l])
             elif ctx.has_bias[l]:
                 grads[3 * l + 1] = _native.colsum(g)
-            own = _fused_sage.GEMM_BACKEND == 'own'
+            own = _fused_sage.own_gemm(m)
             gw = _native.linear_wgrad(g, cat[:m]) if own else torch.mm(g.t(), cat[:m])
             grads[3 * l], grads[3 * l + 2] = gw[:, :Fi], gw[:, Fi:]
             if l > 0 or ctx.needs_input_grad[0]:

@@ -153,3 +153,46 @@ def test_sage_layer_forward_one_kernel(dev, F, Fo, reduce, dtype):
     ref2 = aggr_ref @ wl.t() + x @ wr.t()
     ex2 = aggr_ref.double() @ wl.double().t() + x.double() @ wr.double().t()
     assert_sum_close(out2, ref2, ex2, abs_sum=bound + 1, what='fused layer, no bias / relu')
+
+
+def test_linear_module_routes_large_inputs_to_the_own_gemm(dev):
+    """nn.Linear: >= OWN_GEMM_MIN_ROWS float32 rows on the device run through LinearFunction
+    (forward, input / weight / bias gradients on csrc/gemm.hip); values and gradients against the
+    CPU F.linear, 3-D input included; small inputs stay on F.linear with identical semantics."""
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd.nn import Linear
+    g = gen(31)
+    torch.manual_seed(4)
+    lin = Linear(24, 10)
+    calls = {'n': 0}
+    real = _native.linear_forward
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+
+    _native.linear_forward = counted
+    try:
+        for shape in ((Linear.OWN_GEMM_MIN_ROWS + 5, 24), (130, 130, 24), (50, 24)):
+            x = torch.randn(*shape, generator=g)
+            go = torch.randn(*shape[:-1], 10, generator=g)
+            xr = x.clone().requires_grad_(True)
+            ref = torch.nn.functional.linear(xr, lin.weight, lin.bias)
+            lin.zero_grad()
+            ref.backward(go)
+            want = (ref.detach(), xr.grad, lin.weight.grad.clone(), lin.bias.grad.clone())
+            dl = Linear(24, 10).to(dev)
+            dl.load_state_dict(lin.state_dict())
+            xd = x.to(dev).requires_grad_(True)
+            before = calls['n']
+            out = dl(xd)
+            out.backward(go.to(dev))
+            rows = x.numel() // 24
+            assert (calls['n'] > before) == (rows >= Linear.OWN_GEMM_MIN_ROWS)
+            assert_close(out, want[0], rtol=1e-5, atol=2e-5, what='linear out')
+            assert_close(xd.grad, want[1], rtol=1e-5, atol=2e-5, what='linear grad x')
+            scale = float(rows) ** 0.5  # weight / bias gradients sum over `rows` terms
+            assert_close(dl.weight.grad, want[2], rtol=1e-5, atol=2e-5 * scale, what='grad W')
+            assert_close(dl.bias.grad, want[3], rtol=1e-5, atol=2e-5 * scale, what='grad b')
+    finally:
+        _native.linear_forward = real
