@@ -35,7 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 def spmm_algorithmic_bytes(info) -> float:
     """E*(4F + b) + (N_rows + 1)*b + N_rows*4F  (+ N*4 for the mean's degree
     vector when it is read as a per-source scale, + N_rows*4F when the launch accumulates onto
-    its output, i.e. the fused `grad_root + A^T grad_agg` of the backward)."""
+    its output, i.e. the fused `grad_root + A^T grad_agg` of the backward, + N_rows*4F when its
+    epilogue reads a ReLU output to apply that activation's backward)."""
     b, Fw = info['idx_bytes'], info['F']
     total = info['nnz'] * (4 * Fw + b) + (info['n_rows'] + 1) * b + info['n_rows'] * 4 * Fw
     if info['src_scale']:
@@ -44,6 +45,8 @@ def spmm_algorithmic_bytes(info) -> float:
         total += info['nnz'] * 4
     if info.get('accumulate'):
         total += info['n_rows'] * 4 * Fw  # out += result: the old rows are read as well
+    if info.get('relu_mask'):
+        total += info['n_rows'] * 4 * Fw  # the activation rows the fused ReLU backward reads
     return float(total)
 
 
@@ -510,7 +513,7 @@ def main():
                           'launch, collected by scripts/gpu_r02_profile.sh), not a live counter',
         'kernel': f'spmm_sum_rows<F={dom_F}> (pygamd_spmm_csr: the stand-alone CSR aggregation; '
                   f'with the layer forward fused into one kernel these launches are the '
-                  f'transposed, accumulating backward)',
+                  f'transposed, accumulating backward with the ReLU-backward epilogue)',
         'launches_timed': len(dom), 'avg_launch_ms': round(avg_ms, 4),
         'algorithmic_bytes_per_launch': alg_bytes,
         'all_spmm_ms_per_step': round(spmm_ms_per_step, 3),
@@ -556,9 +559,11 @@ def main():
                 'gemm': gemm_desc(tuned),
                 'schedule': 'fused stack: [agg|x] single GEMM per layer; 256->47 layer '
                             'transforms first and aggregates at width 48; layers 1-2 forward '
-                            'as ONE kernel each (aggregation -> LDS -> MFMA); ReLU backward '
-                            'fused with the bias column sum; the mean\'s 1/deg of the backward '
-                            'applied in the dgrad GEMM epilogue',
+                            'as ONE kernel each (aggregation -> LDS -> MFMA); ReLU backward in '
+                            'the epilogue of the kernel producing each activation gradient '
+                            '(transposed SpMM / dgrad GEMM); bias gradients from the '
+                            'weight-gradient GEMM\'s pass over grad_out; the mean\'s 1/deg of '
+                            'the backward applied in the dgrad GEMM epilogue',
             },
             'roofline': roofline,
         }

@@ -176,6 +176,13 @@ typedef struct {
                                 ties with the zero-initialised output of the reference's
                                 scatter_reduce_).  What pygamd_spmm_csr_minmax_backward_arg
                                 consumes.                                                       */
+  const float* relu_mask;    /* SUM/MEAN only, [n_rows, ld_mask] or NULL: the final value of
+                                out[i, f] (after `accumulate`) is replaced by 0 where
+                                relu_mask[i, f] <= 0 — aten::threshold_backward of the ReLU whose
+                                OUTPUT relu_mask is, applied as the epilogue of the transposed
+                                aggregation that produces that activation's gradient
+                                (nn/models/basic_gnn.py:262-263 backward)                        */
+  int64_t ld_mask;
 } pygamd_spmm_args;
 
 PYGAMD_API int pygamd_spmm_csr_workspace_bytes(const pygamd_spmm_args* args, size_t* bytes);
@@ -447,23 +454,28 @@ PYGAMD_API int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int
  *             (basic_gnn.py:258-266), accumulate != 0 adds onto `out`.
  *   dgrad   : out[M, K] = g[M, N] @ w[N, K], the weight handed over TRANSPOSED (w_t[K, N],
  *             contiguous rows); columns [0, n_scaled) are multiplied by row_scale[row] in the
- *             epilogue (the 1/deg of a mean aggregation that follows, utils/_scatter.py:72-80).
+ *             epilogue (the 1/deg of a mean aggregation that follows, utils/_scatter.py:72-80);
+ *             relu_mask ([M, ld_mask] or NULL): out[r, c] = 0 where relu_mask[r, c] <= 0, applied
+ *             last — the backward of the ReLU whose output relu_mask is (basic_gnn.py:262-263).
  *   wgrad   : out[N, K] = g[M, N]^T @ x[M, K]; deterministic (split over M, slabs summed in
- *             order); workspace from the _workspace_bytes query.                               */
+ *             order); workspace from the _workspace_bytes query.  bias_grad ([N] or NULL)
+ *             receives the column sums of g (the bias gradient of the same Linear,
+ *             nn/dense/linear.py:121-127 backward) from the same pass over g: per-split sums taken
+ *             while the rows are staged, added in split order (deterministic).                 */
 PYGAMD_API int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
                                      const float* bias, int64_t M, int64_t K, int64_t N, int relu,
                                      int accumulate, float* out, int64_t ldo, void* stream);
 PYGAMD_API int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
                                    const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
-                                   int64_t K, int accumulate, float* out, int64_t ldo,
-                                   void* stream);
+                                   int64_t K, int accumulate, const float* relu_mask,
+                                   int64_t ld_mask, float* out, int64_t ldo, void* stream);
 PYGAMD_API int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K,
                                                    size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx,
                                    int64_t M, int64_t N, int64_t K, int accumulate,
                                    int wgs_per_cu /* 0 / 2: fill the chip; 1: leave room for a
                                    bandwidth-bound kernel running on another stream */,
-                                   float* out, int64_t ldo, void* workspace,
+                                   float* out, int64_t ldo, float* bias_grad, void* workspace,
                                    size_t workspace_bytes, void* stream);
 
 /* ---- f3: SAGEConv layer forward in one kernel ----------------------------------------------------

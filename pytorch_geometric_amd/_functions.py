@@ -356,8 +356,8 @@ class HeadDotFunction(Function):
 class LinearFunction(Function):
     """``x @ weight.T + bias`` (nn/dense/linear.py:121-127 ``F.linear``) on the fp32-MFMA kernels
     of csrc/gemm.hip: forward with the bias epilogue, input gradient with the same kernel on the
-    transposed weight, weight gradient as a deterministic split reduction, bias gradient as a
-    column sum."""
+    transposed weight, weight gradient as a deterministic split reduction that also returns the
+    bias gradient (column sums of ``grad_out``) from the same pass."""
 
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor]):
@@ -374,8 +374,11 @@ class LinearFunction(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _native.linear_dgrad(g2, weight.t().contiguous()).view(ctx.x_shape)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = _native.linear_wgrad(g2, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gw = _native.linear_wgrad(g2, x2, bias_grad=need_b)  # column sums from the same pass
+            if need_b:
+                gw, gb = gw
+        elif need_b:
             gb = _native.colsum(g2)
         return gx, gw, gb

@@ -31,7 +31,7 @@ class SpmmArgs(Structure):
         ('head_dim', c_int32), ('hub_rows', c_void_p), ('hub_chunk_ptr', c_void_p),
         ('n_hub', c_int64), ('n_chunks', c_int64), ('hub_threshold', c_int64),
         ('hub_chunk', c_int64), ('accumulate', c_int32), ('hub_phase', c_int32),
-        ('arg32_out', c_void_p),
+        ('arg32_out', c_void_p), ('relu_mask', c_void_p), ('ld_mask', c_int64),
     ]
 
 
@@ -77,11 +77,11 @@ SIGNATURES = {
     'pygamd_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                       c_int, c_int, _P, c_int64, _P]),
     'pygamd_linear_dgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
-                                    c_int64, c_int, _P, c_int64, _P]),
+                                    c_int64, c_int, _P, c_int64, _P, c_int64, _P]),
     'pygamd_linear_wgrad_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
                                                     POINTER(c_size_t)]),
     'pygamd_linear_wgrad': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int,
-                                    c_int, _P, c_int64, _P, c_size_t, _P]),
+                                    c_int, _P, c_int64, _P, _P, c_size_t, _P]),
     'pygamd_segment_matmul_tile_rows': (c_int, []),
     'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64,
                                       c_int64, c_int64, c_int64, _P, c_int64, _P]),

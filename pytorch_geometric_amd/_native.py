@@ -166,9 +166,10 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
              n_rows: Optional[int] = None, eid: Optional[Tensor] = None,
              w: Optional[Tensor] = None, src_scale: Optional[Tensor] = None,
              hub=None, out: Optional[Tensor] = None, return_arg: bool = False,
-             accumulate: bool = False, hub_phase: int = 0, save_arg32: bool = False):
+             accumulate: bool = False, hub_phase: int = 0, save_arg32: bool = False,
+             relu_mask: Optional[Tensor] = None):
     """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h."""
-    _require_device(rowptr, col, x, eid, w, src_scale)
+    _require_device(rowptr, col, x, eid, w, src_scale, relu_mask)
     lib = _lib.load()
     x2 = _f32_rows(x, 'x')
     n_rows = rowptr.numel() - 1 if n_rows is None else n_rows
@@ -210,6 +211,11 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     a.w_heads, a.head_dim = w_heads, head_dim
     a.accumulate = 1 if accumulate else 0
     a.hub_phase = hub_phase
+    if relu_mask is not None:
+        m2 = _f32_rows(relu_mask, 'relu_mask')
+        if tuple(m2.shape) != (n_rows, F):
+            raise ValueError(f"'relu_mask' must be [{n_rows}, {F}], got {tuple(m2.shape)}")
+        a.relu_mask, a.ld_mask = m2.data_ptr(), _ld(m2)
     ws, ws_bytes = None, 0
     if hub is not None and hub[2] > 0:
         hub_rows, hub_cptr, n_hub, n_chunks = hub
@@ -232,7 +238,8 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
         sink.append(({'n_rows': n_rows, 'n_src': x2.size(0), 'nnz': nnz, 'F': F,
                       'reduce': reduce, 'idx_bytes': rowptr.element_size(),
                       'weighted': w is not None, 'src_scale': src_scale is not None,
-                      'accumulate': bool(accumulate), 'n_hub': a.n_hub}, ev0, ev1))
+                      'accumulate': bool(accumulate), 'relu_mask': relu_mask is not None,
+                      'n_hub': a.n_hub}, ev0, ev1))
     if save_arg32:
         return out, arg32
     return (out, arg) if return_arg else out
@@ -610,10 +617,12 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
 
 
 def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_scaled: int = 0,
-                 out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+                 out: Optional[Tensor] = None, accumulate: bool = False,
+                 relu_mask: Optional[Tensor] = None) -> Tensor:
     """``g [M, N] @ w [N, K]`` with the weight handed over transposed (``w_t [K, N]``); columns
-    ``[0, n_scaled)`` of the result are multiplied by ``row_scale[row]``."""
-    _require_device(g, w_t, row_scale, out)
+    ``[0, n_scaled)`` of the result are multiplied by ``row_scale[row]``; where ``relu_mask [M, K]``
+    (a ReLU output) is not positive the result is 0 (that ReLU's backward as the epilogue)."""
+    _require_device(g, w_t, row_scale, out, relu_mask)
     lib = _lib.load()
     g2, w2 = _f32_rows(g, 'grad'), _f32_rows(w_t, 'weight_t')
     M, N = g2.shape
@@ -624,17 +633,24 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
         out = torch.empty(M, K, dtype=torch.float32, device=g.device)
     if row_scale is not None:
         row_scale = row_scale.contiguous()
+    m2 = None
+    if relu_mask is not None:
+        m2 = _f32_rows(relu_mask, 'relu_mask')
+        if tuple(m2.shape) != (M, K):
+            raise ValueError(f"'relu_mask' must be [{M}, {K}], got {tuple(m2.shape)}")
     check(lib.pygamd_linear_dgrad(_p(g2), _ld(g2), _p(w2), _ld(w2), _p(row_scale),
                                   n_scaled if row_scale is not None else 0, M, N, K,
-                                  int(accumulate), _p(out), _ld(out), _stream(g)), 'linear_dgrad')
+                                  int(accumulate), _p(m2), _ld(m2) if m2 is not None else 0,
+                                  _p(out), _ld(out), _stream(g)), 'linear_dgrad')
     return out
 
 
 def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
-                 accumulate: bool = False, wgs_per_cu: int = 0) -> Tensor:
+                 accumulate: bool = False, wgs_per_cu: int = 0, bias_grad: bool = False):
     """``g [M, N].T @ x [M, K]`` -> ``[N, K]`` (deterministic split reduction over M).
     ``wgs_per_cu=1`` halves the launch's footprint (for running under a bandwidth-bound kernel
-    on another stream)."""
+    on another stream).  ``bias_grad=True`` also returns ``g.sum(0)`` — taken from the same pass
+    over ``g`` — as ``(grad_w, grad_b)``."""
     _require_device(g, x, out)
     lib = _lib.load()
     g2, x2 = _f32_rows(g, 'grad'), _f32_rows(x, 'x')
@@ -647,11 +663,16 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
     nbytes = ctypes.c_size_t(0)
     check(lib.pygamd_linear_wgrad_workspace_bytes(M, N, K, ctypes.byref(nbytes)))
     ws = torch.empty(max(nbytes.value, 4), dtype=torch.uint8, device=g.device)
+    gb = None
+    if bias_grad:
+        if K == 0:  # no weight tile passes over g
+            return out, colsum(g2)
+        gb = torch.empty(N, dtype=torch.float32, device=g.device)
     check(lib.pygamd_linear_wgrad(_p(g2), _ld(g2), _p(x2), _ld(x2), M, N, K, int(accumulate),
-                                  int(wgs_per_cu), _p(out), _ld(out), _p(ws), nbytes.value,
-                                  _stream(g)),
+                                  int(wgs_per_cu), _p(out), _ld(out), _p(gb), _p(ws),
+                                  nbytes.value, _stream(g)),
           'linear_wgrad')
-    return out
+    return (out, gb) if bias_grad else out
 
 
 # ---- segment_matmul (grouped GEMM, fp32 MFMA) ---------------------------------------------------

@@ -43,8 +43,9 @@ struct GemmNT {
   const float* __restrict__ b;  // [N, K]
   const float* __restrict__ bias;       // [N] or null
   const float* __restrict__ row_scale;  // [M] or null
+  const float* __restrict__ mask;       // [M, ldm] or null: c = mask <= 0 ? 0 : c (ReLU backward)
   float* __restrict__ c;                // [M, N]
-  int64_t M, lda, ldb, ldc;
+  int64_t M, lda, ldb, ldc, ldm;
   int N, K;
   int relu;
   int n_scaled;   // columns [0, n_scaled) are multiplied by row_scale[row]
@@ -239,6 +240,19 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
         const float bv = p.bias ? p.bias[col] : 0.f;
         const bool scaled = wave_scaled && col < p.n_scaled;
         float* cp = p.c + rbase * p.ldc + col;
+        if (p.mask) {  // uniform: the ReLU-backward epilogue of a dgrad launch
+          const float* mp = p.mask + rbase * p.ldm + col;
+          float mv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mv[e] = mp[((e & 3) + 8 * (e >> 2)) * p.ldm];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv;
+            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
+            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = mv[e] > 0.f ? fmaxf(v, floor_v) : 0.f;
+          }
+          continue;
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           float v = acc[i][j][e] + bv;
@@ -267,6 +281,7 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
           v = fmaxf(v, floor_v);
           float* dst = p.c + row * p.ldc + col;
           if (p.accumulate) v += *dst;
+          if (p.mask) v = p.mask[row * p.ldm + col] > 0.f ? v : 0.f;
           *dst = v;
         }
       }
@@ -283,6 +298,7 @@ struct GemmTN {
   const float* __restrict__ g;  // [M, N]
   const float* __restrict__ x;  // [M, K]
   float* __restrict__ partial;  // [splits][N][K]
+  float* __restrict__ colsum;   // [splits][N] or null: per-split column sums of g (bias gradient)
   int64_t M, ldg, ldx;
   int N, K;
   int tiles_n, tiles_k, splits;
@@ -339,11 +355,20 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
       }
     }
   };
+  // bias gradient for free: the workgroups of the first k tile add up the g rows they stage
+  // (rows past the split are staged as zeros); fixed order: rows of a thread, the 8 staging rows,
+  // then the splits in the reduce kernel
+  const bool do_colsum = p.colsum != nullptr && tk == 0;  // workgroup-uniform
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   auto store_rows = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       *reinterpret_cast<f32x4*>(&Gs[buf][sr + 8 * j][4 * sc]) = rg[j];
       *reinterpret_cast<f32x4*>(&Xs[buf][sr + 8 * j][4 * sc]) = rx[j];
+    }
+    if (do_colsum) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) csum += rg[j];
     }
   };
 
@@ -427,6 +452,18 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
       }
     }
   }
+  if (do_colsum) {  // (uniform branch: the barriers are legal)
+    __syncthreads();  // every wave is done with the ring
+    float* red = smem;  // [8][128]
+    *reinterpret_cast<f32x4*>(&red[sr * kWTile + 4 * sc]) = csum;
+    __syncthreads();
+    if (threadIdx.x < kWTile && n0 + static_cast<int>(threadIdx.x) < p.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += red[r * kWTile + threadIdx.x];
+      p.colsum[split * p.N + n0 + threadIdx.x] = s;
+    }
+  }
   float* __restrict__ slab = p.partial + split * static_cast<int64_t>(p.N) * p.K;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -446,9 +483,18 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
 // out[n, k] (+)= sum over splits, in split order (deterministic)
 __global__ void __launch_bounds__(kBlock)
     gemm_tn_reduce_kernel(const float* __restrict__ partial, int splits, int64_t NK, int K,
-                          float* __restrict__ out, int64_t ldo, int accumulate) {
+                          float* __restrict__ out, int64_t ldo, int accumulate,
+                          const float* __restrict__ colsum, int N, float* __restrict__ bias_grad) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (t >= NK) return;
+  if (t >= NK) {  // the tail threads add up the bias-gradient partials
+    const int64_t n = t - NK;
+    if (bias_grad && n < N) {
+      float s = 0.f;
+      for (int sp = 0; sp < splits; ++sp) s += colsum[static_cast<int64_t>(sp) * N + n];
+      bias_grad[n] = s;
+    }
+    return;
+  }
   float s = 0.f;
   for (int sp = 0; sp < splits; ++sp) s += partial[sp * NK + t];
   const int64_t r = t / K;
@@ -511,8 +557,8 @@ int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t l
   if (M == 0 || N == 0) return PYGAMD_OK;
   if (!out || (K > 0 && (!x || !w))) return PYGAMD_ERR_INVALID_ARG;
   GemmNT p = {};
-  p.a = x; p.b = w; p.bias = bias; p.row_scale = nullptr; p.c = out;
-  p.M = M; p.lda = ldx; p.ldb = ldw; p.ldc = ldo;
+  p.a = x; p.b = w; p.bias = bias; p.row_scale = nullptr; p.mask = nullptr; p.c = out;
+  p.M = M; p.lda = ldx; p.ldb = ldw; p.ldc = ldo; p.ldm = 0;
   p.N = static_cast<int>(N); p.K = static_cast<int>(K);
   p.relu = relu ? 1 : 0; p.n_scaled = 0; p.accumulate = accumulate ? 1 : 0;
   return run_nt(p, as_stream(stream));
@@ -520,17 +566,19 @@ int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t l
 
 int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
                         const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
-                        int64_t K, int accumulate, float* out, int64_t ldo, void* stream) {
+                        int64_t K, int accumulate, const float* relu_mask, int64_t ld_mask,
+                        float* out, int64_t ldo, void* stream) {
   // out[M, K] = g[M, N] @ w[N, K], with w given TRANSPOSED as w_t[K, N]: the same NT kernel
   if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldwt < N ||
-      ldo < K || n_scaled < 0 || n_scaled > K)
+      ldo < K || n_scaled < 0 || n_scaled > K || (relu_mask && ld_mask < K))
     return PYGAMD_ERR_INVALID_ARG;
   if (M == 0 || K == 0) return PYGAMD_OK;
   if (!out || (N > 0 && (!g || !w_t)) || (n_scaled > 0 && !row_scale))
     return PYGAMD_ERR_INVALID_ARG;
   GemmNT p = {};
-  p.a = g; p.b = w_t; p.bias = nullptr; p.row_scale = row_scale; p.c = out;
-  p.M = M; p.lda = ldg; p.ldb = ldwt; p.ldc = ldo;
+  p.a = g; p.b = w_t; p.bias = nullptr; p.row_scale = row_scale; p.mask = relu_mask;
+  p.c = out;
+  p.M = M; p.lda = ldg; p.ldb = ldwt; p.ldc = ldo; p.ldm = ld_mask;
   p.N = static_cast<int>(K); p.K = static_cast<int>(N);
   p.relu = 0; p.n_scaled = static_cast<int>(n_scaled); p.accumulate = accumulate ? 1 : 0;
   return run_nt(p, as_stream(stream));
@@ -550,14 +598,16 @@ static int64_t wgrad_splits(int64_t M, int64_t tiles, int wgs_per_cu = 2) {
 int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t* bytes) {
   if (!bytes || M < 0 || N < 0 || K < 0) return PYGAMD_ERR_INVALID_ARG;
   const int64_t tiles = ceil_div(N, kWTile) * ceil_div(K, kWTile);
+  // [splits][N][K] partial tiles + [splits][N] bias-gradient partials
   *bytes = static_cast<size_t>(wgrad_splits(M, tiles)) * static_cast<size_t>(N) *
-           static_cast<size_t>(K) * sizeof(float);
+           (static_cast<size_t>(K) + 1) * sizeof(float);
   return PYGAMD_OK;
 }
 
 int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t M,
                         int64_t N, int64_t K, int accumulate, int wgs_per_cu, float* out,
-                        int64_t ldo, void* workspace, size_t workspace_bytes, void* stream) {
+                        int64_t ldo, float* bias_grad, void* workspace, size_t workspace_bytes,
+                        void* stream) {
   if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldx < K ||
       ldo < K)
     return PYGAMD_ERR_INVALID_ARG;
@@ -575,6 +625,7 @@ int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
   p.tiles_k = static_cast<int>(ceil_div(K, kWTile));
   const int64_t tiles = static_cast<int64_t>(p.tiles_n) * p.tiles_k;
   p.splits = static_cast<int>(wgrad_splits(M, tiles, wgs_per_cu));
+  p.colsum = bias_grad ? p.partial + static_cast<int64_t>(p.splits) * N * K : nullptr;
   p.rows_per_split = round_up(ceil_div(M > 0 ? M : 1, p.splits), kWRows);
   const bool vec = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) &&
                    aligned16p(g) && aligned16p(x);
@@ -595,9 +646,10 @@ int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
   }
   PYGAMD_LAUNCH_CHECK();
   const int64_t NK = N * K;
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(static_cast<unsigned>(ceil_div(NK, kBlock))),
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel,
+                     dim3(static_cast<unsigned>(ceil_div(NK + (bias_grad ? N : 0), kBlock))),
                      dim3(kBlock), 0, st, p.partial, p.splits, NK, p.K, out, ldo,
-                     accumulate ? 1 : 0);
+                     accumulate ? 1 : 0, p.colsum, p.N, bias_grad);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }

@@ -299,6 +299,8 @@ int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root
     a.g.out = graph->out;
     a.g.arg_out = nullptr;
     a.g.arg32_out = nullptr;
+    a.g.relu_mask = nullptr;
+    a.g.ldm = 0;
     a.g.n_rows = graph->n_rows;
     a.g.F = F;
     a.g.ldx = graph->ldx;

@@ -42,24 +42,38 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
 #pragma unroll
     for (int i = 0; i < VW; ++i) acc[c][i] = 0.f;
   }
+  // The row's epilogue operands (the old output row of `accumulate`, the activation row of the
+  // fused ReLU backward) do not depend on the sum: their loads are issued BEFORE the gather loop
+  // and complete under it, instead of adding one or two exposed HBM latencies to the end of every
+  // wave's life.
+  float* __restrict__ orow = a.out + row * a.ldo;
+  Vec<VW> oldv[CH], maskv[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      oldv[c].v[i] = 0.f;
+      maskv[c].v[i] = 1.f;
+    }
+    if (lane < LPR && fv[c]) {
+      if (a.accumulate) oldv[c] = load_vec<VW>(orow + fo[c]);
+      if (a.relu_mask) maskv[c] = load_vec<VW>(a.relu_mask + row * a.ldm + fo[c]);
+    }
+  }
   spmm_accumulate<IdxT, VW, LPR, CH, WMODE, IDENT>(a, start, end, lane, fo, fv, head, acc);
   combine_subgroups<VW, LPR, CH>(acc);
   if (lane < LPR) {
     const float cntf = static_cast<float>(deg > 0 ? deg : 1);
-    float* __restrict__ orow = a.out + row * a.ldo;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (fv[c]) {
-        Vec<VW> o;
 #pragma unroll
-        for (int i = 0; i < VW; ++i) o.v[i] = a.mean ? acc[c][i] / cntf : acc[c][i];
-        if (a.accumulate) {
-          const Vec<VW> old = load_vec<VW>(orow + fo[c]);
-#pragma unroll
-          for (int i = 0; i < VW; ++i) o.v[i] += old.v[i];
+        for (int i = 0; i < VW; ++i) {
+          float o = a.mean ? acc[c][i] / cntf : acc[c][i];
+          if (a.accumulate) o += oldv[c].v[i];  // (not "+ 0": -0.0 sums stay -0.0)
+          o = maskv[c].v[i] > 0.f ? o : 0.f;
+          __builtin_nontemporal_store(o, orow + fo[c] + i);
         }
-#pragma unroll
-        for (int i = 0; i < VW; ++i) __builtin_nontemporal_store(o.v[i], orow + fo[c] + i);
       }
     }
   }
@@ -121,7 +135,8 @@ __global__ void __launch_bounds__(kBlock)
     spmm_hub_combine(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ hub_rows,
                      const IdxT* __restrict__ hub_chunk_ptr, int64_t n_hub,
                      const float* __restrict__ partial, float* __restrict__ out, int64_t F,
-                     int64_t ldo, int mean, int accumulate) {
+                     int64_t ldo, int mean, int accumulate, const float* __restrict__ relu_mask,
+                     int64_t ldm) {
   const int lane = lane_id();
   const int64_t h = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   if (h >= n_hub) return;
@@ -134,7 +149,9 @@ __global__ void __launch_bounds__(kBlock)
     float s = 0.f;
     for (int64_t c = c0; c < c1; ++c) s += partial[c * F + f];
     s = mean ? s / cntf : s;
-    out[row * ldo + f] = accumulate ? out[row * ldo + f] + s : s;
+    s = accumulate ? out[row * ldo + f] + s : s;
+    if (relu_mask) s = relu_mask[row * ldm + f] > 0.f ? s : 0.f;
+    out[row * ldo + f] = s;
   }
 }
 
@@ -758,6 +775,8 @@ static SpmmDev<IdxT> make_dev(const pygamd_spmm_args* p) {
   a.out = p->out;
   a.arg_out = static_cast<IdxT*>(p->arg_out);
   a.arg32_out = p->arg32_out;
+  a.relu_mask = p->relu_mask;
+  a.ldm = p->ld_mask;
   a.n_rows = p->n_rows;
   a.F = p->F;
   a.ldx = p->ldx;
@@ -781,6 +800,7 @@ static Shape pick_shape(const pygamd_spmm_args* p) {
   Shape s;
   const bool v4 = (p->F % 4 == 0) && (p->ldx % 4 == 0) && (p->ldo % 4 == 0) &&
                   aligned16(p->x) && aligned16(p->out) &&
+                  (!p->relu_mask || (p->ld_mask % 4 == 0 && aligned16(p->relu_mask))) &&
                   (p->w_heads <= 1 || p->head_dim % 4 == 0);
   s.vw = v4 ? 4 : 1;
   const int64_t units = ceil_div(p->F, s.vw);  // lanes needed to cover a row once
@@ -813,7 +833,7 @@ static int launch_sum(const pygamd_spmm_args* p, const Shape& s, float* partial,
     hipLaunchKernelGGL((spmm_hub_combine<IdxT>), cgrid, dim3(kBlock), 0, st, a.rowptr,
                        static_cast<const IdxT*>(p->hub_rows),
                        static_cast<const IdxT*>(p->hub_chunk_ptr), p->n_hub, partial, a.out,
-                       a.F, a.ldo, a.mean, a.accumulate);
+                       a.F, a.ldo, a.mean, a.accumulate, a.relu_mask, a.ldm);
     PYGAMD_LAUNCH_CHECK();
   }
   return PYGAMD_OK;
@@ -1023,7 +1043,8 @@ static int validate(const pygamd_spmm_args* p) {
     return PYGAMD_ERR_UNSUPPORTED;
   if (p->n_rows > 0 && p->F > 0 && (!p->rowptr || !p->x || !p->out)) return PYGAMD_ERR_INVALID_ARG;
   const bool mm = (p->reduce == PYGAMD_MIN || p->reduce == PYGAMD_MAX);
-  if (mm && (p->w || p->src_scale || p->accumulate)) return PYGAMD_ERR_UNSUPPORTED;
+  if (mm && (p->w || p->src_scale || p->accumulate || p->relu_mask)) return PYGAMD_ERR_UNSUPPORTED;
+  if (p->relu_mask && p->ld_mask < p->F) return PYGAMD_ERR_INVALID_ARG;
   if (p->w && p->w_heads > 1) {
     if (p->head_dim < 1 || static_cast<int64_t>(p->head_dim) * p->w_heads != p->F)
       return PYGAMD_ERR_INVALID_ARG;

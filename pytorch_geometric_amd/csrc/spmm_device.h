@@ -18,6 +18,8 @@ struct SpmmDev {
   float* __restrict__ out;
   IdxT* __restrict__ arg_out;
   int32_t* __restrict__ arg32_out;  // MIN/MAX: saved for the backward (see pyg_amd.h)
+  const float* __restrict__ relu_mask;  // SUM/MEAN: out = relu_mask <= 0 ? 0 : out (or null)
+  int64_t ldm;
   int64_t n_rows, F, ldx, ldo;
   int w_heads, head_dim;
   int mean;

@@ -54,7 +54,7 @@ OVERLAP_WGRAD = os.environ.get('PYGAMD_OVERLAP_WGRAD', '0') != '0'
 _side_streams = {}
 # below this many rows a launch of the own row-tiled kernels has fewer tiles than the chip has CUs
 # (cf. nn/dense/linear.py): small sampled batches keep the library GEMM
-OWN_GEMM_MIN_ROWS = 16384
+OWN_GEMM_MIN_ROWS = int(os.environ.get('PYGAMD_OWN_GEMM_MIN_ROWS', '16384'))
 
 
 def own_gemm(rows: int) -> bool:
@@ -192,23 +192,35 @@ class FusedSageStack(Function):
         g = grad_out if grad_out.stride(1) == 1 else grad_out.contiguous()
         grad_x = None
         pending = []  # side streams with weight-gradient launches in flight
+        own = GEMM_BACKEND == 'own'
+        # Own kernels: no stand-alone ReLU-backward / bias-gradient pass.  The kernel that PRODUCES
+        # a layer's input gradient (transposed SpMM for 'post', dgrad GEMM for 'pre') zeroes it
+        # where that input — the ReLU output of the layer below — is not positive, and the weight
+        # gradient GEMM returns the column sums of its `g` operand (= the bias gradient) from the
+        # pass it makes over `g` anyway.
+        masked = True  # grad_out itself has no activation behind it
         for layer in reversed(range(L)):
             buf, wmat = bufs[layer], wmats[layer]
             Fi, Fo = ctx.dims[layer]
-            if layer < L - 1:  # ReLU backward and this layer's bias gradient in one pass
+            want_b = ctx.has_bias[layer]
+            if not masked:  # ReLU backward and this layer's bias gradient in one pass
                 h_next = FusedSageStack._input_view(ctx, bufs, layer + 1)  # post-ReLU output
-                g, grads[3 * layer + 1] = _native.relu_backward_colsum(g, h_next,
-                                                                       ctx.has_bias[layer])
-            elif ctx.has_bias[layer]:
+                g, grads[3 * layer + 1] = _native.relu_backward_colsum(g, h_next, want_b)
+            elif want_b and not own:
                 grads[3 * layer + 1] = _native.colsum(g)
             need_input_grad = layer > 0 or ctx.needs_input_grad[0]
-            own = GEMM_BACKEND == 'own'
+            mask_in = FusedSageStack._input_view(ctx, bufs, layer) if (own and layer > 0) else None
             if ctx.modes[layer] == 'post':
                 # [Fo, 2 Fi] = [grad W_l | grad W_r]
                 overlap = (own and OVERLAP_WGRAD and need_input_grad
                            and not torch.cuda.is_current_stream_capturing())
                 if not overlap:
-                    gw = _native.linear_wgrad(g, buf) if own else torch.mm(g.t(), buf)
+                    if own:
+                        gw = _native.linear_wgrad(g, buf, bias_grad=want_b)
+                        if want_b:
+                            gw, grads[3 * layer + 1] = gw
+                    else:
+                        gw = torch.mm(g.t(), buf)
                 if need_input_grad:
                     # [N, 2 Fi] = [grad_agg | grad_root]
                     if own:  # grad_agg rows leave the GEMM already divided by their degree
@@ -226,12 +238,14 @@ class FusedSageStack(Function):
                         side = _side_stream(g.device)
                         side.wait_stream(cur)
                         with torch.cuda.stream(side):
-                            gw = _native.linear_wgrad(g, buf, wgs_per_cu=1)
+                            gw = _native.linear_wgrad(g, buf, wgs_per_cu=1, bias_grad=want_b)
+                            if want_b:
+                                gw, grads[3 * layer + 1] = gw
                         g.record_stream(side)
                         pending.append(side)
                     _native.spmm_csr(bwd.ptr, bwd.idx, gcat[:, :Fi], 'sum', n_rows=N,
                                      src_scale=None if pre_scaled else scale, hub=bwd.hub,
-                                     out=gcat[:, Fi:], accumulate=True)
+                                     out=gcat[:, Fi:], accumulate=True, relu_mask=mask_in)
                 grads[3 * layer] = gw[:, :Fi]
                 grads[3 * layer + 2] = gw[:, Fi:]
                 if need_input_grad:
@@ -262,16 +276,22 @@ class FusedSageStack(Function):
                     side = _side_stream(g.device)
                     side.wait_stream(cur)
                     with torch.cuda.stream(side):
-                        gw = _native.linear_wgrad(gy, x_in, wgs_per_cu=1)
+                        gw = _native.linear_wgrad(gy, x_in, wgs_per_cu=1, bias_grad=want_b)
                     gy.record_stream(side)
                     pending.append(side)
+                elif own:
+                    gw = _native.linear_wgrad(gy, x_in, bias_grad=want_b)
                 else:
-                    gw = _native.linear_wgrad(gy, x_in) if own else torch.mm(gy.t(), x_in)
+                    gw = torch.mm(gy.t(), x_in)
+                if own and want_b:  # the bias sits on the root half of y = [x W_l^T | x W_r^T + b]
+                    gw, gb = gw
+                    grads[3 * layer + 1] = gb[Fp:Fp + Fo]
                 grads[3 * layer] = gw[:Fo]
                 grads[3 * layer + 2] = gw[Fp:Fp + Fo]
                 if need_input_grad:  # [N, Fi]
-                    g = (_native.linear_dgrad(gy, wmat.t().contiguous()) if own
-                         else torch.mm(gy, wmat))
+                    g = (_native.linear_dgrad(gy, wmat.t().contiguous(), relu_mask=mask_in)
+                         if own else torch.mm(gy, wmat))
+            masked = mask_in is not None
             if layer == 0 and need_input_grad:
                 grad_x = g.contiguous()
         for side in pending:  # the optimizer (main stream) consumes the weight gradients

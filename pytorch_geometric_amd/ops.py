@@ -334,8 +334,13 @@ def linear_backward(grad: Tensor, x: Tensor, weight: Tensor, need_x: bool, need_
     empty = x.new_empty(0)
     gx = (_native.linear_dgrad(g2, weight.t().contiguous()).reshape(x.shape) if need_x
           else empty)
-    gw = _native.linear_wgrad(g2, x2) if need_w else empty
-    gb = _native.colsum(g2) if need_b else empty
+    gw = gb = empty
+    if need_w:
+        gw = _native.linear_wgrad(g2, x2, bias_grad=need_b)
+        if need_b:
+            gw, gb = gw
+    elif need_b:
+        gb = _native.colsum(g2)
     return gx, gw, gb
 
 

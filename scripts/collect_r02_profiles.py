@@ -68,10 +68,11 @@ if fetch and write:
         if f is not None and w is not None:
             res['per_launch'][key] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w,
                                       'hbm_bytes': (2 * f + w) * 1024}
-    alg = E * (4 * F + 8) + (N + 1) * 8 + N * 4 * F + N * 4 * F  # + the rows accumulated onto
+    # + the rows accumulated onto + the activation rows of the fused ReLU backward
+    alg = E * (4 * F + 8) + (N + 1) * 8 + N * 4 * F + N * 4 * F + N * 4 * F
     dom = res['per_launch'].get('spmm_sum_rows_F256_transposed_accumulate')
     if dom:
-        res['kernel'] = 'pygamd::spmm_sum_rows<long,4,64,1,0,false> (transposed, accumulate)'
+        res['kernel'] = 'pygamd::spmm_sum_rows<long,4,64,1,0,false> (transposed, accumulate, ReLU-backward epilogue)'
         res['algorithmic_bytes_per_launch'] = alg
         res['traffic_bytes_per_launch'] = dom['hbm_bytes']
         res['traffic_over_algorithmic'] = round(dom['hbm_bytes'] / alg, 4)

@@ -87,6 +87,29 @@ def test_linear_dgrad_and_wgrad(dev, M, K, N):
     out = _native.linear_wgrad(go.to(dev), x.to(dev))
     assert out.shape == (N, K)
     assert_sum_close(out, ref32, ex, abs_sum=bound, what=f'wgrad {M}x{K}x{N}')
+    # the bias gradient from the same pass over `go`; the weight gradient is bit-identical
+    out2, gb = _native.linear_wgrad(go.to(dev), x.to(dev), bias_grad=True)
+    assert torch.equal(out2, out) and gb.shape == (N, )
+    assert_sum_close(gb, go.sum(0), go.double().sum(0), abs_sum=go.abs().double().sum(0),
+                     what=f'wgrad bias {M}x{K}x{N}')
+    # dgrad with the ReLU-backward epilogue: exact zeros where the mask is not positive, the plain
+    # result (bit-identical) elsewhere; strided mask (right half of an [agg | x] buffer)
+    if K > 0:
+        act = torch.randn(M, 2 * K, generator=g).relu()
+        act[::7, K:] = -0.0
+        act_d = act.to(dev)
+        plain = _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev), scale.to(dev), ns)
+        got = _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev), scale.to(dev), ns,
+                                   relu_mask=act_d[:, K:])
+        assert torch.equal(got, torch.where(act_d[:, K:] > 0, plain, torch.zeros_like(plain)))
+        base = torch.randn(M, K, generator=g).to(dev)
+        acc = base.clone()
+        _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev), out=acc, accumulate=True,
+                             relu_mask=act_d[:, K:])
+        want = torch.where(act_d[:, K:] > 0,
+                           base + _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev)),
+                           torch.zeros_like(base))
+        assert_close(acc, want, rtol=1e-6, atol=1e-6, what='dgrad accumulate + mask')
 
 
 def test_wgrad_long_reduction_is_deterministic_and_accurate(dev):
@@ -96,9 +119,11 @@ def test_wgrad_long_reduction_is_deterministic_and_accurate(dev):
     g = gen(9)
     M, N, K = 200_003, 96, 200
     go, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
-    a = _native.linear_wgrad(go.to(dev), x.to(dev))
-    b = _native.linear_wgrad(go.to(dev), x.to(dev))
-    assert torch.equal(a, b)
+    a, ba = _native.linear_wgrad(go.to(dev), x.to(dev), bias_grad=True)
+    b, bb = _native.linear_wgrad(go.to(dev), x.to(dev), bias_grad=True)
+    assert torch.equal(a, b) and torch.equal(ba, bb)
+    assert_sum_close(ba, go.sum(0), go.double().sum(0), abs_sum=go.abs().double().sum(0),
+                     what='wgrad bias M=200003')
     ex = go.double().t() @ x.double()
     bound = go.abs().double().t() @ x.abs().double()
     assert_sum_close(a, go.t() @ x, ex, abs_sum=bound, what='wgrad M=200003')

@@ -487,6 +487,24 @@ def test_spmm_accumulate(dev, monkeypatch):
         ref = buf[:, F:] + O.spmm(ei, buf[:, :F].contiguous(), 300, 'mean')
         assert_close(bd[:, F:], ref, atol=2e-5, what=f'accumulate F={F}')
         assert_close(bd[:, :F], buf[:, :F], rtol=0, atol=0)
+        # relu_mask: the same launch zeroes the result where a ReLU output (here the right half
+        # of another [agg | x] buffer, a strided view) is not positive — hub rows, vector and
+        # scalar widths; everything else bit-identical to the unmasked launch
+        act = torch.randn(300, 2 * F, generator=gen(F + 1)).relu()
+        act[::5, F:] = -0.0
+        ad = act.to(dev)
+        for acc in (True, False):
+            b1, b2 = buf.to(dev), buf.to(dev)
+            _native.spmm_csr(fwd.ptr, fwd.idx, b1[:, :F], 'mean', n_rows=300, hub=fwd.hub,
+                             out=b1[:, F:], accumulate=acc)
+            _native.spmm_csr(fwd.ptr, fwd.idx, b2[:, :F], 'mean', n_rows=300, hub=fwd.hub,
+                             out=b2[:, F:], accumulate=acc, relu_mask=ad[:, F:])
+            want = torch.where(ad[:, F:] > 0, b1[:, F:], torch.zeros_like(b1[:, F:]))
+            assert torch.equal(b2[:, F:], want), f'relu_mask F={F} accumulate={acc}'
+            assert int((want == 0).sum()) > 0
+    with pytest.raises(RuntimeError):  # extrema have no such epilogue
+        _native.spmm_csr(fwd.ptr, fwd.idx, bd[:, :F], 'max', n_rows=300,
+                         relu_mask=bd[:, :F].contiguous())
 
 
 def test_fused_and_multi_aggregation(dev):
