@@ -266,9 +266,16 @@ def run_minibatch(args, rank, local_rank, world, dev):
 def gemm_desc(tuned: bool) -> str:
     from pytorch_geometric_amd.nn.models import _fused_sage
     if _fused_sage.GEMM_BACKEND == 'own':
+        from pytorch_geometric_amd import get_gemm_mode
+        if get_gemm_mode() == 'split':
+            return ('pytorch_geometric_amd/csrc/gemm.hip, PYGAMD_GEMM_MODE=split (NOT the default): '
+                    'fp32 operands as 3 bf16 terms each, 6 v_mfma_f32_32x32x16_bf16 products, '
+                    'fp32 accumulation, in the stand-alone forward / dgrad / wgrad kernels; the '
+                    'one-kernel layer forward stays on the fp32 instruction')
         return ('pytorch_geometric_amd/csrc/gemm.hip: hand-written fp32 MFMA '
                 '(v_mfma_f32_32x32x2_f32) forward (+bias+ReLU epilogue), dgrad (+1/deg row '
-                'scale epilogue) and split-reduction wgrad kernels')
+                'scale and ReLU-backward epilogues) and split-reduction wgrad (+bias gradient) '
+                'kernels')
     return ('rocBLAS/hipBLASLt via torch.mm (PYGAMD_GEMM=lib), ' +
             ('solution per shape from pytorch_geometric_amd/tuning (TunableOp, read-only)'
              if tuned else 'default heuristics'))

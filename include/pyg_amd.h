@@ -462,6 +462,18 @@ PYGAMD_API int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int
  *             receives the column sums of g (the bias gradient of the same Linear,
  *             nn/dense/linear.py:121-127 backward) from the same pass over g: per-split sums taken
  *             while the rows are staged, added in split order (deterministic).                 */
+/* Arithmetic of the three entry points below and of pygamd_sage_layer_forward (process-wide):
+ *   PYGAMD_GEMM_FP32       (default) v_mfma_f32_32x32x2_f32: IEEE fp32 products and sums, bitwise
+ *                          an fmaf chain over k;
+ *   PYGAMD_GEMM_SPLIT_BF16 every fp32 operand as the exact sum of three bf16 terms, the six
+ *                          leading cross products on v_mfma_f32_32x32x16_bf16 with fp32
+ *                          accumulation: the same fp32 inputs and outputs, error against fp64 at
+ *                          or below the fmaf chain's (profiles/r02_split_bf16_accuracy_probe.txt),
+ *                          not bitwise equal to it; an Inf operand yields NaN.               */
+#define PYGAMD_GEMM_FP32 0
+#define PYGAMD_GEMM_SPLIT_BF16 1
+PYGAMD_API int pygamd_set_gemm_mode(int mode);
+PYGAMD_API int pygamd_get_gemm_mode(void);
 PYGAMD_API int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
                                      const float* bias, int64_t M, int64_t K, int64_t N, int relu,
                                      int accumulate, float* out, int64_t ldo, void* stream);

@@ -19,10 +19,26 @@ from . import nn
 __version__ = '0.1.0'
 
 
+def set_gemm_mode(mode: str) -> str:
+    """Arithmetic of the dense feature-transform kernels (csrc/gemm.hip): ``'fp32'`` (default —
+    the fp32 matrix instruction, bitwise an fmaf chain) or ``'split'`` (every fp32 operand as three
+    bf16 terms, six bf16 matrix products, fp32 accumulation: same fp32 tensors in and out, error
+    against fp64 at or below the fmaf chain's).  Also ``PYGAMD_GEMM_MODE``.  Returns the previous
+    mode."""
+    from . import _native
+    return _native.set_gemm_mode(mode)
+
+
+def get_gemm_mode() -> str:
+    from . import _native
+    return _native.get_gemm_mode()
+
+
 def build(force: bool = False) -> str:
     """Compile the HIP sources for gfx950 into ``lib/libpyg_amd.so`` (in-tree)."""
     return _build.build_library(force=force)
 
 
 __all__ = ['EdgeIndex', 'as_edge_index', 'clear_cache', 'set_cache_enabled', 'index2ptr',
-           'ptr2index', 'utils', 'nn', 'build', 'load_library', 'lib_path', 'PygAmdError']
+           'ptr2index', 'utils', 'nn', 'build', 'load_library', 'lib_path', 'PygAmdError',
+           'set_gemm_mode', 'get_gemm_mode']

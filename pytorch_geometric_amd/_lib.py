@@ -76,6 +76,8 @@ SIGNATURES = {
                                           c_int, c_int, _P, c_int64, _P, c_size_t, _P]),
     'pygamd_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                       c_int, c_int, _P, c_int64, _P]),
+    'pygamd_set_gemm_mode': (c_int, [c_int]),
+    'pygamd_get_gemm_mode': (c_int, []),
     'pygamd_linear_dgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                     c_int64, c_int, _P, c_int64, _P, c_int64, _P]),
     'pygamd_linear_wgrad_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
@@ -133,6 +135,9 @@ def lib_path():
     return _build.LIB_PATH
 
 
+GEMM_MODES = {'fp32': 0, 'split': 1}  # PYGAMD_GEMM_FP32 / PYGAMD_GEMM_SPLIT_BF16
+
+
 def load():
     """Load (building first if the in-tree .so is missing/stale and hipcc exists)."""
     global _lib
@@ -154,6 +159,10 @@ def load():
         fn.argtypes = argtypes
     if lib.pygamd_abi_version() != ABI_VERSION:
         raise PygAmdError(f'ABI mismatch: library reports {lib.pygamd_abi_version()}')
+    mode = os.environ.get('PYGAMD_GEMM_MODE', 'fp32')
+    if mode not in GEMM_MODES:
+        raise PygAmdError(f"PYGAMD_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got '{mode}'")
+    lib.pygamd_set_gemm_mode(GEMM_MODES[mode])
     _lib = lib
     return lib
 

@@ -616,6 +616,24 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     return out
 
 
+def set_gemm_mode(mode: str) -> str:
+    """Arithmetic of the dense transform kernels (``pygamd_set_gemm_mode``): ``'fp32'`` (default:
+    the fp32 matrix instruction, bitwise an fmaf chain) or ``'split'`` (operands as three bf16
+    terms each, six bf16 matrix products with fp32 accumulation: fp32-level accuracy, ~2.5 x the
+    matrix rate).  Returns the previous mode."""
+    lib = _lib.load()
+    if mode not in _lib.GEMM_MODES:
+        raise ValueError(f"mode must be one of {sorted(_lib.GEMM_MODES)}, got '{mode}'")
+    prev = get_gemm_mode()
+    check(lib.pygamd_set_gemm_mode(_lib.GEMM_MODES[mode]), 'set_gemm_mode')
+    return prev
+
+
+def get_gemm_mode() -> str:
+    code = _lib.load().pygamd_get_gemm_mode()
+    return next(k for k, v in _lib.GEMM_MODES.items() if v == code)
+
+
 def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_scaled: int = 0,
                  out: Optional[Tensor] = None, accumulate: bool = False,
                  relu_mask: Optional[Tensor] = None) -> Tensor:

@@ -98,6 +98,21 @@ template <int VW>
 __device__ __forceinline__ Vec<VW> load_vec(const float* p) {
   return *reinterpret_cast<const Vec<VW>*>(p);
 }
+// rows that are read exactly once (epilogue operands): keep them out of the way of the gathered
+// feature rows in L2
+template <int VW>
+__device__ __forceinline__ Vec<VW> load_vec_streamed(const float* p) {
+  typedef float vt __attribute__((ext_vector_type(VW)));
+  Vec<VW> r;
+  if constexpr (VW == 1) {
+    r.v[0] = __builtin_nontemporal_load(p);
+  } else {
+    const vt t = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+#pragma unroll
+    for (int i = 0; i < VW; ++i) r.v[i] = t[i];
+  }
+  return r;
+}
 template <int VW>
 __device__ __forceinline__ void store_vec(float* p, const Vec<VW>& v) {
   *reinterpret_cast<Vec<VW>*>(p) = v;

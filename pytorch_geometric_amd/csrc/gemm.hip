@@ -34,6 +34,67 @@ namespace pygamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- "split" mode: fp32 operands as sums of three bf16 terms --------------------------------------
+// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (both residuals are
+// exact in fp32; three 8-bit significands cover the 24 of an fp32 value).  A product a * b is then
+// the sum of the six cross terms of weight >= 2^-16 (a1 b3, a3 b1, a2 b2, a1 b2, a2 b1, a1 b1 — the
+// three dropped ones are below 2^-24 of the product), each an EXACT bf16 x bf16 product summed in
+// the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  Six instructions of 32 cycles replace eight
+// fp32 instructions of 64 cycles for the same 16 k values.  Measured error against fp64
+// (profiles/r02_split_bf16_accuracy_probe.txt): at or below that of the fp32 fmaf chain for
+// K = 256 .. 2048 on normal, all-positive and wide-dynamic-range inputs.  Differences from the
+// exact mode: results are not bitwise those of an fmaf chain, and an Inf operand gives NaN
+// (Inf - Inf in the residual) where IEEE arithmetic would give Inf.  Opt-in
+// (pygamd_set_gemm_mode), the default stays the exact fp32 instruction.
+struct SplitFrag {
+  bf16x8 p[3];
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32
+}
+
+// eight consecutive k values of one row (two 16-byte LDS reads) -> three bf16x8 operands
+__device__ __forceinline__ SplitFrag split_frag(const f32x4& v0, const f32x4& v1) {
+  u32x4 w[3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = q < 2 ? v0[2 * q] : v1[2 * q - 4];
+    const float x1 = q < 2 ? v0[2 * q + 1] : v1[2 * q - 3];
+    const uint32_t a = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(a << 16);
+    const float r1 = x1 - __uint_as_float(a & 0xffff0000u);
+    const uint32_t b = pack_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(b << 16);
+    const float s1 = r1 - __uint_as_float(b & 0xffff0000u);
+    w[0][q] = a;
+    w[1][q] = b;
+    w[2][q] = pack_bf16(s0, s1);
+  }
+  SplitFrag f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) f.p[t] = __builtin_bit_cast(bf16x8, w[t]);
+  return f;
+}
+
+// The six cross terms in the order they are accumulated (small ones first): term t multiplies
+// part kSplitA[t] of a with part kSplitB[t] of b.  Callers walk the terms in the OUTER loop and
+// their 32 x 32 blocks in the inner one: consecutive instructions then write different
+// accumulators (six back-to-back instructions on one accumulator, with the conversion VALU work
+// scheduled in between, leave the matrix pipe idle waiting on the dependency — measured 31 % busy).
+constexpr int kSplitTerms = 6;
+__device__ __forceinline__ void split_term(int t, const SplitFrag& a, const SplitFrag& b,
+                                           f32x16& acc) {
+  constexpr int ta[kSplitTerms] = {0, 2, 1, 0, 1, 0};
+  constexpr int tb[kSplitTerms] = {2, 0, 1, 1, 0, 0};
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[ta[t]], b.p[tb[t]], acc, 0, 0, 0);
+}
 
 constexpr int kGK = 32;        // k chunk
 constexpr int kGLD = kGK + 4;  // LDS row stride (floats) of the NT kernel's tiles
@@ -51,6 +112,7 @@ struct GemmNT {
   int n_scaled;   // columns [0, n_scaled) are multiplied by row_scale[row]
   int accumulate; // c += result
   int tiles_m, tiles_n;
+  int split;      // 3 x bf16 operand split instead of the fp32 instruction
 };
 
 // Tile numbering: hardware block b runs on XCD b % 8.  Logical order inside an XCD: for each row
@@ -63,7 +125,7 @@ __device__ __forceinline__ void nt_tile_of_block(const GemmNT& p, int& tm, int& 
   tn = static_cast<int>(q - static_cast<int64_t>(tm) * p.tiles_n);
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+template <int WM, int WN, int TM, int TN, bool VEC, bool SPLIT>
 __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -185,6 +247,23 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
                                                             f.b[j][s >> 2][s & 3], acc[i][j], 0, 0,
                                                             0);
   };
+  // Split mode: a half-chunk fragment is ONE bf16 step over the same 16 k values (lane half h holds
+  // its 8 consecutive ones), six instructions per 32 x 32 block.
+  auto split_all = [&](const Frag& f, SplitFrag (&sa)[TM], SplitFrag (&sb)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) sa[i] = split_frag(f.a[i][0], f.a[i][1]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) sb[j] = split_frag(f.b[j][0], f.b[j][1]);
+  };
+  auto mma_terms = [&](const SplitFrag (&sa)[TM], const SplitFrag (&sb)[TN], int t_begin,
+                       int t_end) {
+#pragma unroll
+    for (int t = t_begin; t < t_end; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) split_term(t, sa[i], sb[j], acc[i][j]);
+  };
 
   // Pipeline (ONE barrier per chunk, every LDS read issued at least 16 MFMAs before its use):
   //   iteration c:  LDS[c+1] <- registers;  registers <- global chunk c+2;
@@ -201,21 +280,63 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
   if (n_chunks > 1) load_chunk(kGK);
   __syncthreads();
   if (n_chunks > 0) read_frag(f0, 0, 0);
-  for (int c = 0; c < n_chunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < n_chunks) store_chunk(buf ^ 1, (c + 1) * kGK);
-    if (c + 2 < n_chunks) load_chunk((c + 2) * kGK);
-    read_frag(f1, buf, 1);
-    mma_steps(f0, 0, 4);
-    // keep the barrier in the MIDDLE of the MFMA stream (hipcc hoists it to the top otherwise:
-    // the wave would then sit in lgkmcnt(0) + s_barrier with one MFMA in flight)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    mma_steps(f0, 4, 8);
-    if (c + 1 < n_chunks) read_frag(f0, buf ^ 1, 0);
-    // a K tail of <= 8 leaves the upper 8 steps all zero in both lane halves: skip them
-    if (p.K - c * kGK > 8) mma_steps(f1, 0, 8);
+  if constexpr (SPLIT) {
+    // Software pipeline over half-chunks: while the 6 * TM * TN matrix instructions of one
+    // half-chunk run, the VALU converts the NEXT half-chunk's fp32 fragments into bf16 terms
+    // (a wave issues in order: conversion and multiplication of the same fragment back to back
+    // would leave each pipe idle while the other one works).  sched_group_barrier pins the
+    // interleave: one matrix instruction, then its share of the conversion work.
+    constexpr int kMfma = kSplitTerms * TM * TN;       // per half-chunk
+    constexpr int kValuPer = (TM + TN) * 44 / kMfma + 1;  // ~44 VALU per converted fragment
+    SplitFrag ca[TM], cb[TN], na[TM], nb[TN];
+    if (n_chunks > 0) split_all(f0, ca, cb);
+    for (int c = 0; c < n_chunks; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < n_chunks) store_chunk(buf ^ 1, (c + 1) * kGK);
+      if (c + 2 < n_chunks) load_chunk((c + 2) * kGK);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frag(f1, buf, 1);
+      split_all(f1, na, nb);
+      mma_terms(ca, cb, 0, kSplitTerms);
+#pragma unroll
+      for (int q = 0; q < kMfma; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kValuPer, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      // (the last iteration reads a buffer nobody filled: converted, never multiplied)
+      read_frag(f0, buf ^ 1, 0);
+      split_all(f0, ca, cb);
+      // rows of the K tail are staged as zeros, so the upper half-chunk is always multiplied
+      mma_terms(na, nb, 0, kSplitTerms);
+#pragma unroll
+      for (int q = 0; q < kMfma; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kValuPer, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    for (int c = 0; c < n_chunks; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < n_chunks) store_chunk(buf ^ 1, (c + 1) * kGK);
+      if (c + 2 < n_chunks) load_chunk((c + 2) * kGK);
+      read_frag(f1, buf, 1);
+      mma_steps(f0, 0, 4);
+      // keep the barrier in the MIDDLE of the MFMA stream (hipcc hoists it to the top otherwise:
+      // the wave would then sit in lgkmcnt(0) + s_barrier with one MFMA in flight)
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      mma_steps(f0, 4, 8);
+      if (c + 1 < n_chunks) read_frag(f0, buf ^ 1, 0);
+      // a K tail of <= 8 leaves the upper 8 steps all zero in both lane halves: skip them
+      if (p.K - c * kGK > 8) mma_steps(f1, 0, 8);
+    }
   }
 
   // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
@@ -305,7 +426,13 @@ struct GemmTN {
   int64_t rows_per_split;       // multiple of kWRows
 };
 
-template <bool VEC>
+// eight k values gathered one by one (the TN kernel's operands run DOWN the staged rows)
+__device__ __forceinline__ SplitFrag split_frag8(const float (&v)[8]) {
+  const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+  return split_frag(lo, hi);
+}
+
+template <bool VEC, bool SPLIT>
 __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
   extern __shared__ __align__(16) float smem[];
   float (*Gs)[kWRows][kWLD] = reinterpret_cast<float (*)[kWRows][kWLD]>(smem);
@@ -402,10 +529,77 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
       if (kb1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
   };
+  // split mode: eight values down a staged column -> three bf16x8 operands
+  auto read_split = [&](const float* col) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col[e * kWLD];
+    return split_frag8(v);
+  };
+  auto mma4 = [&](const SplitFrag& a0, const SplitFrag& a1, const SplitFrag& b0,
+                  const SplitFrag& b1) {
+#pragma unroll
+    for (int t = 0; t < kSplitTerms; ++t) {
+      split_term(t, a0, b0, acc[0][0]);
+      split_term(t, a0, b1, acc[0][1]);
+      split_term(t, a1, b0, acc[1][0]);
+      split_term(t, a1, b1, acc[1][1]);
+    }
+  };
+  const bool active = nb0 && kb0;  // wave-uniform: this wave's column ranges are not empty
+  SplitFrag ca0, ca1, cb0, cb1;
+  if (SPLIT && active && n_blocks > 0) {
+    ca0 = read_split(&Gs[0][8 * lh][wn * 64 + li]);
+    ca1 = read_split(&Gs[0][8 * lh][wn * 64 + 32 + li]);
+    cb0 = read_split(&Xs[0][8 * lh][wk * 64 + li]);
+    cb1 = read_split(&Xs[0][8 * lh][wk * 64 + 32 + li]);
+  }
   for (int64_t c = 0; c < n_blocks; ++c) {
     const int buf = static_cast<int>(c & 1);
     if (c + 1 < n_blocks) store_rows(buf ^ 1);
     if (c + 2 < n_blocks) load_rows(ra + (c + 2) * kWRows);
+    if constexpr (SPLIT) {
+      // bf16 step t of a block covers rows 16 t + 8 h + e (e = 0..7 down the staged rows) in lane
+      // half h — the same rows for g and x, which is all the reduction needs.  Columns past N / K
+      // are staged as zeros, so all four 32 x 32 blocks are always computed.  Software pipeline
+      // as in the NT kernel: the matrix instructions of one step run while the VALU converts the
+      // operands of the next one.
+      constexpr int kMfma = kSplitTerms * 4;
+      constexpr int kValuPer = 4 * 44 / kMfma + 1;
+      if (active) {
+        __builtin_amdgcn_sched_barrier(0);
+        const SplitFrag na0 = read_split(&Gs[buf][16 + 8 * lh][wn * 64 + li]);
+        const SplitFrag na1 = read_split(&Gs[buf][16 + 8 * lh][wn * 64 + 32 + li]);
+        const SplitFrag nb0 = read_split(&Xs[buf][16 + 8 * lh][wk * 64 + li]);
+        const SplitFrag nb1 = read_split(&Xs[buf][16 + 8 * lh][wk * 64 + 32 + li]);
+        mma4(ca0, ca1, cb0, cb1);
+#pragma unroll
+        for (int q = 0; q < kMfma; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, kValuPer, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // (after the last block this reads a buffer nobody filled: converted, never multiplied)
+        ca0 = read_split(&Gs[buf ^ 1][8 * lh][wn * 64 + li]);
+        ca1 = read_split(&Gs[buf ^ 1][8 * lh][wn * 64 + 32 + li]);
+        cb0 = read_split(&Xs[buf ^ 1][8 * lh][wk * 64 + li]);
+        cb1 = read_split(&Xs[buf ^ 1][8 * lh][wk * 64 + 32 + li]);
+        mma4(na0, na1, nb0, nb1);
+#pragma unroll
+        for (int q = 0; q < kMfma; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, kValuPer, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        __syncthreads();
+      }
+      continue;
+    }
     const float* gs = &Gs[buf][lh][wn * 64 + li];
     const float* xs = &Xs[buf][lh][wk * 64 + li];
     float ha0[8], ha1[8], hb0[8], hb1[8];  // second half of the block, steps 8..15
@@ -513,25 +707,27 @@ static int launch_nt(GemmNT p, bool vec, hipStream_t st) {
   const size_t lds = sizeof(float) * 2 * (BM + BN) * kGLD;
   // (the opt-in to > 64 KiB of dynamic LDS is per kernel and per device: set it on every launch,
   // it is a host-side attribute write)
-  if (vec) {
-    auto k = gemm_nt_kernel<WM, WN, TM, TN, true>;
-    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds)));
-    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, st, p);
+  void (*k)(GemmNT) = nullptr;
+  if (p.split) {
+    k = vec ? gemm_nt_kernel<WM, WN, TM, TN, true, true>
+            : gemm_nt_kernel<WM, WN, TM, TN, false, true>;
   } else {
-    auto k = gemm_nt_kernel<WM, WN, TM, TN, false>;
-    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds)));
-    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, st, p);
+    k = vec ? gemm_nt_kernel<WM, WN, TM, TN, true, false>
+            : gemm_nt_kernel<WM, WN, TM, TN, false, false>;
   }
+  PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, st, p);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }
 
+static int g_gemm_mode = 0;  // pygamd_set_gemm_mode
+
 static int run_nt(GemmNT p, hipStream_t st) {
   if (p.M == 0 || p.N == 0) return PYGAMD_OK;
+  p.split = g_gemm_mode == PYGAMD_GEMM_SPLIT_BF16 ? 1 : 0;
   const bool vec = (p.K % 4 == 0) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) && aligned16p(p.a) &&
                    aligned16p(p.b);
   // tile shape by output width: wide outputs 128 x 128; 65..96 columns one 128 x 96 tile row;
@@ -547,6 +743,14 @@ static int run_nt(GemmNT p, hipStream_t st) {
 using namespace pygamd;
 
 extern "C" {
+
+int pygamd_set_gemm_mode(int mode) {
+  if (mode != PYGAMD_GEMM_FP32 && mode != PYGAMD_GEMM_SPLIT_BF16) return PYGAMD_ERR_INVALID_ARG;
+  g_gemm_mode = mode;
+  return PYGAMD_OK;
+}
+
+int pygamd_get_gemm_mode(void) { return g_gemm_mode; }
 
 int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
                           const float* bias, int64_t M, int64_t K, int64_t N, int relu,
@@ -631,19 +835,16 @@ int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
                    aligned16p(g) && aligned16p(x);
   const int64_t blocks = round_up(tiles * p.splits, 8);
   const size_t lds = sizeof(float) * 4 * kWRows * kWLD;
-  if (vec) {
-    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds)));
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock),
-                       lds, st, p);
+  void (*kern)(GemmTN) = nullptr;
+  if (g_gemm_mode == PYGAMD_GEMM_SPLIT_BF16) {
+    kern = vec ? gemm_tn_kernel<true, true> : gemm_tn_kernel<false, true>;
   } else {
-    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds)));
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(kBlock),
-                       lds, st, p);
+    kern = vec ? gemm_tn_kernel<true, false> : gemm_tn_kernel<false, false>;
   }
+  PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, st, p);
   PYGAMD_LAUNCH_CHECK();
   const int64_t NK = N * K;
   hipLaunchKernelGGL(gemm_tn_reduce_kernel,

@@ -56,8 +56,8 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
       maskv[c].v[i] = 1.f;
     }
     if (lane < LPR && fv[c]) {
-      if (a.accumulate) oldv[c] = load_vec<VW>(orow + fo[c]);
-      if (a.relu_mask) maskv[c] = load_vec<VW>(a.relu_mask + row * a.ldm + fo[c]);
+      if (a.accumulate) oldv[c] = load_vec_streamed<VW>(orow + fo[c]);
+      if (a.relu_mask) maskv[c] = load_vec_streamed<VW>(a.relu_mask + row * a.ldm + fo[c]);
     }
   }
   spmm_accumulate<IdxT, VW, LPR, CH, WMODE, IDENT>(a, start, end, lane, fo, fv, head, acc);

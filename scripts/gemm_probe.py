@@ -14,11 +14,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--rows', type=int, default=2_449_029)
 ap.add_argument('--no-tuned', action='store_true')
 ap.add_argument('--reps', type=int, default=10)
+ap.add_argument('--mode', default='fp32', choices=['fp32', 'split'])
+ap.add_argument('--only', default='', help='comma list of fwd,dgrad,wgrad')
 args = ap.parse_args()
 if not args.no_tuned:
     from pytorch_geometric_amd.tuning import enable_tuned_gemms
     print('tuned table:', enable_tuned_gemms())
 dev = torch.device('cuda:0')
+_native.set_gemm_mode(args.mode)
+print('gemm mode:', _native.get_gemm_mode())
+only = set(args.only.split(',')) if args.only else {'fwd', 'dgrad', 'wgrad'}
 M = args.rows
 
 
@@ -41,7 +46,7 @@ def report(name, flops, t_own, t_lib, err):
 
 
 g = torch.Generator(device=dev).manual_seed(0)
-for K, N in ((200, 256), (512, 256), (256, 96)):
+for K, N in ((200, 256), (512, 256), (256, 96)) if 'fwd' in only else ():
     x = torch.randn(M, K, device=dev, generator=g)
     w = torch.randn(N, K, device=dev, generator=g) * 0.05
     b = torch.randn(N, device=dev, generator=g)
@@ -52,7 +57,7 @@ for K, N in ((200, 256), (512, 256), (256, 96)):
     err = float((out - ref).abs().max() / ref.abs().max())
     report(f'fwd  [M,{K}]x[{N},{K}]^T+b,relu', 2.0 * M * K * N, t_own, t_lib, err)
     del x, out, ref
-for N, K in ((256, 512), (96, 256)):
+for N, K in ((256, 512), (96, 256)) if 'dgrad' in only else ():
     go = torch.randn(M, N, device=dev, generator=g)
     w = torch.randn(N, K, device=dev, generator=g) * 0.05
     wt = w.t().contiguous()
@@ -65,7 +70,7 @@ for N, K in ((256, 512), (96, 256)):
     err = float((out - ref).abs().max() / ref.abs().max())
     report(f'dgrad [M,{N}]x[{N},{K}] (+row scale)', 2.0 * M * K * N, t_own, t_lib, err)
     del go, out, ref
-for N, K in ((256, 200), (256, 512), (96, 256)):
+for N, K in ((256, 200), (256, 512), (96, 256)) if 'wgrad' in only else ():
     go = torch.randn(M, N, device=dev, generator=g)
     x = torch.randn(M, K, device=dev, generator=g)
     out = torch.empty(N, K, device=dev)

@@ -14,3 +14,5 @@ timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json
 echo "bench rc=$?"; cut -c1-1500 gpurun_out/${tag}_bench.json; tail -3 gpurun_out/${tag}_bench.err
 PYGAMD_GEMM=lib timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_lib.json 2>> gpurun_out/${tag}_bench.err
 echo "bench(lib) rc=$?"; cut -c1-400 gpurun_out/${tag}_bench_lib.json
+PYGAMD_GEMM_MODE=split timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_split.json 2>> gpurun_out/${tag}_bench.err
+echo "bench(split mode) rc=$?"; cut -c1-400 gpurun_out/${tag}_bench_split.json

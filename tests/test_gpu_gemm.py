@@ -221,3 +221,58 @@ def test_linear_module_routes_large_inputs_to_the_own_gemm(dev):
             assert_close(dl.bias.grad, want[3], rtol=1e-5, atol=2e-5 * scale, what='grad b')
     finally:
         _native.linear_forward = real
+
+
+@pytest.fixture
+def split_mode():
+    from pytorch_geometric_amd import _native
+    prev = _native.set_gemm_mode('split')
+    yield
+    _native.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize('M,K,N', SHAPES)
+def test_split_mode_forward_dgrad_wgrad(dev, split_mode, M, K, N):
+    """PYGAMD_GEMM_SPLIT_BF16: the same entry points with every fp32 operand as three bf16 terms
+    (six bf16 matrix products, fp32 accumulation).  Same acceptance as the exact mode: within 1e-5
+    of the fp64 value, or at least as close to it as the CPU fp32 result (tests/_util.py)."""
+    from pytorch_geometric_amd import _native
+    assert _native.get_gemm_mode() == 'split'
+    g = gen(M + K * 13 + N * 101 + 5)
+    x, w, b, go = (torch.randn(M, K, generator=g), torch.randn(N, K, generator=g),
+                   torch.randn(N, generator=g), torch.randn(M, N, generator=g))
+    out = _native.linear_forward(x.to(dev), w.to(dev), b.to(dev), relu=True)
+    ex = (x.double() @ w.double().t() + b.double()).relu()
+    bound = x.abs().double() @ w.abs().double().t() + b.abs().double()
+    assert_sum_close(out, torch.nn.functional.linear(x, w, b).relu(), ex, abs_sum=bound,
+                     what=f'split fwd {M}x{K}x{N}')
+    out = _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev))
+    assert_sum_close(out, go @ w, go.double() @ w.double(),
+                     abs_sum=go.abs().double() @ w.abs().double(), what=f'split dgrad {M}x{K}x{N}')
+    out, gb = _native.linear_wgrad(go.to(dev), x.to(dev), bias_grad=True)
+    assert_sum_close(out, go.t() @ x, go.double().t() @ x.double(),
+                     abs_sum=go.abs().double().t() @ x.abs().double(),
+                     what=f'split wgrad {M}x{K}x{N}')
+    assert_sum_close(gb, go.sum(0), go.double().sum(0), abs_sum=go.abs().double().sum(0),
+                     what='split wgrad bias')
+
+
+def test_split_mode_is_at_least_as_accurate_as_fp32(dev):
+    """Error against fp64 of the two modes on one products-like shape (K = 512): the split mode's
+    worst and mean errors must not exceed those of the exact fp32 instruction by more than 10 %."""
+    from pytorch_geometric_amd import _native
+    g = gen(123)
+    x, w = torch.randn(4096, 512, generator=g), torch.randn(256, 512, generator=g)
+    ex = x.double() @ w.double().t()
+    scale = x.abs().double() @ w.abs().double().t()
+    errs = {}
+    for mode in ('fp32', 'split'):
+        prev = _native.set_gemm_mode(mode)
+        try:
+            out = _native.linear_forward(x.to(dev), w.to(dev), None).cpu().double()
+        finally:
+            _native.set_gemm_mode(prev)
+        rel = (out - ex).abs() / scale
+        errs[mode] = (float(rel.max()), float(rel.mean()))
+    assert errs['split'][0] <= 1.1 * errs['fp32'][0], errs
+    assert errs['split'][1] <= 1.1 * errs['fp32'][1], errs
