@@ -36,7 +36,8 @@ def spmm_algorithmic_bytes(info) -> float:
     """E*(4F + b) + (N_rows + 1)*b + N_rows*4F  (+ N*4 for the mean's degree
     vector when it is read as a per-source scale, + N_rows*4F when the launch accumulates onto
     its output, i.e. the fused `grad_root + A^T grad_agg` of the backward, + N_rows*4F when its
-    epilogue reads a ReLU output to apply that activation's backward)."""
+    epilogue reads a ReLU output — or, 32 x smaller, its one-bit-per-element mask — to apply that
+    activation's backward)."""
     b, Fw = info['idx_bytes'], info['F']
     total = info['nnz'] * (4 * Fw + b) + (info['n_rows'] + 1) * b + info['n_rows'] * 4 * Fw
     if info['src_scale']:
@@ -47,6 +48,8 @@ def spmm_algorithmic_bytes(info) -> float:
         total += info['n_rows'] * 4 * Fw  # out += result: the old rows are read as well
     if info.get('relu_mask'):
         total += info['n_rows'] * 4 * Fw  # the activation rows the fused ReLU backward reads
+    if info.get('relu_bits'):
+        total += info['n_rows'] * 4 * ((Fw + 31) // 32)  # ... or one bit per element
     return float(total)
 
 

@@ -183,6 +183,15 @@ typedef struct {
                                 aggregation that produces that activation's gradient
                                 (nn/models/basic_gnn.py:262-263 backward)                        */
   int64_t ld_mask;
+  const uint32_t* relu_bits; /* the same mask as one BIT per element (32 x less to read), in
+                                tiles of 32 rows x 32 columns: bit (f & 31) of word
+                                relu_bits[((i >> 5) * ld_bits + (f >> 5)) * 32 + (i & 31)] is set
+                                where the activation [i, f] is positive (the 32 words of a tile are
+                                one 128-byte line: the producer's wave writes it with one store).
+                                What pygamd_sage_layer_forward writes next to its output.  At most
+                                one of relu_mask / relu_bits.                                      */
+  int64_t ld_bits;           /* column blocks per row tile, >= ceil(F / 32); the array holds
+                                ceil(n_rows / 32) * ld_bits * 32 words                             */
 } pygamd_spmm_args;
 
 PYGAMD_API int pygamd_spmm_csr_workspace_bytes(const pygamd_spmm_args* args, size_t* bytes);
@@ -456,7 +465,9 @@ PYGAMD_API int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int
  *             contiguous rows); columns [0, n_scaled) are multiplied by row_scale[row] in the
  *             epilogue (the 1/deg of a mean aggregation that follows, utils/_scatter.py:72-80);
  *             relu_mask ([M, ld_mask] or NULL): out[r, c] = 0 where relu_mask[r, c] <= 0, applied
- *             last — the backward of the ReLU whose output relu_mask is (basic_gnn.py:262-263).
+ *             last — the backward of the ReLU whose output relu_mask is (basic_gnn.py:262-263);
+ *             relu_bits (or NULL) is the same mask as one bit per element in the tiled layout of
+ *             pygamd_spmm_args.relu_bits (ld_bits >= ceil(K / 32)); at most one of the two.
  *   wgrad   : out[N, K] = g[M, N]^T @ x[M, K]; deterministic (split over M, slabs summed in
  *             order); workspace from the _workspace_bytes query.  bias_grad ([N] or NULL)
  *             receives the column sums of g (the bias gradient of the same Linear,
@@ -480,7 +491,8 @@ PYGAMD_API int pygamd_linear_forward(const float* x, int64_t ldx, const float* w
 PYGAMD_API int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
                                    const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
                                    int64_t K, int accumulate, const float* relu_mask,
-                                   int64_t ld_mask, float* out, int64_t ldo, void* stream);
+                                   int64_t ld_mask, const uint32_t* relu_bits, int64_t ld_bits,
+                                   float* out, int64_t ldo, void* stream);
 PYGAMD_API int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K,
                                                    size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx,
@@ -499,12 +511,17 @@ PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, 
  * two-stage hub kernels, and with save_agg != 0 every row is stored there once for the weight
  * gradient).  Supported: F % 4 == 0, F <= 256, Fo <= 256, 16-byte aligned operands (query below);
  * otherwise PYGAMD_ERR_UNSUPPORTED and the caller runs pygamd_spmm_csr + pygamd_linear_forward.
+ * relu_bits_out (ceil(n_rows / 32) * ld_bits * 32 words or NULL; needs relu != 0): [y > 0] as
+ * one bit per element in the tiled layout of pygamd_spmm_args.relu_bits — the form of the ReLU mask
+ * that the backward's pygamd_spmm_csr / pygamd_linear_dgrad epilogues take
+ * (ld_bits >= ceil(Fo / 32)).
  * Workspace: pygamd_spmm_csr_workspace_bytes(graph).                                              */
 PYGAMD_API int pygamd_sage_layer_forward_supported(int64_t F, int64_t Fo, int reduce);
 PYGAMD_API int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root,
                                          int64_t ld_root, const float* w, int64_t ldw,
                                          const float* bias, int64_t Fo, int relu, int save_agg,
-                                         float* y, int64_t ldy, void* workspace,
+                                         float* y, int64_t ldy, uint32_t* relu_bits_out,
+                                         int64_t ld_bits, void* workspace,
                                          size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

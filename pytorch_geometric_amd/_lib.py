@@ -32,6 +32,7 @@ class SpmmArgs(Structure):
         ('n_hub', c_int64), ('n_chunks', c_int64), ('hub_threshold', c_int64),
         ('hub_chunk', c_int64), ('accumulate', c_int32), ('hub_phase', c_int32),
         ('arg32_out', c_void_p), ('relu_mask', c_void_p), ('ld_mask', c_int64),
+        ('relu_bits', c_void_p), ('ld_bits', c_int64),
     ]
 
 
@@ -73,13 +74,14 @@ SIGNATURES = {
                                             c_int64, _P, _P]),
     'pygamd_sage_layer_forward_supported': (c_int, [c_int64, c_int64, c_int]),
     'pygamd_sage_layer_forward': (c_int, [POINTER(SpmmArgs), _P, c_int64, _P, c_int64, _P, c_int64,
-                                          c_int, c_int, _P, c_int64, _P, c_size_t, _P]),
+                                          c_int, c_int, _P, c_int64, _P, c_int64, _P, c_size_t,
+                                          _P]),
     'pygamd_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                       c_int, c_int, _P, c_int64, _P]),
     'pygamd_set_gemm_mode': (c_int, [c_int]),
     'pygamd_get_gemm_mode': (c_int, []),
     'pygamd_linear_dgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
-                                    c_int64, c_int, _P, c_int64, _P, c_int64, _P]),
+                                    c_int64, c_int, _P, c_int64, _P, c_int64, _P, c_int64, _P]),
     'pygamd_linear_wgrad_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
                                                     POINTER(c_size_t)]),
     'pygamd_linear_wgrad': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int,

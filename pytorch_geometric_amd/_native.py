@@ -167,9 +167,11 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
              w: Optional[Tensor] = None, src_scale: Optional[Tensor] = None,
              hub=None, out: Optional[Tensor] = None, return_arg: bool = False,
              accumulate: bool = False, hub_phase: int = 0, save_arg32: bool = False,
-             relu_mask: Optional[Tensor] = None):
+             relu_mask: Optional[Tensor] = None, relu_bits: Optional[Tensor] = None):
     """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h."""
-    _require_device(rowptr, col, x, eid, w, src_scale, relu_mask)
+    _require_device(rowptr, col, x, eid, w, src_scale, relu_mask, relu_bits)
+    if relu_mask is not None and relu_bits is not None:
+        raise ValueError("pass at most one of 'relu_mask' / 'relu_bits'")
     lib = _lib.load()
     x2 = _f32_rows(x, 'x')
     n_rows = rowptr.numel() - 1 if n_rows is None else n_rows
@@ -216,6 +218,9 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
         if tuple(m2.shape) != (n_rows, F):
             raise ValueError(f"'relu_mask' must be [{n_rows}, {F}], got {tuple(m2.shape)}")
         a.relu_mask, a.ld_mask = m2.data_ptr(), _ld(m2)
+    if relu_bits is not None:
+        _check_bits(relu_bits, n_rows, F)
+        a.relu_bits, a.ld_bits = relu_bits.data_ptr(), relu_bits.size(1)
     ws, ws_bytes = None, 0
     if hub is not None and hub[2] > 0:
         hub_rows, hub_cptr, n_hub, n_chunks = hub
@@ -239,6 +244,7 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
                       'reduce': reduce, 'idx_bytes': rowptr.element_size(),
                       'weighted': w is not None, 'src_scale': src_scale is not None,
                       'accumulate': bool(accumulate), 'relu_mask': relu_mask is not None,
+                      'relu_bits': relu_bits is not None,
                       'n_hub': a.n_hub}, ev0, ev1))
     if save_arg32:
         return out, arg32
@@ -563,6 +569,38 @@ def linear_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, relu: bo
     return out
 
 
+def relu_bits_like(n_rows: int, width: int, device) -> Tensor:
+    """Storage for a ReLU mask with one bit per element (``pygamd_spmm_args.relu_bits``): int32
+    ``[ceil(n_rows / 32), ceil(width / 32), 32]`` — tiles of 32 rows x 32 columns, word
+    ``[r >> 5, c >> 5, r & 31]`` holds the 32 columns of row ``r`` in its bits ``c & 31``."""
+    return torch.empty((n_rows + 31) // 32, (width + 31) // 32, 32, dtype=torch.int32,
+                       device=device)
+
+
+def pack_relu_bits(act: Tensor) -> Tensor:
+    """``act > 0`` in the layout of :func:`relu_bits_like` (host-side helper for tests / callers
+    that did not get the bits from ``sage_layer_forward``)."""
+    n, f = act.shape
+    rt, w = (n + 31) // 32, (f + 31) // 32
+    pos = torch.zeros(rt * 32, w * 32, dtype=torch.int64, device=act.device)
+    pos[:n, :f] = (act > 0).to(torch.int64)
+    weights = (1 << torch.arange(32, dtype=torch.int64, device=act.device))
+    words = (pos.view(rt, 32, w, 32) * weights).sum(-1)          # [tile, row in tile, block]
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words)  # two's complement int32
+    return words.permute(0, 2, 1).contiguous().to(torch.int32)
+
+
+def _check_bits(bits: Optional[Tensor], n_rows: int, width: int):
+    if bits is None:
+        return
+    if (bits.dtype != torch.int32 or bits.dim() != 3 or bits.size(0) < (n_rows + 31) // 32
+            or bits.size(1) < (width + 31) // 32 or bits.size(2) != 32
+            or not bits.is_contiguous()):
+        raise ValueError(f"'relu_bits' must be a contiguous int32 [>= {(n_rows + 31) // 32}, >= "
+                         f"{(width + 31) // 32}, 32] (see relu_bits_like), got {bits.dtype} "
+                         f"{tuple(bits.shape)}")
+
+
 def sage_layer_forward_supported(F: int, Fo: int, reduce: str) -> bool:
     return bool(_lib.load().pygamd_sage_layer_forward_supported(F, Fo, REDUCE_IDS[reduce]))
 
@@ -570,11 +608,12 @@ def sage_layer_forward_supported(F: int, Fo: int, reduce: str) -> bool:
 def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Tensor, w: Tensor,
                        bias: Optional[Tensor], reduce: str, relu: bool, agg: Tensor, out: Tensor,
                        hub=None, save_agg: bool = True, hub_threshold: int = None,
-                       hub_chunk: int = None) -> Tensor:
+                       hub_chunk: int = None, relu_bits: Optional[Tensor] = None) -> Tensor:
     """``out = act([aggr(x_gather) | x_root] @ w.T + bias)`` in ONE kernel (csrc/sage_fused.hip);
     ``agg`` ([n_rows, F] view, may be a half of a wider buffer) receives the aggregated rows when
-    ``save_agg`` (hub rows always)."""
-    _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out)
+    ``save_agg`` (hub rows always).  ``relu_bits`` (from :func:`relu_bits_like`, needs
+    ``relu``) receives ``out > 0`` as one bit per element (see :func:`relu_bits_like`)."""
+    _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out, relu_bits)
     lib = _lib.load()
     xg, xr, w2 = _f32_rows(x_gather, 'x'), _f32_rows(x_root, 'x_root'), _f32_rows(w, 'weight')
     n_rows, F, Fo = rowptr.numel() - 1, xg.size(1), w2.size(0)
@@ -603,9 +642,12 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     if sink is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(xg.device))
+    _check_bits(relu_bits, n_rows, Fo)
     check(lib.pygamd_sage_layer_forward(ctypes.byref(a), _p(xr), _ld(xr), _p(w2), _ld(w2),
                                         _p(bias), Fo, int(relu), int(save_agg), _p(out),
-                                        _ld(out), _p(ws), ws_bytes, _stream(xg)),
+                                        _ld(out), _p(relu_bits),
+                                        relu_bits.size(1) if relu_bits is not None else 0,
+                                        _p(ws), ws_bytes, _stream(xg)),
           'sage_layer_forward')
     if sink is not None:
         ev1.record(torch.cuda.current_stream(xg.device))
@@ -636,11 +678,15 @@ def get_gemm_mode() -> str:
 
 def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_scaled: int = 0,
                  out: Optional[Tensor] = None, accumulate: bool = False,
-                 relu_mask: Optional[Tensor] = None) -> Tensor:
+                 relu_mask: Optional[Tensor] = None,
+                 relu_bits: Optional[Tensor] = None) -> Tensor:
     """``g [M, N] @ w [N, K]`` with the weight handed over transposed (``w_t [K, N]``); columns
     ``[0, n_scaled)`` of the result are multiplied by ``row_scale[row]``; where ``relu_mask [M, K]``
-    (a ReLU output) is not positive the result is 0 (that ReLU's backward as the epilogue)."""
-    _require_device(g, w_t, row_scale, out, relu_mask)
+    (a ReLU output) is not positive the result is 0 (that ReLU's backward as the epilogue);
+    ``relu_bits`` is the same mask as one bit per element (:func:`relu_bits_like`)."""
+    _require_device(g, w_t, row_scale, out, relu_mask, relu_bits)
+    if relu_mask is not None and relu_bits is not None:
+        raise ValueError("pass at most one of 'relu_mask' / 'relu_bits'")
     lib = _lib.load()
     g2, w2 = _f32_rows(g, 'grad'), _f32_rows(w_t, 'weight_t')
     M, N = g2.shape
@@ -652,6 +698,7 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
     if row_scale is not None:
         row_scale = row_scale.contiguous()
     m2 = None
+    _check_bits(relu_bits, M, K)
     if relu_mask is not None:
         m2 = _f32_rows(relu_mask, 'relu_mask')
         if tuple(m2.shape) != (M, K):
@@ -659,6 +706,8 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
     check(lib.pygamd_linear_dgrad(_p(g2), _ld(g2), _p(w2), _ld(w2), _p(row_scale),
                                   n_scaled if row_scale is not None else 0, M, N, K,
                                   int(accumulate), _p(m2), _ld(m2) if m2 is not None else 0,
+                                  _p(relu_bits),
+                                  relu_bits.size(1) if relu_bits is not None else 0,
                                   _p(out), _ld(out), _stream(g)), 'linear_dgrad')
     return out
 

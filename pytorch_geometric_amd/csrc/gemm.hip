@@ -105,6 +105,8 @@ struct GemmNT {
   const float* __restrict__ bias;       // [N] or null
   const float* __restrict__ row_scale;  // [M] or null
   const float* __restrict__ mask;       // [M, ldm] or null: c = mask <= 0 ? 0 : c (ReLU backward)
+  const uint32_t* __restrict__ mask_bits;  // the same mask as bits (32 x 32 tiles, see pyg_amd.h)
+  int64_t ldmb;
   float* __restrict__ c;                // [M, N]
   int64_t M, lda, ldb, ldc, ldm;
   int N, K;
@@ -374,6 +376,18 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
           }
           continue;
         }
+        if (p.mask_bits) {  // uniform.  This 32 x 32 block is one bit tile = one 128-byte line
+          const int64_t tile_row = (rbase - 4 * lh) >> 5;  // (m0 and the block offsets are % 32)
+          const uint32_t word = p.mask_bits[(tile_row * p.ldmb + (col >> 5)) * 32 + li];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const uint32_t bw = __shfl(word, (e & 3) + 8 * (e >> 2) + 4 * lh, kWave);
+            float v = acc[i][j][e] + bv;
+            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
+            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = ((bw >> li) & 1u) ? fmaxf(v, floor_v) : 0.f;
+          }
+          continue;
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           float v = acc[i][j][e] + bv;
@@ -403,6 +417,11 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
           float* dst = p.c + row * p.ldc + col;
           if (p.accumulate) v += *dst;
           if (p.mask) v = p.mask[row * p.ldm + col] > 0.f ? v : 0.f;
+          if (p.mask_bits)
+            v = ((p.mask_bits[((row >> 5) * p.ldmb + (col >> 5)) * 32 + (row & 31)] >> (col & 31)) &
+                 1u)
+                    ? v
+                    : 0.f;
           *dst = v;
         }
       }
@@ -771,10 +790,12 @@ int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t l
 int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
                         const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
                         int64_t K, int accumulate, const float* relu_mask, int64_t ld_mask,
-                        float* out, int64_t ldo, void* stream) {
+                        const uint32_t* relu_bits, int64_t ld_bits, float* out, int64_t ldo,
+                        void* stream) {
   // out[M, K] = g[M, N] @ w[N, K], with w given TRANSPOSED as w_t[K, N]: the same NT kernel
   if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldwt < N ||
-      ldo < K || n_scaled < 0 || n_scaled > K || (relu_mask && ld_mask < K))
+      ldo < K || n_scaled < 0 || n_scaled > K || (relu_mask && ld_mask < K) ||
+      (relu_bits && (relu_mask || ld_bits < (K + 31) / 32)))
     return PYGAMD_ERR_INVALID_ARG;
   if (M == 0 || K == 0) return PYGAMD_OK;
   if (!out || (N > 0 && (!g || !w_t)) || (n_scaled > 0 && !row_scale))
@@ -783,6 +804,7 @@ int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t l
   p.a = g; p.b = w_t; p.bias = nullptr; p.row_scale = row_scale; p.mask = relu_mask;
   p.c = out;
   p.M = M; p.lda = ldg; p.ldb = ldwt; p.ldc = ldo; p.ldm = ld_mask;
+  p.mask_bits = relu_bits; p.ldmb = ld_bits;
   p.N = static_cast<int>(K); p.K = static_cast<int>(N);
   p.relu = 0; p.n_scaled = static_cast<int>(n_scaled); p.accumulate = accumulate ? 1 : 0;
   return run_nt(p, as_stream(stream));

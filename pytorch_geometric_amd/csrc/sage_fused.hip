@@ -60,6 +60,8 @@ struct SageFusedArgs {
   int64_t ldy;
   int Fo, relu, save_agg;
   int f_pad;                         // F rounded up to a multiple of 32
+  uint32_t* __restrict__ bits;       // null or [y > 0], one bit per element, 32 x 32 tiles
+  int64_t ld_bits;
 };
 
 // aggregated row -> LDS tile (+ global agg buffer); lanes < LPR hold VW features per CH
@@ -215,14 +217,26 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArg
   }
 
   // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
-  if (!col_ok) return;
-  const float bv = a.bias ? a.bias[col] : 0.f;
+  const float bv = (a.bias && col_ok) ? a.bias[col] : 0.f;
   const float floor_v = a.relu ? 0.f : -INFINITY;
   float* yp = a.y + (row0 + 4 * lh) * a.ldy + col;
+  uint32_t my_word = 0;  // lane e < 16: row (e & 3) + 8 (e >> 2); lane 16 + e: that row + 4
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int roff = (e & 3) + 8 * (e >> 2);
-    if (row0 + 4 * lh + roff < a.g.n_rows) yp[roff * a.ldy] = fmaxf(acc[e] + bv, floor_v);
+    const float v = fmaxf(acc[e] + bv, floor_v);
+    if (col_ok && row0 + 4 * lh + roff < a.g.n_rows) yp[roff * a.ldy] = v;
+    if (a.bits) {  // uniform.  One ballot = this 32-column block of two rows (lane halves)
+      const uint64_t m = __ballot(col_ok && v > 0.f);
+      if (lane == e) my_word = static_cast<uint32_t>(m);
+      if (lane == 16 + e) my_word = static_cast<uint32_t>(m >> 32);
+    }
+  }
+  if (a.bits && lane < 32) {  // the tile's 32 words of this column block: one 128-byte line
+    const int e = lane & 15;
+    const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 4);
+    if (row0 + r < a.g.n_rows)
+      a.bits[((row0 >> 5) * a.ld_bits + (wave_col0 >> 5)) * 32 + r] = my_word;
   }
 }
 
@@ -258,7 +272,8 @@ int pygamd_sage_layer_forward_supported(int64_t F, int64_t Fo, int reduce) {
 int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root,
                               int64_t ld_root, const float* w, int64_t ldw, const float* bias,
                               int64_t Fo, int relu, int save_agg, float* y, int64_t ldy,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              uint32_t* relu_bits_out, int64_t ld_bits, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   if (!graph) return PYGAMD_ERR_INVALID_ARG;
   const int64_t F = graph->F;
   if (graph->n_rows < 0 || F < 0 || Fo < 0 || graph->ldx < F || graph->ldo < F ||
@@ -266,8 +281,10 @@ int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root
     return PYGAMD_ERR_INVALID_ARG;
   // (col may be NULL only for a graph without edges: it is never dereferenced then)
   if (!pygamd_sage_layer_forward_supported(F, Fo, graph->reduce) || graph->w ||
-      graph->src_scale || graph->eid || graph->accumulate)
+      graph->src_scale || graph->eid || graph->accumulate || graph->relu_mask ||
+      graph->relu_bits)
     return PYGAMD_ERR_UNSUPPORTED;
+  if (relu_bits_out && (!relu || ld_bits < (Fo + 31) / 32)) return PYGAMD_ERR_INVALID_ARG;
   if (graph->n_rows == 0) return PYGAMD_OK;
   if (!graph->rowptr || !graph->x || !graph->out || !x_root || !w || !y)
     return PYGAMD_ERR_INVALID_ARG;
@@ -301,6 +318,10 @@ int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root
     a.g.arg32_out = nullptr;
     a.g.relu_mask = nullptr;
     a.g.ldm = 0;
+    a.g.relu_bits = nullptr;
+    a.g.ldb = 0;
+    a.bits = relu_bits_out;
+    a.ld_bits = ld_bits;
     a.g.n_rows = graph->n_rows;
     a.g.F = F;
     a.g.ldx = graph->ldx;

@@ -58,6 +58,12 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
     if (lane < LPR && fv[c]) {
       if (a.accumulate) oldv[c] = load_vec_streamed<VW>(orow + fo[c]);
       if (a.relu_mask) maskv[c] = load_vec_streamed<VW>(a.relu_mask + row * a.ldm + fo[c]);
+      if (a.relu_bits) {  // VW divides 32 and fo[c] is a multiple of VW: one word holds the bits
+        const uint32_t w =
+            a.relu_bits[((row >> 5) * a.ldb + (fo[c] >> 5)) * 32 + (row & 31)] >> (fo[c] & 31);
+#pragma unroll
+        for (int i = 0; i < VW; ++i) maskv[c].v[i] = ((w >> i) & 1u) ? 1.f : 0.f;
+      }
     }
   }
   spmm_accumulate<IdxT, VW, LPR, CH, WMODE, IDENT>(a, start, end, lane, fo, fv, head, acc);
@@ -136,7 +142,7 @@ __global__ void __launch_bounds__(kBlock)
                      const IdxT* __restrict__ hub_chunk_ptr, int64_t n_hub,
                      const float* __restrict__ partial, float* __restrict__ out, int64_t F,
                      int64_t ldo, int mean, int accumulate, const float* __restrict__ relu_mask,
-                     int64_t ldm) {
+                     int64_t ldm, const uint32_t* __restrict__ relu_bits, int64_t ldb) {
   const int lane = lane_id();
   const int64_t h = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   if (h >= n_hub) return;
@@ -151,6 +157,8 @@ __global__ void __launch_bounds__(kBlock)
     s = mean ? s / cntf : s;
     s = accumulate ? out[row * ldo + f] + s : s;
     if (relu_mask) s = relu_mask[row * ldm + f] > 0.f ? s : 0.f;
+    if (relu_bits)
+      s = ((relu_bits[((row >> 5) * ldb + (f >> 5)) * 32 + (row & 31)] >> (f & 31)) & 1u) ? s : 0.f;
     out[row * ldo + f] = s;
   }
 }
@@ -777,6 +785,8 @@ static SpmmDev<IdxT> make_dev(const pygamd_spmm_args* p) {
   a.arg32_out = p->arg32_out;
   a.relu_mask = p->relu_mask;
   a.ldm = p->ld_mask;
+  a.relu_bits = p->relu_bits;
+  a.ldb = p->ld_bits;
   a.n_rows = p->n_rows;
   a.F = p->F;
   a.ldx = p->ldx;
@@ -833,7 +843,7 @@ static int launch_sum(const pygamd_spmm_args* p, const Shape& s, float* partial,
     hipLaunchKernelGGL((spmm_hub_combine<IdxT>), cgrid, dim3(kBlock), 0, st, a.rowptr,
                        static_cast<const IdxT*>(p->hub_rows),
                        static_cast<const IdxT*>(p->hub_chunk_ptr), p->n_hub, partial, a.out,
-                       a.F, a.ldo, a.mean, a.accumulate, a.relu_mask, a.ldm);
+                       a.F, a.ldo, a.mean, a.accumulate, a.relu_mask, a.ldm, a.relu_bits, a.ldb);
     PYGAMD_LAUNCH_CHECK();
   }
   return PYGAMD_OK;
@@ -1043,8 +1053,10 @@ static int validate(const pygamd_spmm_args* p) {
     return PYGAMD_ERR_UNSUPPORTED;
   if (p->n_rows > 0 && p->F > 0 && (!p->rowptr || !p->x || !p->out)) return PYGAMD_ERR_INVALID_ARG;
   const bool mm = (p->reduce == PYGAMD_MIN || p->reduce == PYGAMD_MAX);
-  if (mm && (p->w || p->src_scale || p->accumulate || p->relu_mask)) return PYGAMD_ERR_UNSUPPORTED;
+  if (mm && (p->w || p->src_scale || p->accumulate || p->relu_mask || p->relu_bits))
+    return PYGAMD_ERR_UNSUPPORTED;
   if (p->relu_mask && p->ld_mask < p->F) return PYGAMD_ERR_INVALID_ARG;
+  if (p->relu_bits && (p->relu_mask || p->ld_bits < (p->F + 31) / 32)) return PYGAMD_ERR_INVALID_ARG;
   if (p->w && p->w_heads > 1) {
     if (p->head_dim < 1 || static_cast<int64_t>(p->head_dim) * p->w_heads != p->F)
       return PYGAMD_ERR_INVALID_ARG;

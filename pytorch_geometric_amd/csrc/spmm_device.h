@@ -20,6 +20,8 @@ struct SpmmDev {
   int32_t* __restrict__ arg32_out;  // MIN/MAX: saved for the backward (see pyg_amd.h)
   const float* __restrict__ relu_mask;  // SUM/MEAN: out = relu_mask <= 0 ? 0 : out (or null)
   int64_t ldm;
+  const uint32_t* __restrict__ relu_bits;  // the same mask, one bit per element (or null)
+  int64_t ldb;
   int64_t n_rows, F, ldx, ldo;
   int w_heads, head_dim;
   int mean;

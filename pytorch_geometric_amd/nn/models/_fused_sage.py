@@ -107,6 +107,9 @@ class FusedSageStack(Function):
                 #               2F-stride of the [agg | x] buffer (matters for F = 100)
         bufs: List[Tensor] = []
         wmats: List[Tensor] = []
+        # bits[l]: [input of layer l > 0] as one bit per element, written by the one-kernel layer
+        # forward next to the activation (the backward's ReLU epilogues then read 1/32 of it)
+        bits: List[Optional[Tensor]] = [None] * L
         out = None
         for layer in range(L):
             W_l, b, W_r = params[3 * layer:3 * layer + 3]
@@ -125,10 +128,13 @@ class FusedSageStack(Function):
                               and _native.sage_layer_forward_supported(Fi, Fo, aggr)
                               and src.stride(0) % 4 == 0 and buf.stride(0) % 4 == 0)
                 if one_kernel:
+                    if not last:
+                        bits[layer + 1] = _native.relu_bits_like(N, Fo, dev)
                     # the aggregated rows are stored once (write-only) for the weight gradient
                     _native.sage_layer_forward(fwd.ptr, fwd.idx, src, buf[:, Fi:], wmat, b, aggr,
                                                not last, buf[:, :Fi], dst, hub=fwd.hub,
-                                               save_agg=True)
+                                               save_agg=True,
+                                               relu_bits=None if last else bits[layer + 1])
                     relu_done = True
                 else:
                     _native.spmm_csr(fwd.ptr, fwd.idx, src, aggr, n_rows=N, hub=fwd.hub,
@@ -172,7 +178,8 @@ class FusedSageStack(Function):
             buf, inp = nbuf, dst
         ctx.graph, ctx.aggr, ctx.L, ctx.dims, ctx.modes = graph, aggr, L, dims, modes
         ctx.has_bias = [params[3 * i + 1] is not None for i in range(L)]
-        ctx.save_for_backward(*bufs, *wmats)
+        ctx.has_bits = [t is not None for t in bits]
+        ctx.save_for_backward(*bufs, *wmats, *[t for t in bits if t is not None])
         return out
 
     @staticmethod
@@ -184,7 +191,9 @@ class FusedSageStack(Function):
     def backward(ctx, grad_out: Tensor):
         L, graph, aggr = ctx.L, ctx.graph, ctx.aggr
         saved = ctx.saved_tensors
-        bufs, wmats = saved[:L], saved[L:]
+        bufs, wmats = saved[:L], saved[L:2 * L]
+        packed = list(saved[2 * L:])
+        bits = [packed.pop(0) if has else None for has in ctx.has_bits]
         bwd = graph.by_src()
         scale = graph.by_dst().inv_degree() if aggr == 'mean' else None
         N = grad_out.size(0)
@@ -210,6 +219,8 @@ class FusedSageStack(Function):
                 grads[3 * layer + 1] = _native.colsum(g)
             need_input_grad = layer > 0 or ctx.needs_input_grad[0]
             mask_in = FusedSageStack._input_view(ctx, bufs, layer) if (own and layer > 0) else None
+            bits_in = bits[layer] if mask_in is not None else None
+            mask_f = mask_in if bits_in is None else None  # the float form only without the bits
             if ctx.modes[layer] == 'post':
                 # [Fo, 2 Fi] = [grad W_l | grad W_r]
                 overlap = (own and OVERLAP_WGRAD and need_input_grad
@@ -245,7 +256,8 @@ class FusedSageStack(Function):
                         pending.append(side)
                     _native.spmm_csr(bwd.ptr, bwd.idx, gcat[:, :Fi], 'sum', n_rows=N,
                                      src_scale=None if pre_scaled else scale, hub=bwd.hub,
-                                     out=gcat[:, Fi:], accumulate=True, relu_mask=mask_in)
+                                     out=gcat[:, Fi:], accumulate=True, relu_mask=mask_f,
+                                     relu_bits=bits_in)
                 grads[3 * layer] = gw[:, :Fi]
                 grads[3 * layer + 2] = gw[:, Fi:]
                 if need_input_grad:
@@ -289,7 +301,8 @@ class FusedSageStack(Function):
                 grads[3 * layer] = gw[:Fo]
                 grads[3 * layer + 2] = gw[Fp:Fp + Fo]
                 if need_input_grad:  # [N, Fi]
-                    g = (_native.linear_dgrad(gy, wmat.t().contiguous(), relu_mask=mask_in)
+                    g = (_native.linear_dgrad(gy, wmat.t().contiguous(), relu_mask=mask_f,
+                                              relu_bits=bits_in)
                          if own else torch.mm(gy, wmat))
             masked = mask_in is not None
             if layer == 0 and need_input_grad:

@@ -72,3 +72,27 @@ def test_argument_validation_without_gpu():
     a.n_hub, a.n_chunks = 2, 5
     assert lib.pygamd_spmm_csr_workspace_bytes(ctypes.byref(a), ctypes.byref(n)) == 0
     assert n.value == 5 * 8 * 4
+
+
+def test_pack_relu_bits_layout():
+    """Host helper for the one-bit-per-element ReLU mask of include/pyg_amd.h
+    (pygamd_spmm_args.relu_bits): bit (c & 31) of word [r >> 5, c >> 5, r & 31] <=> act[r, c] > 0
+    (tiles of 32 x 32), unused bits / rows zero, int32 two's complement storage."""
+    import torch
+    from pytorch_geometric_amd._native import pack_relu_bits
+    g = torch.Generator().manual_seed(5)
+    for f in (1, 31, 32, 33, 100, 256):
+        n = 37
+        act = torch.randn(n, f, generator=g)
+        act[0] = 1.0    # all bits set: exercises the sign bit of the int32 words
+        act[1] = -0.0
+        words = pack_relu_bits(act)
+        assert words.dtype == torch.int32 and tuple(words.shape) == (2, (f + 31) // 32, 32)
+        for r in range(64):
+            for w in range(words.size(1)):
+                want = 0
+                for b in range(32):
+                    c = 32 * w + b
+                    if r < n and c < f and float(act[r, c]) > 0:
+                        want |= 1 << b
+                assert (int(words[r >> 5, w, r & 31]) & 0xffffffff) == want

@@ -102,6 +102,13 @@ def test_linear_dgrad_and_wgrad(dev, M, K, N):
         got = _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev), scale.to(dev), ns,
                                    relu_mask=act_d[:, K:])
         assert torch.equal(got, torch.where(act_d[:, K:] > 0, plain, torch.zeros_like(plain)))
+        # the same mask as one bit per element (rows padded to one more word than needed)
+        packed = _native.pack_relu_bits(act_d[:, K:])
+        wide = torch.zeros(packed.size(0), packed.size(1) + 1, 32, dtype=torch.int32, device=dev)
+        wide[:, :packed.size(1)] = packed
+        got_b = _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev), scale.to(dev), ns,
+                                     relu_bits=wide)
+        assert torch.equal(got_b, got)
         base = torch.randn(M, K, generator=g).to(dev)
         acc = base.clone()
         _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev), out=acc, accumulate=True,
@@ -110,6 +117,10 @@ def test_linear_dgrad_and_wgrad(dev, M, K, N):
                            base + _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev)),
                            torch.zeros_like(base))
         assert_close(acc, want, rtol=1e-6, atol=1e-6, what='dgrad accumulate + mask')
+        acc_b = base.clone()
+        _native.linear_dgrad(go.to(dev), w.t().contiguous().to(dev), out=acc_b, accumulate=True,
+                             relu_bits=packed)
+        assert torch.equal(acc_b, acc)
 
 
 def test_wgrad_long_reduction_is_deterministic_and_accurate(dev):
@@ -165,9 +176,21 @@ def test_sage_layer_forward_one_kernel(dev, F, Fo, reduce, dtype):
     out = torch.full((n, Fo + 8), float('nan'), device=dev)
     wcat = torch.cat([wl, wr], 1).to(dev)
     assert _native.sage_layer_forward_supported(F, Fo, reduce)
+    bits = torch.full(((n + 31) // 32, (Fo + 31) // 32 + 1, 32), -1, dtype=torch.int32,
+                      device=dev)
     _native.sage_layer_forward(fwd.ptr, fwd.idx, x.to(dev), buf[:, F:], wcat, b.to(dev), reduce,
-                               True, buf[:, :F], out[:, :Fo], hub=fwd.hub, save_agg=True)
+                               True, buf[:, :F], out[:, :Fo], hub=fwd.hub, save_agg=True,
+                               relu_bits=bits)
     assert_sum_close(out[:, :Fo], ref, ex, abs_sum=bound + 1, what=f'fused layer F={F} Fo={Fo}')
+    # the one-bit-per-element ReLU mask written next to the output: exactly [out > 0], zero bits
+    # past Fo inside the last word, nothing written past the last word
+    want_bits = _native.pack_relu_bits(out[:, :Fo])
+    tail = n - (n // 32) * 32  # rows of the last (partial) tile that exist
+    assert torch.equal(bits[:-1, :-1], want_bits[:-1])
+    assert torch.equal(bits[-1, :-1, :tail], want_bits[-1, :, :tail])
+    assert bool((bits[-1, :-1, tail:] == -1).all())  # rows past n_rows: untouched
+    assert bool((bits[:, -1] == -1).all())            # column blocks past Fo: untouched
+    assert 0 < int((out[:, :Fo] > 0).sum()) < n * Fo
     assert bool(torch.isnan(out[:, Fo:]).all())               # nothing written past Fo
     assert_sum_close(buf[:, :F], aggr_ref, O.spmm(ei, x.double(), n, reduce),
                      what='saved aggregated rows')

@@ -502,6 +502,11 @@ def test_spmm_accumulate(dev, monkeypatch):
             want = torch.where(ad[:, F:] > 0, b1[:, F:], torch.zeros_like(b1[:, F:]))
             assert torch.equal(b2[:, F:], want), f'relu_mask F={F} accumulate={acc}'
             assert int((want == 0).sum()) > 0
+            b3 = buf.to(dev)  # the same mask as one bit per element
+            _native.spmm_csr(fwd.ptr, fwd.idx, b3[:, :F], 'mean', n_rows=300, hub=fwd.hub,
+                             out=b3[:, F:], accumulate=acc,
+                             relu_bits=_native.pack_relu_bits(ad[:, F:]))
+            assert torch.equal(b3[:, F:], want), f'relu_bits F={F} accumulate={acc}'
     with pytest.raises(RuntimeError):  # extrema have no such epilogue
         _native.spmm_csr(fwd.ptr, fwd.idx, bd[:, :F], 'max', n_rows=300,
                          relu_mask=bd[:, :F].contiguous())
