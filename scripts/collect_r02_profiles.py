@@ -19,6 +19,9 @@ N, E, F = 2449029, 61859140, 256
 for name, steps, title in (
         ('bench', 7, 'rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 '
                      '--no-cpu-baseline (round 2; 7 steps, MI355X)'),
+        ('bench_split', 7, 'PYGAMD_GEMM_MODE=split rocprofv3 --kernel-trace --stats -- python bench.py '
+                           '--steps 5 --warmup 2 --no-cpu-baseline (round 2; the opt-in 3 x bf16 split '
+                           'arithmetic of the stand-alone GEMM kernels; 7 steps)'),
         ('minibatch', 50, 'rocprofv3 --kernel-trace --stats -- python bench.py --mode minibatch '
                           '--steps 40 --warmup 10 (round 2; full papers100M shape, 50 batches)'),
         ('minmax', 1, 'rocprofv3 --kernel-trace --stats -- python scripts/reduce_probe.py (round 2; '
@@ -62,14 +65,14 @@ if fetch and write:
                      ('sage_fused_fwd_F256', 'sage_fused_fwd_kernel<long, 64>'),
                      ('sage_fused_fwd_F100', 'sage_fused_fwd_kernel<long, 32>'),
                      ('spmm_sum_rows_F48', 'spmm_sum_rows<long, 4, 16, 1, 0'),
-                     ('gemm_tn_wgrad', 'gemm_tn_kernel<true>'),
-                     ('gemm_nt_128x128', 'gemm_nt_kernel<2, 2, 2, 2, true>')):
+                     ('gemm_tn_wgrad', 'gemm_tn_kernel<true, false>'),
+                     ('gemm_nt_128x128', 'gemm_nt_kernel<2, 2, 2, 2, true, false>')):
         f, w = pick(fetch, sub), pick(write, sub)
         if f is not None and w is not None:
             res['per_launch'][key] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w,
                                       'hbm_bytes': (2 * f + w) * 1024}
-    # + the rows accumulated onto + the activation rows of the fused ReLU backward
-    alg = E * (4 * F + 8) + (N + 1) * 8 + N * 4 * F + N * 4 * F + N * 4 * F
+    # + the rows accumulated onto + the one-bit-per-element ReLU mask of the fused ReLU backward
+    alg = E * (4 * F + 8) + (N + 1) * 8 + N * 4 * F + N * 4 * F + N * 4 * (F // 32)
     dom = res['per_launch'].get('spmm_sum_rows_F256_transposed_accumulate')
     if dom:
         res['kernel'] = 'pygamd::spmm_sum_rows<long,4,64,1,0,false> (transposed, accumulate, ReLU-backward epilogue)'
