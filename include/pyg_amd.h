@@ -501,6 +501,15 @@ PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, 
                                    bandwidth-bound kernel running on another stream */,
                                    float* out, int64_t ldo, float* bias_grad, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/* The same against two operands side by side: out[N, K1 + K2] = g^T @ [x | x2] (x2 NULL, K2 = 0:
+ * identical to pygamd_linear_wgrad) — SAGEConv's `[grad W_l | grad W_r]` (sage_conv.py:134-139
+ * backward) from the aggregated rows and the layer input where they are, without a concatenated
+ * copy.  Workspace as for K = K1 + K2.                                                           */
+PYGAMD_API int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ldx,
+                                    int64_t K1, const float* x2, int64_t ldx2, int64_t K2,
+                                    int64_t M, int64_t N, int accumulate, int wgs_per_cu,
+                                    float* out, int64_t ldo, float* bias_grad, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* ---- f3: SAGEConv layer forward in one kernel ----------------------------------------------------
  * y[i, :] = act([aggr_{j->i} x[j] | x_root[i]] @ w[Fo, 2F]^T + bias) — `propagate` + `lin_l(agg)

@@ -86,6 +86,9 @@ SIGNATURES = {
                                                     POINTER(c_size_t)]),
     'pygamd_linear_wgrad': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int,
                                     c_int, _P, c_int64, _P, _P, c_size_t, _P]),
+    'pygamd_linear_wgrad2': (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                     c_int64, c_int64, c_int, c_int, _P, c_int64, _P, _P,
+                                     c_size_t, _P]),
     'pygamd_segment_matmul_tile_rows': (c_int, []),
     'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64,
                                       c_int64, c_int64, c_int64, _P, c_int64, _P]),

@@ -713,18 +713,25 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
 
 
 def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
-                 accumulate: bool = False, wgs_per_cu: int = 0, bias_grad: bool = False):
+                 accumulate: bool = False, wgs_per_cu: int = 0, bias_grad: bool = False,
+                 x2: Optional[Tensor] = None):
     """``g [M, N].T @ x [M, K]`` -> ``[N, K]`` (deterministic split reduction over M).
     ``wgs_per_cu=1`` halves the launch's footprint (for running under a bandwidth-bound kernel
     on another stream).  ``bias_grad=True`` also returns ``g.sum(0)`` — taken from the same pass
-    over ``g`` — as ``(grad_w, grad_b)``."""
-    _require_device(g, x, out)
+    over ``g`` — as ``(grad_w, grad_b)``.  ``x2`` (``[M, K2]``): the gradient against
+    ``[x | x2]`` -> ``[N, K + K2]`` without concatenating the two."""
+    _require_device(g, x, out, x2)
     lib = _lib.load()
+    second = None if x2 is None else _f32_rows(x2, 'x2')
     g2, x2 = _f32_rows(g, 'grad'), _f32_rows(x, 'x')
     M, N = g2.shape
-    K = x2.size(1)
-    if x2.size(0) != M:
+    K1 = x2.size(1)
+    K2 = 0 if second is None else second.size(1)
+    K = K1 + K2
+    if x2.size(0) != M or (second is not None and second.size(0) != M):
         raise ValueError(f"'grad' has {M} rows but 'x' has {x2.size(0)}")
+    if second is not None and (K1 == 0 or K2 == 0):
+        raise ValueError("both operands of a two-operand weight gradient need columns")
     if out is None:
         out = torch.empty(N, K, dtype=torch.float32, device=g.device)
     nbytes = ctypes.c_size_t(0)
@@ -735,9 +742,10 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
         if K == 0:  # no weight tile passes over g
             return out, colsum(g2)
         gb = torch.empty(N, dtype=torch.float32, device=g.device)
-    check(lib.pygamd_linear_wgrad(_p(g2), _ld(g2), _p(x2), _ld(x2), M, N, K, int(accumulate),
-                                  int(wgs_per_cu), _p(out), _ld(out), _p(gb), _p(ws),
-                                  nbytes.value, _stream(g)),
+    check(lib.pygamd_linear_wgrad2(_p(g2), _ld(g2), _p(x2), _ld(x2), K1, _p(second),
+                                   _ld(second) if second is not None else 0, K2, M, N,
+                                   int(accumulate), int(wgs_per_cu), _p(out), _ld(out), _p(gb),
+                                   _p(ws), nbytes.value, _stream(g)),
           'linear_wgrad')
     return (out, gb) if bias_grad else out
 

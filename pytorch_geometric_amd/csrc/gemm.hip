@@ -436,7 +436,11 @@ constexpr int kWLD = kWTile + 4;    // LDS row stride
 
 struct GemmTN {
   const float* __restrict__ g;  // [M, N]
-  const float* __restrict__ x;  // [M, K]
+  const float* __restrict__ x;  // [M, K]  (x2 == null)  or  [M, K1]: output columns [0, K1)
+  const float* __restrict__ x2; // null or [M, K - K1]: output columns [K1, K) — the weight
+                                // gradient against [x | x2] without the concatenated copy
+  int64_t ldx2;
+  int K1, tiles_k1;             // (x2 != null) column tiles never straddle the two operands
   float* __restrict__ partial;  // [splits][N][K]
   float* __restrict__ colsum;   // [splits][N] or null: per-split column sums of g (bias gradient)
   int64_t M, ldg, ldx;
@@ -466,7 +470,16 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
   if (split >= p.splits) return;
   const int t = static_cast<int>(q - split * tiles);
   const int tn = t / p.tiles_k, tk = t - tn * p.tiles_k;
-  const int n0 = tn * kWTile, k0 = tk * kWTile;
+  const int n0 = tn * kWTile;
+  // the tile's operand, its first column inside that operand (k0), the operand's width (Kop) and
+  // the tile's first OUTPUT column (kout0)
+  const bool two = p.K1 < p.K;  // a second operand supplies the output columns [K1, K)
+  const bool second = two && tk >= p.tiles_k1;
+  const float* __restrict__ xsrc = second ? p.x2 : p.x;
+  const int64_t xld = second ? p.ldx2 : p.ldx;
+  const int k0 = (second ? tk - p.tiles_k1 : tk) * kWTile;
+  const int Kop = second ? p.K - p.K1 : p.K1;
+  const int kout0 = (second ? p.K1 : 0) + k0;
   const int64_t ra = split * p.rows_per_split;
   int64_t rb = ra + p.rows_per_split;
   rb = rb < p.M ? rb : p.M;
@@ -486,17 +499,17 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
       const bool ok = row < rb;
       const int64_t rs = ok ? row : ra;
       const float* gp = p.g + rs * p.ldg + gcol;
-      const float* xp = p.x + rs * p.ldx + xcol;
+      const float* xp = xsrc + rs * xld + xcol;
       if (VEC) {
         rg[j] = (ok && gcol < p.N) ? *reinterpret_cast<const f32x4*>(gp)
                                    : f32x4{0.f, 0.f, 0.f, 0.f};
-        rx[j] = (ok && xcol < p.K) ? *reinterpret_cast<const f32x4*>(xp)
+        rx[j] = (ok && xcol < Kop) ? *reinterpret_cast<const f32x4*>(xp)
                                    : f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           rg[j][e] = (ok && gcol + e < p.N) ? gp[e] : 0.f;
-          rx[j][e] = (ok && xcol + e < p.K) ? xp[e] : 0.f;
+          rx[j][e] = (ok && xcol + e < Kop) ? xp[e] : 0.f;
         }
       }
     }
@@ -527,7 +540,7 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // wave-uniform: which 32-wide blocks of this wave's range exist
   const bool nb0 = n0 + wn * 64 < p.N, nb1 = n0 + wn * 64 + 32 < p.N;
-  const bool kb0 = k0 + wk * 64 < p.K, kb1 = k0 + wk * 64 + 32 < p.K;
+  const bool kb0 = k0 + wk * 64 < Kop, kb1 = k0 + wk * 64 + 32 < Kop;
 
   const int64_t n_blocks = (rb - ra + kWRows - 1) / kWRows;
   if (n_blocks > 0) {
@@ -682,8 +695,8 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = k0 + wk * 64 + j * 32 + li;
-      if (col >= p.K) continue;
+      if (k0 + wk * 64 + j * 32 + li >= Kop) continue;
+      const int col = kout0 + wk * 64 + j * 32 + li;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -823,6 +836,7 @@ static int64_t wgrad_splits(int64_t M, int64_t tiles, int wgs_per_cu = 2) {
 
 int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t* bytes) {
   if (!bytes || M < 0 || N < 0 || K < 0) return PYGAMD_ERR_INVALID_ARG;
+  // (a two-operand launch has at most one more column tile: fewer splits, never more)
   const int64_t tiles = ceil_div(N, kWTile) * ceil_div(K, kWTile);
   // [splits][N][K] partial tiles + [splits][N] bias-gradient partials
   *bytes = static_cast<size_t>(wgrad_splits(M, tiles)) * static_cast<size_t>(N) *
@@ -834,7 +848,19 @@ int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
                         int64_t N, int64_t K, int accumulate, int wgs_per_cu, float* out,
                         int64_t ldo, float* bias_grad, void* workspace, size_t workspace_bytes,
                         void* stream) {
-  if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldx < K ||
+  return pygamd_linear_wgrad2(g, ldg, x, ldx, K, nullptr, 0, 0, M, N, accumulate, wgs_per_cu, out,
+                              ldo, bias_grad, workspace, workspace_bytes, stream);
+}
+
+int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t K1,
+                         const float* x2, int64_t ldx2, int64_t K2, int64_t M, int64_t N,
+                         int accumulate, int wgs_per_cu, float* out, int64_t ldo,
+                         float* bias_grad, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  if (K1 < 0 || K2 < 0 || (K2 > 0 && (K1 == 0 || ldx2 < K2 || (M > 0 && !x2))))
+    return PYGAMD_ERR_INVALID_ARG;
+  const int64_t K = K1 + K2;
+  if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldx < K1 ||
       ldo < K)
     return PYGAMD_ERR_INVALID_ARG;
   if (N == 0 || K == 0) return PYGAMD_OK;
@@ -847,14 +873,17 @@ int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx
   p.g = g; p.x = x; p.partial = static_cast<float*>(workspace);
   p.M = M; p.ldg = ldg; p.ldx = ldx;
   p.N = static_cast<int>(N); p.K = static_cast<int>(K);
+  p.x2 = x2; p.ldx2 = ldx2; p.K1 = static_cast<int>(K1);
   p.tiles_n = static_cast<int>(ceil_div(N, kWTile));
-  p.tiles_k = static_cast<int>(ceil_div(K, kWTile));
+  p.tiles_k1 = static_cast<int>(ceil_div(K1, kWTile));
+  p.tiles_k = p.tiles_k1 + static_cast<int>(ceil_div(K2, kWTile));
   const int64_t tiles = static_cast<int64_t>(p.tiles_n) * p.tiles_k;
   p.splits = static_cast<int>(wgrad_splits(M, tiles, wgs_per_cu));
   p.colsum = bias_grad ? p.partial + static_cast<int64_t>(p.splits) * N * K : nullptr;
   p.rows_per_split = round_up(ceil_div(M > 0 ? M : 1, p.splits), kWRows);
-  const bool vec = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) &&
-                   aligned16p(g) && aligned16p(x);
+  const bool vec = (N % 4 == 0) && (K1 % 4 == 0) && (K2 % 4 == 0) && (ldg % 4 == 0) &&
+                   (ldx % 4 == 0) && (ldx2 % 4 == 0) && aligned16p(g) && aligned16p(x) &&
+                   aligned16p(x2);
   const int64_t blocks = round_up(tiles * p.splits, 8);
   const size_t lds = sizeof(float) * 4 * kWRows * kWLD;
   void (*kern)(GemmTN) = nullptr;

@@ -97,7 +97,16 @@ class FusedSageStack(Function):
             return buf, buf
 
         agg_src0 = None
-        if modes[0] == 'pre' and x.is_contiguous():
+        # A first 'post' layer that runs as one kernel reads its root rows from `x` itself and keeps
+        # its aggregated rows in a buffer of their own: no `[agg | x]` copy of the input (0.5 ms at
+        # the products shape); the weight gradient then takes the two operands side by side.
+        split0 = (modes[0] == 'post' and FUSE_LAYER and GEMM_BACKEND == 'own' and x.is_contiguous()
+                  and dims[0][0] % 4 == 0 and x.data_ptr() % 16 == 0
+                  and _native.sage_layer_forward_supported(dims[0][0], dims[0][1], aggr))
+        if split0:
+            buf = torch.empty(N, dims[0][0], dtype=torch.float32, device=dev)  # agg only
+            inp = x
+        elif modes[0] == 'pre' and x.is_contiguous():
             buf, inp = x, x
         else:
             buf, inp = new_input(0)
@@ -124,15 +133,17 @@ class FusedSageStack(Function):
                 src = agg_src0 if (layer == 0 and agg_src0 is not None) else inp
                 wmat = torch.cat([W_l, W_r], dim=1)  # [Fo, 2 Fi]
                 relu_done = False
-                one_kernel = (FUSE_LAYER and GEMM_BACKEND == 'own'
-                              and _native.sage_layer_forward_supported(Fi, Fo, aggr)
-                              and src.stride(0) % 4 == 0 and buf.stride(0) % 4 == 0)
+                lone = layer == 0 and split0  # buf = the aggregated rows alone, root rows = x
+                one_kernel = lone or (FUSE_LAYER and GEMM_BACKEND == 'own'
+                                      and _native.sage_layer_forward_supported(Fi, Fo, aggr)
+                                      and src.stride(0) % 4 == 0 and buf.stride(0) % 4 == 0)
                 if one_kernel:
                     if not last:
                         bits[layer + 1] = _native.relu_bits_like(N, Fo, dev)
                     # the aggregated rows are stored once (write-only) for the weight gradient
-                    _native.sage_layer_forward(fwd.ptr, fwd.idx, src, buf[:, Fi:], wmat, b, aggr,
-                                               not last, buf[:, :Fi], dst, hub=fwd.hub,
+                    _native.sage_layer_forward(fwd.ptr, fwd.idx, src, inp if lone else buf[:, Fi:],
+                                               wmat, b, aggr, not last,
+                                               buf if lone else buf[:, :Fi], dst, hub=fwd.hub,
                                                save_agg=True,
                                                relu_bits=None if last else bits[layer + 1])
                     relu_done = True
@@ -179,7 +190,9 @@ class FusedSageStack(Function):
         ctx.graph, ctx.aggr, ctx.L, ctx.dims, ctx.modes = graph, aggr, L, dims, modes
         ctx.has_bias = [params[3 * i + 1] is not None for i in range(L)]
         ctx.has_bits = [t is not None for t in bits]
-        ctx.save_for_backward(*bufs, *wmats, *[t for t in bits if t is not None])
+        ctx.split0 = split0
+        ctx.save_for_backward(*bufs, *wmats, *[t for t in bits if t is not None],
+                              *([x] if split0 else []))
         return out
 
     @staticmethod
@@ -194,6 +207,7 @@ class FusedSageStack(Function):
         bufs, wmats = saved[:L], saved[L:2 * L]
         packed = list(saved[2 * L:])
         bits = [packed.pop(0) if has else None for has in ctx.has_bits]
+        x0 = packed.pop(0) if ctx.split0 else None  # layer 0: buf = agg rows, root rows = x0
         bwd = graph.by_src()
         scale = graph.by_dst().inv_degree() if aggr == 'mean' else None
         N = grad_out.size(0)
@@ -225,9 +239,10 @@ class FusedSageStack(Function):
                 # [Fo, 2 Fi] = [grad W_l | grad W_r]
                 overlap = (own and OVERLAP_WGRAD and need_input_grad
                            and not torch.cuda.is_current_stream_capturing())
+                lone_x = x0 if layer == 0 else None  # [agg | x] as two operands side by side
                 if not overlap:
                     if own:
-                        gw = _native.linear_wgrad(g, buf, bias_grad=want_b)
+                        gw = _native.linear_wgrad(g, buf, bias_grad=want_b, x2=lone_x)
                         if want_b:
                             gw, grads[3 * layer + 1] = gw
                     else:
@@ -249,7 +264,8 @@ class FusedSageStack(Function):
                         side = _side_stream(g.device)
                         side.wait_stream(cur)
                         with torch.cuda.stream(side):
-                            gw = _native.linear_wgrad(g, buf, wgs_per_cu=1, bias_grad=want_b)
+                            gw = _native.linear_wgrad(g, buf, wgs_per_cu=1, bias_grad=want_b,
+                                                      x2=lone_x)
                             if want_b:
                                 gw, grads[3 * layer + 1] = gw
                         g.record_stream(side)

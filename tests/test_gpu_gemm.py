@@ -92,6 +92,22 @@ def test_linear_dgrad_and_wgrad(dev, M, K, N):
     assert torch.equal(out2, out) and gb.shape == (N, )
     assert_sum_close(gb, go.sum(0), go.double().sum(0), abs_sum=go.abs().double().sum(0),
                      what=f'wgrad bias {M}x{K}x{N}')
+    # two operands side by side: g^T @ [x | x2] without the concatenated copy (strided x2: the
+    # right half of a wider buffer); the number of row splits differs from the one-operand launch,
+    # so the comparison is against fp64 like everywhere else
+    if K > 0:
+        K2 = K // 2 + 3
+        wide = torch.randn(M, 2 * K2, generator=g)
+        x2 = wide[:, K2:]
+        both = torch.cat([x, x2], 1)
+        got, gb2 = _native.linear_wgrad(go.to(dev), x.to(dev), bias_grad=True,
+                                        x2=wide.to(dev)[:, K2:])
+        assert got.shape == (N, K + K2)
+        assert_sum_close(got, go.t() @ both, go.double().t() @ both.double(),
+                         abs_sum=go.abs().double().t() @ both.abs().double(),
+                         what=f'wgrad two operands {M}x({K}+{K2})x{N}')
+        assert_sum_close(gb2, go.sum(0), go.double().sum(0), abs_sum=go.abs().double().sum(0),
+                         what='wgrad two operands, bias')
     # dgrad with the ReLU-backward epilogue: exact zeros where the mask is not positive, the plain
     # result (bit-identical) elsewhere; strided mask (right half of an [agg | x] buffer)
     if K > 0:
