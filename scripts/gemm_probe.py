@@ -16,6 +16,7 @@ ap.add_argument('--no-tuned', action='store_true')
 ap.add_argument('--reps', type=int, default=10)
 ap.add_argument('--mode', default='fp32', choices=['fp32', 'split'])
 ap.add_argument('--only', default='', help='comma list of fwd,dgrad,wgrad')
+ap.add_argument('--pad', type=int, default=0, help='extra floats in the leading dimension of the activations')
 args = ap.parse_args()
 if not args.no_tuned:
     from pytorch_geometric_amd.tuning import enable_tuned_gemms
@@ -47,11 +48,11 @@ def report(name, flops, t_own, t_lib, err):
 
 g = torch.Generator(device=dev).manual_seed(0)
 for K, N in ((200, 256), (512, 256), (256, 96)) if 'fwd' in only else ():
-    x = torch.randn(M, K, device=dev, generator=g)
+    x = torch.randn(M, K + args.pad, device=dev, generator=g)[:, :K]
     w = torch.randn(N, K, device=dev, generator=g) * 0.05
     b = torch.randn(N, device=dev, generator=g)
-    out = torch.empty(M, N, device=dev)
-    ref = torch.empty(M, N, device=dev)
+    out = torch.empty(M, N + args.pad, device=dev)[:, :N]
+    ref = torch.empty(M, N + args.pad, device=dev)[:, :N]
     t_own = timeit(lambda: _native.linear_forward(x, w, b, relu=True, out=out))
     t_lib = timeit(lambda: torch.relu_(torch.addmm(b, x, w.t(), out=ref)))
     err = float((out - ref).abs().max() / ref.abs().max())

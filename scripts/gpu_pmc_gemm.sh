@@ -4,7 +4,7 @@
 TAG=${1:-gemm}; shift
 R=$(pwd); export TMPDIR=/tmp
 CTRS=${CTRS:-"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU"}
-for MODE in split fp32; do
+for MODE in ${MODES:-split fp32}; do
   OUT=$R/gpurun_out/pmc_${TAG}_$MODE; rm -rf $OUT; mkdir -p $OUT
   (cd /tmp && timeout 600 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT -o pmc --output-format csv -- python $R/scripts/gemm_probe.py --mode $MODE --reps 2 "$@" > $OUT/stdout.log 2>&1)
   grep -v amdgpu.ids $OUT/stdout.log | grep "own" | cut -c1-120
