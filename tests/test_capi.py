@@ -96,3 +96,67 @@ def test_pack_relu_bits_layout():
                     if r < n and c < f and float(act[r, c]) > 0:
                         want |= 1 << b
                 assert (int(words[r >> 5, w, r & 31]) & 0xffffffff) == want
+
+
+def test_round2_entry_points_validate_without_gpu():
+    """The entry points added in round 2 reject inconsistent arguments on the host (no device
+    work is reached): mask arguments of the SpMM / dgrad epilogues, the two-operand weight
+    gradient, the arithmetic mode switch."""
+    import ctypes
+    from pytorch_geometric_amd import _lib
+    lib = _lib.load()
+    # arithmetic mode: process-wide switch with a checked range
+    assert lib.pygamd_get_gemm_mode() in (0, 1)
+    prev = lib.pygamd_get_gemm_mode()
+    assert lib.pygamd_set_gemm_mode(7) == 1 and lib.pygamd_get_gemm_mode() == prev
+    assert lib.pygamd_set_gemm_mode(1) == 0 and lib.pygamd_get_gemm_mode() == 1
+    assert lib.pygamd_set_gemm_mode(prev) == 0
+    # SpMM: a float mask narrower than F, both mask forms at once, a mask on an extremum
+    a = _lib.SpmmArgs()
+    a.n_rows, a.F, a.ldx, a.ldo, a.idx_dtype, a.reduce = 4, 64, 64, 64, 1, 0
+    a.rowptr = a.col = a.x = a.out = 16  # (never dereferenced: every call below is rejected)
+    a.relu_mask, a.ld_mask = 16, 32
+    assert lib.pygamd_spmm_csr(ctypes.byref(a), None, 0, None) == 1
+    a.ld_mask, a.relu_bits, a.ld_bits = 64, 16, 2
+    assert lib.pygamd_spmm_csr(ctypes.byref(a), None, 0, None) == 1
+    a.relu_mask, a.ld_bits = None, 1  # 64 columns need two words per row tile
+    assert lib.pygamd_spmm_csr(ctypes.byref(a), None, 0, None) == 1
+    a.ld_bits, a.reduce = 2, 3
+    assert lib.pygamd_spmm_csr(ctypes.byref(a), None, 0, None) == 2
+    # dgrad: mask leading dimensions
+    P = ctypes.c_void_p
+    assert lib.pygamd_linear_dgrad(P(16), 8, P(16), 8, None, 0, 4, 8, 64, 0, P(16), 32, None, 0,
+                                   P(16), 64, None) == 1
+    assert lib.pygamd_linear_dgrad(P(16), 8, P(16), 8, None, 0, 4, 8, 64, 0, None, 0, P(16), 1,
+                                   P(16), 64, None) == 1
+    # two-operand weight gradient: a second width without a second operand (M > 0), an empty
+    # first operand, an output narrower than K1 + K2
+    ws = ctypes.c_size_t(0)
+    assert lib.pygamd_linear_wgrad_workspace_bytes(1000, 8, 24, ctypes.byref(ws)) == 0
+    assert ws.value >= 8 * 25 * 4
+    assert lib.pygamd_linear_wgrad2(P(16), 8, P(16), 16, 16, None, 8, 8, 1000, 8, 0, 0, P(16), 24,
+                                    None, P(16), ws.value, None) == 1
+    assert lib.pygamd_linear_wgrad2(P(16), 8, P(16), 16, 0, P(16), 8, 8, 1000, 8, 0, 0, P(16), 24,
+                                    None, P(16), ws.value, None) == 1
+    assert lib.pygamd_linear_wgrad2(P(16), 8, P(16), 16, 16, P(16), 8, 8, 1000, 8, 0, 0, P(16), 16,
+                                    None, P(16), ws.value, None) == 1
+    assert lib.pygamd_linear_wgrad2(P(16), 8, P(16), 16, 16, P(16), 8, 8, 1000, 8, 0, 0, P(16), 24,
+                                    None, P(16), 4, None) == 3
+
+
+def test_gemm_mode_python_api_and_relu_bits_checks():
+    import torch
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    prev = pga.get_gemm_mode()
+    assert prev in ('fp32', 'split')
+    with pytest.raises(ValueError):
+        pga.set_gemm_mode('tf32')
+    assert pga.set_gemm_mode('split') == prev and pga.get_gemm_mode() == 'split'
+    pga.set_gemm_mode(prev)
+    bits = _native.relu_bits_like(70, 100, 'cpu')
+    assert tuple(bits.shape) == (3, 4, 32) and bits.dtype == torch.int32
+    _native._check_bits(bits, 70, 100)
+    for bad in (bits[:, :3], bits.to(torch.int64), bits[:2], bits.transpose(0, 1)):
+        with pytest.raises(ValueError):
+            _native._check_bits(bad, 70, 100)
