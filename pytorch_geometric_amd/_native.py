@@ -723,13 +723,14 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
     _require_device(g, x, out, x2)
     lib = _lib.load()
     second = None if x2 is None else _f32_rows(x2, 'x2')
-    g2, x2 = _f32_rows(g, 'grad'), _f32_rows(x, 'x')
+    g2, first = _f32_rows(g, 'grad'), _f32_rows(x, 'x')
     M, N = g2.shape
-    K1 = x2.size(1)
+    K1 = first.size(1)
     K2 = 0 if second is None else second.size(1)
     K = K1 + K2
-    if x2.size(0) != M or (second is not None and second.size(0) != M):
-        raise ValueError(f"'grad' has {M} rows but 'x' has {x2.size(0)}")
+    if first.size(0) != M or (second is not None and second.size(0) != M):
+        raise ValueError(f"'grad' has {M} rows but 'x' has {first.size(0)}"
+                         + ('' if second is None else f" and 'x2' {second.size(0)}"))
     if second is not None and (K1 == 0 or K2 == 0):
         raise ValueError("both operands of a two-operand weight gradient need columns")
     if out is None:
@@ -742,7 +743,7 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
         if K == 0:  # no weight tile passes over g
             return out, colsum(g2)
         gb = torch.empty(N, dtype=torch.float32, device=g.device)
-    check(lib.pygamd_linear_wgrad2(_p(g2), _ld(g2), _p(x2), _ld(x2), K1, _p(second),
+    check(lib.pygamd_linear_wgrad2(_p(g2), _ld(g2), _p(first), _ld(first), K1, _p(second),
                                    _ld(second) if second is not None else 0, K2, M, N,
                                    int(accumulate), int(wgs_per_cu), _p(out), _ld(out), _p(gb),
                                    _p(ws), nbytes.value, _stream(g)),
