@@ -28,8 +28,6 @@
 // Splits write their partial tiles to a slab; a second kernel adds the slabs in split order
 // (deterministic, no atomics).  Workgroups of one split are adjacent on one XCD: each row of g and
 // x leaves HBM once.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace pygamd {
@@ -127,101 +125,6 @@ __device__ __forceinline__ void nt_tile_of_block(const GemmNT& p, int& tm, int& 
   const int64_t q = (b & 7) * per_xcd + (b >> 3);  // logical id, contiguous per XCD
   tm = static_cast<int>(q / p.tiles_n);
   tn = static_cast<int>(q - static_cast<int64_t>(tm) * p.tiles_n);
-}
-
-// ---- epilogue shared by the NT kernels: bias, ReLU, row scale, accumulate, ReLU-backward mask ------
-// Wave (wm, wn) of the workgroup owns TM x TN blocks of 32 x 32 starting at row m0 + wm TM 32,
-// column n0 + wn TN 32; BM x BN is the workgroup's tile.
-template <int TM, int TN>
-__device__ __forceinline__ void nt_epilogue(const GemmNT& p, const f32x16 (&acc)[TM][TN],
-                                            int64_t m0, int n0, int BM, int BN, int wm, int wn,
-                                            int li, int lh) {
-  // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-  const float floor_v = p.relu ? 0.f : -INFINITY;  // branch-free ReLU switch
-  const bool wave_scaled = p.n_scaled > n0 + wn * TN * 32;  // wave-uniform
-  if (full && !p.accumulate) {
-    // interior tile (all but the last row block): no bounds checks, no read-modify-write
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int64_t rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
-      f32x4 sc[4];
-      if (wave_scaled) {  // rows rbase + 8 g + {0..3}: four aligned 16-byte loads
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sc[g4][e] = p.row_scale[rbase + 8 * g4 + e];
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + li;
-        const float bv = p.bias ? p.bias[col] : 0.f;
-        const bool scaled = wave_scaled && col < p.n_scaled;
-        float* cp = p.c + rbase * p.ldc + col;
-        if (p.mask) {  // uniform: the ReLU-backward epilogue of a dgrad launch
-          const float* mp = p.mask + rbase * p.ldm + col;
-          float mv[16];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) mv[e] = mp[((e & 3) + 8 * (e >> 2)) * p.ldm];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float v = acc[i][j][e] + bv;
-            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
-            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = mv[e] > 0.f ? fmaxf(v, floor_v) : 0.f;
-          }
-          continue;
-        }
-        if (p.mask_bits) {  // uniform.  This 32 x 32 block is one bit tile = one 128-byte line
-          const int64_t tile_row = (rbase - 4 * lh) >> 5;  // (m0 and the block offsets are % 32)
-          const uint32_t word = p.mask_bits[(tile_row * p.ldmb + (col >> 5)) * 32 + li];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const uint32_t bw = __shfl(word, (e & 3) + 8 * (e >> 2) + 4 * lh, kWave);
-            float v = acc[i][j][e] + bv;
-            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
-            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = ((bw >> li) & 1u) ? fmaxf(v, floor_v) : 0.f;
-          }
-          continue;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[i][j][e] + bv;
-          if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
-          cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = fmaxf(v, floor_v);
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int64_t rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + li;
-      if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[col] : 0.f;
-      const bool scaled = col < p.n_scaled;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
-        if (row < p.M) {
-          float v = acc[i][j][e] + bv;
-          if (scaled) v *= p.row_scale[row];
-          v = fmaxf(v, floor_v);
-          float* dst = p.c + row * p.ldc + col;
-          if (p.accumulate) v += *dst;
-          if (p.mask) v = p.mask[row * p.ldm + col] > 0.f ? v : 0.f;
-          if (p.mask_bits)
-            v = ((p.mask_bits[((row >> 5) * p.ldmb + (col >> 5)) * 32 + (row & 31)] >> (col & 31)) &
-                 1u)
-                    ? v
-                    : 0.f;
-          *dst = v;
-        }
-      }
-    }
-  }
 }
 
 template <int WM, int WN, int TM, int TN, bool VEC, bool SPLIT>
@@ -438,243 +341,92 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
     }
   }
 
-  nt_epilogue<TM, TN>(p, acc, m0, n0, BM, BN, wm, wn, li, lh);
-}
-
-// ---- NT, split arithmetic, conversion at LDS-store time --------------------------------------------
-// The first split kernel above converts a fragment in the wave that multiplies it: every operand
-// element is converted twice (two waves share it) and the kernel is VALU-issue bound (9 VALU per
-// matrix instruction, matrix pipe 31 % busy).  Here every element is converted ONCE, by the thread
-// that stages it, and LDS holds three bf16 planes per operand: a fragment is then a 16-byte
-// ds_read per plane, nothing else.  Shape: 512 threads = 8 waves as 4 (M) x 2 (N), workgroup tile
-// 256 x 128 (the weight tile serves twice as many rows), wave tile 64 x 64, K in steps of 16 = ONE
-// bf16 matrix step: per step and wave 24 matrix instructions, 12 ds_read_b128, and per thread
-// 3 global 16-byte loads (two steps ahead), 54 conversion VALU, 9 ds_write_b64.
-constexpr int kS3Threads = 512;
-constexpr int kS3BM = 256, kS3BN = 128, kS3K = 16;
-constexpr int kS3Row = 48;  // bytes per staged row of one plane: 16 bf16 + 16 bytes of padding
-                            // (row i starts at bank 12 i: 16 rows x 16 bytes cover all 64 banks)
-constexpr int kS3PlaneA = kS3BM * kS3Row, kS3PlaneB = kS3BN * kS3Row;
-constexpr int kS3Buf = 3 * (kS3PlaneA + kS3PlaneB);  // bytes per ring slot
-
-// four consecutive k -> 8 bytes in each of the three planes
-__device__ __forceinline__ void split4_store(const f32x4& v, char* row_ptr, int plane_stride) {
-  uint32_t w[3][2];
+  // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const float floor_v = p.relu ? 0.f : -INFINITY;  // branch-free ReLU switch
+  const bool wave_scaled = p.n_scaled > n0 + wn * TN * 32;  // wave-uniform
+  if (full && !p.accumulate) {
+    // interior tile (all but the last row block): no bounds checks, no read-modify-write
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float x0 = v[2 * q], x1 = v[2 * q + 1];
-    const uint32_t a = pack_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(a << 16);
-    const float r1 = x1 - __uint_as_float(a & 0xffff0000u);
-    const uint32_t b = pack_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(b << 16);
-    const float s1 = r1 - __uint_as_float(b & 0xffff0000u);
-    w[0][q] = a;
-    w[1][q] = b;
-    w[2][q] = pack_bf16(s0, s1);
-  }
+    for (int i = 0; i < TM; ++i) {
+      const int64_t rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+      f32x4 sc[4];
+      if (wave_scaled) {  // rows rbase + 8 g + {0..3}: four aligned 16-byte loads
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 o = {w[t][0], w[t][1]};
-    *reinterpret_cast<u32x2*>(row_ptr + t * plane_stride) = o;
-  }
-}
-
-template <bool VEC>
-__global__ void __launch_bounds__(kS3Threads, 2) gemm_nt_split3_kernel(GemmNT p) {
-  extern __shared__ __align__(16) float smem[];
-  char* lds = reinterpret_cast<char*>(smem);  // [2][A planes | B planes]
-  int tile_m, tile_n;
-  nt_tile_of_block(p, tile_m, tile_n);
-  if (tile_m >= p.tiles_m) return;
-  const int64_t m0 = static_cast<int64_t>(tile_m) * kS3BM;
-  const int n0 = tile_n * kS3BN;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, lh = lane >> 5;
-
-  // staging map: thread -> row t >> 2 (+128 for the second A load), 16-byte column t & 3
-  const int sq = threadIdx.x & 3, sr = threadIdx.x >> 2;
-  const float* pa[2];
+        for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int64_t row = m0 + sr + 128 * q;
-    row = row < p.M ? row : p.M - 1;
-    pa[q] = p.a + row * p.lda;
-  }
-  const bool okb = n0 + sr < p.N;
-  const float* pb = p.b + static_cast<int64_t>(okb ? n0 + sr : p.N - 1) * p.ldb;
-  struct Stage {
-    f32x4 a[2], b;
-  };
-  // VEC: the three 16-byte loads of a step are issued through inline assembly and waited for with
-  // an explicit `s_waitcnt vmcnt(3)` two iterations later (wait_step): hipcc's own counter
-  // insertion drains everything at the loop header (vmcnt(0)), i.e. gives a load ONE iteration to
-  // land; the explicit count leaves the youngest step in flight.  Every wait names the registers
-  // it guards as in/out operands, so no use can move above it.
-  auto load_step = [&](Stage& st, int k0) {  // issue only; masked when it moves to LDS
-    const int k = k0 + 4 * sq;
-    if (VEC) {
-      const int kc = k < p.K ? k : 0;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st.a[0]) : "v"(pa[0] + kc) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st.a[1]) : "v"(pa[1] + kc) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st.b) : "v"(pb + kc) : "memory");
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int kc = k + e < p.K ? k + e : 0;
-        st.a[0][e] = pa[0][kc];
-        st.a[1][e] = pa[1][kc];
-        st.b[e] = pb[kc];
+          for (int e = 0; e < 4; ++e) sc[g4][e] = p.row_scale[rbase + 8 * g4 + e];
       }
-    }
-  };
-  auto wait_step = [&](Stage& st, bool youngest_may_fly) {
-    if (VEC) {
-      if (youngest_may_fly) {
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.b) : : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.b) : : "memory");
-      }
-    }
-  };
-  auto store_step = [&](const Stage& st, int slot, int k0) {
-    const int k = k0 + 4 * sq;
-    char* base = lds + slot * kS3Buf;
-    f32x4 va[2] = {st.a[0], st.a[1]}, vb = st.b;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const bool kv = k + e < p.K;  // both operands zero past K (Inf * 0 would be NaN)
-      va[0][e] = kv ? va[0][e] : 0.f;
-      va[1][e] = kv ? va[1][e] : 0.f;
-      vb[e] = (kv && okb) ? vb[e] : 0.f;
-    }
-    split4_store(va[0], base + sr * kS3Row + 8 * sq, kS3PlaneA);
-    split4_store(va[1], base + (sr + 128) * kS3Row + 8 * sq, kS3PlaneA);
-    split4_store(vb, base + 3 * kS3PlaneA + sr * kS3Row + 8 * sq, kS3PlaneB);
-  };
-  struct Frags {
-    SplitFrag a[2], b[2];
-  };
-  auto read_frags = [&](Frags& f, int slot) {
-    const char* base = lds + slot * kS3Buf;
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + li;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        const bool scaled = wave_scaled && col < p.n_scaled;
+        float* cp = p.c + rbase * p.ldc + col;
+        if (p.mask) {  // uniform: the ReLU-backward epilogue of a dgrad launch
+          const float* mp = p.mask + rbase * p.ldm + col;
+          float mv[16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+          for (int e = 0; e < 16; ++e) mv[e] = mp[((e & 3) + 8 * (e >> 2)) * p.ldm];
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
-        f.a[i].p[t] = *reinterpret_cast<const bf16x8*>(base + t * kS3PlaneA +
-                                                       (wm * 64 + i * 32 + li) * kS3Row + 16 * lh);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        f.b[j].p[t] = *reinterpret_cast<const bf16x8*>(base + 3 * kS3PlaneA + t * kS3PlaneB +
-                                                       (wn * 64 + j * 32 + li) * kS3Row + 16 * lh);
-  };
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // ring of two LDS slots, global loads two steps ahead of their store:
-  //   iteration c: fragments <- LDS[c];  LDS[c+1] <- convert(s0);  s0 <- s1;  s1 <- global step c+3;
-  //                24 matrix instructions on the fragments;  barrier.
-  const int n_steps = (p.K + kS3K - 1) / kS3K;
-  // Pipeline (measured floor of a version that read its fragments at the top of every step: the
-  // 96 KB of ds_read_b128 per step and CU cost as much as half of the step's matrix time, exposed).
-  //   iteration c:  fragments(c + 1) <- LDS[(c + 1) & 1]      (issued first, land under the MFMAs)
-  //                 step c + 2: wait for its loads (issued at iteration c - 2), convert, store
-  //                             into LDS[c & 1] (whose fragments were read during iteration c - 1)
-  //                 loads of step c + 4 -> the staging registers just freed
-  //                 24 matrix instructions on fragments(c), the 18 conversion slices between them
-  //                 barrier (step c + 2 visible; everybody is done reading LDS[(c + 1) & 1])
-  // Registers alternate by parity — staging sE / sO (a step waits in them for two iterations, no
-  // copies: a copy would wait for the youngest load at once) and fragments fE / fO — so the loop
-  // is unrolled by two.  Loads past the last step are clamped to valid addresses and their stores
-  // write zeros nobody reads: every iteration is the same straight-line block and the explicit
-  // vmcnt(3) (three younger loads in flight) is exact.
-  Stage sE, sO;
-  load_step(sE, 0);
-  load_step(sO, kS3K);
-  wait_step(sE, false);
-  wait_step(sO, false);
-  store_step(sE, 0, 0);
-  store_step(sO, 1, kS3K);
-  load_step(sE, 2 * kS3K);
-  load_step(sO, 3 * kS3K);
-  __syncthreads();
-  Frags fE, fO;
-  read_frags(fE, 0);
-  char* const st_a0 = lds + sr * kS3Row + 8 * sq;
-  char* const st_a1 = lds + (sr + 128) * kS3Row + 8 * sq;
-  char* const st_b = lds + 3 * kS3PlaneA + sr * kS3Row + 8 * sq;
-  // st: staging registers of step c + 2 (then of c + 4);  f: fragments(c);  fn: fragments(c + 1)
-  auto iteration = [&](int c, Stage& st, const Frags& f, Frags& fn) {
-    const int slot = c & 1;
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(fn, slot ^ 1);
-    wait_step(st, true);
-    // pairs 0,1 = first A row, 2,3 = second A row, 4,5 = B row of the step being staged
-    float xi[6][2], rr[6][2], ss[6][2];
-    uint32_t w0[6], w1[6], w2[6];
-    {
-      const int k = (c + 2) * kS3K + 4 * sq;
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const f32x4& src = q < 2 ? st.a[0] : (q < 4 ? st.a[1] : st.b);
-          const bool kv = k + 2 * (q & 1) + e < p.K && (q < 4 || okb);
-          xi[q][e] = kv ? src[2 * (q & 1) + e] : 0.f;
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv;
+            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
+            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = mv[e] > 0.f ? fmaxf(v, floor_v) : 0.f;
+          }
+          continue;
         }
-    }
-    load_step(st, (c + 4) * kS3K);
-    auto slice = [&](int n) {  // n = 6 * level + pair
-      const int q = n % 6;
-      if (n < 6) {
-        w0[q] = pack_bf16(xi[q][0], xi[q][1]);
-        rr[q][0] = xi[q][0] - __uint_as_float(w0[q] << 16);
-        rr[q][1] = xi[q][1] - __uint_as_float(w0[q] & 0xffff0000u);
-      } else if (n < 12) {
-        w1[q] = pack_bf16(rr[q][0], rr[q][1]);
-        ss[q][0] = rr[q][0] - __uint_as_float(w1[q] << 16);
-        ss[q][1] = rr[q][1] - __uint_as_float(w1[q] & 0xffff0000u);
-      } else {
-        w2[q] = pack_bf16(ss[q][0], ss[q][1]);
-        if (q & 1) {  // both pairs of a 16-byte load are done: 8 bytes into each plane
-          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-          char* dst = (q == 1 ? st_a0 : (q == 3 ? st_a1 : st_b)) + slot * kS3Buf;
-          const int ps = q == 5 ? kS3PlaneB : kS3PlaneA;
-          *reinterpret_cast<u32x2*>(dst) = u32x2{w0[q - 1], w0[q]};
-          *reinterpret_cast<u32x2*>(dst + ps) = u32x2{w1[q - 1], w1[q]};
-          *reinterpret_cast<u32x2*>(dst + 2 * ps) = u32x2{w2[q - 1], w2[q]};
+        if (p.mask_bits) {  // uniform.  This 32 x 32 block is one bit tile = one 128-byte line
+          const int64_t tile_row = (rbase - 4 * lh) >> 5;  // (m0 and the block offsets are % 32)
+          const uint32_t word = p.mask_bits[(tile_row * p.ldmb + (col >> 5)) * 32 + li];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const uint32_t bw = __shfl(word, (e & 3) + 8 * (e >> 2) + 4 * lh, kWave);
+            float v = acc[i][j][e] + bv;
+            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
+            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = ((bw >> li) & 1u) ? fmaxf(v, floor_v) : 0.f;
+          }
+          continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][j][e] + bv;
+          if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
+          cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = fmaxf(v, floor_v);
         }
       }
-    };
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < 24; ++m) {
-      const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
-      split_term(t, f.a[i], f.b[j], acc[i][j]);
-      if (m < 18) slice(m);
-      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-  };
-  int c = 0;
-  for (; c + 1 < n_steps; c += 2) {
-    iteration(c, sE, fE, fO);
-    iteration(c + 1, sO, fO, fE);
+    return;
   }
-  if (c < n_steps) iteration(c, sE, fE, fO);
-  // nothing may still be writing registers when the epilogue re-uses them
-  wait_step(sE, false);
-  wait_step(sO, false);
-  nt_epilogue<2, 2>(p, acc, m0, n0, kS3BM, kS3BN, wm, wn, li, lh);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + li;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+      const bool scaled = col < p.n_scaled;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
+        if (row < p.M) {
+          float v = acc[i][j][e] + bv;
+          if (scaled) v *= p.row_scale[row];
+          v = fmaxf(v, floor_v);
+          float* dst = p.c + row * p.ldc + col;
+          if (p.accumulate) v += *dst;
+          if (p.mask) v = p.mask[row * p.ldm + col] > 0.f ? v : 0.f;
+          if (p.mask_bits)
+            v = ((p.mask_bits[((row >> 5) * p.ldmb + (col >> 5)) * 32 + (row & 31)] >> (col & 31)) &
+                 1u)
+                    ? v
+                    : 0.f;
+          *dst = v;
+        }
+      }
+    }
+  }
 }
 
 // ---- TN: out[N, K] = g[M, N]^T @ x[M, K], split over M -------------------------------------------
@@ -1004,26 +756,6 @@ static int launch_nt(GemmNT p, bool vec, hipStream_t st) {
 }
 
 static int g_gemm_mode = 0;  // pygamd_set_gemm_mode
-// which NT kernel serves the split mode for wide outputs: 3 = conversion at LDS-store time (above),
-// 2 = conversion in the multiplying wave (gemm_nt_kernel<..., SPLIT>); PYGAMD_SPLIT_KERNEL
-static int g_split_kernel = [] {
-  const char* e = std::getenv("PYGAMD_SPLIT_KERNEL");
-  return (e && e[0] == '2') ? 2 : 3;
-}();
-
-static int launch_nt_split3(GemmNT p, bool vec, hipStream_t st) {
-  p.tiles_m = static_cast<int>(ceil_div(p.M, kS3BM));
-  p.tiles_n = static_cast<int>(ceil_div(p.N, kS3BN));
-  const int64_t blocks = round_up(static_cast<int64_t>(p.tiles_m) * p.tiles_n, 8);
-  const size_t lds = 2 * kS3Buf;
-  void (*k)(GemmNT) = vec ? gemm_nt_split3_kernel<true> : gemm_nt_split3_kernel<false>;
-  PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds)));
-  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(blocks)), dim3(kS3Threads), lds, st, p);
-  PYGAMD_LAUNCH_CHECK();
-  return PYGAMD_OK;
-}
 
 static int run_nt(GemmNT p, hipStream_t st) {
   if (p.M == 0 || p.N == 0) return PYGAMD_OK;
@@ -1032,7 +764,6 @@ static int run_nt(GemmNT p, hipStream_t st) {
                    aligned16p(p.b);
   // tile shape by output width: wide outputs 128 x 128; 65..96 columns one 128 x 96 tile row;
   // narrow outputs 128 x 64 / 128 x 32 tiles (all four waves stacked along M)
-  if (p.split && p.N > 96 && p.K > 0 && g_split_kernel == 3) return launch_nt_split3(p, vec, st);
   if (p.N > 96) return launch_nt<2, 2, 2, 2>(p, vec, st);
   if (p.N > 64) return launch_nt<4, 1, 1, 3>(p, vec, st);
   if (p.N > 32) return launch_nt<4, 1, 1, 2>(p, vec, st);
