@@ -1,0 +1,233 @@
+"""Host logic of the fused GraphSAGE stack (nn/models/_fused_sage.py) WITHOUT a GPU: every native
+entry point the stack calls is replaced — inside this test only — by a plain-torch stand-in that
+honours the same arguments (strided halves of `[agg | x]` buffers, `accumulate`, the `1/deg` row
+scale of the dgrad, the ReLU mask as floats or as 32 x 32-bit tiles, the bias gradient returned by
+the weight gradient, the two-operand weight gradient).  What is checked is the WIRING: which
+buffers, masks and operands each step of the forward / backward schedule hands to which kernel.
+Values and gradients must equal the oracle's layer-by-layer GraphSAGE under autograd.  The kernels
+themselves are tested on the device (tests/test_gpu_*.py); nothing here ships."""
+import pytest
+import torch
+
+from oracle import pyg_oracle as O
+from tests._util import assert_close, gen, random_graph
+
+
+class _Csr:
+    def __init__(self, key, other, n_rows, n_cols):
+        order = torch.sort(key, stable=True).indices
+        self.ptr = torch._convert_indices_from_coo_to_csr(key[order], n_rows)
+        self.idx, self.perm = other[order].contiguous(), order
+        self.n_rows, self.n_cols, self.hub = n_rows, n_cols, None
+
+    def inv_degree(self):
+        return 1.0 / (self.ptr[1:] - self.ptr[:-1]).clamp(min=1).to(torch.float32)
+
+
+class _Graph:
+    """Duck type of pytorch_geometric_amd.EdgeIndex for FusedSageStack."""
+
+    def __init__(self, ei, n):
+        self._fwd, self._bwd = _Csr(ei[1], ei[0], n, n), _Csr(ei[0], ei[1], n, n)
+
+    def by_dst(self):
+        return self._fwd
+
+    def by_src(self):
+        return self._bwd
+
+
+def _aggregate(ptr, idx, x, reduce):
+    n = ptr.numel() - 1
+    rows = torch.repeat_interleave(torch.arange(n), ptr[1:] - ptr[:-1])
+    out = torch.zeros(n, x.size(1)).index_add_(0, rows, x[idx])
+    if reduce == 'mean':
+        out = out / (ptr[1:] - ptr[:-1]).clamp(min=1).view(-1, 1)
+    return out
+
+
+def _unpack_bits(bits, n, f):
+    w = bits.to(torch.int64) & 0xffffffff                     # [tile, block, row in tile]
+    shifts = torch.arange(32)
+    m = ((w.unsqueeze(-1) >> shifts) & 1).permute(0, 2, 1, 3)  # [tile, row, block, bit]
+    return m.reshape(m.size(0) * 32, -1)[:n, :f].bool()
+
+
+@pytest.fixture
+def fake_native(monkeypatch):
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    log = []
+
+    def spmm_csr(ptr, idx, x, reduce, *, n_rows=None, hub=None, out=None, accumulate=False,
+                 src_scale=None, relu_mask=None, relu_bits=None, **kw):
+        assert not kw, kw
+        xs = x if src_scale is None else x * src_scale.view(-1, 1)
+        res = _aggregate(ptr, idx, xs, reduce)
+        if accumulate:
+            res = res + out
+        assert relu_mask is None or relu_bits is None
+        if relu_mask is not None:
+            res = torch.where(relu_mask > 0, res, torch.zeros_like(res))
+        if relu_bits is not None:
+            res = torch.where(_unpack_bits(relu_bits, *res.shape), res, torch.zeros_like(res))
+        log.append(('spmm', reduce, accumulate, relu_mask is not None, relu_bits is not None))
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
+
+    def sage_layer_forward(ptr, idx, x_gather, x_root, w, bias, reduce, relu, agg, out, hub=None,
+                           save_agg=True, relu_bits=None, **kw):
+        assert not kw, kw
+        a = _aggregate(ptr, idx, x_gather, reduce)
+        y = torch.cat([a, x_root], 1) @ w.t()
+        if bias is not None:
+            y = y + bias
+        if relu:
+            y = y.relu()
+        if save_agg:
+            agg.copy_(a)
+        if relu_bits is not None:
+            assert relu
+            relu_bits.copy_(_native.pack_relu_bits(y))
+        out.copy_(y)
+        # (root rows read from a dense tensor = the layer input itself, not a half of [agg | x])
+        log.append(('fused_layer', x_root.is_contiguous(), relu_bits is not None))
+        return out
+
+    def linear_forward(x, w, bias=None, relu=False, out=None, accumulate=False):
+        y = x @ w.t()
+        if bias is not None:
+            y = y + bias
+        if relu:
+            y = y.relu()
+        if out is None:
+            return y
+        out.copy_(y + out if accumulate else y)
+        return out
+
+    def linear_dgrad(g, w_t, row_scale=None, n_scaled=0, out=None, accumulate=False,
+                     relu_mask=None, relu_bits=None):
+        y = g @ w_t.t()
+        if row_scale is not None and n_scaled:
+            y[:, :n_scaled] *= row_scale.view(-1, 1)
+        assert relu_mask is None or relu_bits is None
+        if relu_mask is not None:
+            y = torch.where(relu_mask > 0, y, torch.zeros_like(y))
+        if relu_bits is not None:
+            y = torch.where(_unpack_bits(relu_bits, *y.shape), y, torch.zeros_like(y))
+        log.append(('dgrad', relu_mask is not None, relu_bits is not None))
+        return y
+
+    def linear_wgrad(g, x, out=None, accumulate=False, wgs_per_cu=0, bias_grad=False, x2=None):
+        both = x if x2 is None else torch.cat([x, x2], 1)
+        gw = g.t() @ both
+        log.append(('wgrad', bias_grad, x2 is not None))
+        return (gw, g.sum(0)) if bias_grad else gw
+
+    for name, fn in dict(spmm_csr=spmm_csr, sage_layer_forward=sage_layer_forward,
+                         linear_forward=linear_forward, linear_dgrad=linear_dgrad,
+                         linear_wgrad=linear_wgrad).items():
+        monkeypatch.setattr(_native, name, fn)
+    monkeypatch.setattr(_native, 'sage_layer_forward_supported', lambda F, Fo, r: F % 4 == 0)
+    monkeypatch.setattr(_native, 'colsum', lambda g: g.sum(0))
+    monkeypatch.setattr(_native, 'relu_backward_colsum',
+                        lambda g, h, want: (torch.where(h > 0, g, torch.zeros_like(g)),
+                                            torch.where(h > 0, g, torch.zeros_like(g)).sum(0)
+                                            if want else None))
+    monkeypatch.setattr(_fused_sage, 'GEMM_BACKEND', 'own')
+    monkeypatch.setattr(_fused_sage, 'FUSE_LAYER', True)
+    monkeypatch.setattr(_fused_sage, 'OVERLAP_WGRAD', False)
+    return log
+
+
+@pytest.mark.parametrize('dims,aggr,x_grad', [
+    ((100, 256, 256, 47), 'mean', False),   # the headline shape: post, post, pre
+    ((100, 256, 256, 47), 'mean', True),
+    ((16, 8, 24, 12), 'sum', True),          # pre, post, pre
+    ((10, 20, 6), 'mean', True),             # F % 4 != 0: the [agg | x] buffer path of layer 1
+    ((32, 32), 'sum', False),                # a single layer
+])
+@pytest.mark.parametrize('bias', [True, False])
+def test_fused_stack_wiring_against_the_oracle(fake_native, dims, aggr, x_grad, bias):
+    from pytorch_geometric_amd.nn.models._fused_sage import FusedSageStack
+    n = 75  # three 32-row bit tiles, the last one partial
+    g = gen(sum(dims) + n)
+    ei = random_graph(n, n, 600, seed=dims[0], skew=True)
+    ei[1][ei[1] == 7] = 8  # a node without in-edges
+    x = torch.randn(n, dims[0], generator=g)
+    params = []
+    for fi, fo in zip(dims[:-1], dims[1:]):
+        params.append((torch.randn(fo, fi, generator=g) * 0.3,
+                       torch.randn(fo, generator=g) if bias else None,
+                       torch.randn(fo, fi, generator=g) * 0.3))
+    go = torch.randn(n, dims[-1], generator=g)
+
+    def leaves():
+        xs = x.clone().requires_grad_(x_grad)
+        ps = [tuple(None if t is None else t.clone().requires_grad_(True) for t in p)
+              for p in params]
+        return xs, ps
+
+    xr, pr = leaves()
+    ref = O.graphsage(xr, ei, pr, aggr)
+    ref.backward(go)
+    xf, pf = leaves()
+    flat = [t for p in pf for t in p]
+    out = FusedSageStack.apply(xf, _Graph(ei, n), aggr, True, *flat)
+    out.backward(go)
+    assert_close(out, ref, rtol=1e-4, atol=1e-4, what='fused stack output')
+    for layer, (a, b) in enumerate(zip(pf, pr)):
+        for name, t, r in zip(('W_l', 'b', 'W_r'), a, b):
+            if t is not None:
+                assert_close(t.grad, r.grad, rtol=1e-4, atol=2e-4, what=f'layer {layer} {name}')
+    if x_grad:
+        assert_close(xf.grad, xr.grad, rtol=1e-4, atol=2e-4, what='grad x')
+    else:
+        assert xf.grad is None
+
+    # the schedule itself: no stand-alone ReLU / bias pass, bits wherever a fused layer made them
+    kinds = [e[0] for e in fake_native]
+    L = len(dims) - 1
+    assert kinds.count('wgrad') == L
+    for e in fake_native:
+        if e[0] == 'wgrad':
+            assert e[1] == bias          # the bias gradient rides on the weight gradient
+    if dims == (100, 256, 256, 47):
+        fused = [e for e in fake_native if e[0] == 'fused_layer']
+        assert [e[1] for e in fused] == [True, False]   # layer 1 roots on x itself (no copy)
+        assert ('wgrad', bias, True) in fake_native      # ... and its wgrad takes [agg | x] apart
+        masked = [e for e in fake_native if e[0] in ('spmm', 'dgrad') and e[-1]]
+        assert len(masked) == 2                          # h1 (transposed SpMM) and h2 (dgrad)
+        # ... and never as floats: both activations came out of the one-kernel layer forward
+        assert not [e for e in fake_native if e[0] in ('spmm', 'dgrad') and e[-2]]
+
+
+@pytest.mark.parametrize('dims', [(12, 20, 20, 5), (16, 8, 12)])
+def test_library_gemm_schedule_wiring(fake_native, monkeypatch, dims):
+    """PYGAMD_GEMM=lib: the dense transforms go to torch.mm / addmm, the transposed SpMM takes the
+    `1/deg` as a per-source scale, ReLU backward + bias gradient stay one stand-alone pass."""
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    from pytorch_geometric_amd.nn.models._fused_sage import FusedSageStack
+    monkeypatch.setattr(_fused_sage, 'GEMM_BACKEND', 'lib')
+    n = 40
+    g = gen(sum(dims))
+    ei = random_graph(n, n, 300, seed=3)
+    x = torch.randn(n, dims[0], generator=g)
+    params = [(torch.randn(fo, fi, generator=g) * 0.3, torch.randn(fo, generator=g),
+               torch.randn(fo, fi, generator=g) * 0.3) for fi, fo in zip(dims[:-1], dims[1:])]
+    go = torch.randn(n, dims[-1], generator=g)
+    res = []
+    for fused in (False, True):
+        xs = x.clone().requires_grad_(True)
+        ps = [tuple(t.clone().requires_grad_(True) for t in p) for p in params]
+        if fused:
+            out = FusedSageStack.apply(xs, _Graph(ei, n), 'mean', True, *[t for p in ps for t in p])
+        else:
+            out = O.graphsage(xs, ei, ps, 'mean')
+        out.backward(go)
+        res.append([out.detach(), xs.grad] + [t.grad for p in ps for t in p])
+    for a, b in zip(*res):
+        assert_close(b, a, rtol=1e-4, atol=2e-4, what='library-GEMM schedule')
+    assert not [e for e in fake_native if e[0] in ('wgrad', 'dgrad', 'fused_layer')]
