@@ -29,6 +29,7 @@ class _Graph:
 
     def __init__(self, ei, n):
         self._fwd, self._bwd = _Csr(ei[1], ei[0], n, n), _Csr(ei[0], ei[1], n, n)
+        self.edge_index, self.num_edges = ei, ei.size(1)
 
     def by_dst(self):
         return self._fwd
@@ -40,6 +41,7 @@ class _Graph:
 def _aggregate(ptr, idx, x, reduce):
     n = ptr.numel() - 1
     rows = torch.repeat_interleave(torch.arange(n), ptr[1:] - ptr[:-1])
+    idx = idx[int(ptr[0]):int(ptr[-1])]  # (a clipped pointer covers a prefix of the slots)
     out = torch.zeros(n, x.size(1)).index_add_(0, rows, x[idx])
     if reduce == 'mean':
         out = out / (ptr[1:] - ptr[:-1]).clamp(min=1).view(-1, 1)
@@ -231,3 +233,69 @@ def test_library_gemm_schedule_wiring(fake_native, monkeypatch, dims):
     for a, b in zip(*res):
         assert_close(b, a, rtol=1e-4, atol=2e-4, what='library-GEMM schedule')
     assert not [e for e in fake_native if e[0] in ('wgrad', 'dgrad', 'fused_layer')]
+
+
+def _sampled_batch(nodes_per_hop, fanout, g):
+    """A NeighborLoader-shaped batch: nodes listed hop by hop, the edges of hop h lead from nodes of
+    hops <= h + 1 to the nodes of hop h, destination-sorted (so the whole list is, too)."""
+    starts = [0]
+    for c in nodes_per_hop:
+        starts.append(starts[-1] + c)
+    src, dst, per_hop = [], [], []
+    for h in range(len(nodes_per_hop) - 1):
+        count = 0
+        for d in range(starts[h], starts[h + 1]):
+            k = int(torch.randint(0, fanout + 1, (1, ), generator=g))
+            src.append(torch.randint(0, starts[h + 2], (k, ), generator=g))
+            dst.append(torch.full((k, ), d))
+            count += k
+        per_hop.append(count)
+    return torch.stack([torch.cat(src), torch.cat(dst)]), per_hop
+
+
+@pytest.mark.parametrize('own', [False, True])
+@pytest.mark.parametrize('aggr', ['mean', 'sum'])
+def test_hop_aware_stack_wiring(fake_native, monkeypatch, own, aggr):
+    """nn/models/_fused_sage_hops.py: every layer computes only the rows the next one consumes,
+    from a prefix of the destination-sorted edge list.  The seed rows of its output, and the
+    gradients of a loss on them, must equal the full GraphSAGE on the sampled subgraph (rows
+    further out see fewer neighbours by construction: trim_to_layer,
+    utils/_trim_to_layer.py:44-127)."""
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    from pytorch_geometric_amd.nn.models._fused_sage_hops import FusedSageHopStack
+
+    def gather_scatter_add(x, gather_idx, scatter_idx, n_out, scale=None, w=None, out=None):
+        assert w is None
+        v = x[gather_idx] if scale is None else x[gather_idx] * scale[gather_idx].view(-1, 1)
+        if out is None:
+            out = torch.zeros(n_out, x.size(1))
+        out.index_add_(0, scatter_idx, v)
+        return out
+
+    monkeypatch.setattr(_native, 'gather_scatter_add', gather_scatter_add)
+    monkeypatch.setattr(_fused_sage, 'OWN_GEMM_MIN_ROWS', 0 if own else 1 << 30)
+    g = gen(17)
+    nodes_per_hop = [5, 9, 14, 20]
+    ei, edges_per_hop = _sampled_batch(nodes_per_hop, 4, g)
+    n, dims = sum(nodes_per_hop), (12, 16, 16, 7)
+    x = torch.randn(n, dims[0], generator=g)
+    params = [(torch.randn(fo, fi, generator=g) * 0.3, torch.randn(fo, generator=g),
+               torch.randn(fo, fi, generator=g) * 0.3) for fi, fo in zip(dims[:-1], dims[1:])]
+    seeds = nodes_per_hop[0]
+    go = torch.randn(seeds, dims[-1], generator=g)
+    res = []
+    for fused in (False, True):
+        xs = x.clone().requires_grad_(True)
+        ps = [tuple(t.clone().requires_grad_(True) for t in p) for p in params]
+        if fused:
+            out = FusedSageHopStack.apply(xs, _Graph(ei, n), aggr, nodes_per_hop, edges_per_hop,
+                                          *[t for p in ps for t in p])
+            assert out.size(0) == n - nodes_per_hop[-1] - nodes_per_hop[-2]
+        else:
+            out = O.graphsage(xs, ei, ps, aggr)
+        out[:seeds].backward(go)
+        res.append([out[:seeds].detach(), xs.grad] + [t.grad for p in ps for t in p])
+    for a, b in zip(*res):
+        assert_close(b, a, rtol=1e-4, atol=2e-4, what=f'hop-aware stack (own={own})')
+    assert bool([e for e in fake_native if e[0] == 'wgrad']) == own
