@@ -36,8 +36,8 @@ def spmm_algorithmic_bytes(info) -> float:
     """E*(4F + b) + (N_rows + 1)*b + N_rows*4F  (+ N*4 for the mean's degree
     vector when it is read as a per-source scale, + N_rows*4F when the launch accumulates onto
     its output, i.e. the fused `grad_root + A^T grad_agg` of the backward, + N_rows*4F when its
-    epilogue reads a ReLU output — or, 32 x smaller, its one-bit-per-element mask — to apply that
-    activation's backward)."""
+    epilogue reads a ReLU output — or, 32 x smaller, its one-bit-per-element mask — to apply
+    that activation's backward)."""
     b, Fw = info['idx_bytes'], info['F']
     total = info['nnz'] * (4 * Fw + b) + (info['n_rows'] + 1) * b + info['n_rows'] * 4 * Fw
     if info['src_scale']:
@@ -271,7 +271,8 @@ def gemm_desc(tuned: bool) -> str:
     if _fused_sage.GEMM_BACKEND == 'own':
         from pytorch_geometric_amd import get_gemm_mode
         if get_gemm_mode() == 'split':
-            return ('pytorch_geometric_amd/csrc/gemm.hip, PYGAMD_GEMM_MODE=split (NOT the default): '
+            return ('pytorch_geometric_amd/csrc/gemm.hip, PYGAMD_GEMM_MODE=split (NOT the '
+                    'default): '
                     'fp32 operands as 3 bf16 terms each, 6 v_mfma_f32_32x32x16_bf16 products, '
                     'fp32 accumulation, in the stand-alone forward / dgrad / wgrad kernels; the '
                     'one-kernel layer forward stays on the fp32 instruction')

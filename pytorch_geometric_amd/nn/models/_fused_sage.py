@@ -61,7 +61,6 @@ def own_gemm(rows: int) -> bool:
     return GEMM_BACKEND == 'own' and rows >= OWN_GEMM_MIN_ROWS
 
 
-
 def _side_stream(device):
     st = _side_streams.get(device)
     if st is None:
