@@ -12,9 +12,11 @@ gradient all-reduce over RCCL), Adam update.  Inputs are resident in HBM before 
 over graph replicas: each rank owns its own synthetic graph of the same shape (seed + rank), so
 per-GPU work is fixed ("weak").  value = L * E * N / t_step.
 
-Prints ONE JSON line on rank 0, including `roofline` (dominant kernel = the F=256 CSR SpMM,
-HIP-event timed inside the timed region) and `cpu_baseline` (the oracle's CPU scatter path on a
-bounded sample of the same workload).
+Prints ONE JSON line on rank 0, including `roofline` (the kernel with the largest share of the
+timed region — found from HIP events around every launch of this repo's kernels — against the
+HBM roofline, plus whole-step aggregation / GEMM figures), `cpu_baseline` (the unmodified reference
+on the host cores, on a bounded sample of the same workload) and `parity_at_cpu_scale` (the same
+sample through the GPU stack: loss, output and every parameter gradient against the reference).
 """
 import argparse
 import json
@@ -53,22 +55,38 @@ def spmm_algorithmic_bytes(info) -> float:
     return float(total)
 
 
-def pmc_traffic(args, N, E, F_dom):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_spmm_f256.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, collected by
-    scripts/gpu_r02_profile.sh over this very command).  Counters cannot be read from inside this
-    process, so the number is only reported when this run is the workload the counters were
-    collected on; otherwise null."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_spmm_f256.json')
+def pmc_traffic(args, N, E, kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this very command
+    (profiles/r03_pmc_bench.json: FETCH_SIZE and WRITE_SIZE in separate passes, converted as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes; collected by scripts/gpu_r03_profile.sh).
+    Counters cannot be read from inside this process, so a number is only reported when this run is
+    the workload the counters were collected on; otherwise null."""
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_bench.json')
     try:
         with open(path) as f:
             d = json.load(f)
-    except OSError:
+    except (OSError, ValueError):
         return None
-    w = d['workload']
-    same = (w['N'] == N and w['E'] == E and w['F'] == F_dom and not args.uniform
-            and w['index_dtype'] == args.index_dtype)
-    return d['traffic_bytes_per_launch'] if same else None
+    w = d.get('workload', {})
+    same = (w.get('N') == N and w.get('E') == E and not args.uniform
+            and w.get('index_dtype') == args.index_dtype)
+    return d.get('traffic_bytes_per_launch', {}).get(kernel) if same else None
+
+
+def fused_algorithmic_bytes(info) -> float:
+    """One-kernel SAGE layer (csrc/sage_fused.hip), forward or input gradient: the aggregation's
+    SURVEY 8(d) bytes — E*(4F+b) + (N+1)*b, + N*4F only when the aggregated rows are stored
+    (forward: the weight gradient reads them) — + the root rows N*4F + the output N*4Fo
+    (+ N*Fo/8 of ReLU-mask bits read or written, + N*4Fo for the row-scaled second output)."""
+    b, Fw, n = info['idx_bytes'], info['F'], info['n_rows']
+    fg = info['fused_gemm']
+    total = info['nnz'] * (4 * Fw + b) + (n + 1) * b + n * 4 * Fw + n * 4 * fg['Fo']
+    if fg.get('save_agg', True):
+        total += n * 4 * Fw
+    total += n * 4 * ((fg['Fo'] + 31) // 32)
+    if fg.get('scaled_copy'):
+        total += n * 4 * fg['Fo']
+    return float(total)
 
 
 def _time_steps(step_fn, steps: int, warmup: int = 1):
@@ -88,7 +106,10 @@ def cpu_baseline(scale: float, steps: int = 3):
     oracle/make_ref.py; kind "reference") — primary line = the scatter path (plain `edge_index`
     tensor: index_select + scatter_add_), second line = its fast path (`adj_t` as a torch CSR
     tensor -> torch.sparse.mm).  Falls back to the oracle port (kind "port") only when no staged
-    reference travelled with the snapshot."""
+    reference travelled with the snapshot.
+
+    Returns ``(json_dict, sample)``; ``sample`` = the inputs, the initial weights and the
+    reference's loss / output / parameter gradients of one step, for `parity_at_cpu_scale`."""
     from pytorch_geometric_amd.datasets import products_like
     x, y, ei, c = products_like(seed=1, scale=scale)
     E = ei.size(1)
@@ -97,6 +118,7 @@ def cpu_baseline(scale: float, steps: int = 3):
     threads = torch.get_num_threads()
     base = {'unit': 'edges/s', 'cores': threads, 'host_cpus': os.cpu_count()}
     shape = f'{scale:g} x ogbn-products shape: N={x.size(0)}, E={E}'
+    sample = {'x': x, 'y': y, 'ei': ei, 'train_idx': train_idx, 'classes': c}
     try:
         from oracle import make_ref
         make_ref.import_reference()
@@ -109,36 +131,49 @@ def cpu_baseline(scale: float, steps: int = 3):
         from pytorch_geometric_amd.nn import GraphSAGE
         torch.manual_seed(0)
         model = GraphSAGE(100, 256, num_layers=3, out_channels=c)
+        sample['state'] = {k: v.detach().clone() for k, v in model.state_dict().items()}
         params = [(cv.lin_l.weight, cv.lin_l.bias, cv.lin_r.weight) for cv in model.convs]
+        last = {}
 
         def step():
             t0 = time.perf_counter()
             for p in model.parameters():
                 p.grad = None
-            loss = F.cross_entropy(O.graphsage(x, ei, params)[train_idx], y[train_idx])
+            out = O.graphsage(x, ei, params)
+            loss = F.cross_entropy(out[train_idx], y[train_idx])
             t1 = time.perf_counter()
             loss.backward()
+            last['out'], last['loss'] = out.detach(), loss.detach()
             return t1 - t0, time.perf_counter() - t1
 
         t, tf, tb = _time_steps(step, steps)
+        sample.update(out=last['out'], loss=last['loss'], kind='port',
+                      grads={k: p.grad.clone() for k, p in model.named_parameters()})
         return dict(base, value=3 * E / t, kind='port',
                     sample=(f'oracle/pyg_oracle.py graphsage fwd+bwd (index_select + scatter_add_ '
                             f'mean), {shape}, median of {steps} steps after 1 warm-up, '
-                            f'{t * 1e3:.0f} ms/step'))
+                            f'{t * 1e3:.0f} ms/step')), sample
     torch.manual_seed(0)
     model = RefSAGE(100, 256, num_layers=3, out_channels=c)
+    sample['state'] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    last = {}
 
     def make_step(graph):
         def step():
             t0 = time.perf_counter()
             model.zero_grad(set_to_none=True)
-            loss = F.cross_entropy(model(x, graph)[train_idx], y[train_idx])
+            out = model(x, graph)
+            loss = F.cross_entropy(out[train_idx], y[train_idx])
             t1 = time.perf_counter()
             loss.backward()
+            last['out'], last['loss'] = out.detach(), loss.detach()
             return t1 - t0, time.perf_counter() - t1
         return step
 
     t, tf, tb = _time_steps(make_step(ei), steps)
+    # (the weights never change: any step's results are THE reference results of this sample)
+    sample.update(out=last['out'], loss=last['loss'], kind='reference',
+                  grads={k: p.grad.clone() for k, p in model.named_parameters()})
     adj_t = to_torch_csc_tensor(ei, size=(x.size(0), x.size(0))).t()  # CSR
     t2, tf2, tb2 = _time_steps(make_step(adj_t), steps)
     return dict(
@@ -150,7 +185,41 @@ def cpu_baseline(scale: float, steps: int = 3):
                 f'{os.cpu_count()} host CPUs'),
         csr_fast_path={'value': 3 * E / t2, 'unit': 'edges/s',
                        'sample': f'same model and sample, adj_t = torch.sparse_csr -> '
-                                 f'torch.sparse.mm: fwd {tf2:.2f} s + bwd {tb2:.2f} s'})
+                                 f'torch.sparse.mm: fwd {tf2:.2f} s + bwd {tb2:.2f} s'}), sample
+
+
+def parity_at_cpu_scale(sample, dev):
+    """The CPU baseline's sample through the GPU stack (same initial weights): loss, output and
+    EVERY parameter gradient against the reference's, each error relative to the largest magnitude
+    of the reference tensor.  Contract: 1e-5 (north_star); gradients through two ReLU layers get
+    2e-5 because an activation within an ulp of 0 may land on the other side (tests/_util.py)."""
+    from pytorch_geometric_amd.nn import GraphSAGE
+    model = GraphSAGE(100, 256, num_layers=3, out_channels=sample['classes'])
+    model.load_state_dict(sample['state'])
+    model = model.to(dev)
+    x, ei = sample['x'].to(dev), sample['ei'].to(dev)
+    ti = sample['train_idx'].to(dev)
+    out = model(x, ei)
+    loss = F.cross_entropy(out[ti], sample['y'].to(dev)[ti])
+    loss.backward()
+    torch.cuda.synchronize(dev)
+
+    def rel(got, ref):
+        got, ref = got.detach().cpu().double(), ref.double()
+        if not bool(torch.isfinite(got).all()):
+            return float('inf')
+        return float((got - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
+
+    errs = {'loss': rel(loss, sample['loss']), 'out': rel(out, sample['out'])}
+    grads = {k: rel(p.grad, sample['grads'][k]) for k, p in model.named_parameters()}
+    errs['max_param_grad'] = max(grads.values())
+    errs['worst_param'] = max(grads, key=grads.get)
+    errs['n_param_tensors'] = len(grads)
+    errs['tol'] = {'loss': 1e-5, 'out': 1e-5, 'param_grad': 2e-5}
+    errs['against'] = sample['kind']
+    errs['ok'] = bool(errs['loss'] <= 1e-5 and errs['out'] <= 1e-5
+                      and errs['max_param_grad'] <= 2e-5)
+    return {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in errs.items()}
 
 
 def run_minibatch(args, rank, local_rank, world, dev):
@@ -505,52 +574,86 @@ def main():
                     if world > 1 else 0.0)
     n_pg = dist.get_world_size() if dist.is_initialized() else 1
 
-    # ---- roofline of the dominant kernel: the CSR SpMM at F = 256 (2 of the 5 SpMM launches per
-    # step — layer 2 forward and its transposed backward; layer 3 is re-ordered to width 48) ----
-    groups, fused = {}, {}
+    # ---- roofline: every launch of this repo's kernels in the timed region carries HIP events
+    # (aggregation, one-kernel layers, GEMMs); the DOMINANT kernel is the device symbol with the
+    # largest summed time ----
+    def symbol(info):
+        if info.get('kind') == 'gemm':
+            return {'wgrad': 'gemm_tn_kernel', 'dgrad': 'gemm_nt_kernel',
+                    'forward': 'gemm_nt_kernel'}[info['op']]
+        lpr = 4
+        while lpr < 64 and lpr * 4 < info['F']:
+            lpr <<= 1
+        it = 'long' if info['idx_bytes'] == 8 else 'int'
+        if info.get('fused_gemm'):
+            name = ('sage_fused_fwd_kernel' if _native.SAGE_FUSED_VARIANT == 1
+                    else 'sage_fused_stream_kernel')
+            return f'{name}<{it},{lpr}>'
+        return f'spmm_sum_rows<{it},F={info["F"]}>'
+
+    def alg_bytes(info):
+        return (fused_algorithmic_bytes(info) if info.get('fused_gemm')
+                else spmm_algorithmic_bytes(info))
+
+    by_sym = {}
     for info, ev0, ev1 in sink:
-        dst = fused if info.get('fused_gemm') else groups
-        dst.setdefault(info['F'], []).append((info, ev0.elapsed_time(ev1)))
-    dom_F = 256 if 256 in groups else max(groups)
-    dom = groups[dom_F]
-    avg_ms = sum(ms for _, ms in dom) / len(dom)
-    alg_bytes = sum(spmm_algorithmic_bytes(i) for i, _ in dom) / len(dom)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    spmm_ms_per_step = sum(ms for g in groups.values() for _, ms in g) / args.steps
-    roofline = {
-        'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(args, N, E, dom_F),
-        'traffic_source': 'profiles/ PMC passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE per '
-                          'launch, collected by scripts/gpu_r02_profile.sh), not a live counter',
-        'kernel': f'spmm_sum_rows<F={dom_F}> (pygamd_spmm_csr: the stand-alone CSR aggregation; '
-                  f'with the layer forward fused into one kernel these launches are the '
-                  f'transposed, accumulating backward with the ReLU-backward epilogue)',
-        'launches_timed': len(dom), 'avg_launch_ms': round(avg_ms, 4),
-        'algorithmic_bytes_per_launch': alg_bytes,
-        'all_spmm_ms_per_step': round(spmm_ms_per_step, 3),
-        'per_width_avg_ms': {str(k): round(sum(ms for _, ms in v) / len(v), 4)
-                             for k, v in sorted(groups.items())},
-    }
-    if fused:
-        # the one-kernel layer forward (csrc/sage_fused.hip) is bound by BOTH rooflines at once:
-        # its gather phase by HBM, its transform phase by the fp32 matrix cores
-        fl = {}
-        for Fw, items in sorted(fused.items()):
-            ms = sum(t for _, t in items) / len(items)
-            i0 = items[0][0]
-            Fo, K = i0['fused_gemm']['Fo'], i0['fused_gemm']['K']
-            # gather + rowptr/col + root rows read + aggregated rows written once + output written
-            byts = (spmm_algorithmic_bytes(i0) + i0['n_rows'] * 4 * Fw + i0['n_rows'] * 4 * Fo)
-            flops = 2.0 * i0['n_rows'] * K * Fo
-            fl[str(Fw)] = {'avg_launch_ms': round(ms, 4), 'launches_timed': len(items),
-                           'hbm_algorithmic_bytes': byts,
-                           'hbm_GBps': round(byts / (ms * 1e-3) / 1e9, 1),
-                           'hbm_frac': round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           'mfma_TFLOPs': round(flops / (ms * 1e-3) / 1e12, 1),
-                           'mfma_frac_of_157.3': round(flops / (ms * 1e-3) / 1e12 / 157.3, 4)}
-        roofline['fused_layer_forward'] = {
-            'kernel': 'sage_fused_fwd_kernel (pygamd_sage_layer_forward: aggregation + '
-                      '[agg|x] @ W^T + bias + ReLU)', 'per_width': fl}
+        by_sym.setdefault(symbol(info), []).append((info, ev0.elapsed_time(ev1)))
+    tot_ms = {k: sum(ms for _, ms in v) for k, v in by_sym.items()}
+    agg_syms = [k for k in by_sym if not k.startswith('gemm')]
+    dom = max(agg_syms, key=tot_ms.get) if agg_syms else None
+    if tot_ms and max(tot_ms, key=tot_ms.get) != dom:
+        dom_any = max(tot_ms, key=tot_ms.get)
+    else:
+        dom_any = dom
+
+    def hbm_entry(sym):
+        items = by_sym[sym]
+        ms = sum(t for _, t in items) / len(items)
+        byts = sum(alg_bytes(i) for i, _ in items) / len(items)
+        strict = sum(spmm_algorithmic_bytes(dict(i, accumulate=False, relu_mask=False,
+                                                 relu_bits=False)) for i, _ in items) / len(items)
+        ach = byts / (ms * 1e-3) / 1e9
+        e = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(args, N, E, sym),
+             'kernel': sym, 'launches_per_step': round(len(items) / args.steps, 2),
+             'avg_launch_ms': round(ms, 4), 'ms_per_step': round(tot_ms[sym] / args.steps, 3),
+             'algorithmic_bytes_per_launch': byts,
+             'frac_strict_8d': round(strict / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        fg = [i['fused_gemm'] for i, _ in items if i.get('fused_gemm')]
+        if fg:
+            flops = sum(2.0 * i['n_rows'] * i['fused_gemm']['K'] * i['fused_gemm']['Fo']
+                        for i, _ in items) / len(items)
+            e['mfma_frac_of_157.3'] = round(flops / (ms * 1e-3) / 1e12 / 157.3, 4)
+        return e
+
+    roofline = hbm_entry(dom) if dom else {}
+    roofline['share_of_step'] = round(tot_ms.get(dom, 0.0) / (elapsed * 1e3), 4) if dom else None
+    roofline['others'] = {k: round(tot_ms[k] / args.steps, 3) for k in sorted(tot_ms) if k != dom}
+    if dom_any != dom:  # (a GEMM symbol leads: say so; the HBM entry above stays the aggregation)
+        roofline['largest_symbol'] = dom_any
+    second = sorted((k for k in agg_syms if k != dom), key=tot_ms.get, reverse=True)[:1]
+    if second:
+        e2 = hbm_entry(second[0])
+        roofline['second'] = {k: e2[k] for k in ('kernel', 'frac', 'achieved', 'avg_launch_ms',
+                                                 'ms_per_step', 'traffic')}
+    # whole-step figures: every aggregation launch against HBM, every stand-alone GEMM against the
+    # fp32 matrix peak (the flops inside the one-kernel layers are listed, not priced twice)
+    agg_ms = sum(tot_ms[k] for k in agg_syms) / args.steps
+    agg_bytes = sum(alg_bytes(i) for k in agg_syms for i, _ in by_sym[k]) / args.steps
+    gemm_items = [(i, ms) for k in by_sym if k.startswith('gemm') for i, ms in by_sym[k]]
+    gemm_ms = sum(ms for _, ms in gemm_items) / args.steps
+    gemm_flop = sum(2.0 * i['M'] * i['N'] * i['K'] for i, _ in gemm_items) / args.steps
+    fused_flop = sum(2.0 * i['n_rows'] * i['fused_gemm']['K'] * i['fused_gemm']['Fo']
+                     for k in agg_syms for i, _ in by_sym[k] if i.get('fused_gemm')) / args.steps
+    roofline['step'] = {
+        'agg_ms': round(agg_ms, 3), 'agg_GB': round(agg_bytes / 1e9, 2),
+        'agg_frac_of_hbm_peak': round(agg_bytes / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if agg_ms > 0 else None,
+        'gemm_ms': round(gemm_ms, 3), 'gemm_GFLOP': round(gemm_flop / 1e9, 1),
+        'gemm_frac_of_157.3TF': round(gemm_flop / (gemm_ms * 1e-3) / 1e12 / 157.3, 4)
+        if gemm_ms > 0 else None,
+        'GFLOP_inside_fused_layers': round(fused_flop / 1e9, 1),
+        'other_ms': round(ms_per_step - agg_ms - gemm_ms, 3)}
 
     if rank == 0:
         result = {
@@ -568,18 +671,16 @@ def main():
                 'allreduce_ms_per_step': round(allreduce_ms, 4),
                 'graph_gen_s': round(t_gen, 1),
                 'gemm': gemm_desc(tuned),
-                'schedule': 'fused stack: [agg|x] single GEMM per layer; 256->47 layer '
-                            'transforms first and aggregates at width 48; layers 1-2 forward '
-                            'as ONE kernel each (aggregation -> LDS -> MFMA); ReLU backward in '
-                            'the epilogue of the kernel producing each activation gradient '
-                            '(transposed SpMM / dgrad GEMM); bias gradients from the '
-                            'weight-gradient GEMM\'s pass over grad_out; the mean\'s 1/deg of '
-                            'the backward applied in the dgrad GEMM epilogue',
+                'schedule': 'layers 1-2 forward AND layer 2 input gradient as ONE kernel each '
+                            '(gather -> LDS -> fp32 MFMA); 256->47 layer transforms first, '
+                            'aggregates at width 48; ReLU backward / bias grads / 1/deg in '
+                            'epilogues',
             },
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            result['cpu_baseline'] = cpu_baseline(args.cpu_scale)
+            result['cpu_baseline'], sample = cpu_baseline(args.cpu_scale)
+            result['parity_at_cpu_scale'] = parity_at_cpu_scale(sample, dev)
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 2
+#define PYGAMD_ABI_VERSION 3
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -493,6 +493,16 @@ PYGAMD_API int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t
                                    int64_t K, int accumulate, const float* relu_mask,
                                    int64_t ld_mask, const uint32_t* relu_bits, int64_t ld_bits,
                                    float* out, int64_t ldo, void* stream);
+/* pygamd_linear_dgrad with a second output: out_scaled[M, K] (or NULL) = out * row_scale[row] in
+ * every column (row_scale required then; not with accumulate).  The one-kernel layer backward
+ * (pygamd_sage_layer_fused with mask_bits) gathers the 1/deg-scaled gradient rows and takes the
+ * unscaled ones as its root operand: this writes both from one pass.                             */
+PYGAMD_API int pygamd_linear_dgrad2(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
+                                    const float* row_scale, int64_t n_scaled, int64_t M,
+                                    int64_t N, int64_t K, int accumulate, const float* relu_mask,
+                                    int64_t ld_mask, const uint32_t* relu_bits, int64_t ld_bits,
+                                    float* out, int64_t ldo, float* out_scaled, int64_t ld_scaled,
+                                    void* stream);
 PYGAMD_API int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K,
                                                    size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx,
@@ -532,6 +542,44 @@ PYGAMD_API int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const fl
                                          float* y, int64_t ldy, uint32_t* relu_bits_out,
                                          int64_t ld_bits, void* workspace,
                                          size_t workspace_bytes, void* stream);
+
+/* The same kernel with every epilogue it has, as one argument block (zero-initialise, fill what is
+ * needed).  Beyond pygamd_sage_layer_forward:
+ *  - mask_bits: y = bit ? y : 0 from a one-bit-per-element ReLU mask in the tiled layout of
+ *    pygamd_spmm_args.relu_bits.  With the transposed graph, x = the (degree-scaled) gradient rows
+ *    and w = [W_l^T | W_r^T] this launch IS a SAGEConv layer's input gradient,
+ *      grad_x = [relu'(x)] * ((A^T D^-1 g) W_l + g W_r)
+ *    (sage_conv.py:134-139 differentiated; the aggregation commutes with the right-multiplication
+ *    by W_l), i.e. pygamd_linear_dgrad + the transposed pygamd_spmm_csr in one pass over the graph.
+ *  - y_scaled / row_scale: a second copy y * row_scale[row] of the output (the next such launch
+ *    gathers the 1/deg-scaled rows and takes the unscaled ones as its root operand).
+ *  - variant: 0 = default (2), 1 = row-at-a-time gather phase (round 2), 2 = streamed gather phase
+ *    (column indices of the tile staged in LDS, row loads software-pipelined across rows; needs
+ *    n_src < 2^31).  Same results bit for bit.                                                    */
+typedef struct pygamd_sage_fused_args {
+  const float* x_root;       /* [n_rows, F] root rows                   */
+  int64_t ld_root;
+  const float* w;            /* [Fo, 2F] = [W_l | W_r]                  */
+  int64_t ldw;
+  const float* bias;         /* [Fo] or NULL                            */
+  int64_t Fo;
+  int32_t relu;
+  int32_t save_agg;
+  float* y;                  /* [n_rows, Fo]                            */
+  int64_t ldy;
+  uint32_t* relu_bits_out;   /* NULL or [y > 0] as bits (needs relu)    */
+  int64_t ld_bits_out;
+  const uint32_t* mask_bits; /* NULL or the mask applied to y           */
+  int64_t ld_mask_bits;
+  const float* row_scale;    /* [n_rows], with y_scaled                 */
+  float* y_scaled;           /* NULL or [n_rows, Fo]                    */
+  int64_t ldy_scaled;
+  int32_t variant;
+  int32_t reserved;
+} pygamd_sage_fused_args;
+PYGAMD_API int pygamd_sage_layer_fused(const pygamd_spmm_args* graph,
+                                       const pygamd_sage_fused_args* f, void* workspace,
+                                       size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 from . import _build
 
-ABI_VERSION = 2  # PYGAMD_ABI_VERSION of include/pyg_amd.h
+ABI_VERSION = 3  # PYGAMD_ABI_VERSION of include/pyg_amd.h
 IDX_I32, IDX_I64 = 0, 1
 SUM, MEAN, MIN, MAX, MUL, ANY = 0, 1, 2, 3, 4, 5
 REDUCE_IDS = {'sum': SUM, 'add': SUM, 'mean': MEAN, 'min': MIN, 'amin': MIN, 'max': MAX,
@@ -33,6 +33,18 @@ class SpmmArgs(Structure):
         ('hub_chunk', c_int64), ('accumulate', c_int32), ('hub_phase', c_int32),
         ('arg32_out', c_void_p), ('relu_mask', c_void_p), ('ld_mask', c_int64),
         ('relu_bits', c_void_p), ('ld_bits', c_int64),
+    ]
+
+
+class SageFusedArgs(Structure):
+    """Mirror of ``pygamd_sage_fused_args`` (include/pyg_amd.h)."""
+    _fields_ = [
+        ('x_root', c_void_p), ('ld_root', c_int64), ('w', c_void_p), ('ldw', c_int64),
+        ('bias', c_void_p), ('Fo', c_int64), ('relu', c_int32), ('save_agg', c_int32),
+        ('y', c_void_p), ('ldy', c_int64), ('relu_bits_out', c_void_p), ('ld_bits_out', c_int64),
+        ('mask_bits', c_void_p), ('ld_mask_bits', c_int64), ('row_scale', c_void_p),
+        ('y_scaled', c_void_p), ('ldy_scaled', c_int64), ('variant', c_int32),
+        ('reserved', c_int32),
     ]
 
 
@@ -76,12 +88,17 @@ SIGNATURES = {
     'pygamd_sage_layer_forward': (c_int, [POINTER(SpmmArgs), _P, c_int64, _P, c_int64, _P, c_int64,
                                           c_int, c_int, _P, c_int64, _P, c_int64, _P, c_size_t,
                                           _P]),
+    'pygamd_sage_layer_fused': (c_int, [POINTER(SpmmArgs), POINTER(SageFusedArgs), _P, c_size_t,
+                                        _P]),
     'pygamd_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                       c_int, c_int, _P, c_int64, _P]),
     'pygamd_set_gemm_mode': (c_int, [c_int]),
     'pygamd_get_gemm_mode': (c_int, []),
     'pygamd_linear_dgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                     c_int64, c_int, _P, c_int64, _P, c_int64, _P, c_int64, _P]),
+    'pygamd_linear_dgrad2': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
+                                     c_int64, c_int, _P, c_int64, _P, c_int64, _P, c_int64, _P,
+                                     c_int64, _P]),
     'pygamd_linear_wgrad_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
                                                     POINTER(c_size_t)]),
     'pygamd_linear_wgrad': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int,

@@ -5,6 +5,7 @@ PyTorch is plumbing only (device memory, streams).  Every function requires HIP 
 and raises otherwise — there is no CPU fallback.
 """
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -160,6 +161,28 @@ def hub_plan(rowptr: Tensor, threshold: int = None, chunk: int = None):
 # Optional launch timing (bench.py): when a list is installed here, every spmm_csr call appends
 # (info, start_event, end_event) recorded on the launch stream around the kernel(s).
 timing_sink = None
+
+
+class _timed:
+    """Context manager: when bench.py installed a sink, record HIP events on the launch stream
+    around the call(s) inside and append ``(info, start, end)``."""
+
+    def __init__(self, info: dict, ref: Tensor):
+        self.sink, self.info, self.ref = timing_sink, info, ref
+
+    def __enter__(self):
+        if self.sink is not None:
+            st = torch.cuda.current_stream(self.ref.device)
+            self.ev0 = torch.cuda.Event(enable_timing=True)
+            self.ev1 = torch.cuda.Event(enable_timing=True)
+            self.ev0.record(st)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.sink is not None and exc_type is None:
+            self.ev1.record(torch.cuda.current_stream(self.ref.device))
+            self.sink.append((self.info, self.ev0, self.ev1))
+        return False
 
 
 def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
@@ -563,9 +586,10 @@ def linear_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, relu: bo
         raise ValueError("'out' must be a float32 [M, N] tensor with unit inner stride")
     if bias is not None:
         bias = bias.contiguous()
-    check(lib.pygamd_linear_forward(_p(x2), _ld(x2), _p(w2), _ld(w2), _p(bias), M, K, N,
-                                    int(relu), int(accumulate), _p(out), _ld(out), _stream(x)),
-          'linear_forward')
+    with _timed({'kind': 'gemm', 'op': 'forward', 'M': M, 'N': N, 'K': K}, x):
+        check(lib.pygamd_linear_forward(_p(x2), _ld(x2), _p(w2), _ld(w2), _p(bias), M, K, N,
+                                        int(relu), int(accumulate), _p(out), _ld(out),
+                                        _stream(x)), 'linear_forward')
     return out
 
 
@@ -605,15 +629,28 @@ def sage_layer_forward_supported(F: int, Fo: int, reduce: str) -> bool:
     return bool(_lib.load().pygamd_sage_layer_forward_supported(F, Fo, REDUCE_IDS[reduce]))
 
 
+# gather phase of the one-kernel layer: 0 = library default (streamed), 1 = row-at-a-time
+# (round 2), 2 = streamed; the env switch exists for A/B timing on the device
+SAGE_FUSED_VARIANT = int(os.environ.get('PYGAMD_FUSED_VARIANT', '0'))
+
+
 def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Tensor, w: Tensor,
                        bias: Optional[Tensor], reduce: str, relu: bool, agg: Tensor, out: Tensor,
                        hub=None, save_agg: bool = True, hub_threshold: int = None,
-                       hub_chunk: int = None, relu_bits: Optional[Tensor] = None) -> Tensor:
+                       hub_chunk: int = None, relu_bits: Optional[Tensor] = None,
+                       mask_bits: Optional[Tensor] = None, row_scale: Optional[Tensor] = None,
+                       out_scaled: Optional[Tensor] = None, variant: Optional[int] = None) -> Tensor:
     """``out = act([aggr(x_gather) | x_root] @ w.T + bias)`` in ONE kernel (csrc/sage_fused.hip);
     ``agg`` ([n_rows, F] view, may be a half of a wider buffer) receives the aggregated rows when
     ``save_agg`` (hub rows always).  ``relu_bits`` (from :func:`relu_bits_like`, needs
-    ``relu``) receives ``out > 0`` as one bit per element (see :func:`relu_bits_like`)."""
-    _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out, relu_bits)
+    ``relu``) receives ``out > 0`` as one bit per element (see :func:`relu_bits_like`).
+    ``mask_bits`` (same layout): ``out`` is zeroed where its bit is clear — with the transposed
+    graph, the degree-scaled gradient rows as ``x_gather``, the unscaled ones as ``x_root`` and
+    ``w = [W_l^T | W_r^T]`` the launch is the layer's INPUT GRADIENT (dgrad GEMM + transposed
+    aggregation + ReLU backward in one pass).  ``out_scaled`` receives ``out * row_scale[:, None]``
+    as a second output (what the next such launch gathers)."""
+    _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out, relu_bits, mask_bits,
+                    row_scale, out_scaled)
     lib = _lib.load()
     xg, xr, w2 = _f32_rows(x_gather, 'x'), _f32_rows(x_root, 'x_root'), _f32_rows(w, 'weight')
     n_rows, F, Fo = rowptr.numel() - 1, xg.size(1), w2.size(0)
@@ -638,23 +675,43 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xg.device)
     if bias is not None:
         bias = bias.contiguous()
+    _check_bits(relu_bits, n_rows, Fo)
+    _check_bits(mask_bits, n_rows, Fo)
+    f = _lib.SageFusedArgs()
+    f.x_root, f.ld_root = xr.data_ptr(), _ld(xr)
+    f.w, f.ldw = w2.data_ptr(), _ld(w2)
+    f.bias = 0 if bias is None else bias.data_ptr()
+    f.Fo, f.relu, f.save_agg = Fo, int(relu), int(save_agg)
+    f.y, f.ldy = out.data_ptr(), _ld(out)
+    if relu_bits is not None:
+        f.relu_bits_out, f.ld_bits_out = relu_bits.data_ptr(), relu_bits.size(1)
+    if mask_bits is not None:
+        f.mask_bits, f.ld_mask_bits = mask_bits.data_ptr(), mask_bits.size(1)
+    if out_scaled is not None:
+        if row_scale is None or row_scale.numel() != n_rows or row_scale.dtype != torch.float32:
+            raise ValueError("'out_scaled' needs a float32 'row_scale' with one entry per row")
+        if out_scaled.shape != (n_rows, Fo) or out_scaled.dtype != torch.float32 \
+                or (Fo > 1 and out_scaled.stride(1) != 1):
+            raise ValueError("'out_scaled' must be a float32 [n_rows, Fo] tensor with unit inner "
+                             "stride")
+        row_scale = row_scale.contiguous()
+        f.row_scale = row_scale.data_ptr()
+        f.y_scaled, f.ldy_scaled = out_scaled.data_ptr(), _ld(out_scaled)
+    f.variant = SAGE_FUSED_VARIANT if variant is None else variant
     sink = timing_sink
     if sink is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(xg.device))
-    _check_bits(relu_bits, n_rows, Fo)
-    check(lib.pygamd_sage_layer_forward(ctypes.byref(a), _p(xr), _ld(xr), _p(w2), _ld(w2),
-                                        _p(bias), Fo, int(relu), int(save_agg), _p(out),
-                                        _ld(out), _p(relu_bits),
-                                        relu_bits.size(1) if relu_bits is not None else 0,
-                                        _p(ws), ws_bytes, _stream(xg)),
-          'sage_layer_forward')
+    check(lib.pygamd_sage_layer_fused(ctypes.byref(a), ctypes.byref(f), _p(ws), ws_bytes,
+                                      _stream(xg)), 'sage_layer_forward')
     if sink is not None:
         ev1.record(torch.cuda.current_stream(xg.device))
         sink.append(({'n_rows': n_rows, 'n_src': xg.size(0), 'nnz': col.numel(), 'F': F,
                       'reduce': reduce, 'idx_bytes': rowptr.element_size(), 'weighted': False,
                       'src_scale': False, 'accumulate': False, 'n_hub': a.n_hub,
-                      'fused_gemm': {'Fo': Fo, 'K': 2 * F}}, ev0, ev1))
+                      'fused_gemm': {'Fo': Fo, 'K': 2 * F, 'save_agg': bool(save_agg),
+                                     'backward': mask_bits is not None,
+                                     'scaled_copy': out_scaled is not None}}, ev0, ev1))
     return out
 
 
@@ -678,13 +735,15 @@ def get_gemm_mode() -> str:
 
 def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_scaled: int = 0,
                  out: Optional[Tensor] = None, accumulate: bool = False,
-                 relu_mask: Optional[Tensor] = None,
-                 relu_bits: Optional[Tensor] = None) -> Tensor:
+                 relu_mask: Optional[Tensor] = None, relu_bits: Optional[Tensor] = None,
+                 out_scaled: Optional[Tensor] = None) -> Tensor:
     """``g [M, N] @ w [N, K]`` with the weight handed over transposed (``w_t [K, N]``); columns
     ``[0, n_scaled)`` of the result are multiplied by ``row_scale[row]``; where ``relu_mask [M, K]``
     (a ReLU output) is not positive the result is 0 (that ReLU's backward as the epilogue);
-    ``relu_bits`` is the same mask as one bit per element (:func:`relu_bits_like`)."""
-    _require_device(g, w_t, row_scale, out, relu_mask, relu_bits)
+    ``relu_bits`` is the same mask as one bit per element (:func:`relu_bits_like`).
+    ``out_scaled [M, K]`` receives ``result * row_scale[:, None]`` (all columns) as a second
+    output of the same pass."""
+    _require_device(g, w_t, row_scale, out, relu_mask, relu_bits, out_scaled)
     if relu_mask is not None and relu_bits is not None:
         raise ValueError("pass at most one of 'relu_mask' / 'relu_bits'")
     lib = _lib.load()
@@ -697,18 +756,27 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
         out = torch.empty(M, K, dtype=torch.float32, device=g.device)
     if row_scale is not None:
         row_scale = row_scale.contiguous()
+    if out_scaled is not None:
+        if row_scale is None or accumulate:
+            raise ValueError("'out_scaled' needs 'row_scale' and no 'accumulate'")
+        if out_scaled.shape != (M, K) or out_scaled.dtype != torch.float32 \
+                or (K > 1 and out_scaled.stride(1) != 1):
+            raise ValueError("'out_scaled' must be a float32 [M, K] tensor with unit inner stride")
     m2 = None
     _check_bits(relu_bits, M, K)
     if relu_mask is not None:
         m2 = _f32_rows(relu_mask, 'relu_mask')
         if tuple(m2.shape) != (M, K):
             raise ValueError(f"'relu_mask' must be [{M}, {K}], got {tuple(m2.shape)}")
-    check(lib.pygamd_linear_dgrad(_p(g2), _ld(g2), _p(w2), _ld(w2), _p(row_scale),
-                                  n_scaled if row_scale is not None else 0, M, N, K,
-                                  int(accumulate), _p(m2), _ld(m2) if m2 is not None else 0,
-                                  _p(relu_bits),
-                                  relu_bits.size(1) if relu_bits is not None else 0,
-                                  _p(out), _ld(out), _stream(g)), 'linear_dgrad')
+    with _timed({'kind': 'gemm', 'op': 'dgrad', 'M': M, 'N': K, 'K': N}, g):
+        check(lib.pygamd_linear_dgrad2(_p(g2), _ld(g2), _p(w2), _ld(w2), _p(row_scale),
+                                       n_scaled if row_scale is not None else 0, M, N, K,
+                                       int(accumulate), _p(m2), _ld(m2) if m2 is not None else 0,
+                                       _p(relu_bits),
+                                       relu_bits.size(1) if relu_bits is not None else 0,
+                                       _p(out), _ld(out), _p(out_scaled),
+                                       _ld(out_scaled) if out_scaled is not None else 0,
+                                       _stream(g)), 'linear_dgrad')
     return out
 
 
@@ -743,11 +811,11 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
         if K == 0:  # no weight tile passes over g
             return out, colsum(g2)
         gb = torch.empty(N, dtype=torch.float32, device=g.device)
-    check(lib.pygamd_linear_wgrad2(_p(g2), _ld(g2), _p(first), _ld(first), K1, _p(second),
-                                   _ld(second) if second is not None else 0, K2, M, N,
-                                   int(accumulate), int(wgs_per_cu), _p(out), _ld(out), _p(gb),
-                                   _p(ws), nbytes.value, _stream(g)),
-          'linear_wgrad')
+    with _timed({'kind': 'gemm', 'op': 'wgrad', 'M': M, 'N': N, 'K': K}, g):
+        check(lib.pygamd_linear_wgrad2(_p(g2), _ld(g2), _p(first), _ld(first), K1, _p(second),
+                                       _ld(second) if second is not None else 0, K2, M, N,
+                                       int(accumulate), int(wgs_per_cu), _p(out), _ld(out),
+                                       _p(gb), _p(ws), nbytes.value, _stream(g)), 'linear_wgrad')
     return (out, gb) if bias_grad else out
 
 

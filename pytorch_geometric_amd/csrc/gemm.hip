@@ -108,6 +108,8 @@ struct GemmNT {
   const uint32_t* __restrict__ mask_bits;  // the same mask as bits (32 x 32 tiles, see pyg_amd.h)
   int64_t ldmb;
   float* __restrict__ c;                // [M, N]
+  float* __restrict__ c2;               // null or [M, N]: c * row_scale[row], every column (a
+  int64_t ldc2;                         // second, row-scaled copy of the result)
   int64_t M, lda, ldb, ldc, ldm;
   int N, K;
   int relu;
@@ -343,7 +345,6 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
 
   // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
   const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-  const float floor_v = p.relu ? 0.f : -INFINITY;  // branch-free ReLU switch
   const bool wave_scaled = p.n_scaled > n0 + wn * TN * 32;  // wave-uniform
   if (full && !p.accumulate) {
     // interior tile (all but the last row block): no bounds checks, no read-modify-write
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
     for (int i = 0; i < TM; ++i) {
       const int64_t rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
       f32x4 sc[4];
-      if (wave_scaled) {  // rows rbase + 8 g + {0..3}: four aligned 16-byte loads
+      if (wave_scaled || p.c2) {  // rows rbase + 8 g + {0..3}: four aligned 16-byte loads
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
@@ -363,36 +364,34 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
         const float bv = p.bias ? p.bias[col] : 0.f;
         const bool scaled = wave_scaled && col < p.n_scaled;
         float* cp = p.c + rbase * p.ldc + col;
+        float* cp2 = p.c2 ? p.c2 + rbase * p.ldc2 + col : nullptr;
+        auto emit = [&](auto keep) {  // keep(e): the result of register e survives the mask
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv;
+            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
+            if (p.relu) v = (v > 0.f || v != v) ? v : 0.f;  // NaN propagates like torch.relu
+            v = keep(e) ? v : 0.f;
+            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = v;
+            if (cp2) cp2[((e & 3) + 8 * (e >> 2)) * p.ldc2] = v * sc[e >> 2][e & 3];
+          }
+        };
         if (p.mask) {  // uniform: the ReLU-backward epilogue of a dgrad launch
           const float* mp = p.mask + rbase * p.ldm + col;
           float mv[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) mv[e] = mp[((e & 3) + 8 * (e >> 2)) * p.ldm];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float v = acc[i][j][e] + bv;
-            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
-            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = mv[e] > 0.f ? fmaxf(v, floor_v) : 0.f;
-          }
-          continue;
-        }
-        if (p.mask_bits) {  // uniform.  This 32 x 32 block is one bit tile = one 128-byte line
+          emit([&](int e) { return mv[e] > 0.f; });
+        } else if (p.mask_bits) {  // uniform.  This 32 x 32 block is one bit tile = one 128-byte line
           const int64_t tile_row = (rbase - 4 * lh) >> 5;  // (m0 and the block offsets are % 32)
           const uint32_t word = p.mask_bits[(tile_row * p.ldmb + (col >> 5)) * 32 + li];
+          uint32_t bw[16];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const uint32_t bw = __shfl(word, (e & 3) + 8 * (e >> 2) + 4 * lh, kWave);
-            float v = acc[i][j][e] + bv;
-            if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
-            cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = ((bw >> li) & 1u) ? fmaxf(v, floor_v) : 0.f;
-          }
-          continue;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[i][j][e] + bv;
-          if (wave_scaled) v = scaled ? v * sc[e >> 2][e & 3] : v;
-          cp[((e & 3) + 8 * (e >> 2)) * p.ldc] = fmaxf(v, floor_v);
+          for (int e = 0; e < 16; ++e)
+            bw[e] = __shfl(word, (e & 3) + 8 * (e >> 2) + 4 * lh, kWave);
+          emit([&](int e) { return ((bw[e] >> li) & 1u) != 0; });
+        } else {
+          emit([](int) { return true; });
         }
       }
     }
@@ -413,7 +412,7 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
         if (row < p.M) {
           float v = acc[i][j][e] + bv;
           if (scaled) v *= p.row_scale[row];
-          v = fmaxf(v, floor_v);
+          if (p.relu) v = (v > 0.f || v != v) ? v : 0.f;
           float* dst = p.c + row * p.ldc + col;
           if (p.accumulate) v += *dst;
           if (p.mask) v = p.mask[row * p.ldm + col] > 0.f ? v : 0.f;
@@ -423,6 +422,7 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
                     ? v
                     : 0.f;
           *dst = v;
+          if (p.c2) p.c2[row * p.ldc2 + col] = v * p.row_scale[row];
         }
       }
     }
@@ -800,27 +800,38 @@ int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t l
   return run_nt(p, as_stream(stream));
 }
 
-int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
-                        const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
-                        int64_t K, int accumulate, const float* relu_mask, int64_t ld_mask,
-                        const uint32_t* relu_bits, int64_t ld_bits, float* out, int64_t ldo,
-                        void* stream) {
+int pygamd_linear_dgrad2(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
+                         const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
+                         int64_t K, int accumulate, const float* relu_mask, int64_t ld_mask,
+                         const uint32_t* relu_bits, int64_t ld_bits, float* out, int64_t ldo,
+                         float* out_scaled, int64_t ld_scaled, void* stream) {
   // out[M, K] = g[M, N] @ w[N, K], with w given TRANSPOSED as w_t[K, N]: the same NT kernel
   if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldwt < N ||
       ldo < K || n_scaled < 0 || n_scaled > K || (relu_mask && ld_mask < K) ||
-      (relu_bits && (relu_mask || ld_bits < (K + 31) / 32)))
+      (relu_bits && (relu_mask || ld_bits < (K + 31) / 32)) ||
+      (out_scaled && (ld_scaled < K || accumulate)))
     return PYGAMD_ERR_INVALID_ARG;
   if (M == 0 || K == 0) return PYGAMD_OK;
-  if (!out || (N > 0 && (!g || !w_t)) || (n_scaled > 0 && !row_scale))
+  if (!out || (N > 0 && (!g || !w_t)) || ((n_scaled > 0 || out_scaled) && !row_scale))
     return PYGAMD_ERR_INVALID_ARG;
   GemmNT p = {};
   p.a = g; p.b = w_t; p.bias = nullptr; p.row_scale = row_scale; p.mask = relu_mask;
   p.c = out;
+  p.c2 = out_scaled; p.ldc2 = ld_scaled;
   p.M = M; p.lda = ldg; p.ldb = ldwt; p.ldc = ldo; p.ldm = ld_mask;
   p.mask_bits = relu_bits; p.ldmb = ld_bits;
   p.N = static_cast<int>(K); p.K = static_cast<int>(N);
   p.relu = 0; p.n_scaled = static_cast<int>(n_scaled); p.accumulate = accumulate ? 1 : 0;
   return run_nt(p, as_stream(stream));
+}
+
+int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
+                        const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
+                        int64_t K, int accumulate, const float* relu_mask, int64_t ld_mask,
+                        const uint32_t* relu_bits, int64_t ld_bits, float* out, int64_t ldo,
+                        void* stream) {
+  return pygamd_linear_dgrad2(g, ldg, w_t, ldwt, row_scale, n_scaled, M, N, K, accumulate,
+                              relu_mask, ld_mask, relu_bits, ld_bits, out, ldo, nullptr, 0, stream);
 }
 
 static int64_t wgrad_splits(int64_t M, int64_t tiles, int wgs_per_cu = 2) {

@@ -62,7 +62,120 @@ struct SageFusedArgs {
   int f_pad;                         // F rounded up to a multiple of 32
   uint32_t* __restrict__ bits;       // null or [y > 0], one bit per element, 32 x 32 tiles
   int64_t ld_bits;
+  const uint32_t* __restrict__ mask_bits;  // null or: y = bit ? y : 0 (same tiled layout) — the
+  int64_t ld_mask;                         // ReLU backward of the layer below, when this kernel
+                                           // runs a layer's input gradient
+  const float* __restrict__ row_scale;     // with y2: y2[i, :] = y[i, :] * row_scale[i]
+  float* __restrict__ y2;                  // null or a second, row-scaled copy of the output
+  int64_t ldy2;
 };
+
+// ---- phase 2 + epilogue, shared by both kernels: [32 x Fo] = [agg | x_root] @ w^T from the two
+// LDS tiles.  The caller has closed phase 1 with a barrier (both tiles visible to every wave).
+template <typename IdxT>
+__device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
+                                                const float* __restrict__ agg,
+                                                const float* __restrict__ xr, int agg_ld,
+                                                int64_t row0, int wave, int lane) {
+  const int F = static_cast<int>(a.g.F);
+  // ---- phase 2: [32 x Fo] = [agg | x_root] @ w^T.  No staging and no barrier: wave w owns the
+  // output columns [32 w, 32 w + 32), so of every weight chunk it needs exactly its own 32 rows x
+  // 32 k — and the MFMA operand layout (lane (j, h): 16 consecutive k of row j) IS a coalesced
+  // global access pattern (a wave reads 32 full 128-byte lines).  The weight fragments therefore
+  // go global -> registers directly, one chunk ahead of the MFMAs (every weight byte once per
+  // workgroup); both halves of A come from the LDS tiles.
+  const int wave_col0 = wave * 32;
+  if (wave_col0 >= a.Fo) return;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n_half = a.f_pad / kFK;  // chunks per half (aggregated / root)
+  const int n_chunks = 2 * n_half;
+  const int col = wave_col0 + li;
+  const bool col_ok = col < a.Fo;
+  const float* __restrict__ wrow = a.w + static_cast<int64_t>(col_ok ? col : a.Fo - 1) * a.ldw;
+  const float* agg_row = agg + li * agg_ld + 16 * lh;
+  const float* xr_row = xr + li * agg_ld + 16 * lh;
+  f32x4 fb[4], fa[4], nb[4];
+  // weight fragments of chunk c: k = (chunk base) + 16 lh + 4 v + e; columns past F are clamped
+  // to a valid address here and zeroed right before use
+  auto load_b = [&](int c, f32x4 (&dst)[4]) {
+    const bool root = c >= n_half;
+    const int kl = (root ? c - n_half : c) * kFK + 16 * lh;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = kl + 4 * v;
+      dst[v] = *reinterpret_cast<const f32x4*>(wrow + (root ? F : 0) + (k < F ? k : 0));
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  load_b(0, nb);
+  for (int c = 0; c < n_chunks; ++c) {
+    const bool root = c >= n_half;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) fb[v] = nb[v];
+    if (c + 1 < n_chunks) load_b(c + 1, nb);
+    const int base = (root ? c - n_half : c) * kFK;
+    const float* ap = (root ? xr_row : agg_row) + base;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) fa[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
+    const int rem = F - base;  // > 0: valid k of this chunk (multiple of 4)
+    if (rem < kFK || !col_ok) {  // boundary chunk / padding column: zero B past F (the LDS
+      const int kl = base + 16 * lh;  // tiles are zero there already)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          fb[v][e] = (col_ok && (kl + 4 * v + e < F)) ? fb[v][e] : 0.f;
+    }
+    // a tail shorter than 16 leaves the upper lane half all zero: only `rem` steps carry data
+    const int groups = rem >= 16 ? 4 : rem / 4;  // wave-uniform
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (v < groups) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[v][e], fb[v][e], acc, 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
+  const float bv = (a.bias && col_ok) ? a.bias[col] : 0.f;
+  const int64_t rbase = row0 + 4 * lh;
+  float* yp = a.y + rbase * a.ldy + col;
+  float* yp2 = a.y2 ? a.y2 + rbase * a.ldy2 + col : nullptr;
+  // mask word of row (row0 + li) for this 32-column block: one 128-byte line per wave, fetched
+  // before the stores and handed out by ds_bpermute
+  uint32_t mword = 0xffffffffu;
+  if (a.mask_bits && row0 + li < a.g.n_rows)
+    mword = a.mask_bits[((row0 >> 5) * a.ld_mask + (wave_col0 >> 5)) * 32 + li];
+  uint32_t my_word = 0;  // lane e < 16: row (e & 3) + 8 (e >> 2); lane 16 + e: that row + 4
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int roff = (e & 3) + 8 * (e >> 2);
+    float v = acc[e] + bv;
+    if (a.relu) v = (v > 0.f || v != v) ? v : 0.f;  // NaN propagates like torch.relu
+    if (a.mask_bits) {  // uniform
+      const uint32_t mw = __shfl(mword, roff + 4 * lh, kWave);
+      v = ((mw >> li) & 1u) ? v : 0.f;
+    }
+    const bool ok = col_ok && rbase + roff < a.g.n_rows;
+    if (ok) yp[roff * a.ldy] = v;
+    if (yp2 && ok) yp2[roff * a.ldy2] = v * a.row_scale[rbase + roff];
+    if (a.bits) {  // uniform.  One ballot = this 32-column block of two rows (lane halves)
+      const uint64_t m = __ballot(col_ok && v > 0.f);
+      if (lane == e) my_word = static_cast<uint32_t>(m);
+      if (lane == 16 + e) my_word = static_cast<uint32_t>(m >> 32);
+    }
+  }
+  if (a.bits && lane < 32) {  // the tile's 32 words of this column block: one 128-byte line
+    const int e = lane & 15;
+    const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 4);
+    if (row0 + r < a.g.n_rows)
+      a.bits[((row0 >> 5) * a.ld_bits + (wave_col0 >> 5)) * 32 + r] = my_word;
+  }
+}
 
 // aggregated row -> LDS tile (+ global agg buffer); lanes < LPR hold VW features per CH
 template <typename IdxT, int VW, int LPR>
@@ -153,99 +266,247 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArg
     fused_gather_row<IdxT, 4, LPR>(a, row0 + r, agg + r * agg_ld, lane);
   }
 
-  // ---- phase 2: [32 x Fo] = [agg | x_root] @ w^T.  No staging and no barrier: wave w owns the
-  // output columns [32 w, 32 w + 32), so of every weight chunk it needs exactly its own 32 rows x
-  // 32 k — and the MFMA operand layout (lane (j, h): 16 consecutive k of row j) IS a coalesced
-  // global access pattern (a wave reads 32 full 128-byte lines).  The weight fragments therefore
-  // go global -> registers directly, one chunk ahead of the MFMAs (every weight byte once per
-  // workgroup); both halves of A come from the LDS tiles.
   __syncthreads();  // phase 1 complete: both tiles visible to every wave
-  const int wave_col0 = wave * 32;
-  if (wave_col0 >= a.Fo) return;
-  const int li = lane & 31, lh = lane >> 5;
-  const int n_half = a.f_pad / kFK;  // chunks per half (aggregated / root)
-  const int n_chunks = 2 * n_half;
-  const int col = wave_col0 + li;
-  const bool col_ok = col < a.Fo;
-  const float* __restrict__ wrow = a.w + static_cast<int64_t>(col_ok ? col : a.Fo - 1) * a.ldw;
-  const float* agg_row = agg + li * agg_ld + 16 * lh;
-  const float* xr_row = xr + li * agg_ld + 16 * lh;
-  f32x4 fb[4], fa[4], nb[4];
-  // weight fragments of chunk c: k = (chunk base) + 16 lh + 4 v + e; columns past F are clamped
-  // to a valid address here and zeroed right before use
-  auto load_b = [&](int c, f32x4 (&dst)[4]) {
-    const bool root = c >= n_half;
-    const int kl = (root ? c - n_half : c) * kFK + 16 * lh;
+  fused_transform<IdxT>(a, agg, xr, agg_ld, row0, wave, lane);
+}
+
+// ---- v2: the gather phase as a software-pipelined stream ------------------------------------------
+// The row-at-a-time phase 1 above pays three dependent memory latencies per destination row
+// (rowptr -> slot indices -> source rows) and drains its loads at every batch, with only 16 waves
+// per CU to hide them (an SpMM launch has 32): at the products shape the two phases of the kernel
+// ran back to back on a CU (48 us per tile = 35 us gather + 13.7 us MFMA) although two workgroups
+// share it.  Here the dependent chain is paid ONCE PER TILE and the row loads never drain:
+//   1. every wave reads the tile's 33 row pointers into its lanes and scans the non-hub degrees
+//      (compacted slot offsets cp[0..32]); the tile's column indices — one contiguous run of the
+//      CSR array — go to LDS as int32 with one coalesced pass of the whole workgroup;
+//   2. the 32 rows are split into 8 contiguous runs of about equal slot count, one per wave;
+//   3. a wave walks its run as a sequence of UNITS (one row, STEP = U * 64/LPR consecutive slots,
+//      U row loads per lane) through two register buffers: the loads of unit i+1 are issued before
+//      unit i is added up, across row boundaries — 2 x U x 1 KiB in flight per wave at all times,
+//      issued unconditionally (clamped slot, select at the add) so that the compiler's vmcnt
+//      bookkeeping stays exact.  A finished row is scaled (mean) and written to the LDS tile.
+// The order of the additions is the SpMM's (slot order per lane group, groups combined by the same
+// butterfly): the result is bitwise that of pygamd_spmm_csr + pygamd_linear_forward.
+// Tiles with more than kFCap non-hub slots read their indices from global memory instead (same
+// pipeline, rare).  The aggregated tile is written to global memory (save_agg) from LDS after the
+// barrier, coalesced, so that phase 1 contains no global store.
+constexpr int kFCap = 3072;  // column indices staged per tile (12 KiB)
+
+template <typename IdxT, int LPR, bool LDS_IDX>
+__device__ __forceinline__ void stream_gather(const SageFusedArgs<IdxT>& a, float* __restrict__ agg,
+                                              int agg_ld, const int32_t* __restrict__ cidx,
+                                              IdxT rp_l, int cp_l, int rb, int re, int lane) {
+  constexpr int VW = 4, U = 8;
+  constexpr int EPI = kWave / LPR, STEP = U * EPI;
+  const int sub = lane / LPR;
+  const int fo = (lane % LPR) * VW;
+  const bool fv = fo < static_cast<int>(a.g.F);
+  const float* __restrict__ xb = a.g.x + (fv ? fo : 0);  // loads are unconditional
+  // unit iterator (all wave-uniform): row it_r, slots [it_j, it_j + STEP) of its it_deg, first
+  // compacted slot it_base
+  int it_r = rb - 1, it_j = 0, it_deg = 0, it_base = 0;
+  bool done = false;
+  auto advance = [&]() -> bool {
+    if (done) return false;
+    int j = it_j + STEP, r = it_r, deg = it_deg, base = it_base;
+    while (j >= deg) {
+      ++r;
+      if (r >= re) {
+        done = true;
+        return false;
+      }
+      base = bcast_uniform(cp_l, r);
+      deg = bcast_uniform(cp_l, r + 1) - base;
+      j = 0;
+    }
+    it_r = r;
+    it_j = j;
+    it_deg = deg;
+    it_base = base;
+    return true;
+  };
+  struct Unit {
+    int row, j0, deg;
+    bool live;
+  };
+  // (after the last unit the iterator keeps its coordinates: a dead unit re-issues the loads of
+  // the last live one — cache hits — so that every pass of the loop issues exactly U loads)
+  auto issue = [&](Unit& un, Vec<VW> (&b)[U], bool live) {
+    un.row = it_r;
+    un.j0 = it_j;
+    un.deg = it_deg;
+    un.live = live;
+    IdxT g0 = 0;
+    if constexpr (!LDS_IDX) g0 = bcast_uniform(rp_l, it_r);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int k = kl + 4 * v;
-      dst[v] = *reinterpret_cast<const f32x4*>(wrow + (root ? F : 0) + (k < F ? k : 0));
+    for (int u = 0; u < U; ++u) {
+      int k = it_j + u * EPI + sub;
+      k = k < it_deg ? k : it_deg - 1;
+      int64_t c;
+      if constexpr (LDS_IDX) {
+        c = cidx[it_base + k];
+      } else {
+        c = static_cast<int64_t>(a.g.col[g0 + k]);
+      }
+      b[u] = load_vec<VW>(xb + c * a.g.ldx);
+    }
+    // every load of the unit is issued before the first add of the previous one (hipcc otherwise
+    // starts the adds between the loads and parks the wave on the oldest load in flight)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  float acc[1][VW];
+#pragma unroll
+  for (int i = 0; i < VW; ++i) acc[0][i] = 0.f;
+  auto consume = [&](const Unit& un, const Vec<VW> (&b)[U]) {
+    const int lim = un.live ? un.deg : 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool valid = un.j0 + u * EPI + sub < lim;
+#pragma unroll
+      for (int i = 0; i < VW; ++i) acc[0][i] += valid ? b[u].v[i] : 0.f;
+    }
+    if (un.live && un.j0 + STEP >= un.deg) {  // the row is complete
+      combine_subgroups<VW, LPR, 1>(acc);
+      if (lane < LPR && fv) {
+        const float cntf = static_cast<float>(un.deg);
+        Vec<VW> o;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = a.g.mean ? acc[0][i] / cntf : acc[0][i];
+        store_vec<VW>(agg + un.row * agg_ld + fo, o);
+      }
+#pragma unroll
+      for (int i = 0; i < VW; ++i) acc[0][i] = 0.f;
     }
   };
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  load_b(0, nb);
-  for (int c = 0; c < n_chunks; ++c) {
-    const bool root = c >= n_half;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) fb[v] = nb[v];
-    if (c + 1 < n_chunks) load_b(c + 1, nb);
-    const int base = (root ? c - n_half : c) * kFK;
-    const float* ap = (root ? xr_row : agg_row) + base;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) fa[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
-    const int rem = F - base;  // > 0: valid k of this chunk (multiple of 4)
-    if (rem < kFK || !col_ok) {  // boundary chunk / padding column: zero B past F (the LDS
-      const int kl = base + 16 * lh;  // tiles are zero there already)
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          fb[v][e] = (col_ok && (kl + 4 * v + e < F)) ? fb[v][e] : 0.f;
+  Unit ua, ub;
+  Vec<VW> va[U], vb[U];
+  if (!advance()) return;
+  issue(ua, va, true);
+  for (;;) {  // invariant: `ua` is live and its loads are in flight
+    issue(ub, vb, advance());
+    consume(ua, va);
+    const bool more = advance();
+    issue(ua, va, more);
+    consume(ub, vb);
+    if (!more) break;
+  }
+}
+
+template <typename IdxT, int LPR>
+__global__ void __launch_bounds__(kFBlock, 4) sage_fused_stream_kernel(SageFusedArgs<IdxT> a) {
+  extern __shared__ __align__(16) float smem[];
+  const int agg_ld = a.f_pad + 4;
+  float* agg = smem;                    // [32][f_pad + 4]  aggregated rows
+  float* xr = smem + kFTile * agg_ld;   // [32][f_pad + 4]  root rows of the tile
+  int32_t* cidx = reinterpret_cast<int32_t*>(smem + 2 * kFTile * agg_ld);  // [kFCap]
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t tile = xcd_logical_block();
+  const int64_t row0 = tile * kFTile;
+  if (row0 >= a.g.n_rows) return;
+  const int F = static_cast<int>(a.g.F);
+
+  // ---- the tile's row pointers, one per lane (rows past n_rows repeat the last pointer: degree 0)
+  IdxT rp_l = 0;
+  if (lane <= kFTile) {
+    int64_t rr = row0 + lane;
+    rr = rr < a.g.n_rows ? rr : a.g.n_rows;
+    rp_l = a.g.rowptr[rr];
+  }
+  // root rows -> LDS (issued before anything waits on the row pointers)
+  {
+    const int units = F / 4;  // 16-byte pieces per row
+    for (int t = threadIdx.x; t < kFTile * units; t += kFBlock) {
+      const int r = t / units;
+      const int u = t - r * units;
+      int64_t rr = row0 + r;
+      rr = rr < a.g.n_rows ? rr : a.g.n_rows - 1;
+      *reinterpret_cast<f32x4*>(xr + r * agg_ld + 4 * u) =
+          *reinterpret_cast<const f32x4*>(a.x_root + rr * a.ld_root + 4 * u);
     }
-    // a tail shorter than 16 leaves the upper lane half all zero: only `rem` steps carry data
-    const int groups = rem >= 16 ? 4 : rem / 4;  // wave-uniform
+  }
+  if (a.f_pad > F) {  // padding columns [F, f_pad) of both tiles are zeroed once
+    const int padw = a.f_pad - F;
+    for (int t = threadIdx.x; t < 2 * kFTile * padw; t += kFBlock) {
+      const int r = t / padw;
+      smem[r * agg_ld + F + (t - r * padw)] = 0.f;
+    }
+  }
+  const IdxT rp_n = bcast_lane(rp_l, lane + 1 < kWave ? lane + 1 : lane);
+  const int64_t deg_l = lane < kFTile ? static_cast<int64_t>(rp_n - rp_l) : 0;
+  const bool hub_l = a.g.hub_threshold > 0 && deg_l > a.g.hub_threshold;
+  const int act_l = hub_l ? 0 : static_cast<int>(deg_l);
+  int inc = act_l;  // inclusive scan over the lanes
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      if (v < groups) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[v][e], fb[v][e], acc, 0, 0, 0);
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int t = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += t;
+  }
+  const int cp_l = inc - act_l;  // compacted first slot of row `lane`; lane 32: the tile's total
+  const int total = bcast_uniform(cp_l, kFTile);
+  const bool any_hub = __ballot(hub_l) != 0;
+  const bool staged = total <= kFCap;
+
+  // ---- rows that are not gathered here (wave w looks after rows w, w + 8, ...): hub rows come
+  // from the global agg buffer (two-stage hub kernels, before this launch), empty rows are zero;
+  // with hub rows in the tile the indices are staged row by row, otherwise in one flat pass
+  const IdxT g_first = bcast_uniform(rp_l, 0);
+  if (staged && !any_hub) {
+    for (int k = threadIdx.x; k < total; k += kFBlock)
+      cidx[k] = static_cast<int32_t>(__builtin_nontemporal_load(&a.g.col[g_first + k]));
+  }
+  for (int r = wave; r < kFTile; r += kFWaves) {
+    const IdxT g0 = bcast_uniform(rp_l, r);
+    const int64_t deg = static_cast<int64_t>(bcast_uniform(rp_l, r + 1) - g0);
+    const bool hub = a.g.hub_threshold > 0 && deg > a.g.hub_threshold;
+    float* arow = agg + r * agg_ld;
+    if (hub) {
+      const float* __restrict__ src = a.g.out + (row0 + r) * a.g.ldo;
+      for (int f = 4 * lane; f < F; f += 4 * kWave)
+        *reinterpret_cast<f32x4*>(arow + f) = *reinterpret_cast<const f32x4*>(src + f);
+    } else if (deg == 0) {
+      for (int f = 4 * lane; f < F; f += 4 * kWave)
+        *reinterpret_cast<f32x4*>(arow + f) = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (staged && any_hub) {
+      const int s0 = bcast_uniform(cp_l, r);
+      for (int i = lane; i < deg; i += kWave)
+        cidx[s0 + i] = static_cast<int32_t>(__builtin_nontemporal_load(&a.g.col[g0 + i]));
+    }
+  }
+  // ---- this wave's run of rows: [rb, re) = the rows whose first slot lies in its share
+  const int t_lo = static_cast<int>(static_cast<int64_t>(total) * wave / kFWaves);
+  const int t_hi = static_cast<int>(static_cast<int64_t>(total) * (wave + 1) / kFWaves);
+  const int rb = __popcll(__ballot(lane < kFTile && cp_l < t_lo));
+  const int re = __popcll(__ballot(lane < kFTile && cp_l < t_hi));
+  __syncthreads();  // indices staged
+  if (staged) {
+    stream_gather<IdxT, LPR, true>(a, agg, agg_ld, cidx, rp_l, cp_l, rb, re, lane);
+  } else {
+    stream_gather<IdxT, LPR, false>(a, agg, agg_ld, cidx, rp_l, cp_l, rb, re, lane);
+  }
+  __syncthreads();  // phase 1 complete: both tiles visible to every wave
+  if (a.save_agg) {  // the aggregated rows, once, for the weight gradient (write-only)
+    const int units = F / 4;
+    for (int t = threadIdx.x; t < kFTile * units; t += kFBlock) {
+      const int r = t / units;
+      const int u = t - r * units;
+      if (row0 + r < a.g.n_rows) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(agg + r * agg_ld + 4 * u);
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.g.out + (row0 + r) * a.g.ldo +
+                                                                4 * u));
       }
     }
   }
-
-  // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
-  const float bv = (a.bias && col_ok) ? a.bias[col] : 0.f;
-  const float floor_v = a.relu ? 0.f : -INFINITY;
-  float* yp = a.y + (row0 + 4 * lh) * a.ldy + col;
-  uint32_t my_word = 0;  // lane e < 16: row (e & 3) + 8 (e >> 2); lane 16 + e: that row + 4
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int roff = (e & 3) + 8 * (e >> 2);
-    const float v = fmaxf(acc[e] + bv, floor_v);
-    if (col_ok && row0 + 4 * lh + roff < a.g.n_rows) yp[roff * a.ldy] = v;
-    if (a.bits) {  // uniform.  One ballot = this 32-column block of two rows (lane halves)
-      const uint64_t m = __ballot(col_ok && v > 0.f);
-      if (lane == e) my_word = static_cast<uint32_t>(m);
-      if (lane == 16 + e) my_word = static_cast<uint32_t>(m >> 32);
-    }
-  }
-  if (a.bits && lane < 32) {  // the tile's 32 words of this column block: one 128-byte line
-    const int e = lane & 15;
-    const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 4);
-    if (row0 + r < a.g.n_rows)
-      a.bits[((row0 >> 5) * a.ld_bits + (wave_col0 >> 5)) * 32 + r] = my_word;
-  }
+  fused_transform<IdxT>(a, agg, xr, agg_ld, row0, wave, lane);
 }
 
 static bool aligned16f(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename IdxT, int LPR>
-static int launch_fused(const SageFusedArgs<IdxT>& a, hipStream_t st) {
-  const size_t lds = sizeof(float) * 2 * kFTile * (a.f_pad + 4);
-  auto k = sage_fused_fwd_kernel<IdxT, LPR>;
+static int launch_fused(const SageFusedArgs<IdxT>& a, bool streamed, hipStream_t st) {
+  size_t lds = sizeof(float) * 2 * kFTile * (a.f_pad + 4);
+  if (streamed) lds += sizeof(int32_t) * kFCap;
+  auto k = streamed ? sage_fused_stream_kernel<IdxT, LPR> : sage_fused_fwd_kernel<IdxT, LPR>;
   PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));
@@ -269,30 +530,32 @@ int pygamd_sage_layer_forward_supported(int64_t F, int64_t Fo, int reduce) {
              : 0;
 }
 
-int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root,
-                              int64_t ld_root, const float* w, int64_t ldw, const float* bias,
-                              int64_t Fo, int relu, int save_agg, float* y, int64_t ldy,
-                              uint32_t* relu_bits_out, int64_t ld_bits, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-  if (!graph) return PYGAMD_ERR_INVALID_ARG;
-  const int64_t F = graph->F;
+int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fused_args* f,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!graph || !f) return PYGAMD_ERR_INVALID_ARG;
+  const int64_t F = graph->F, Fo = f->Fo;
   if (graph->n_rows < 0 || F < 0 || Fo < 0 || graph->ldx < F || graph->ldo < F ||
-      ld_root < F || ldw < 2 * F || ldy < Fo)
+      f->ld_root < F || f->ldw < 2 * F || f->ldy < Fo)
     return PYGAMD_ERR_INVALID_ARG;
   // (col may be NULL only for a graph without edges: it is never dereferenced then)
   if (!pygamd_sage_layer_forward_supported(F, Fo, graph->reduce) || graph->w ||
       graph->src_scale || graph->eid || graph->accumulate || graph->relu_mask ||
       graph->relu_bits)
     return PYGAMD_ERR_UNSUPPORTED;
-  if (relu_bits_out && (!relu || ld_bits < (Fo + 31) / 32)) return PYGAMD_ERR_INVALID_ARG;
+  const int64_t words = (Fo + 31) / 32;
+  if (f->relu_bits_out && (!f->relu || f->ld_bits_out < words)) return PYGAMD_ERR_INVALID_ARG;
+  if (f->mask_bits && f->ld_mask_bits < words) return PYGAMD_ERR_INVALID_ARG;
+  if (f->y_scaled && (!f->row_scale || f->ldy_scaled < Fo)) return PYGAMD_ERR_INVALID_ARG;
+  if (f->variant < 0 || f->variant > 2) return PYGAMD_ERR_INVALID_ARG;
   if (graph->n_rows == 0) return PYGAMD_OK;
-  if (!graph->rowptr || !graph->x || !graph->out || !x_root || !w || !y)
+  if (!graph->rowptr || !graph->x || !graph->out || !f->x_root || !f->w || !f->y)
     return PYGAMD_ERR_INVALID_ARG;
   if (graph->idx_dtype != PYGAMD_IDX_I32 && graph->idx_dtype != PYGAMD_IDX_I64)
     return PYGAMD_ERR_INVALID_ARG;
   // 16-byte accesses everywhere
-  if ((graph->ldx % 4) || (graph->ldo % 4) || (ld_root % 4) || (ldw % 4) ||
-      !aligned16f(graph->x) || !aligned16f(graph->out) || !aligned16f(x_root) || !aligned16f(w))
+  if ((graph->ldx % 4) || (graph->ldo % 4) || (f->ld_root % 4) || (f->ldw % 4) ||
+      !aligned16f(graph->x) || !aligned16f(graph->out) || !aligned16f(f->x_root) ||
+      !aligned16f(f->w))
     return PYGAMD_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
   // hub rows first (two-stage, deterministic) into the global agg buffer; the fused kernel copies
@@ -303,6 +566,8 @@ int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root
     const int rc = pygamd_spmm_csr(&hubs, workspace, workspace_bytes, stream);
     if (rc != PYGAMD_OK) return rc;
   }
+  // the streamed gather keeps column indices as int32 in LDS
+  const bool streamed = f->variant != 1 && graph->n_src < (static_cast<int64_t>(1) << 31);
   int lpr = 4;
   while (lpr < 64 && lpr * 4 < F) lpr <<= 1;
   return PYGAMD_DISPATCH_IDX(graph->idx_dtype, [&]() -> int {
@@ -320,8 +585,6 @@ int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root
     a.g.ldm = 0;
     a.g.relu_bits = nullptr;
     a.g.ldb = 0;
-    a.bits = relu_bits_out;
-    a.ld_bits = ld_bits;
     a.g.n_rows = graph->n_rows;
     a.g.F = F;
     a.g.ldx = graph->ldx;
@@ -331,25 +594,53 @@ int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root
     a.g.mean = (graph->reduce == PYGAMD_MEAN);
     a.g.accumulate = 0;
     a.g.hub_threshold = graph->n_hub > 0 ? graph->hub_threshold : 0;
-    a.x_root = x_root;
-    a.ld_root = ld_root;
-    a.w = w;
-    a.ldw = ldw;
-    a.bias = bias;
-    a.y = y;
-    a.ldy = ldy;
+    a.x_root = f->x_root;
+    a.ld_root = f->ld_root;
+    a.w = f->w;
+    a.ldw = f->ldw;
+    a.bias = f->bias;
+    a.y = f->y;
+    a.ldy = f->ldy;
     a.Fo = static_cast<int>(Fo);
-    a.relu = relu ? 1 : 0;
-    a.save_agg = save_agg ? 1 : 0;
+    a.relu = f->relu ? 1 : 0;
+    a.save_agg = f->save_agg ? 1 : 0;
     a.f_pad = static_cast<int>(round_up(F, kFK));
+    a.bits = f->relu_bits_out;
+    a.ld_bits = f->ld_bits_out;
+    a.mask_bits = f->mask_bits;
+    a.ld_mask = f->ld_mask_bits;
+    a.row_scale = f->row_scale;
+    a.y2 = f->y_scaled;
+    a.ldy2 = f->ldy_scaled;
     switch (lpr) {
-      case 4: return launch_fused<IdxT, 4>(a, st);
-      case 8: return launch_fused<IdxT, 8>(a, st);
-      case 16: return launch_fused<IdxT, 16>(a, st);
-      case 32: return launch_fused<IdxT, 32>(a, st);
-      default: return launch_fused<IdxT, 64>(a, st);
+      case 4: return launch_fused<IdxT, 4>(a, streamed, st);
+      case 8: return launch_fused<IdxT, 8>(a, streamed, st);
+      case 16: return launch_fused<IdxT, 16>(a, streamed, st);
+      case 32: return launch_fused<IdxT, 32>(a, streamed, st);
+      default: return launch_fused<IdxT, 64>(a, streamed, st);
     }
   });
+}
+
+int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root,
+                              int64_t ld_root, const float* w, int64_t ldw, const float* bias,
+                              int64_t Fo, int relu, int save_agg, float* y, int64_t ldy,
+                              uint32_t* relu_bits_out, int64_t ld_bits, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  pygamd_sage_fused_args f = {};
+  f.x_root = x_root;
+  f.ld_root = ld_root;
+  f.w = w;
+  f.ldw = ldw;
+  f.bias = bias;
+  f.Fo = Fo;
+  f.relu = relu;
+  f.save_agg = save_agg;
+  f.y = y;
+  f.ldy = ldy;
+  f.relu_bits_out = relu_bits_out;
+  f.ld_bits_out = ld_bits;
+  return pygamd_sage_layer_fused(graph, &f, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -46,6 +46,12 @@ GEMM_BACKEND = os.environ.get('PYGAMD_GEMM', 'own')
 # tile goes from the gather phase to the MFMA loop through LDS); PYGAMD_FUSE_LAYER=0 runs the SpMM
 # and the GEMM as two launches
 FUSE_LAYER = os.environ.get('PYGAMD_FUSE_LAYER', '1') != '0'
+# backward of a 'post' layer's input gradient as ONE launch of the same kernel on the transposed
+# graph: grad_x = [x > 0] * ((A^T D^-1 g) W_l + g W_r) — aggregation and right-multiplication
+# commute, so the dgrad GEMM's flops run under the gather of the transposed SpMM instead of in
+# front of it, and the [N, 2 F] `[grad_agg | grad_root]` buffer is never written.
+# PYGAMD_FUSE_BWD=0 restores dgrad GEMM + transposed SpMM as two launches.
+FUSE_BWD = os.environ.get('PYGAMD_FUSE_BWD', '1') != '0'
 # backward: weight-gradient GEMMs (MFMA-bound, needed only by the optimizer) on a side stream with
 # HALF the usual workgroups (one per CU), under the transposed SpMM of the same layer (HBM-bound,
 # matrix cores idle).  0 = everything on one stream.  (Round 1 measured the same idea with a
@@ -221,6 +227,16 @@ class FusedSageStack(Function):
         # gradient GEMM returns the column sums of its `g` operand (= the bias gradient) from the
         # pass it makes over `g` anyway.
         masked = True  # grad_out itself has no activation behind it
+        needs_in = [layer > 0 or ctx.needs_input_grad[0] for layer in range(L)]
+
+        def fused_bwd(layer: int) -> bool:
+            """this layer's input gradient runs as one launch of the fused kernel"""
+            Fi, Fo = ctx.dims[layer]
+            return (own and FUSE_BWD and FUSE_LAYER and ctx.modes[layer] == 'post'
+                    and needs_in[layer] and (layer == 0 or bits[layer] is not None)
+                    and _native.sage_layer_forward_supported(Fo, Fi, 'sum'))
+
+        g_scaled = None  # g * (1 / deg) per row, when the producer of `g` wrote it as well
         for layer in reversed(range(L)):
             buf, wmat = bufs[layer], wmats[layer]
             Fi, Fo = ctx.dims[layer]
@@ -228,15 +244,19 @@ class FusedSageStack(Function):
             if not masked:  # ReLU backward and this layer's bias gradient in one pass
                 h_next = FusedSageStack._input_view(ctx, bufs, layer + 1)  # post-ReLU output
                 g, grads[3 * layer + 1] = _native.relu_backward_colsum(g, h_next, want_b)
+                g_scaled = None
             elif want_b and not own:
                 grads[3 * layer + 1] = _native.colsum(g)
-            need_input_grad = layer > 0 or ctx.needs_input_grad[0]
+            need_input_grad = needs_in[layer]
             mask_in = FusedSageStack._input_view(ctx, bufs, layer) if (own and layer > 0) else None
             bits_in = bits[layer] if mask_in is not None else None
             mask_f = mask_in if bits_in is None else None  # the float form only without the bits
+            # the layer below takes the gradient this layer produces: 1/deg-scaled as well?
+            scaled_for_next = layer > 0 and scale is not None and fused_bwd(layer - 1)
             if ctx.modes[layer] == 'post':
                 # [Fo, 2 Fi] = [grad W_l | grad W_r]
-                overlap = (own and OVERLAP_WGRAD and need_input_grad
+                one_launch = fused_bwd(layer) and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0
+                overlap = (own and OVERLAP_WGRAD and need_input_grad and not one_launch
                            and not torch.cuda.is_current_stream_capturing())
                 lone_x = x0 if layer == 0 else None  # [agg | x] as two operands side by side
                 if not overlap:
@@ -246,6 +266,34 @@ class FusedSageStack(Function):
                             gw, grads[3 * layer + 1] = gw
                     else:
                         gw = torch.mm(g.t(), buf)
+                if one_launch:
+                    if scale is None:
+                        gsrc = g
+                    elif g_scaled is not None:
+                        gsrc = g_scaled
+                    else:  # (grad_out itself: nobody upstream could write the scaled copy)
+                        gsrc = g * scale.view(-1, 1)
+                    # w[i, :] = [W_l[:, i] | W_r[:, i]]
+                    wc = torch.cat([wmat[:, :Fi].t(), wmat[:, Fi:].t()], dim=1)
+                    gin = torch.empty(N, Fi, dtype=torch.float32, device=g.device)
+                    gin_s = torch.empty_like(gin) if scaled_for_next else None
+                    # hub rows of the transposed graph are aggregated into a global buffer first;
+                    # the output itself serves when the widths agree (a tile reads its hub rows
+                    # before it writes its result)
+                    scratch = gin if Fi == Fo else torch.empty(N, Fo, dtype=torch.float32,
+                                                               device=g.device)
+                    _native.sage_layer_forward(bwd.ptr, bwd.idx, gsrc, g, wc, None, 'sum', False,
+                                               scratch, gin, hub=bwd.hub, save_agg=False,
+                                               mask_bits=bits_in,
+                                               row_scale=scale if gin_s is not None else None,
+                                               out_scaled=gin_s)
+                    grads[3 * layer] = gw[:, :Fi]
+                    grads[3 * layer + 2] = gw[:, Fi:]
+                    g, g_scaled = gin, gin_s
+                    masked = mask_in is not None
+                    if layer == 0:
+                        grad_x = g
+                    continue
                 if need_input_grad:
                     # [N, 2 Fi] = [grad_agg | grad_root]
                     if own:  # grad_agg rows leave the GEMM already divided by their degree
@@ -276,7 +324,7 @@ class FusedSageStack(Function):
                 grads[3 * layer] = gw[:, :Fi]
                 grads[3 * layer + 2] = gw[:, Fi:]
                 if need_input_grad:
-                    g = gcat[:, Fi:]
+                    g, g_scaled = gcat[:, Fi:], None
             else:
                 Fp = _pad4(Fo)
                 gy = torch.empty(N, 2 * Fp, dtype=torch.float32, device=g.device)
@@ -315,10 +363,17 @@ class FusedSageStack(Function):
                     grads[3 * layer + 1] = gb[Fp:Fp + Fo]
                 grads[3 * layer] = gw[:Fo]
                 grads[3 * layer + 2] = gw[Fp:Fp + Fo]
+                g_scaled = None
                 if need_input_grad:  # [N, Fi]
-                    g = (_native.linear_dgrad(gy, wmat.t().contiguous(), relu_mask=mask_f,
-                                              relu_bits=bits_in)
-                         if own else torch.mm(gy, wmat))
+                    if own:
+                        if scaled_for_next:
+                            g_scaled = torch.empty(N, Fi, dtype=torch.float32, device=g.device)
+                        g = _native.linear_dgrad(gy, wmat.t().contiguous(),
+                                                 row_scale=scale if scaled_for_next else None,
+                                                 relu_mask=mask_f, relu_bits=bits_in,
+                                                 out_scaled=g_scaled)
+                    else:
+                        g = torch.mm(gy, wmat)
             masked = mask_in is not None
             if layer == 0 and need_input_grad:
                 grad_x = g.contiguous()

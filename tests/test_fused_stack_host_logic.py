@@ -80,7 +80,8 @@ def fake_native(monkeypatch):
         return out
 
     def sage_layer_forward(ptr, idx, x_gather, x_root, w, bias, reduce, relu, agg, out, hub=None,
-                           save_agg=True, relu_bits=None, **kw):
+                           save_agg=True, relu_bits=None, mask_bits=None, row_scale=None,
+                           out_scaled=None, **kw):
         assert not kw, kw
         a = _aggregate(ptr, idx, x_gather, reduce)
         y = torch.cat([a, x_root], 1) @ w.t()
@@ -88,14 +89,20 @@ def fake_native(monkeypatch):
             y = y + bias
         if relu:
             y = y.relu()
+        if mask_bits is not None:  # the launch is a layer's input gradient
+            y = torch.where(_unpack_bits(mask_bits, *y.shape), y, torch.zeros_like(y))
         if save_agg:
             agg.copy_(a)
         if relu_bits is not None:
             assert relu
             relu_bits.copy_(_native.pack_relu_bits(y))
         out.copy_(y)
+        if out_scaled is not None:
+            out_scaled.copy_(y * row_scale.view(-1, 1))
         # (root rows read from a dense tensor = the layer input itself, not a half of [agg | x])
-        log.append(('fused_layer', x_root.is_contiguous(), relu_bits is not None))
+        log.append(('fused_layer', x_root.is_contiguous(), relu_bits is not None)
+                   if not (mask_bits is not None or not save_agg) else
+                   ('fused_layer_bwd', mask_bits is not None, out_scaled is not None))
         return out
 
     def linear_forward(x, w, bias=None, relu=False, out=None, accumulate=False):
@@ -110,7 +117,7 @@ def fake_native(monkeypatch):
         return out
 
     def linear_dgrad(g, w_t, row_scale=None, n_scaled=0, out=None, accumulate=False,
-                     relu_mask=None, relu_bits=None):
+                     relu_mask=None, relu_bits=None, out_scaled=None):
         y = g @ w_t.t()
         if row_scale is not None and n_scaled:
             y[:, :n_scaled] *= row_scale.view(-1, 1)
@@ -119,7 +126,9 @@ def fake_native(monkeypatch):
             y = torch.where(relu_mask > 0, y, torch.zeros_like(y))
         if relu_bits is not None:
             y = torch.where(_unpack_bits(relu_bits, *y.shape), y, torch.zeros_like(y))
-        log.append(('dgrad', relu_mask is not None, relu_bits is not None))
+        if out_scaled is not None:
+            out_scaled.copy_(y * row_scale.view(-1, 1))
+        log.append(('dgrad', relu_mask is not None, relu_bits is not None, out_scaled is not None))
         return y
 
     def linear_wgrad(g, x, out=None, accumulate=False, wgs_per_cu=0, bias_grad=False, x2=None):
@@ -152,8 +161,12 @@ def fake_native(monkeypatch):
     ((32, 32), 'sum', False),                # a single layer
 ])
 @pytest.mark.parametrize('bias', [True, False])
-def test_fused_stack_wiring_against_the_oracle(fake_native, dims, aggr, x_grad, bias):
+@pytest.mark.parametrize('fuse_bwd', [True, False])
+def test_fused_stack_wiring_against_the_oracle(fake_native, monkeypatch, dims, aggr, x_grad, bias,
+                                               fuse_bwd):
+    from pytorch_geometric_amd.nn.models import _fused_sage
     from pytorch_geometric_amd.nn.models._fused_sage import FusedSageStack
+    monkeypatch.setattr(_fused_sage, 'FUSE_BWD', fuse_bwd)
     n = 75  # three 32-row bit tiles, the last one partial
     g = gen(sum(dims) + n)
     ei = random_graph(n, n, 600, seed=dims[0], skew=True)
@@ -200,10 +213,29 @@ def test_fused_stack_wiring_against_the_oracle(fake_native, dims, aggr, x_grad, 
         fused = [e for e in fake_native if e[0] == 'fused_layer']
         assert [e[1] for e in fused] == [True, False]   # layer 1 roots on x itself (no copy)
         assert ('wgrad', bias, True) in fake_native      # ... and its wgrad takes [agg | x] apart
-        masked = [e for e in fake_native if e[0] in ('spmm', 'dgrad') and e[-1]]
-        assert len(masked) == 2                          # h1 (transposed SpMM) and h2 (dgrad)
-        # ... and never as floats: both activations came out of the one-kernel layer forward
-        assert not [e for e in fake_native if e[0] in ('spmm', 'dgrad') and e[-2]]
+        # ReLU backward of h1 and h2 in the epilogues of the kernels producing their gradients,
+        # and never from the float activations: both came out of the one-kernel layer forward
+        floats = [e for e in fake_native if (e[0] == 'spmm' and e[3]) or (e[0] == 'dgrad' and e[1])]
+        assert not floats
+        bwd = [e for e in fake_native if e[0] == 'fused_layer_bwd']
+        if fuse_bwd:
+            # layer 2's input gradient = ONE launch (no dgrad GEMM, no transposed SpMM at width
+            # 256); the dgrad of layer 3 hands it the 1/deg-scaled rows as a second output
+            # (with a gradient for x, layer 1 runs the same way — unmasked — and layer 2 hands it
+            # its scaled rows)
+            assert bwd == ([('fused_layer_bwd', True, x_grad)]
+                           + ([('fused_layer_bwd', False, False)] if x_grad else []))
+            assert [e for e in fake_native if e[0] == 'dgrad'] == [('dgrad', False, True, True)]
+            assert not [e for e in fake_native if e[0] == 'spmm' and e[4]]
+        else:
+            assert not bwd
+            masked = [e for e in fake_native
+                      if (e[0] == 'spmm' and e[4]) or (e[0] == 'dgrad' and e[2])]
+            assert len(masked) == 2                      # h1 (transposed SpMM) and h2 (dgrad)
+    if dims == (16, 8, 24, 12):
+        # pre, post, pre: the post layer's input came out of a GEMM + SpMM pair (no bit mask), so
+        # its gradient keeps the two-launch form with the float mask
+        assert not [e for e in fake_native if e[0] == 'fused_layer_bwd']
 
 
 @pytest.mark.parametrize('dims', [(12, 20, 20, 5), (16, 8, 12)])

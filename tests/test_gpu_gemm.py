@@ -162,7 +162,8 @@ def test_wgrad_long_reduction_is_deterministic_and_accurate(dev):
 @pytest.mark.parametrize('F,Fo,reduce', [(256, 256, 'mean'), (100, 256, 'mean'), (64, 200, 'sum'),
                                          (8, 47, 'mean'), (128, 32, 'sum')])
 @pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
-def test_sage_layer_forward_one_kernel(dev, F, Fo, reduce, dtype):
+@pytest.mark.parametrize('variant', [1, 2])  # row-at-a-time / streamed gather phase
+def test_sage_layer_forward_one_kernel(dev, F, Fo, reduce, dtype, variant):
     """csrc/sage_fused.hip: aggregation + transform + bias + ReLU of a SAGEConv layer in one
     kernel against the oracle's sage_conv (index_select + scatter + two matmuls), with hub rows,
     empty rows, a row count that is no multiple of the 32-row tile, and strided operands (the
@@ -196,7 +197,7 @@ def test_sage_layer_forward_one_kernel(dev, F, Fo, reduce, dtype):
                       device=dev)
     _native.sage_layer_forward(fwd.ptr, fwd.idx, x.to(dev), buf[:, F:], wcat, b.to(dev), reduce,
                                True, buf[:, :F], out[:, :Fo], hub=fwd.hub, save_agg=True,
-                               relu_bits=bits)
+                               relu_bits=bits, variant=variant)
     assert_sum_close(out[:, :Fo], ref, ex, abs_sum=bound + 1, what=f'fused layer F={F} Fo={Fo}')
     # the one-bit-per-element ReLU mask written next to the output: exactly [out > 0], zero bits
     # past Fo inside the last word, nothing written past the last word
@@ -213,10 +214,124 @@ def test_sage_layer_forward_one_kernel(dev, F, Fo, reduce, dtype):
     # without ReLU / bias, gathering from the strided half of the buffer itself
     out2 = torch.empty(n, Fo, device=dev)
     _native.sage_layer_forward(fwd.ptr, fwd.idx, buf[:, F:], buf[:, F:], wcat, None, reduce, False,
-                               buf[:, :F], out2, hub=fwd.hub, save_agg=False)
+                               buf[:, :F], out2, hub=fwd.hub, save_agg=False, variant=variant)
     ref2 = aggr_ref @ wl.t() + x @ wr.t()
     ex2 = aggr_ref.double() @ wl.double().t() + x.double() @ wr.double().t()
     assert_sum_close(out2, ref2, ex2, abs_sum=bound + 1, what='fused layer, no bias / relu')
+
+
+@pytest.mark.parametrize('F,Fo', [(256, 256), (100, 256), (48, 64), (8, 47)])
+def test_sage_layer_streamed_gather_is_bitwise_the_spmm(dev, F, Fo):
+    """The streamed gather phase (variant 2) adds a row's slots in the order pygamd_spmm_csr does:
+    output, saved aggregated rows and ReLU bits are bitwise those of the row-at-a-time variant
+    (itself bitwise SpMM + GEMM).  The graph has hub rows, empty rows, a tile whose non-hub slots
+    exceed the LDS index cache (indices then come from global memory) and a partial last tile."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    from tests._util import random_graph
+    n = 1500
+    g = gen(F + 7 * Fo)
+    ei = random_graph(n, n, 40000, seed=3 * F + Fo, skew=True)
+    # rows 64..95 (one tile): 200 in-edges each = 6400 slots > the 3072 staged indices
+    dense_dst = torch.arange(64, 96).repeat_interleave(200)
+    dense_src = torch.randint(0, n, (dense_dst.numel(), ), generator=g)
+    ei = torch.cat([ei, torch.stack([dense_src, dense_dst])], 1)
+    ei = ei[:, (ei[1] != 5) & (ei[1] != 130) & (ei[1] != 131)]  # rows without in-edges
+    x = torch.randn(n, F, generator=g).to(dev)
+    w = (torch.randn(Fo, 2 * F, generator=g) * 0.1).to(dev)
+    b = torch.randn(Fo, generator=g).to(dev)
+    h = pga.EdgeIndex(ei.to(dev), (n, n))
+    fwd = h.by_dst()
+    assert fwd.hub[2] > 0
+    res = []
+    for variant in (1, 2):
+        agg = torch.full((n, F), float('nan'), device=dev)
+        out = torch.full((n, Fo), float('nan'), device=dev)
+        bits = _native.relu_bits_like(n, Fo, dev).fill_(-1)
+        _native.sage_layer_forward(fwd.ptr, fwd.idx, x, x, w, b, 'mean', True, agg, out,
+                                   hub=fwd.hub, save_agg=True, relu_bits=bits, variant=variant)
+        res.append((agg, out, bits))
+    for a, b2, what in zip(res[0], res[1], ('aggregated rows', 'output', 'ReLU bits')):
+        assert torch.equal(a, b2), f'{what}: streamed variant differs from row-at-a-time'
+    two = _native.spmm_csr(fwd.ptr, fwd.idx, x, 'mean', n_rows=n, hub=fwd.hub)
+    assert torch.equal(res[1][0], two), 'aggregated rows differ from pygamd_spmm_csr'
+    assert not bool(torch.isnan(res[1][1]).any())
+
+
+@pytest.mark.parametrize('Fi,Fo', [(256, 256), (64, 128), (100, 40)])
+@pytest.mark.parametrize('reduce', ['mean', 'sum'])
+@pytest.mark.parametrize('variant', [1, 2])
+def test_sage_layer_input_gradient_one_kernel(dev, Fi, Fo, reduce, variant):
+    """pygamd_sage_layer_fused as a layer's INPUT GRADIENT: on the transposed graph, with the
+    1/deg-scaled gradient rows gathered, the unscaled ones as root operand, w = [W_l^T | W_r^T] and
+    the ReLU mask of the layer input as bits, one launch equals the oracle's autograd through
+    sage_conv(relu(h)) — and the second, row-scaled output is that times row_scale."""
+    import pytorch_geometric_amd as pga
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd import _native
+    from tests._util import random_graph
+    n = 1100
+    g = gen(Fi + Fo + len(reduce))
+    ei = random_graph(n, n, 30000, seed=Fi * 3 + Fo, skew=True)
+    ei[0][ei[0] == 9] = 10                           # node 9 has no out-edges (empty transposed row)
+    # hubs in the TRANSPOSED graph too: a few very popular sources
+    ei[0][:3000] = torch.randint(0, 2, (3000, ), generator=g)
+    pre = torch.randn(n, Fi, generator=g)            # pre-activation of the layer below
+    wl, wr = torch.randn(Fo, Fi, generator=g) * 0.1, torch.randn(Fo, Fi, generator=g) * 0.1
+    go = torch.randn(n, Fo, generator=g)
+    pr = pre.clone().requires_grad_(True)
+    out = O.sage_conv(pr.relu(), ei, wl, None, wr, reduce)
+    out.backward(go)
+    ref = pr.grad
+    h = pga.EdgeIndex(ei.to(dev), (n, n))
+    bwd, fwd = h.by_src(), h.by_dst()
+    assert bwd.hub[2] > 0
+    scale = fwd.inv_degree() if reduce == 'mean' else None
+    g_dev = go.to(dev)
+    gs = g_dev * scale.view(-1, 1) if scale is not None else g_dev
+    bits = _native.pack_relu_bits(pre.to(dev))
+    wc = torch.cat([wl.t(), wr.t()], 1).to(dev)      # [Fi, 2 Fo]
+    gin = torch.full((n, Fi), float('nan'), device=dev)
+    rs = torch.rand(n, generator=g).to(dev) + 0.5
+    gin_s = torch.full((n, Fi), float('nan'), device=dev)
+    scratch = gin if Fi == Fo else torch.empty(n, Fo, device=dev)
+    _native.sage_layer_forward(bwd.ptr, bwd.idx, gs, g_dev, wc, None, 'sum', False, scratch, gin,
+                               hub=bwd.hub, save_agg=False, mask_bits=bits, row_scale=rs,
+                               out_scaled=gin_s, variant=variant)
+    # error scale: the sum of |terms| of the two products (hub rows add thousands of rows)
+    ga = O.spmm(ei.flip(0), (gs.cpu()).abs(), n, 'sum').double()
+    bound = ga @ wl.abs().double() + go.abs().double() @ wr.abs().double()
+    ex = pre.double().requires_grad_(True)
+    O.sage_conv(ex.relu(), ei, wl.double(), None, wr.double(), reduce).backward(go.double())
+    assert_sum_close(gin, ref, ex.grad, abs_sum=bound + 1, what='fused input gradient')
+    assert_close(gin_s, gin * rs.view(-1, 1), rtol=1e-6, atol=1e-6, what='row-scaled second output')
+    assert bool((gin[pre.to(dev) <= 0] == 0).all())
+
+
+def test_linear_dgrad_second_scaled_output(dev):
+    """pygamd_linear_dgrad2: the row-scaled copy of the result comes out of the same pass, with
+    the ReLU-bit epilogue applied to both and independently of `n_scaled`; interior and boundary
+    tiles (M not a multiple of the tile)."""
+    from pytorch_geometric_amd import _native
+    g = gen(77)
+    M, N, K = 70003, 96, 256
+    go = torch.randn(M, N, generator=g).to(dev)
+    w_t = (torch.randn(K, N, generator=g) * 0.1).to(dev)
+    act = torch.randn(M, K, generator=g).to(dev)
+    rs = (torch.rand(M, generator=g) + 0.5).to(dev)
+    bits = _native.pack_relu_bits(act)
+    plain = _native.linear_dgrad(go, w_t, relu_bits=bits)
+    second = torch.full((M, K), float('nan'), device=dev)
+    first = _native.linear_dgrad(go, w_t, row_scale=rs, relu_bits=bits, out_scaled=second)
+    assert torch.equal(first, plain)
+    assert torch.equal(second, plain * rs.view(-1, 1))
+    second.fill_(float('nan'))
+    first = _native.linear_dgrad(go, w_t, row_scale=rs, n_scaled=64, out_scaled=second)
+    want = go @ w_t.t()
+    want_first = want.clone()
+    want_first[:, :64] *= rs.view(-1, 1)
+    assert_close(first, want_first, rtol=1e-5, atol=1e-5, what='n_scaled columns')
+    assert torch.equal(second, first * rs.view(-1, 1))
 
 
 def test_linear_module_routes_large_inputs_to_the_own_gemm(dev):

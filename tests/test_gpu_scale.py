@@ -168,3 +168,40 @@ def test_headline_config_against_the_cpu_paths_full_size(products):
     small_t = (tptr[1:] - tptr[:-1]) <= 64
     assert_close(grad[small_t], ref_grad[small_t], rtol=1e-5, atol=1e-5,
                  what='grad rows with out-degree <= 64')
+
+
+def test_headline_step_parity_at_cpu_scale(dev):
+    """The schedule bench.py times — GraphSAGE(100 -> 256 -> 256 -> 47), CE on the 8 % split,
+    backward — at 1/16 of the products shape (N = 153 k, E = 3.9 M, power-law hubs > 1024 edges):
+    large enough that the split-M weight-gradient reductions, the hub chunks, the 32 x 32 ReLU bit
+    tiles and the one-kernel forward / input-gradient launches all engage.  Loss, output and EVERY
+    parameter gradient against the oracle (which tests/test_oracle_golden.py pins to the
+    reference); bench.py repeats the same comparison against the unmodified reference itself
+    (`parity_at_cpu_scale` in its JSON line)."""
+    import torch.nn.functional as F
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd.datasets import products_like
+    from pytorch_geometric_amd.nn import GraphSAGE
+    from tests._util import assert_close_outliers, assert_close_scaled
+    x, y, ei, c = products_like(seed=1, scale=1 / 16)
+    N = x.size(0)
+    ti = torch.randperm(N, generator=torch.Generator().manual_seed(7))[:int(0.0803 * N)]
+    torch.manual_seed(0)
+    model = GraphSAGE(100, 256, num_layers=3, out_channels=c)
+    st = {k: v.clone() for k, v in model.state_dict().items()}
+    params = [tuple(st[f'convs.{i}.{n}'].requires_grad_(True)
+                    for n in ('lin_l.weight', 'lin_l.bias', 'lin_r.weight')) for i in range(3)]
+    ref = O.graphsage(x, ei, params)
+    ref_loss = F.cross_entropy(ref[ti], y[ti])
+    ref_loss.backward()
+    model = model.to(dev)
+    out = model(x.to(dev), ei.to(dev))
+    loss = F.cross_entropy(out[ti.to(dev)], y.to(dev)[ti.to(dev)])
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * max(1.0, abs(ref_loss.item()))
+    assert_close_scaled(out, ref, tol=1e-5, what='headline-width stack output')
+    for i, conv in enumerate(model.convs):
+        for got, want, name in ((conv.lin_l.weight.grad, params[i][0].grad, 'lin_l.weight'),
+                                (conv.lin_l.bias.grad, params[i][1].grad, 'lin_l.bias'),
+                                (conv.lin_r.weight.grad, params[i][2].grad, 'lin_r.weight')):
+            assert_close_outliers(got, want, tol=2e-5, what=f'convs.{i}.{name}.grad')
