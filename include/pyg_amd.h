@@ -575,7 +575,7 @@ typedef struct pygamd_sage_fused_args {
   float* y_scaled;           /* NULL or [n_rows, Fo]                    */
   int64_t ldy_scaled;
   int32_t variant;
-  int32_t reserved;
+  int32_t reserved;          /* 0 (timing probes of scripts/fused_probe.py only) */
 } pygamd_sage_fused_args;
 PYGAMD_API int pygamd_sage_layer_fused(const pygamd_spmm_args* graph,
                                        const pygamd_sage_fused_args* f, void* workspace,

@@ -632,6 +632,7 @@ def sage_layer_forward_supported(F: int, Fo: int, reduce: str) -> bool:
 # gather phase of the one-kernel layer: 0 = library default (streamed), 1 = row-at-a-time
 # (round 2), 2 = streamed; the env switch exists for A/B timing on the device
 SAGE_FUSED_VARIANT = int(os.environ.get('PYGAMD_FUSED_VARIANT', '0'))
+SAGE_FUSED_PROBE = 0  # scripts/fused_probe.py: skip the gather (1) / MFMA (2) loop of the kernel
 
 
 def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Tensor, w: Tensor,
@@ -698,6 +699,7 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
         f.row_scale = row_scale.data_ptr()
         f.y_scaled, f.ldy_scaled = out_scaled.data_ptr(), _ld(out_scaled)
     f.variant = SAGE_FUSED_VARIANT if variant is None else variant
+    f.reserved = SAGE_FUSED_PROBE
     sink = timing_sink
     if sink is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -68,11 +68,15 @@ struct SageFusedArgs {
   const float* __restrict__ row_scale;     // with y2: y2[i, :] = y[i, :] * row_scale[i]
   float* __restrict__ y2;                  // null or a second, row-scaled copy of the output
   int64_t ldy2;
+  int probe;  // timing probes only (scripts/fused_probe.py): bit 0 = skip the gather loop (the
+              // aggregated tile stays undefined), bit 1 = skip the MFMA loop, bits 2-3 = weight
+              // prefetch depth, bit 4 = no weight loads after the first chunks, bit 5 = no LDS
+              // fragment reads after the first chunk.  0 in production.
 };
 
 // ---- phase 2 + epilogue, shared by both kernels: [32 x Fo] = [agg | x_root] @ w^T from the two
 // LDS tiles.  The caller has closed phase 1 with a barrier (both tiles visible to every wave).
-template <typename IdxT>
+template <typename IdxT, int PF>
 __device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
                                                 const float* __restrict__ agg,
                                                 const float* __restrict__ xr, int agg_ld,
@@ -94,7 +98,7 @@ __device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
   const float* __restrict__ wrow = a.w + static_cast<int64_t>(col_ok ? col : a.Fo - 1) * a.ldw;
   const float* agg_row = agg + li * agg_ld + 16 * lh;
   const float* xr_row = xr + li * agg_ld + 16 * lh;
-  f32x4 fb[4], fa[4], nb[4];
+  f32x4 fb[4], fa[4];
   // weight fragments of chunk c: k = (chunk base) + 16 lh + 4 v + e; columns past F are clamped
   // to a valid address here and zeroed right before use
   auto load_b = [&](int c, f32x4 (&dst)[4]) {
@@ -106,19 +110,18 @@ __device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
       dst[v] = *reinterpret_cast<const f32x4*>(wrow + (root ? F : 0) + (k < F ? k : 0));
     }
   };
-  f32x16 acc;
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  load_b(0, nb);
-  for (int c = 0; c < n_chunks; ++c) {
+  for (int e = 0; e < 16; ++e) acc[e] = acc2[e] = 0.f;
+  const bool dual = (a.probe & 128) != 0;  // probe: two independent accumulation chains
+  auto chunk = [&](int c) {  // MFMAs of chunk c with the weight fragments in `fb`
     const bool root = c >= n_half;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) fb[v] = nb[v];
-    if (c + 1 < n_chunks) load_b(c + 1, nb);
     const int base = (root ? c - n_half : c) * kFK;
     const float* ap = (root ? xr_row : agg_row) + base;
+    if (!(a.probe & 32) || c == 0) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) fa[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
+      for (int v = 0; v < 4; ++v) fa[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
+    }
     const int rem = F - base;  // > 0: valid k of this chunk (multiple of 4)
     if (rem < kFK || !col_ok) {  // boundary chunk / padding column: zero B past F (the LDS
       const int kl = base + 16 * lh;  // tiles are zero there already)
@@ -134,12 +137,40 @@ __device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
     for (int v = 0; v < 4; ++v) {
       if (v < groups) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[v][e], fb[v][e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          if (dual && (v & 1)) {
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[v][e], fb[v][e], acc2, 0, 0, 0);
+          } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[v][e], fb[v][e], acc, 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  // weight fragments run PF chunks ahead of the MFMAs through a register ring (the loads share the
+  // CU's vector-memory path with the other workgroup's gather: one chunk of lead is not enough)
+  const int n_run = (a.probe & 2) ? 0 : n_chunks;
+  f32x4 ring[PF][4];
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
+    if (q < n_chunks) load_b(q, ring[q]);
+  for (int c0 = 0; c0 < n_run; c0 += PF) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int c = c0 + q;
+      if (c < n_run) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) fb[v] = ring[q][v];
+        if (c + PF < n_chunks && !(a.probe & 16)) load_b(c + PF, ring[q]);
+        chunk(c);
       }
     }
   }
 
+  if (dual) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
+  }
   // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
   const float bv = (a.bias && col_ok) ? a.bias[col] : 0.f;
   const int64_t rbase = row0 + 4 * lh;
@@ -258,8 +289,8 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArg
     }
   }
   __syncthreads();  // next_row armed
-  for (;;) {  // rows are handed out one by one: long and short rows balance over the 8 waves
-    int r = 0;
+  for (; !(a.probe & 1);) {  // rows are handed out one by one: long and short rows balance over
+    int r = 0;               // the 8 waves
     if (lane == 0) r = atomicAdd(&next_row, 1);
     r = __builtin_amdgcn_readfirstlane(r);
     if (r >= kFTile) break;
@@ -267,7 +298,7 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArg
   }
 
   __syncthreads();  // phase 1 complete: both tiles visible to every wave
-  fused_transform<IdxT>(a, agg, xr, agg_ld, row0, wave, lane);
+  fused_transform<IdxT, 1>(a, agg, xr, agg_ld, row0, wave, lane);
 }
 
 // ---- v2: the gather phase as a software-pipelined stream ------------------------------------------
@@ -392,7 +423,7 @@ __device__ __forceinline__ void stream_gather(const SageFusedArgs<IdxT>& a, floa
   }
 }
 
-template <typename IdxT, int LPR>
+template <typename IdxT, int LPR, int PF>
 __global__ void __launch_bounds__(kFBlock, 4) sage_fused_stream_kernel(SageFusedArgs<IdxT> a) {
   extern __shared__ __align__(16) float smem[];
   const int agg_ld = a.f_pad + 4;
@@ -479,7 +510,8 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_stream_kernel(SageFused
   const int rb = __popcll(__ballot(lane < kFTile && cp_l < t_lo));
   const int re = __popcll(__ballot(lane < kFTile && cp_l < t_hi));
   __syncthreads();  // indices staged
-  if (staged) {
+  if (a.probe & 1) {
+  } else if (staged) {
     stream_gather<IdxT, LPR, true>(a, agg, agg_ld, cidx, rp_l, cp_l, rb, re, lane);
   } else {
     stream_gather<IdxT, LPR, false>(a, agg, agg_ld, cidx, rp_l, cp_l, rb, re, lane);
@@ -497,7 +529,7 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_stream_kernel(SageFused
       }
     }
   }
-  fused_transform<IdxT>(a, agg, xr, agg_ld, row0, wave, lane);
+  fused_transform<IdxT, PF>(a, agg, xr, agg_ld, row0, wave, lane);
 }
 
 static bool aligned16f(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -506,7 +538,13 @@ template <typename IdxT, int LPR>
 static int launch_fused(const SageFusedArgs<IdxT>& a, bool streamed, hipStream_t st) {
   size_t lds = sizeof(float) * 2 * kFTile * (a.f_pad + 4);
   if (streamed) lds += sizeof(int32_t) * kFCap;
-  auto k = streamed ? sage_fused_stream_kernel<IdxT, LPR> : sage_fused_fwd_kernel<IdxT, LPR>;
+  if (a.probe & 64) lds = 100 * 1024;  // timing probe: one workgroup per CU
+  // (probe bits 2-3: weight-prefetch depth of the transform phase, for A/B timing)
+  const int pf = (a.probe >> 2) & 3;
+  auto k = !streamed ? sage_fused_fwd_kernel<IdxT, LPR>
+           : pf == 1 ? sage_fused_stream_kernel<IdxT, LPR, 1>
+           : pf == 3 ? sage_fused_stream_kernel<IdxT, LPR, 3>
+                     : sage_fused_stream_kernel<IdxT, LPR, 2>;
   PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));
@@ -612,6 +650,7 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
     a.row_scale = f->row_scale;
     a.y2 = f->y_scaled;
     a.ldy2 = f->ldy_scaled;
+    a.probe = f->reserved;
     switch (lpr) {
       case 4: return launch_fused<IdxT, 4>(a, streamed, st);
       case 8: return launch_fused<IdxT, 8>(a, streamed, st);

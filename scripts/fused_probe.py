@@ -1,5 +1,7 @@
-"""Times the one-kernel SAGE layer forward (csrc/sage_fused.hip) against the two-launch schedule
-(SpMM + own GEMM) at the ogbn-products shape.  Usage: python scripts/fused_probe.py [--scale s]"""
+"""Times the one-kernel SAGE layer (csrc/sage_fused.hip) at the ogbn-products shape: both gather
+variants, the weight-prefetch depths, and — through the kernel's probe bits — its phases in
+isolation (gather loop skipped / MFMA loop skipped), next to the stand-alone SpMM and GEMM.
+Usage: python scripts/fused_probe.py [--scale s]"""
 import argparse
 import os
 import sys
@@ -13,6 +15,7 @@ from pytorch_geometric_amd.datasets import products_like  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--scale', type=float, default=1.0)
+ap.add_argument('--widths', default='256,100')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 x0, _, ei, _ = products_like(seed=1, scale=args.scale)
@@ -22,8 +25,8 @@ fwd = h.by_dst()
 fwd.hub
 
 
-def timeit(fn, reps=10):
-    for _ in range(3):
+def timeit(fn, reps=8):
+    for _ in range(2):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,7 +39,8 @@ def timeit(fn, reps=10):
 
 
 g = torch.Generator(device=dev).manual_seed(0)
-for F, Fo in ((256, 256), (100, 256)):
+for F in [int(v) for v in args.widths.split(',')]:
+    Fo = 256
     buf = torch.empty(N, 2 * F, device=dev)
     buf[:, F:] = torch.randn(N, F, device=dev, generator=g)
     xsrc = buf[:, F:].contiguous() if F == 100 else buf[:, F:]
@@ -45,17 +49,41 @@ for F, Fo in ((256, 256), (100, 256)):
     out = torch.empty(N, Fo, device=dev)
     ref = torch.empty(N, Fo, device=dev)
 
-    def two():
-        _native.spmm_csr(fwd.ptr, fwd.idx, xsrc, 'mean', n_rows=N, hub=fwd.hub, out=buf[:, :F])
-        _native.linear_forward(buf, w, b, relu=True, out=ref)
-
-    def one():
+    def one(variant, probe=0, save_agg=True):
+        _native.SAGE_FUSED_PROBE = probe
         _native.sage_layer_forward(fwd.ptr, fwd.idx, xsrc, buf[:, F:], w, b, 'mean', True,
-                                   buf[:, :F], out, hub=fwd.hub, save_agg=True)
+                                   buf[:, :F], out, hub=fwd.hub, save_agg=save_agg,
+                                   variant=variant)
+        _native.SAGE_FUSED_PROBE = 0
 
     t_spmm = timeit(lambda: _native.spmm_csr(fwd.ptr, fwd.idx, xsrc, 'mean', n_rows=N,
                                              hub=fwd.hub, out=buf[:, :F]))
-    t2, t1 = timeit(two), timeit(one)
+    t_gemm = timeit(lambda: _native.linear_forward(buf, w, b, relu=True, out=ref))
+    print(f'F={F} Fo={Fo}: SpMM {t_spmm:.3f} ms, GEMM {t_gemm:.3f} ms', flush=True)
+    one(1)
     err = float((out - ref).abs().max() / ref.abs().max())
-    print(f'F={F} Fo={Fo}: SpMM {t_spmm:.3f} ms, SpMM+GEMM {t2:.3f} ms, one kernel {t1:.3f} ms '
-          f'(max rel diff {err:.2e})', flush=True)
+    print(f'  v1 (row-at-a-time)      {timeit(lambda: one(1)):.3f} ms   (max rel diff {err:.1e})',
+          flush=True)
+    for pf in (1, 2, 3):
+        one(2, pf << 2)
+        err = float((out - ref).abs().max() / ref.abs().max())
+        print(f'  v2 (streamed) PF={pf}      {timeit(lambda: one(2, pf << 2)):.3f} ms   '
+              f'(max rel diff {err:.1e})', flush=True)
+    print(f'  v2 PF=2, agg not stored {timeit(lambda: one(2, 8, False)):.3f} ms', flush=True)
+    for variant in (1, 2):
+        print(f'  v{variant}: gather loop skipped {timeit(lambda: one(variant, 8 | 1)):.3f} ms, '
+              f'MFMA loop skipped {timeit(lambda: one(variant, 8 | 2)):.3f} ms, '
+              f'both skipped {timeit(lambda: one(variant, 8 | 3)):.3f} ms', flush=True)
+    for variant in (1, 2):
+        print(f'  v{variant}: no weight loads after the first chunk(s) '
+              f'{timeit(lambda: one(variant, 8 | 16)):.3f} ms, no LDS fragment reads '
+              f'{timeit(lambda: one(variant, 8 | 32)):.3f} ms, neither '
+              f'{timeit(lambda: one(variant, 8 | 48)):.3f} ms; gather skipped + no weight loads '
+              f'{timeit(lambda: one(variant, 8 | 16 | 1)):.3f} ms', flush=True)
+    for variant in (1, 2):
+        print(f'  v{variant}, ONE workgroup per CU: full {timeit(lambda: one(variant, 8 | 64)):.3f} ms, '
+              f'MFMA loop skipped {timeit(lambda: one(variant, 8 | 64 | 2)):.3f} ms, gather skipped '
+              f'{timeit(lambda: one(variant, 8 | 64 | 1)):.3f} ms', flush=True)
+    for variant in (1, 2):
+        print(f'  v{variant}, two accumulation chains: full {timeit(lambda: one(variant, 8 | 128)):.3f} ms, '
+              f'gather skipped {timeit(lambda: one(variant, 8 | 128 | 1)):.3f} ms', flush=True)
