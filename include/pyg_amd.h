@@ -553,9 +553,11 @@ PYGAMD_API int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const fl
  *    by W_l), i.e. pygamd_linear_dgrad + the transposed pygamd_spmm_csr in one pass over the graph.
  *  - y_scaled / row_scale: a second copy y * row_scale[row] of the output (the next such launch
  *    gathers the 1/deg-scaled rows and takes the unscaled ones as its root operand).
- *  - variant: 0 = default (2), 1 = row-at-a-time gather phase (round 2), 2 = streamed gather phase
+ *  - variant: 0 = default (1), 1 = row-at-a-time gather phase (round 2), 2 = streamed gather phase
  *    (column indices of the tile staged in LDS, row loads software-pipelined across rows; needs
- *    n_src < 2^31).  Same results bit for bit.                                                    */
+ *    n_src < 2^31) — 1 and 2 give the same results bit for bit; 3 / 4 = one persistent workgroup
+ *    per CU whose gather waves feed 4 / 8 transform waves through LDS tiles (the two phases overlap
+ *    by construction; sums run root half first: equal to rounding, not bitwise).                  */
 typedef struct pygamd_sage_fused_args {
   const float* x_root;       /* [n_rows, F] root rows                   */
   int64_t ld_root;

@@ -629,8 +629,9 @@ def sage_layer_forward_supported(F: int, Fo: int, reduce: str) -> bool:
     return bool(_lib.load().pygamd_sage_layer_forward_supported(F, Fo, REDUCE_IDS[reduce]))
 
 
-# gather phase of the one-kernel layer: 0 = library default (streamed), 1 = row-at-a-time
-# (round 2), 2 = streamed; the env switch exists for A/B timing on the device
+# schedule of the one-kernel layer: 0 = library default (1), 1 = row-at-a-time gather
+# phase (round 2), 2 = streamed gather phase, 3 / 4 = persistent producer / consumer waves (4 / 8
+# transform waves); the env switch exists for A/B timing on the device
 SAGE_FUSED_VARIANT = int(os.environ.get('PYGAMD_FUSED_VARIANT', '0'))
 SAGE_FUSED_PROBE = 0  # scripts/fused_probe.py: skip the gather (1) / MFMA (2) loop of the kernel
 

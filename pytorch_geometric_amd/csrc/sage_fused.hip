@@ -68,11 +68,57 @@ struct SageFusedArgs {
   const float* __restrict__ row_scale;     // with y2: y2[i, :] = y[i, :] * row_scale[i]
   float* __restrict__ y2;                  // null or a second, row-scaled copy of the output
   int64_t ldy2;
+  int nbuf;   // specialised kernel: aggregated-tile buffers in LDS
   int probe;  // timing probes only (scripts/fused_probe.py): bit 0 = skip the gather loop (the
               // aggregated tile stays undefined), bit 1 = skip the MFMA loop, bits 2-3 = weight
               // prefetch depth, bit 4 = no weight loads after the first chunks, bit 5 = no LDS
               // fragment reads after the first chunk.  0 in production.
 };
+
+// ---- epilogue of one 32 x 32 accumulator: bias, optional ReLU / mask bits, 128-byte row segments
+// to `y` (+ the row-scaled copy, + the [y > 0] bits).  Reg e of lane l is
+// C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31].
+template <typename IdxT>
+__device__ __forceinline__ void fused_epilogue(const SageFusedArgs<IdxT>& a, const f32x16& acc,
+                                               int64_t row0, int wave_col0, int lane) {
+  const int li = lane & 31, lh = lane >> 5;
+  const int col = wave_col0 + li;
+  const bool col_ok = col < a.Fo;
+  const float bv = (a.bias && col_ok) ? a.bias[col] : 0.f;
+  const int64_t rbase = row0 + 4 * lh;
+  float* yp = a.y + rbase * a.ldy + col;
+  float* yp2 = a.y2 ? a.y2 + rbase * a.ldy2 + col : nullptr;
+  // mask word of row (row0 + li) for this 32-column block: one 128-byte line per wave, fetched
+  // before the stores and handed out by ds_bpermute
+  uint32_t mword = 0xffffffffu;
+  if (a.mask_bits && row0 + li < a.g.n_rows)
+    mword = a.mask_bits[((row0 >> 5) * a.ld_mask + (wave_col0 >> 5)) * 32 + li];
+  uint32_t my_word = 0;  // lane e < 16: row (e & 3) + 8 (e >> 2); lane 16 + e: that row + 4
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int roff = (e & 3) + 8 * (e >> 2);
+    float v = acc[e] + bv;
+    if (a.relu) v = (v > 0.f || v != v) ? v : 0.f;  // NaN propagates like torch.relu
+    if (a.mask_bits) {  // uniform
+      const uint32_t mw = __shfl(mword, roff + 4 * lh, kWave);
+      v = ((mw >> li) & 1u) ? v : 0.f;
+    }
+    const bool ok = col_ok && rbase + roff < a.g.n_rows;
+    if (ok) yp[roff * a.ldy] = v;
+    if (yp2 && ok) yp2[roff * a.ldy2] = v * a.row_scale[rbase + roff];
+    if (a.bits) {  // uniform.  One ballot = this 32-column block of two rows (lane halves)
+      const uint64_t m = __ballot(col_ok && v > 0.f);
+      if (lane == e) my_word = static_cast<uint32_t>(m);
+      if (lane == 16 + e) my_word = static_cast<uint32_t>(m >> 32);
+    }
+  }
+  if (a.bits && lane < 32) {  // the tile's 32 words of this column block: one 128-byte line
+    const int e = lane & 15;
+    const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 4);
+    if (row0 + r < a.g.n_rows)
+      a.bits[((row0 >> 5) * a.ld_bits + (wave_col0 >> 5)) * 32 + r] = my_word;
+  }
+}
 
 // ---- phase 2 + epilogue, shared by both kernels: [32 x Fo] = [agg | x_root] @ w^T from the two
 // LDS tiles.  The caller has closed phase 1 with a barrier (both tiles visible to every wave).
@@ -171,41 +217,7 @@ __device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
   }
-  // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
-  const float bv = (a.bias && col_ok) ? a.bias[col] : 0.f;
-  const int64_t rbase = row0 + 4 * lh;
-  float* yp = a.y + rbase * a.ldy + col;
-  float* yp2 = a.y2 ? a.y2 + rbase * a.ldy2 + col : nullptr;
-  // mask word of row (row0 + li) for this 32-column block: one 128-byte line per wave, fetched
-  // before the stores and handed out by ds_bpermute
-  uint32_t mword = 0xffffffffu;
-  if (a.mask_bits && row0 + li < a.g.n_rows)
-    mword = a.mask_bits[((row0 >> 5) * a.ld_mask + (wave_col0 >> 5)) * 32 + li];
-  uint32_t my_word = 0;  // lane e < 16: row (e & 3) + 8 (e >> 2); lane 16 + e: that row + 4
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int roff = (e & 3) + 8 * (e >> 2);
-    float v = acc[e] + bv;
-    if (a.relu) v = (v > 0.f || v != v) ? v : 0.f;  // NaN propagates like torch.relu
-    if (a.mask_bits) {  // uniform
-      const uint32_t mw = __shfl(mword, roff + 4 * lh, kWave);
-      v = ((mw >> li) & 1u) ? v : 0.f;
-    }
-    const bool ok = col_ok && rbase + roff < a.g.n_rows;
-    if (ok) yp[roff * a.ldy] = v;
-    if (yp2 && ok) yp2[roff * a.ldy2] = v * a.row_scale[rbase + roff];
-    if (a.bits) {  // uniform.  One ballot = this 32-column block of two rows (lane halves)
-      const uint64_t m = __ballot(col_ok && v > 0.f);
-      if (lane == e) my_word = static_cast<uint32_t>(m);
-      if (lane == 16 + e) my_word = static_cast<uint32_t>(m >> 32);
-    }
-  }
-  if (a.bits && lane < 32) {  // the tile's 32 words of this column block: one 128-byte line
-    const int e = lane & 15;
-    const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 4);
-    if (row0 + r < a.g.n_rows)
-      a.bits[((row0 >> 5) * a.ld_bits + (wave_col0 >> 5)) * 32 + r] = my_word;
-  }
+  fused_epilogue<IdxT>(a, acc, row0, wave_col0, lane);
 }
 
 // aggregated row -> LDS tile (+ global agg buffer); lanes < LPR hold VW features per CH
@@ -532,6 +544,300 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_stream_kernel(SageFused
   fused_transform<IdxT, PF>(a, agg, xr, agg_ld, row0, wave, lane);
 }
 
+// ---- v3: producer / consumer waves, persistent workgroup ------------------------------------------
+// In the two kernels above a workgroup alternates between its HBM-bound phase and its MFMA-bound
+// phase, and whether the two phases of DIFFERENT workgroups overlap on a CU is left to chance: at
+// the products shape the layer runs 14.1 ms against 11.8 ms with the MFMA loop skipped and 6.4 ms
+// with the gather skipped (scripts/fused_probe.py, profiles/r03_fused_phase_probe.txt).  Here the
+// overlap holds by construction.  ONE workgroup of 16 waves per CU walks tiles b, b + G, b + 2G...:
+//   waves [0, NG)        GATHER.  They draw destination rows one by one from an LDS ticket counter
+//                        that runs ACROSS tile boundaries (row ticket t = tile t / 32 of this
+//                        workgroup, row t % 32), aggregate each with the SpMM's row loop into one of
+//                        `nbuf` LDS tiles, and count the finished row on that tile's `done` counter.
+//                        No barrier, nothing drains between tiles; a wave only waits (s_sleep poll)
+//                        when the tile `nbuf` tiles back has not been consumed yet.
+//   waves [NG, 16)       TRANSFORM (one per SIMD with NM = 4).  Per tile: the root half of K first —
+//                        A fragments straight from global memory (the tile's own rows, one 128-byte
+//                        line per row and chunk), no dependence on the gather — then wait for
+//                        done == 32 * (use + 1), the aggregated half with A from the LDS tile,
+//                        release the tile (`free` counter), epilogue.  Fragments run through a
+//                        register ring D half-chunks ahead of the MFMAs.
+// The MFMA waves need about a third of a tile's gather time, so the gather waves set the pace:
+// the layer costs what its aggregation costs.  Sums run root half first, so results equal the
+// two-launch path to rounding (not bitwise like v1 / v2).
+constexpr int kSBlock = 1024;
+constexpr int kSWaves = kSBlock / kWave;
+
+__device__ __forceinline__ int lds_counter_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// every earlier LDS access of this wave is complete before the counter moves (the LDS queue is in
+// order per CU; the wait is on lgkmcnt only — a workgroup release fence would also wait for the
+// gather's global loads and stores).
+// The add is executed by ALL lanes without a branch: lane 0 targets the counter, lane l > 0 its own
+// word of `sink`.  With `if (lane == 0)` around the atomics, hipcc threads the branch at the end of
+// one loop iteration into the identical branch at the head of the next (ticket draw), and the
+// readfirstlane between them ends up evaluated by lanes 1..63 alone on their constant 0: those
+// lanes then spin on ticket 0 forever (seen on the device: the kernel never ended).
+__device__ __forceinline__ int lds_counter_add(int* p, int* sink, int lane) {
+  int* q = lane == 0 ? p : sink + lane;
+  return __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_counter_signal(int* p, int* sink, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  lds_counter_add(p, sink, lane);
+}
+// A poll that never succeeds would hang the GPU: after ~2 s of polling the workgroup gives up (every
+// later wait of the workgroup returns at once; its results are then wrong, which the callers' tests
+// catch — the protocol has no cycle, see the kernel's comment, so this is a guard, not a path).
+constexpr int kSpinLimit = 1 << 24;
+__device__ __forceinline__ void lds_counter_wait(const int* p, int target, int* abort_flag) {
+  int spins = 0;
+  while (lds_counter_load(p) < target) {
+    if (lds_counter_load(abort_flag) != 0) break;
+    if (++spins > kSpinLimit) {
+      __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  asm volatile("" ::: "memory");
+}
+
+// one half of K for NB 32-column blocks: ROOT = A from global rows (row clamped by the caller),
+// otherwise from the LDS tile.  `wait_p` (aggregated half): polled after the weight prefetch and
+// before the first LDS read.  A step = one 16-byte fragment group v of a chunk (k = 32 c + 16 lh +
+// 4 v + e: 4 MFMAs per column block); the fragments of the F / 32 full chunks run through a
+// register ring four steps ahead of the MFMAs in a loop WITHOUT branches (hipcc's s_waitcnt
+// bookkeeping is exact only then: with a conditional load anywhere in the loop it waits for
+// vmcnt(0) before every MFMA group); a partial last chunk (F % 32) is done after the loop.
+template <typename IdxT, int NB, bool ROOT>
+__device__ __forceinline__ void spec_half(const SageFusedArgs<IdxT>& a, const float* a_row,
+                                          const float* const (&wrow)[NB],
+                                          const bool (&col_ok)[NB], int lh,
+                                          const int* wait_p, int wait_target, int* abort_flag,
+                                          f32x16 (&acc)[NB]) {
+  constexpr int D = 4;
+  const int F = static_cast<int>(a.g.F);
+  const int n_steps = 4 * (F / kFK);  // steps of the full chunks
+  const float* wp[NB];
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) wp[blk] = wrow[blk] + (ROOT ? F : 0) + 16 * lh;
+  const float* ap = a_row + 16 * lh;
+  auto off_of = [&](int s) { return (s >> 2) * kFK + 4 * (s & 3); };
+  auto mfmas = [&](const f32x4& av, const f32x4 (&bv)[NB]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+        acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], col_ok[blk] ? bv[blk][e] : 0.f,
+                                                        acc[blk], 0, 0, 0);
+    }
+  };
+  if (n_steps > 0) {
+    f32x4 ra[D], rb[D][NB];
+    const int last = n_steps - 1;
+    // (prologue in the loop's issue order — weights, then A, step by step: with any other order
+    // the s_waitcnt pass merges the two histories at the loop head into vmcnt(0))
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+        rb[q][blk] = *reinterpret_cast<const f32x4*>(wp[blk] + off_of(q));
+      if constexpr (ROOT) {
+        ra[q] = *reinterpret_cast<const f32x4*>(ap + off_of(q));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (!ROOT) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (wait_p) lds_counter_wait(wait_p, wait_target, abort_flag);
+#pragma unroll
+      for (int q = 0; q < D; ++q) ra[q] = *reinterpret_cast<const f32x4*>(ap + off_of(q));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int s0 = 0; s0 < n_steps; s0 += D) {  // n_steps is a multiple of D = 4
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        mfmas(ra[q], rb[q]);
+        int sn = s0 + q + D;  // past the end: the last step again (never used)
+        sn = sn < last ? sn : last;
+        const int off = off_of(sn);
+        // (timing probes: bit 5 = every weight fragment from one hot address, bit 6 = every root
+        // fragment from one hot address — same instruction stream, no memory latency)
+        const int off_b = (a.probe & 32) ? 0 : off;
+        const int off_a = (ROOT && (a.probe & 64)) ? 0 : off;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+          rb[q][blk] = *reinterpret_cast<const f32x4*>(wp[blk] + off_b);
+        ra[q] = *reinterpret_cast<const f32x4*>(ap + off_a);
+        // the loads of a step stay behind its MFMAs and ahead of the next step's (the scheduler
+        // otherwise sinks every load down to its use and waits for it there)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else if (wait_p) {
+    lds_counter_wait(wait_p, wait_target, abort_flag);
+  }
+  const int rem = F % kFK;  // partial chunk: k = base + 16 lh + 4 v + e < F (rem is a multiple of 4)
+  if (rem > 0) {
+    const int base = F - rem;
+    const int groups = rem >= 16 ? 4 : rem / 4;  // groups whose lower lane half carries data
+    for (int v = 0; v < groups; ++v) {
+      const int kk = base + 16 * lh + 4 * v;
+      const bool ok = kk < F;  // whole 16-byte group valid or not
+      const int kc = ok ? kk : 0;
+      f32x4 av, bv[NB];
+      if constexpr (ROOT) {
+        av = *reinterpret_cast<const f32x4*>(a_row + kc);
+      } else {
+        av = *reinterpret_cast<const f32x4*>(a_row + kk);  // LDS tile: zero past F
+      }
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        bv[blk] = *reinterpret_cast<const f32x4*>(wrow[blk] + (ROOT ? F : 0) + kc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[blk][e] = ok ? bv[blk][e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) av[e] = ok ? av[e] : 0.f;
+      mfmas(av, bv);
+    }
+  }
+}
+
+template <typename IdxT, int LPR, int NM>
+__global__ void __launch_bounds__(kSBlock) sage_fused_spec_kernel(SageFusedArgs<IdxT> a) {
+  constexpr int NG = kSWaves - NM;        // gather waves
+  constexpr int NB = (kFMaxFo / 32) / NM;  // 32-column blocks per transform wave
+  constexpr int kMaxBuf = 8;
+  extern __shared__ __align__(16) float smem[];
+  __shared__ int ticket;
+  __shared__ int done_cnt[kMaxBuf];  // rows finished, summed over the uses of the buffer
+  __shared__ int free_cnt[kMaxBuf];  // transform waves finished with it, summed over the uses
+  __shared__ int abort_flag;
+  __shared__ int sink[kWave];        // where the lanes > 0 of a counter update add
+  __shared__ int simd_cnt[4];        // waves of this workgroup per SIMD
+  const int agg_ld = a.f_pad + 4;
+  const int tile_floats = kFTile * agg_ld;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int F = static_cast<int>(a.g.F);
+  const int nbuf = a.nbuf;
+  const int64_t tiles = (a.g.n_rows + kFTile - 1) / kFTile;
+  const int64_t G = gridDim.x;
+
+  if (threadIdx.x == 0) ticket = abort_flag = 0;
+  if (threadIdx.x < kMaxBuf) done_cnt[threadIdx.x] = free_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 4) simd_cnt[threadIdx.x] = 0;
+  if (a.f_pad > F) {  // padding columns [F, f_pad) of every buffer are zeroed once
+    const int padw = a.f_pad - F;
+    for (int t = threadIdx.x; t < nbuf * kFTile * padw; t += kSBlock) {
+      const int r = t / padw;
+      smem[r * agg_ld + F + (t - r * padw)] = 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- roles.  The transform waves must sit on DIFFERENT SIMDs (each SIMD has its own MFMA pipe):
+  // which SIMD a wave of the workgroup lands on is the dispatcher's choice, so every wave reads its
+  // SIMD id (HW_REG_HW_ID bits [5:4]) and the first NM / 4 waves to register on each SIMD become
+  // the transform waves; if a SIMD holds fewer waves of this workgroup than that, the last NM
+  // waves do (correct either way).
+  constexpr int MPS = NM / 4;
+  const int simd = static_cast<int>(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4));
+  const int rank = __builtin_amdgcn_readfirstlane(lds_counter_add(&simd_cnt[simd], sink, lane));
+  __syncthreads();  // the last barrier of the kernel
+  const bool spread = simd_cnt[0] >= MPS && simd_cnt[1] >= MPS && simd_cnt[2] >= MPS &&
+                      simd_cnt[3] >= MPS && !(a.probe & 16);  // (probe: static roles)
+  int m = -1;  // transform wave index, -1 = gather wave
+  if (spread) {
+    if (rank < MPS) m = simd * MPS + rank;
+  } else if (wave >= NG) {
+    m = wave - NG;
+  }
+  m = __builtin_amdgcn_readfirstlane(m);
+
+  if (m < 0) {
+    // ---- gather waves
+    for (;;) {
+      const int t = __builtin_amdgcn_readfirstlane(lds_counter_add(&ticket, sink, lane));
+      const int lt = t >> 5, r = t & 31;
+      const int64_t tile = blockIdx.x + lt * G;
+      if (tile >= tiles) break;
+      const int b = lt % nbuf, use = lt / nbuf;
+      if (use > 0) lds_counter_wait(&free_cnt[b], NM * use, &abort_flag);
+      if (!(a.probe & 1))
+        fused_gather_row<IdxT, 4, LPR>(a, tile * kFTile + r, smem + b * tile_floats + r * agg_ld,
+                                       lane);
+      lds_counter_signal(&done_cnt[b], sink, lane);
+    }
+    return;
+  }
+
+  // ---- transform waves
+  const int li = lane & 31, lh = lane >> 5;
+  const float* wrow[NB];
+  bool col_ok[NB];
+  bool any_col = false;
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const int col = (m * NB + blk) * 32 + li;
+    col_ok[blk] = col < a.Fo;
+    any_col = any_col || (m * NB + blk) * 32 < a.Fo;
+    wrow[blk] = a.w + static_cast<int64_t>(col_ok[blk] ? col : a.Fo - 1) * a.ldw;
+  }
+  for (int lt = 0;; ++lt) {
+    const int64_t tile = blockIdx.x + lt * G;
+    if (tile >= tiles) break;
+    const int b = lt % nbuf, use = lt / nbuf;
+    const int64_t row0 = tile * kFTile;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[blk][e] = 0.f;
+    if (any_col && !(a.probe & 2)) {
+      int64_t rr = row0 + li;
+      rr = rr < a.g.n_rows ? rr : a.g.n_rows - 1;
+      spec_half<IdxT, NB, true>(a, a.x_root + rr * a.ld_root, wrow, col_ok, lh, nullptr, 0,
+                                &abort_flag, acc);
+      spec_half<IdxT, NB, false>(a, smem + b * tile_floats + li * agg_ld, wrow, col_ok, lh,
+                                 &done_cnt[b], kFTile * (use + 1), &abort_flag, acc);
+    } else {
+      lds_counter_wait(&done_cnt[b], kFTile * (use + 1), &abort_flag);
+    }
+    lds_counter_signal(&free_cnt[b], sink, lane);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      const int col0 = (m * NB + blk) * 32;
+      if (col0 < a.Fo && !(a.probe & 128)) fused_epilogue<IdxT>(a, acc[blk], row0, col0, lane);
+    }
+  }
+}
+
+template <typename IdxT, int LPR>
+static int launch_spec(SageFusedArgs<IdxT> a, int nm, hipStream_t st) {
+  int dev = 0, cus = 0;
+  PYGAMD_HIP_CHECK(hipGetDevice(&dev));
+  PYGAMD_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const size_t tile_bytes = sizeof(float) * kFTile * (a.f_pad + 4);
+  int nbuf = static_cast<int>((150 * 1024) / tile_bytes);
+  nbuf = nbuf > 6 ? 6 : nbuf;
+  const int forced = (a.probe >> 8) & 7;  // timing probe: buffer count
+  if (forced >= 2 && forced <= nbuf) nbuf = forced;
+  a.nbuf = nbuf;
+  const size_t lds = tile_bytes * nbuf;
+  auto k = nm == 8 ? sage_fused_spec_kernel<IdxT, LPR, 8> : sage_fused_spec_kernel<IdxT, LPR, 4>;
+  PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+  const int64_t tiles = ceil_div(a.g.n_rows, kFTile);
+  const unsigned grid = static_cast<unsigned>(tiles < cus ? tiles : cus);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kSBlock), lds, st, a);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
+
 static bool aligned16f(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename IdxT, int LPR>
@@ -584,7 +890,7 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
   if (f->relu_bits_out && (!f->relu || f->ld_bits_out < words)) return PYGAMD_ERR_INVALID_ARG;
   if (f->mask_bits && f->ld_mask_bits < words) return PYGAMD_ERR_INVALID_ARG;
   if (f->y_scaled && (!f->row_scale || f->ldy_scaled < Fo)) return PYGAMD_ERR_INVALID_ARG;
-  if (f->variant < 0 || f->variant > 2) return PYGAMD_ERR_INVALID_ARG;
+  if (f->variant < 0 || f->variant > 4) return PYGAMD_ERR_INVALID_ARG;
   if (graph->n_rows == 0) return PYGAMD_OK;
   if (!graph->rowptr || !graph->x || !graph->out || !f->x_root || !f->w || !f->y)
     return PYGAMD_ERR_INVALID_ARG;
@@ -604,8 +910,12 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
     const int rc = pygamd_spmm_csr(&hubs, workspace, workspace_bytes, stream);
     if (rc != PYGAMD_OK) return rc;
   }
-  // the streamed gather keeps column indices as int32 in LDS
-  const bool streamed = f->variant != 1 && graph->n_src < (static_cast<int64_t>(1) << 31);
+  // default = row-at-a-time (measured fastest at the products shape: 53.8 ms/step against 55.1
+  // streamed and 61.6 / 66.8 with the producer / consumer kernels); the streamed gather keeps
+  // column indices as int32 in LDS
+  const bool streamed = f->variant == 2 && graph->n_src < (static_cast<int64_t>(1) << 31);
+  // producer / consumer waves: 3 = four transform waves of 64 columns, 4 = eight of 32
+  const int spec_nm = f->variant == 3 ? 4 : f->variant == 4 ? 8 : 0;
   int lpr = 4;
   while (lpr < 64 && lpr * 4 < F) lpr <<= 1;
   return PYGAMD_DISPATCH_IDX(graph->idx_dtype, [&]() -> int {
@@ -651,6 +961,16 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
     a.y2 = f->y_scaled;
     a.ldy2 = f->ldy_scaled;
     a.probe = f->reserved;
+    a.nbuf = 0;
+    if (spec_nm) {
+      switch (lpr) {
+        case 4: return launch_spec<IdxT, 4>(a, spec_nm, st);
+        case 8: return launch_spec<IdxT, 8>(a, spec_nm, st);
+        case 16: return launch_spec<IdxT, 16>(a, spec_nm, st);
+        case 32: return launch_spec<IdxT, 32>(a, spec_nm, st);
+        default: return launch_spec<IdxT, 64>(a, spec_nm, st);
+      }
+    }
     switch (lpr) {
       case 4: return launch_fused<IdxT, 4>(a, streamed, st);
       case 8: return launch_fused<IdxT, 8>(a, streamed, st);

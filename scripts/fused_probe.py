@@ -16,6 +16,7 @@ from pytorch_geometric_amd.datasets import products_like  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--scale', type=float, default=1.0)
 ap.add_argument('--widths', default='256,100')
+ap.add_argument('--only-spec', action='store_true', help='only the producer/consumer variants')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 x0, _, ei, _ = products_like(seed=1, scale=args.scale)
@@ -60,6 +61,26 @@ for F in [int(v) for v in args.widths.split(',')]:
                                              hub=fwd.hub, out=buf[:, :F]))
     t_gemm = timeit(lambda: _native.linear_forward(buf, w, b, relu=True, out=ref))
     print(f'F={F} Fo={Fo}: SpMM {t_spmm:.3f} ms, GEMM {t_gemm:.3f} ms', flush=True)
+    for variant in (3, 4):
+        out.fill_(float('nan'))
+        one(variant)
+        err = float((out - ref).abs().max() / ref.abs().max())
+        print(f'  v{variant} (producer/consumer, {4 if variant == 3 else 8} transform waves) '
+              f'{timeit(lambda: one(variant)):.3f} ms   (max rel diff {err:.1e}); '
+              f'agg not stored {timeit(lambda: one(variant, 0, False)):.3f} ms; '
+              f'gather skipped {timeit(lambda: one(variant, 1)):.3f} ms, MFMA skipped '
+              f'{timeit(lambda: one(variant, 2)):.3f} ms, both {timeit(lambda: one(variant, 3)):.3f} ms; '
+              f'2 buffers {timeit(lambda: one(variant, 2 << 8)):.3f} ms, 3 buffers '
+              f'{timeit(lambda: one(variant, 3 << 8)):.3f} ms; static roles '
+              f'{timeit(lambda: one(variant, 16)):.3f} ms, gather skipped '
+              f'{timeit(lambda: one(variant, 17)):.3f} ms', flush=True)
+        print(f'     hot-address probes: weights {timeit(lambda: one(variant, 32)):.3f} ms, root '
+              f'{timeit(lambda: one(variant, 64)):.3f} ms, both {timeit(lambda: one(variant, 96)):.3f} ms, '
+              f'no epilogue {timeit(lambda: one(variant, 128)):.3f} ms, all three '
+              f'{timeit(lambda: one(variant, 224)):.3f} ms; gather skipped + all three '
+              f'{timeit(lambda: one(variant, 225)):.3f} ms', flush=True)
+    if args.only_spec:
+        continue
     one(1)
     err = float((out - ref).abs().max() / ref.abs().max())
     print(f'  v1 (row-at-a-time)      {timeit(lambda: one(1)):.3f} ms   (max rel diff {err:.1e})',

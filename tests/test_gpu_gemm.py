@@ -162,7 +162,8 @@ def test_wgrad_long_reduction_is_deterministic_and_accurate(dev):
 @pytest.mark.parametrize('F,Fo,reduce', [(256, 256, 'mean'), (100, 256, 'mean'), (64, 200, 'sum'),
                                          (8, 47, 'mean'), (128, 32, 'sum')])
 @pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
-@pytest.mark.parametrize('variant', [1, 2])  # row-at-a-time / streamed gather phase
+@pytest.mark.parametrize('variant', [1, 2, 3, 4])  # row-at-a-time / streamed gather phase /
+# producer-consumer waves with 4 or 8 transform waves
 def test_sage_layer_forward_one_kernel(dev, F, Fo, reduce, dtype, variant):
     """csrc/sage_fused.hip: aggregation + transform + bias + ReLU of a SAGEConv layer in one
     kernel against the oracle's sage_conv (index_select + scatter + two matmuls), with hub rows,
@@ -260,7 +261,7 @@ def test_sage_layer_streamed_gather_is_bitwise_the_spmm(dev, F, Fo):
 
 @pytest.mark.parametrize('Fi,Fo', [(256, 256), (64, 128), (100, 40)])
 @pytest.mark.parametrize('reduce', ['mean', 'sum'])
-@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4])
 def test_sage_layer_input_gradient_one_kernel(dev, Fi, Fo, reduce, variant):
     """pygamd_sage_layer_fused as a layer's INPUT GRADIENT: on the transposed graph, with the
     1/deg-scaled gradient rows gathered, the unscaled ones as root operand, w = [W_l^T | W_r^T] and
