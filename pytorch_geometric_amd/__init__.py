@@ -34,6 +34,15 @@ def get_gemm_mode() -> str:
     return _native.get_gemm_mode()
 
 
+def check_index_errors() -> None:
+    """Scatter kernels skip indices outside ``[0, dim_size)`` and flag them; the flag reaches the
+    host asynchronously (``PYGAMD_CHECK_INDEX``: ``async`` default | ``sync`` | ``off``).  This
+    waits for every scatter launched so far and raises ``IndexError`` if one was flagged — the
+    counterpart of synchronising after a device-side assert in the reference's GPU path."""
+    from . import _native
+    _native.check_index_errors()
+
+
 def build(force: bool = False) -> str:
     """Compile the HIP sources for gfx950 into ``lib/libpyg_amd.so`` (in-tree)."""
     return _build.build_library(force=force)
@@ -41,4 +50,4 @@ def build(force: bool = False) -> str:
 
 __all__ = ['EdgeIndex', 'as_edge_index', 'clear_cache', 'set_cache_enabled', 'index2ptr',
            'ptr2index', 'utils', 'nn', 'build', 'load_library', 'lib_path', 'PygAmdError',
-           'set_gemm_mode', 'get_gemm_mode']
+           'set_gemm_mode', 'get_gemm_mode', 'check_index_errors']

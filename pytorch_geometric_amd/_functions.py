@@ -5,6 +5,7 @@ from typing import Optional
 import torch
 from torch import Tensor
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 import math
 
@@ -60,7 +61,11 @@ class SpmmFunction(Function):
             else:
                 out, arg32 = _native.spmm_csr(fwd.ptr, fwd.idx, x2, reduce, n_rows=fwd.n_rows,
                                               hub=fwd.hub), None
-            ctx.save_for_backward(x2, out, arg32)
+            # (the RETURNED tensor is saved, not its 2-D alias: autograd's version check then sees an
+            # in-place edit of the result between forward and backward)
+            res = _shaped(out, (fwd.n_rows, *x.shape[1:]))
+            ctx.save_for_backward(x2, res, arg32)
+            return res
         else:
             eid = fwd.perm if (w is not None and w_order == 'coo') else None
             out = _native.spmm_csr(fwd.ptr, fwd.idx, x2, reduce, n_rows=fwd.n_rows, eid=eid, w=w,
@@ -76,6 +81,7 @@ class SpmmFunction(Function):
         grad_x = grad_w = None
         if reduce in ('min', 'max'):
             x2, out, arg32 = ctx.saved_tensors
+            out = _rows(out)
             if ctx.needs_input_grad[0]:
                 fwd = graph.by_dst()
                 if torch.are_deterministic_algorithms_enabled():
@@ -148,12 +154,13 @@ class ScatterFunction(Function):
         if reduce == 'mean':
             out, count = _native.scatter_rows(s2, index, dim_size, reduce, return_count=True)
             ctx.save_for_backward(index, count)
-        elif reduce in ('min', 'max'):
-            out = _native.scatter_rows(s2, index, dim_size, reduce)
-            ctx.save_for_backward(index, s2, out)
-        elif reduce == 'mul':
-            out = _native.scatter_rows(s2, index, dim_size, reduce)
-            ctx.save_for_backward(index, s2, out)
+        elif reduce in ('min', 'max', 'mul'):
+            # the RETURNED tensor is what the backward compares against: saving it (not its 2-D
+            # alias) lets autograd detect an in-place edit of the result
+            res = _shaped(_native.scatter_rows(s2, index, dim_size, reduce),
+                          (dim_size, *src.shape[1:]))
+            ctx.save_for_backward(index, s2, res)
+            return res
         else:
             out = _native.scatter_rows(s2, index, dim_size, reduce)
             ctx.save_for_backward(index)
@@ -171,13 +178,13 @@ class ScatterFunction(Function):
             grad = _native.gather_rows(g2 / count.clamp(min=1).view(-1, 1), index)
         elif reduce in ('min', 'max'):
             index, s2, out = ctx.saved_tensors
-            grad = _native.scatter_minmax_backward(s2, index, out, g2)
+            grad = _native.scatter_minmax_backward(s2, index, _rows(out), g2)
         elif reduce == 'mul':
             # ATen's scatter_reduce 'prod' backward incl. its zero-count rule (one zero in the
             # group: that element gets g * prod(others); two or more: all 0) — g * out / src alone
             # would be NaN there
             index, s2, out = ctx.saved_tensors
-            grad = _native.scatter_mul_backward(s2, index, out, g2)
+            grad = _native.scatter_mul_backward(s2, index, _rows(out), g2)
         else:
             raise NotImplementedError(f"backward of scatter(reduce='{reduce}') is undefined")
         return grad.view(ctx.src_shape), None, None, None
@@ -230,11 +237,12 @@ class SegmentFunction(Function):
         n_seg = ptr.numel() - 1
         out = _native.spmm_csr(ptr, None, s2, reduce, n_rows=n_seg)
         ctx.reduce, ctx.src_shape = reduce, src.shape
+        res = _shaped(out, (n_seg, *src.shape[1:]))
         if reduce in ('min', 'max'):
-            ctx.save_for_backward(ptr, s2, out)
+            ctx.save_for_backward(ptr, s2, res)
         else:
             ctx.save_for_backward(ptr)
-        return _shaped(out, (n_seg, *src.shape[1:]))
+        return res
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
@@ -243,6 +251,7 @@ class SegmentFunction(Function):
         n = ctx.src_shape[0]
         if reduce in ('min', 'max'):
             ptr, s2, out = ctx.saved_tensors
+            out = _rows(out)
             ntie = _native.spmm_tie_count(ptr, None, s2, out, count_self=False)
             index = _native.ptr2index(ptr, n)
             # each row belongs to exactly one segment: grad = [src == out[seg]] * g[seg] / ntie[seg]
@@ -270,14 +279,15 @@ class SegmentSoftmaxFunction(Function):
     @staticmethod
     def forward(ctx, src: Tensor, ptr: Tensor):
         s2 = _rows(src)
-        out = _native.segment_softmax_forward(s2, ptr)
-        ctx.save_for_backward(out, ptr)
+        res = _shaped(_native.segment_softmax_forward(s2, ptr), src.shape)
+        ctx.save_for_backward(res, ptr)
         ctx.src_shape = src.shape
-        return _shaped(out, src.shape)
+        return res
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         out, ptr = ctx.saved_tensors
+        out = _rows(out)
         g = _native.segment_softmax_backward(out, grad_out.reshape(out.shape), ptr)
         return g.view(ctx.src_shape), None
 
@@ -289,15 +299,16 @@ class SegmentLogSumExpFunction(Function):
     @staticmethod
     def forward(ctx, src: Tensor, ptr: Tensor):
         s2 = _rows(src)
-        out = _native.segment_logsumexp_forward(s2, ptr)
-        ctx.save_for_backward(s2, out, ptr)
+        res = _shaped(_native.segment_logsumexp_forward(s2, ptr),
+                      (ptr.numel() - 1, *src.shape[1:]))
+        ctx.save_for_backward(s2, res, ptr)
         ctx.src_shape = src.shape
-        return _shaped(out, (ptr.numel() - 1, *src.shape[1:]))
+        return res
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         s2, out, ptr = ctx.saved_tensors
-        g = _native.segment_logsumexp_backward(s2, out, _rows(grad_out), ptr)
+        g = _native.segment_logsumexp_backward(s2, _rows(out), _rows(grad_out), ptr)
         return g.view(ctx.src_shape), None
 
 
@@ -368,7 +379,8 @@ class LinearFunction(Function):
         return _shaped(out, (*x.shape[:-1], weight.size(0)))
 
     @staticmethod
-    def backward(ctx, grad_out: Tensor):
+    @once_differentiable  # the kernels record no graph: create_graph=True raises instead of
+    def backward(ctx, grad_out: Tensor):  # silently dropping the second derivative
         x2, weight = ctx.saved_tensors
         g2 = grad_out.reshape(-1, grad_out.size(-1))
         gx = gw = gb = None

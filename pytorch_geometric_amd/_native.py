@@ -4,6 +4,7 @@ allocator, pass raw device pointers + the current HIP stream.  No arithmetic hap
 PyTorch is plumbing only (device memory, streams).  Every function requires HIP device tensors
 and raises otherwise — there is no CPU fallback.
 """
+import collections
 import ctypes
 import os
 from typing import Optional, Tuple
@@ -390,16 +391,94 @@ class IndexOutOfRange(PygAmdError, IndexError):
     kernels raise 'index ... is out of bounds' at the same place)."""
 
 
+# How the error flag of the scatter kernels reaches the host:
+#   'async' (default)  the flag is copied to pinned host memory behind the kernel and looked at —
+#                      without waiting — at the next scatter call or by `check_index_errors()`
+#                      (the reference's GPU path reports such indices as an asynchronous device
+#                      assert too; a per-call blocking read would serialise host and device on
+#                      every scatter / degree / aggregation forward);
+#   'sync'             one blocking 4-byte read per call (raises at the call site);
+#   'off'              the kernels still skip such rows, nothing is reported.
+INDEX_CHECK = os.environ.get('PYGAMD_CHECK_INDEX', 'async')
+
+
+class _FlagRing:
+    """256 device flags + their pinned host mirrors, handed out round-robin per device."""
+    SLOTS = 256
+
+    def __init__(self, device):
+        self.dev = torch.zeros(self.SLOTS, dtype=torch.int32, device=device)
+        self.host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+        self.next = 0
+        self.pending = collections.deque()  # (slot, event, what, size, index, style)
+
+    def acquire(self) -> int:
+        slot = self.next
+        self.next = (self.next + 1) % self.SLOTS
+        while self.pending and self.pending[0][0] == slot:  # the ring wrapped: wait for the oldest
+            self.pending[0][1].synchronize()
+            self.poll()
+        return slot
+
+    def publish(self, slot: int, what: str, size: int, index: Tensor):
+        self.host[slot:slot + 1].copy_(self.dev[slot:slot + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev.device))
+        self.pending.append((slot, ev, what, size, index, error_style))
+
+    def poll(self, wait: bool = False):
+        while self.pending:
+            slot, ev, what, size, index, style = self.pending[0]
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            self.pending.popleft()
+            if int(self.host[slot]) != 0:
+                self.host[slot] = 0
+                self.dev[slot:slot + 1].zero_()
+                _raise_out_of_range(index, size, what, style)
+
+
+_flag_rings = {}
+
+
+def _flag_ring(device) -> _FlagRing:
+    ring = _flag_rings.get(device)
+    if ring is None:
+        ring = _flag_rings[device] = _FlagRing(device)
+    return ring
+
+
+def check_index_errors():
+    """Waits for every scatter launched so far (on any device) and raises `IndexOutOfRange` if one
+    of them met an index outside ``[0, dim_size)`` (see ``INDEX_CHECK``)."""
+    for ring in list(_flag_rings.values()):
+        ring.poll(wait=True)
+
+
+# 'dim_size' while an `Aggregation.__call__` is running: a flagged launch is then reported the way
+# the reference's wrapper reports it (nn/aggr/base.py:131-141), whenever the flag arrives
+error_style = None
+
+
+def _raise_out_of_range(index: Tensor, size: int, what: str, style=None):
+    lo, hi = index_minmax(index)
+    if style == 'dim_size' and size <= hi:
+        raise ValueError(f"Encountered invalid 'dim_size' (got '{size}' but expected "
+                         f">= '{hi + 1}')")
+    bad = hi if hi >= size else lo
+    raise IndexOutOfRange(f'{what}: index {bad} is out of bounds for dimension 0 with size '
+                          f'{size} (indices span [{lo}, {hi}])')
+
+
 def _raise_if_flagged(err: Tensor, index: Tensor, size: int, what: str):
-    """One 4-byte host read of the kernel's error flag.  Skipped while the stream is being
-    captured into a hipGraph (no sync allowed there; the kernels still skip such rows)."""
+    """One 4-byte host read of the kernel's error flag ('sync' mode).  Skipped while the stream is
+    being captured into a hipGraph (no sync allowed there; the kernels still skip such rows)."""
     if torch.cuda.is_current_stream_capturing():
         return
     if int(err.item()) != 0:
-        lo, hi = index_minmax(index)
-        bad = hi if hi >= size else lo
-        raise IndexOutOfRange(f'{what}: index {bad} is out of bounds for dimension 0 with size '
-                              f'{size} (indices span [{lo}, {hi}])')
+        _raise_out_of_range(index, size, what)
 
 
 def gather_rows(x: Tensor, index: Tensor, check_bounds: bool = False) -> Tensor:
@@ -434,10 +513,20 @@ def scatter_rows(src: Tensor, index: Tensor, dim_size: int, reduce: str,
     st = _stream(src)
     check(lib.pygamd_scatter_init(_p(out), _ld(out), dim_size, F, red, _p(count), st),
           'scatter_init')
-    err = torch.zeros(1, dtype=torch.int32, device=src.device)
+    capturing = torch.cuda.is_current_stream_capturing()
+    ring = slot = None
+    if INDEX_CHECK == 'async' and not capturing and n > 0 and F > 0:
+        ring = _flag_ring(src.device)
+        ring.poll()  # raises for an EARLIER launch whose flag has arrived meanwhile
+        slot = ring.acquire()
+        err = ring.dev[slot:slot + 1]
+    else:
+        err = torch.zeros(1, dtype=torch.int32, device=src.device)
     check(lib.pygamd_scatter_rows(_p(s2), _ld(s2), _p(index), _idx_dtype(index), n, F, _p(out),
                                   _ld(out), dim_size, red, _p(count), _p(err), st), 'scatter_rows')
-    if n > 0 and F > 0:
+    if ring is not None:
+        ring.publish(slot, 'scatter', dim_size, index)
+    elif INDEX_CHECK == 'sync' and n > 0 and F > 0:
         # before anything is saved for a backward that would index with the same values
         _raise_if_flagged(err, index, dim_size, 'scatter')
     check(lib.pygamd_scatter_finalize(_p(out), _ld(out), dim_size, F, red, _p(count), st),

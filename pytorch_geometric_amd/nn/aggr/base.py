@@ -35,6 +35,7 @@ class Aggregation(torch.nn.Module):
                                  f"'{ptr.numel() - 1}')")
         if index is not None and dim_size is None:
             dim_size = _native.index_minmax(index)[1] + 1 if index.numel() > 0 else 0
+        prev, _native.error_style = _native.error_style, 'dim_size'
         try:
             return super().__call__(x, index=index, ptr=ptr, dim_size=dim_size, dim=dim, **kwargs)
         except (IndexError, RuntimeError) as e:  # same recovery as nn/aggr/base.py:131-141
@@ -45,6 +46,8 @@ class Aggregation(torch.nn.Module):
                                      f"'{dim_size}' but expected "
                                      f">= '{hi + 1}')")
             raise e
+        finally:
+            _native.error_style = prev
 
     def __repr__(self) -> str:
         return f'{self.__class__.__name__}()'

@@ -65,7 +65,7 @@ class Linear(torch.nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         if (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32
                 and x.dim() >= 2 and x.numel() // max(x.size(-1), 1) >= self.OWN_GEMM_MIN_ROWS
-                and not torch.jit.is_scripting()):
+                and not torch.jit.is_scripting() and not torch.is_autocast_enabled()):
             from ..._functions import LinearFunction
             return LinearFunction.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)

@@ -382,6 +382,20 @@ class FusedSageStack(Function):
         return (grad_x, None, None, None, *grads)
 
 
+def params_ready(conv, x: Tensor) -> bool:
+    """The layer's weights exist (a lazily initialised ``SAGEConv(-1, ...)`` materialises them in
+    its first ORIGINAL forward, nn/dense/linear.py:139-150 in the reference), are fp32 and live on
+    ``x``'s device."""
+    for lin in (conv.lin_l, conv.lin_r):
+        ps = [lin.weight] + ([lin.bias] if getattr(lin, 'bias', None) is not None else [])
+        for p in ps:
+            if isinstance(p, torch.nn.parameter.UninitializedParameter):
+                return False
+            if p.dtype != torch.float32 or p.device != x.device:
+                return False
+    return True
+
+
 def eligible(model, x, edge_index, trim: bool) -> bool:
     """Conditions under which the fused stack computes exactly what the layer loop does.  Duck-typed
     on purpose: ``backend.install()`` routes the REFERENCE's ``GraphSAGE`` here too, whose layers
@@ -418,6 +432,8 @@ def eligible(model, x, edge_index, trim: bool) -> bool:
         if aggr is not None and conv.aggr != aggr:
             return False
         aggr = conv.aggr
+        if not params_ready(conv, x):
+            return False
     if isinstance(edge_index, EdgeIndex):
         if edge_index.atomic_backward:  # single-use batch handle: keep the no-sort layer path
             return False

@@ -120,6 +120,7 @@ class FusedSageHopStack(Function):
 
 def eligible(model, x, edge_index, nodes_per_hop, edges_per_hop) -> bool:
     from ..conv import SAGEConv
+    from ._fused_sage import params_ready
     if not getattr(model, 'fuse_stack', True) or nodes_per_hop is None or edges_per_hop is None:
         return False
     if not (isinstance(edge_index, EdgeIndex) and edge_index.sort_order == 'col'
@@ -142,6 +143,8 @@ def eligible(model, x, edge_index, nodes_per_hop, edges_per_hop) -> bool:
         if conv.flow != 'source_to_target' or (aggr is not None and conv.aggr != aggr):
             return False
         aggr = conv.aggr
+        if not params_ready(conv, x):
+            return False
     return True
 
 

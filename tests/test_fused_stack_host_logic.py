@@ -331,3 +331,28 @@ def test_hop_aware_stack_wiring(fake_native, monkeypatch, own, aggr):
     for a, b in zip(*res):
         assert_close(b, a, rtol=1e-4, atol=2e-4, what=f'hop-aware stack (own={own})')
     assert bool([e for e in fake_native if e[0] == 'wgrad']) == own
+
+
+def test_fused_stack_steps_aside_for_lazy_or_foreign_parameters():
+    """a lazily initialised model (in_channels = -1) has UninitializedParameter weights
+    until its first ORIGINAL forward; the fused route must not be taken then (nor for parameters of
+    another dtype / device than the input)."""
+    from pytorch_geometric_amd.nn.models._fused_sage import params_ready
+
+    class Lin:
+        def __init__(self, weight, bias=None):
+            self.weight, self.bias = weight, bias
+
+    class Conv:
+        def __init__(self, wl, wr, b=None):
+            self.lin_l, self.lin_r = Lin(wl, b), Lin(wr)
+
+    x = torch.randn(4, 3)
+    w = torch.nn.Parameter(torch.randn(5, 3))
+    assert params_ready(Conv(w, w, torch.nn.Parameter(torch.zeros(5))), x)
+    lazy = torch.nn.parameter.UninitializedParameter()
+    assert not params_ready(Conv(lazy, w), x)
+    assert not params_ready(Conv(w, lazy), x)
+    assert not params_ready(Conv(w.double(), w), x)
+    assert not params_ready(Conv(w, w, torch.nn.Parameter(torch.zeros(5, dtype=torch.float64))), x)
+    assert not params_ready(Conv(w.to('meta'), w), x)

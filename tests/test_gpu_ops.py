@@ -108,11 +108,34 @@ def test_scatter_out_of_range_raises(dev):
     import pytorch_geometric_amd as pga
     src = torch.randn(6, 3, device=dev, requires_grad=True)
     idx = torch.tensor([0, 1, 7, 1, 0, 2], device=dev)
+    from pytorch_geometric_amd import _native
+    # default: the flag travels asynchronously; `check_index_errors()` (or a later scatter call
+    # once the flag has arrived) raises
+    assert _native.INDEX_CHECK == 'async'
     for red in ('sum', 'mean', 'max', 'mul'):
         with pytest.raises((IndexError, RuntimeError), match='out of bounds'):
             pga.utils.scatter(src, idx, 0, 4, red)
+            pga.check_index_errors()
     with pytest.raises((IndexError, RuntimeError), match='out of bounds'):
         pga.utils.scatter(src, torch.tensor([0, 1, -1, 1, 0, 2], device=dev), 0, 4, 'sum')
+        pga.check_index_errors()
+    pga.check_index_errors()  # nothing left pending, flags cleared
+    ok = pga.utils.scatter(src, torch.tensor([0, 1, 3, 1, 0, 2], device=dev), 0, 4, 'sum')
+    pga.check_index_errors()
+    assert ok.shape == (4, 3)
+    # a later call reports an earlier launch without an explicit check
+    pga.utils.scatter(src.detach(), idx, 0, 4, 'sum')
+    torch.cuda.synchronize()
+    with pytest.raises((IndexError, RuntimeError), match='out of bounds'):
+        pga.utils.scatter(src.detach(), torch.tensor([0, 1, 3, 1, 0, 2], device=dev), 0, 4, 'sum')
+    # 'sync': raises at the call site
+    _native.INDEX_CHECK = 'sync'
+    try:
+        for red in ('sum', 'max'):
+            with pytest.raises((IndexError, RuntimeError), match='out of bounds'):
+                pga.utils.scatter(src, idx, 0, 4, red)
+    finally:
+        _native.INDEX_CHECK = 'async'
 
 
 def test_scatter_errors(dev):
@@ -130,6 +153,7 @@ def test_scatter_errors(dev):
     agg = pga.nn.MeanAggregation()
     with pytest.raises(ValueError, match="invalid 'dim_size'"):
         agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
+        pga.check_index_errors()  # (the flag travels asynchronously by default)
     with pytest.raises(ValueError, match='invalid dimension'):
         agg(torch.randn(5, 3, device=dev), idx, dim=2)
 
@@ -843,3 +867,24 @@ def test_round2_entry_points_on_empty_and_degenerate_inputs(dev):
     _native.sage_layer_forward(h2.by_dst().ptr, h2.by_dst().idx, xs, buf[:, 8:], wc, None, 'mean',
                                False, buf[:, :8], y, hub=h2.by_dst().hub)
     assert_close(y, (xs @ wc[:, 8:].t()).cpu(), rtol=1e-5, atol=1e-5)
+
+
+def test_inplace_edit_of_a_saved_output_is_detected(dev):
+    """Functions whose backward compares against their OUTPUT (min / max / mul scatter,
+    segment softmax, ...) save the tensor they return, so autograd's version counter catches an
+    in-place edit between forward and backward also when the public shape is not [n, F]."""
+    import pytorch_geometric_amd as pga
+    g = gen(5)
+    idx = torch.randint(0, 7, (40, ), generator=g).to(dev)
+    for make in (lambda s: pga.utils.scatter(s, idx, 0, 7, 'max'),
+                 lambda s: pga.utils.scatter(s, idx, 0, 7, 'mul'),
+                 lambda s: pga.utils.softmax(s, ptr=torch.tensor([0, 10, 25, 40], device=dev))):
+        for shape in ((40, ), (40, 2, 3)):
+            src = torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+            out = make(src)
+            out.sum().backward()          # untouched: fine
+            src.grad = None
+            out = make(src)
+            out.mul_(2.0)
+            with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+                out.sum().backward()

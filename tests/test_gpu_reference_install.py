@@ -251,8 +251,15 @@ def test_reference_utils_and_aggregations_on_device(pyg, installed, dev):
         ref = mod(src, index, dim_size=160)
         out = mod(src.to(dev), index.to(dev), dim_size=160)
         assert_close(out, ref, rtol=2e-5, atol=2e-5, what=type(mod).__name__)
-    with pytest.raises(ValueError, match="invalid 'dim_size'"):
-        aggr.MeanAggregation()(src.to(dev), index.to(dev), dim_size=3)
+    # the reference's own wrapper converts an error raised AT the call (nn/aggr/base.py:131-141):
+    # that needs the blocking flag read
+    from pytorch_geometric_amd import _native
+    _native.INDEX_CHECK = 'sync'
+    try:
+        with pytest.raises(ValueError, match="invalid 'dim_size'"):
+            aggr.MeanAggregation()(src.to(dev), index.to(dev), dim_size=3)
+    finally:
+        _native.INDEX_CHECK = 'async'
     # the reference edits scatter outputs in place (gcn_conv.py:109 `deg.pow_(-0.5)`): outputs of
     # the custom autograd Functions must not be views
     w = torch.rand(2000, generator=g).to(dev).requires_grad_(True)
