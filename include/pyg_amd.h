@@ -405,7 +405,7 @@ PYGAMD_API int pygamd_gat_edge_softmax_backward(const void* rowptr, const void* 
                                                 int64_t H, float slope, float* grad_alpha_src,
                                                 float* grad_alpha_dst, void* stream);
 
-/* ---- §8(f)-1 (next): one hop of uniform neighbour sampling without replacement ---------------
+/* ---- §8(f)-1 (next): one hop of uniform neighbour sampling ------------------------------------
  * Device-side counterpart of torch.ops.pyg.neighbor_sample (sampler/neighbor_sampler.py:550-577)
  * on a CSC graph (colptr over destinations, row = source of every slot).  For frontier node
  * frontier[f] the caller provides offsets[f] / offsets[f+1] with offsets[f+1]-offsets[f] =
@@ -413,21 +413,26 @@ PYGAMD_API int pygamd_gat_edge_softmax_backward(const void* rowptr, const void* 
  * id, f (the position of the destination in the frontier) and the CSC slot (-> edge id through
  * the handle's permutation).  deg <= count: all neighbours; else a uniform subset (Floyd's
  * algorithm, counter-based hash of (seed, node, draw): reproducible).  max_per_node = the largest
- * bounded count requested (<= pygamd_sample_max_fanout(); pass 0 when every node takes all).    */
+ * bounded count requested (<= pygamd_sample_max_fanout(); pass 0 when every node takes all).
+ * flags bit 0 (the reference's `replace=True`, loader/neighbor_loader.py:209; needs a bounded
+ * fan-out): every frontier node with at least one in-neighbour gets exactly k independent uniform
+ * draws (offsets from pygamd_sample_counts with replace set).  flags bit 1: the draws of a node
+ * depend on its position in the frontier as well (disjoint sampling: one tree per seed).       */
 PYGAMD_API int pygamd_sample_max_fanout(void);
 PYGAMD_API int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
                                        const void* frontier, int64_t n_frontier,
                                        const void* offsets, int64_t max_per_node, uint64_t seed,
-                                       void* src_out, void* dstpos_out, void* slot_out,
-                                       void* stream);
+                                       int flags, void* src_out, void* dstpos_out,
+                                       void* slot_out, void* stream);
 
-/* cnt[f] = min(deg(frontier[f]), k) (k < 0: deg) — the per-node sample counts of one hop.
+/* cnt[f] = min(deg(frontier[f]), k) (k < 0: deg; replace != 0 and k >= 0: k wherever deg > 0, else
+ * 0) — the per-node sample counts of one hop.
  * `n_valid` (device int64, may be NULL): only the first *n_valid entries of the fixed-capacity
  * `frontier` are real; the rest (which must hold valid node ids, e.g. 0) get count 0.  With it a
  * hop can be sized by the static bound frontier x fan-out and run WITHOUT a host sync.           */
 PYGAMD_API int pygamd_sample_counts(const void* colptr, int idx_dtype, const void* frontier,
-                                    int64_t n, int64_t k, const int64_t* n_valid, void* cnt_out,
-                                    void* stream);
+                                    int64_t n, int64_t k, int replace, const int64_t* n_valid,
+                                    void* cnt_out, void* stream);
 /* Relabelling of the sampled sources (global -> local ids, new nodes in order of first
  * appearance, deterministic).  `local_map` has one entry per graph node; entries
  * not in the batch hold a value below -(m+1) (the host side uses the type's minimum).

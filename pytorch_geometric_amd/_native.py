@@ -987,10 +987,14 @@ def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int, blocks: int = 1
 
 # ---- neighbour sampling (one hop) ---------------------------------------------------------------
 def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Tensor, total: int,
-                     max_per_node: int, seed: int, zero_fill: bool = False):
+                     max_per_node: int, seed: int, zero_fill: bool = False,
+                     replace: bool = False, salt_position: bool = False):
     """(src_global, dst_pos_in_frontier, csc_slot) for the sampled in-edges of `frontier`.
     ``total`` sizes the outputs; ``zero_fill`` for a static capacity larger than what the hop
-    really samples (the tail then holds 0 = a valid node / slot id)."""
+    really samples (the tail then holds 0 = a valid node / slot id).  ``replace``: draws with
+    replacement (``offsets`` from :func:`sample_counts` with the same flag).  ``salt_position``:
+    the draws of a node also depend on its position in ``frontier`` (disjoint sampling: the same
+    node in two trees draws independently)."""
     _require_device(colptr, row, frontier, offsets)
     lib = _lib.load()
     alloc = torch.zeros if zero_fill else torch.empty
@@ -1000,7 +1004,9 @@ def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Ten
     if total > 0:
         check(lib.pygamd_sample_neighbors(_p(colptr), _p(row), _idx_dtype(colptr), _p(frontier),
                                           frontier.numel(), _p(offsets), max_per_node,
-                                          seed & 0xFFFFFFFFFFFFFFFF, _p(src), _p(dstpos),
+                                          seed & 0xFFFFFFFFFFFFFFFF,
+                                          int(replace) | (2 if salt_position else 0), _p(src),
+                                          _p(dstpos),
                                           _p(slot), _stream(colptr)), 'sample_neighbors')
     return src, dstpos, slot
 
@@ -1066,14 +1072,15 @@ def head_dot_backward(x: Tensor, att_a: Tensor, att_b: Optional[Tensor], grad_a:
 
 
 def sample_counts(colptr: Tensor, frontier: Tensor, k: int,
-                  n_valid: Optional[Tensor] = None) -> Tensor:
-    """min(deg, k) per frontier entry; entries past the device-side count ``n_valid`` (int64
-    [1]) of a fixed-capacity frontier get 0."""
+                  n_valid: Optional[Tensor] = None, replace: bool = False) -> Tensor:
+    """min(deg, k) per frontier entry (``replace`` with ``k >= 0``: k wherever deg > 0); entries
+    past the device-side count ``n_valid`` (int64 [1]) of a fixed-capacity frontier get 0."""
     _require_device(colptr, frontier, n_valid)
     lib = _lib.load()
     cnt = torch.empty_like(frontier)
     check(lib.pygamd_sample_counts(_p(colptr), _idx_dtype(colptr), _p(frontier),
-                                   frontier.numel(), k, _p(n_valid), _p(cnt), _stream(colptr)),
+                                   frontier.numel(), k, int(replace and k >= 0), _p(n_valid),
+                                   _p(cnt), _stream(colptr)),
           'sample_counts')
     return cnt
 

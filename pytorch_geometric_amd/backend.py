@@ -382,23 +382,32 @@ def _wrap_propagate(cls) -> Callable:
 _sampler_cls = None
 
 
-def neighbor_sampler(data, num_neighbors: List[int], seed: int = 0):
+def neighbor_sampler(data, num_neighbors: List[int], seed: int = 0, replace: bool = False,
+                     disjoint: bool = False, subgraph_type='directional'):
     """A ``torch_geometric.sampler.BaseSampler`` (sampler/base.py:932-998) whose
     ``sample_from_nodes(NodeSamplerInput) -> SamplerOutput`` runs on the GPU
     (:class:`pytorch_geometric_amd.sampler.NeighborSampler`), so that the reference's
     ``NodeLoader(data, node_sampler=...)`` (loader/node_loader.py:90-152) drives it unchanged and
     joins the features with its own ``filter_data``.  ``data``: a ``torch_geometric.data.Data`` on
-    the device (``edge_index``, ``num_nodes``) or a ``(edge_index, num_nodes)`` pair."""
+    the device (``edge_index``, ``num_nodes``) or a ``(edge_index, num_nodes)`` pair.  ``replace``,
+    ``disjoint`` and ``subgraph_type`` (``'directional'`` | ``'bidirectional'``, string or the
+    reference's ``SubgraphType``) are the options ``NeighborLoader`` forwards to its sampler
+    (loader/neighbor_loader.py:209-233)."""
     global _sampler_cls
     import torch_geometric.sampler as pyg_sampler
     from .sampler import NeighborSampler
     if _sampler_cls is None:
 
         class MI355XNeighborSampler(pyg_sampler.BaseSampler):
-            def __init__(self, edge_index, num_nodes, num_neighbors, seed=0):
+            def __init__(self, edge_index, num_nodes, num_neighbors, seed=0, replace=False,
+                         disjoint=False, subgraph_type='directional'):
                 self.impl = NeighborSampler(edge_index, num_nodes, num_neighbors, seed=seed,
-                                            output_cls=pyg_sampler.SamplerOutput)
+                                            output_cls=pyg_sampler.SamplerOutput,
+                                            replace=replace, disjoint=disjoint,
+                                            subgraph_type=subgraph_type)
                 self.num_neighbors = list(num_neighbors)
+                self.replace, self.disjoint = self.impl.replace, self.impl.disjoint
+                self.subgraph_type = self.impl.subgraph_type
 
             def sample_from_nodes(self, index, **kwargs):
                 return self.impl.sample_from_nodes(index, **kwargs)
@@ -418,7 +427,8 @@ def neighbor_sampler(data, num_neighbors: List[int], seed: int = 0):
     if not (isinstance(edge_index, Tensor) and edge_index.is_cuda):
         raise ValueError("the sampler needs 'edge_index' on the HIP device (there is no CPU "
                          "fallback): move the data with `.to('cuda')` first")
-    return _sampler_cls(edge_index, int(num_nodes), num_neighbors, seed)
+    return _sampler_cls(edge_index, int(num_nodes), num_neighbors, seed, replace, disjoint,
+                        subgraph_type)
 
 
 def install() -> None:

@@ -1,4 +1,5 @@
-// sample.hip — uniform neighbour sampling without replacement on a CSC graph:
+// sample.hip — uniform neighbour sampling (without or with replacement) on a CSC graph (SURVEY.md
+// §8(f)-1):
 // the device-side counterpart of torch.ops.pyg.neighbor_sample for one hop
 // (torch_geometric/sampler/neighbor_sampler.py:550-577: colptr, row, seed nodes, fan-out k).
 //
@@ -6,8 +7,10 @@
 // slot range, coalesced).  Otherwise the wave draws a uniform k-subset of the deg(v) slots with
 // Floyd's algorithm (k <= 64: lane c makes draw c from a counter-based hash of (seed, v, c), the
 // k insertions are k wave-wide membership tests), so a batch is reproducible from its seed
-// regardless of scheduling; lanes 0..k-1 then emit one edge each.  HBM-bound integer work: 3 index reads + 3 index writes per
-// sampled edge.
+// regardless of scheduling; lanes 0..k-1 then emit one edge each.  With replacement
+// (`replace`, the reference's `replace=True`, loader/neighbor_loader.py:209) every node with at
+// least one in-neighbour emits exactly k edges, lane c an independent uniform draw of the same
+// hash.  HBM-bound integer work: 3 index reads + 3 index writes per sampled edge.
 #include "common.h"
 
 namespace pygamd {
@@ -25,7 +28,7 @@ template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
     sample_neighbors_kernel(const IdxT* __restrict__ colptr, const IdxT* __restrict__ row,
                             const IdxT* __restrict__ frontier, int64_t n_frontier,
-                            const IdxT* __restrict__ offsets, uint64_t seed,
+                            const IdxT* __restrict__ offsets, uint64_t seed, int flags,
                             IdxT* __restrict__ src_out, IdxT* __restrict__ dstpos_out,
                             IdxT* __restrict__ slot_out) {
   const int lane = lane_id();
@@ -37,6 +40,20 @@ __global__ void __launch_bounds__(kBlock)
   const int64_t o = offsets[f];
   const int64_t cnt = static_cast<int64_t>(offsets[f + 1]) - o;
   if (cnt <= 0) return;
+  const bool replace = (flags & 1) != 0;
+  // flags & 2: the draws depend on the frontier position too (disjoint trees)
+  const uint64_t salt = (flags & 2) ? mix64(0xD1B54A32D192ED03ull * static_cast<uint64_t>(f + 1)) : 0;
+  const uint64_t key = mix64(seed ^ mix64(static_cast<uint64_t>(v)) ^ salt);
+  if (replace) {  // cnt = k independent draws from the deg in-neighbours (deg > 0 here)
+    if (lane < cnt) {
+      const uint64_t r = mix64(key + static_cast<uint64_t>(lane));
+      const int64_t t = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(deg)));
+      src_out[o + lane] = row[s + t];
+      dstpos_out[o + lane] = static_cast<IdxT>(f);
+      slot_out[o + lane] = static_cast<IdxT>(s + t);
+    }
+    return;
+  }
   if (deg <= cnt) {  // take every in-neighbour
     for (int64_t t = lane; t < deg; t += kWave) {
       src_out[o + t] = row[s + t];
@@ -52,7 +69,6 @@ __global__ void __launch_bounds__(kBlock)
   const int64_t jl = deg - cnt + lane;  // Floyd's j of this lane's draw
   int64_t t = 0;
   if (lane < k) {
-    const uint64_t key = mix64(seed ^ mix64(static_cast<uint64_t>(v)));
     const uint64_t r = mix64(key + static_cast<uint64_t>(lane));
     t = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(jl + 1)));
   }
@@ -69,11 +85,11 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// cnt[f] = min(deg(frontier[f]), k)   (k < 0: deg)
+// cnt[f] = min(deg(frontier[f]), k)   (k < 0: deg; with replacement: k wherever deg > 0)
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
     sample_counts_kernel(const IdxT* __restrict__ colptr, const IdxT* __restrict__ frontier,
-                         int64_t n, int64_t k, const int64_t* __restrict__ n_valid,
+                         int64_t n, int64_t k, int replace, const int64_t* __restrict__ n_valid,
                          IdxT* __restrict__ cnt) {
   const int64_t f = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (f >= n) return;
@@ -83,7 +99,11 @@ __global__ void __launch_bounds__(kBlock)
   }
   const int64_t v = frontier[f];
   const int64_t deg = static_cast<int64_t>(colptr[v + 1]) - static_cast<int64_t>(colptr[v]);
-  cnt[f] = static_cast<IdxT>((k >= 0 && deg > k) ? k : deg);
+  if (replace && k >= 0) {
+    cnt[f] = static_cast<IdxT>(deg > 0 ? k : 0);
+  } else {
+    cnt[f] = static_cast<IdxT>((k >= 0 && deg > k) ? k : deg);
+  }
 }
 
 // ---- relabelling: global ids of the sampled sources -> local ids, new nodes in order of first
@@ -163,7 +183,7 @@ int pygamd_sample_max_fanout(void) { return kMaxFanout; }
 
 int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
                             const void* frontier, int64_t n_frontier, const void* offsets,
-                            int64_t max_per_node, uint64_t seed, void* src_out,
+                            int64_t max_per_node, uint64_t seed, int flags, void* src_out,
                             void* dstpos_out, void* slot_out, void* stream) {
   if (n_frontier < 0) return PYGAMD_ERR_INVALID_ARG;
   if (n_frontier == 0) return PYGAMD_OK;
@@ -171,12 +191,13 @@ int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
     return PYGAMD_ERR_INVALID_ARG;
   // a bounded fan-out larger than the LDS draw table is not supported (k < 0 = "all" is)
   if (max_per_node > kMaxFanout) return PYGAMD_ERR_UNSUPPORTED;
+  if ((flags & 1) && max_per_node <= 0) return PYGAMD_ERR_INVALID_ARG;  // "all": no replacement
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     const unsigned grid = static_cast<unsigned>(ceil_div(n_frontier, kWavesPerBlock));
     hipLaunchKernelGGL((sample_neighbors_kernel<IdxT>), dim3(grid), dim3(kBlock), 0,
                        as_stream(stream), static_cast<const IdxT*>(colptr),
                        static_cast<const IdxT*>(row), static_cast<const IdxT*>(frontier),
-                       n_frontier, static_cast<const IdxT*>(offsets), seed,
+                       n_frontier, static_cast<const IdxT*>(offsets), seed, flags,
                        static_cast<IdxT*>(src_out), static_cast<IdxT*>(dstpos_out),
                        static_cast<IdxT*>(slot_out));
     PYGAMD_LAUNCH_CHECK();
@@ -185,7 +206,8 @@ int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
 }
 
 int pygamd_sample_counts(const void* colptr, int idx_dtype, const void* frontier, int64_t n,
-                         int64_t k, const int64_t* n_valid, void* cnt_out, void* stream) {
+                         int64_t k, int replace, const int64_t* n_valid, void* cnt_out,
+                         void* stream) {
   if (n < 0) return PYGAMD_ERR_INVALID_ARG;
   if (n == 0) return PYGAMD_OK;
   if (!colptr || !frontier || !cnt_out) return PYGAMD_ERR_INVALID_ARG;
@@ -193,7 +215,7 @@ int pygamd_sample_counts(const void* colptr, int idx_dtype, const void* frontier
     hipLaunchKernelGGL((sample_counts_kernel<IdxT>),
                        dim3(static_cast<unsigned>(ceil_div(n, kBlock))), dim3(kBlock), 0,
                        as_stream(stream), static_cast<const IdxT*>(colptr),
-                       static_cast<const IdxT*>(frontier), n, k, n_valid,
+                       static_cast<const IdxT*>(frontier), n, k, replace ? 1 : 0, n_valid,
                        static_cast<IdxT*>(cnt_out));
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;

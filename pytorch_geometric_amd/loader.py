@@ -28,11 +28,13 @@ class Batch:
     e_id: Tensor
     input_id: Tensor
     batch_size: int
-    num_sampled_nodes: List[int]
-    num_sampled_edges: List[int]
+    num_sampled_nodes: Optional[List[int]]
+    num_sampled_edges: Optional[List[int]]
+    batch: Optional[Tensor] = None  # disjoint sampling: the seed (tree) index of every node
 
     def record_stream(self, stream) -> None:
-        for t in (self.x, self.y, self.edge_index, self.n_id, self.e_id, self.input_id):
+        for t in (self.x, self.y, self.edge_index, self.n_id, self.e_id, self.input_id,
+                  self.batch):
             if isinstance(t, Tensor) and t.is_cuda:
                 t.record_stream(stream)
         self.graph.record_stream(stream)
@@ -54,17 +56,23 @@ class NeighborLoader:
             gives to ``num_workers`` DataLoader processes (loader/node_loader.py:90-152), without
             leaving the device.  Batches are handed over with an event the consumer's stream
             waits on.
+        replace, disjoint, subgraph_type: the sampler options of the reference's loader
+            (loader/neighbor_loader.py:209-233; see :class:`~.sampler.NeighborSampler`).
     """
 
     def __init__(self, x: Tensor, edge_index: Tensor, num_neighbors: List[int],
                  batch_size: int = 1024, y: Optional[Tensor] = None,
                  input_nodes: Optional[Tensor] = None, shuffle: bool = False,
-                 drop_last: bool = False, seed: int = 0, prefetch: int = 0):
+                 drop_last: bool = False, seed: int = 0, prefetch: int = 0,
+                 replace: bool = False, disjoint: bool = False,
+                 subgraph_type: str = 'directional'):
         self.prefetch = int(prefetch)
         self._side = None
         self.x, self.y = x, y
         self.num_nodes = x.size(0)
-        self.sampler = NeighborSampler(edge_index, self.num_nodes, num_neighbors, seed=seed)
+        self.sampler = NeighborSampler(edge_index, self.num_nodes, num_neighbors, seed=seed,
+                                       replace=replace, disjoint=disjoint,
+                                       subgraph_type=subgraph_type)
         if input_nodes is None:
             input_nodes = torch.arange(self.num_nodes, device=x.device)
         self.input_nodes = input_nodes.to(x.device)
@@ -81,12 +89,13 @@ class NeighborLoader:
         y = None if self.y is None else self.y[out.node]
         ei = torch.stack([out.row, out.col])
         fan = self.sampler.num_neighbors
+        bounded = min(fan) >= 0 and self.sampler.subgraph_type == 'directional'
         graph = EdgeIndex.from_sorted_batch(
-            ei, out.node.numel(), max_in_degree=None if min(fan) < 0 else max(fan))
+            ei, out.node.numel(), max_in_degree=max(fan) if bounded else None)
         return Batch(x=x, y=y, edge_index=ei, graph=graph, n_id=out.node,
                      e_id=out.edge, input_id=seeds if input_id is None else input_id,
                      batch_size=seeds.numel(), num_sampled_nodes=out.num_sampled_nodes,
-                     num_sampled_edges=out.num_sampled_edges)
+                     num_sampled_edges=out.num_sampled_edges, batch=out.batch)
 
     def _plan(self):
         n = self.input_nodes.numel()

@@ -268,3 +268,147 @@ def test_padded_sampling_is_hipgraph_capturable(dev):
         for name, parts in (('row', p.rows), ('col', p.cols), ('edge', p.edges)):
             got = torch.cat([t[:n] for t, n in zip(parts, n_edge)])
             assert torch.equal(got, getattr(want, name)), name
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_sampling_with_replacement(dev, dtype):
+    """`replace=True` (loader/neighbor_loader.py:209): every frontier node with at least one
+    in-neighbour contributes EXACTLY k edges (also when it has fewer than k neighbours), each an
+    existing edge into that node; draws are uniform over the in-neighbours; `-1` hops still take
+    each neighbour once; padded (sync-free) and compacted paths agree."""
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    n = 2500
+    ei = random_graph(n, n, 20_000, seed=4, skew=True)
+    ei = ei[:, ei[1] != 17]                      # node 17 has no in-neighbours
+    seeds = torch.cat([torch.tensor([17]), torch.randperm(n, generator=gen(3))[:150]]).unique()
+    indeg = torch.bincount(ei[1], minlength=n)
+    fanouts = [6, 4]
+    s = NeighborSampler(ei.to(dtype).to(dev), n, fanouts, seed=11, replace=True)
+    out = s.sample_from_nodes(seeds.to(dev))
+    node, row, col, edge = out.node.cpu(), out.row.cpu(), out.col.cpu(), out.edge.cpu()
+    assert torch.equal(node[:seeds.numel()], seeds) and node.unique().numel() == node.numel()
+    assert torch.equal(node[row], ei[0, edge]) and torch.equal(node[col], ei[1, edge])
+    nb = [0] + torch.tensor(out.num_sampled_nodes).cumsum(0).tolist()
+    eb = [0] + torch.tensor(out.num_sampled_edges).cumsum(0).tolist()
+    dup = False
+    for h, k in enumerate(fanouts):
+        c = col[eb[h]:eb[h + 1]]
+        got = torch.bincount(c - nb[h], minlength=nb[h + 1] - nb[h])
+        deg = indeg[node[nb[h]:nb[h + 1]]]
+        assert torch.equal(got, torch.where(deg > 0, torch.full_like(deg, k), deg))
+        e = edge[eb[h]:eb[h + 1]]
+        dup = dup or e.unique().numel() < e.numel()
+    assert dup                                   # low-degree nodes MUST repeat neighbours
+    assert int((s._local != s._unset).sum()) == 0
+    # uniformity: one node with 5 in-neighbours, k = 4, many independent batches
+    hub = int((indeg == 5).nonzero()[0])
+    srcs = ei[0, ei[1] == hub]
+    s1 = NeighborSampler(ei.to(dtype).to(dev), n, [4], seed=0, replace=True)
+    hits = torch.zeros(n)
+    trials = 600
+    for b in range(trials):
+        o = s1.sample_from_nodes(torch.tensor([hub], device=dev), seed=b)
+        hits += torch.bincount(o.node.cpu()[o.row.cpu()], minlength=n).float()
+    freq = hits[srcs] / (4 * trials)
+    assert float(hits.sum()) == 4 * trials and float((freq - 0.2).abs().max()) < 0.04
+    # -1 with replace: every neighbour exactly once
+    s2 = NeighborSampler(ei.to(dtype).to(dev), n, [-1], seed=0, replace=True)
+    o = s2.sample_from_nodes(seeds.to(dev))
+    assert o.edge.unique().numel() == o.edge.numel() == int(indeg[seeds].sum())
+    # the sync-free path draws the same edges
+    p = s.sample_padded(seeds.to(dev), seed=11)
+    o = s.sample_from_nodes(seeds.to(dev), seed=11)
+    ne = [int(t) for t in p.n_edges]
+    assert torch.equal(torch.cat([e[:k] for e, k in zip(p.edges, ne)]), o.edge)
+
+
+def test_disjoint_sampling_builds_one_tree_per_seed(dev):
+    """`disjoint=True` (sampler/neighbor_sampler.py:590-591): a batch node is a (seed, node) pair;
+    `batch` holds the seed index; edges stay inside their tree; with full fan-out every tree is the
+    k-hop in-neighbourhood of its seed alone (= the non-disjoint sampler run on that one seed)."""
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    n = 400
+    ei = random_graph(n, n, 2400, seed=9)
+    seeds = torch.tensor([5, 17, 5 + 100, 250, 17 + 200])
+    for fanouts, replace in (([3, 2], False), ([-1, -1], False), ([4, 3], True)):
+        s = NeighborSampler(ei.to(dev), n, fanouts, seed=3, disjoint=True, replace=replace)
+        out = s.sample_from_nodes(seeds.to(dev))
+        node, row, col = out.node.cpu(), out.row.cpu(), out.col.cpu()
+        edge, batch = out.edge.cpu(), out.batch.cpu()
+        B = seeds.numel()
+        assert torch.equal(node[:B], seeds) and torch.equal(batch[:B], torch.arange(B))
+        assert sum(out.num_sampled_nodes) == node.numel() == batch.numel()
+        assert sum(out.num_sampled_edges) == row.numel()
+        pair = batch * n + node
+        assert pair.unique().numel() == pair.numel()          # unique within a tree ...
+        assert torch.equal(node[row], ei[0, edge]) and torch.equal(node[col], ei[1, edge])
+        assert torch.equal(batch[row], batch[col])            # ... and edges never cross trees
+        assert bool((col[1:] >= col[:-1]).all())
+        nb = [0] + torch.tensor(out.num_sampled_nodes).cumsum(0).tolist()
+        eb = [0] + torch.tensor(out.num_sampled_edges).cumsum(0).tolist()
+        indeg = torch.bincount(ei[1], minlength=n)
+        for h, k in enumerate(fanouts):
+            c = col[eb[h]:eb[h + 1]]
+            got = torch.bincount(c - nb[h], minlength=nb[h + 1] - nb[h])
+            deg = indeg[node[nb[h]:nb[h + 1]]]
+            want = deg if k < 0 else (torch.where(deg > 0, torch.full_like(deg, k), deg)
+                                      if replace else deg.clamp(max=k))
+            assert torch.equal(got, want)
+            fresh = row[eb[h]:eb[h + 1]]
+            fresh = fresh[fresh >= nb[h + 1]]
+            if fresh.numel():                                 # order of first appearance
+                running_max = torch.cummax(fresh, 0).values
+                first = torch.ones_like(fresh, dtype=torch.bool)
+                first[1:] = fresh[1:] > running_max[:-1]
+                assert torch.equal(fresh[first], torch.arange(nb[h + 1], nb[h + 2]))
+        if fanouts == [-1, -1]:
+            single = NeighborSampler(ei.to(dev), n, fanouts, seed=3)
+            for t in range(B):
+                ref = single.sample_from_nodes(seeds[t:t + 1].to(dev))
+                mine = node[batch == t]
+                assert torch.equal(mine.sort().values, ref.node.cpu().sort().values)
+                e_mine = edge[batch[col] == t]
+                assert torch.equal(e_mine.sort().values, ref.edge.cpu().sort().values)
+    # the same node in two trees draws independently (position-salted hash): over many batches
+    # the two copies of node 5 do not always pick the same neighbours
+    ei2 = torch.stack([torch.arange(1, 41), torch.zeros(40, dtype=torch.long)])  # 40 nbrs of node 0
+    s = NeighborSampler(ei2.to(dev), 41, [3], seed=0, disjoint=True)
+    same = 0
+    for b in range(50):
+        o = s.sample_from_nodes(torch.tensor([0, 0], device=dev), seed=b)
+        e = o.edge.cpu()
+        same += int(torch.equal(e[:3].sort().values, e[3:].sort().values))
+    assert same < 5
+    with pytest.raises(ValueError):
+        s.sample_padded(torch.tensor([0], device=dev))
+
+
+def test_bidirectional_subgraph_type(dev):
+    """`subgraph_type='bidirectional'` = SamplerOutput.to_bidirectional() (sampler/base.py:248-276):
+    sampled edges + their reverses, coalesced by destination, `num_sampled_*` dropped; against the
+    same construction in plain torch on the directional sample of the same seed."""
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    n = 800
+    ei = random_graph(n, n, 6000, seed=2, skew=True)
+    seeds = torch.randperm(n, generator=gen(8))[:60]
+    for fanouts in ([4, 3], [-1]):
+        d = NeighborSampler(ei.to(dev), n, fanouts, seed=5).sample_from_nodes(seeds.to(dev), seed=5)
+        b = NeighborSampler(ei.to(dev), n, fanouts, seed=5,
+                            subgraph_type='bidirectional').sample_from_nodes(seeds.to(dev), seed=5)
+        assert torch.equal(b.node, d.node)
+        assert b.num_sampled_nodes is None and b.num_sampled_edges is None
+        m = d.node.numel()
+        row = torch.cat([d.row, d.col]).cpu()
+        col = torch.cat([d.col, d.row]).cpu()
+        key = (col * m + row).unique()                      # sorted, destination-major
+        assert torch.equal(b.col.cpu() * m + b.row.cpu(), key)
+        fwd = set((d.col.cpu() * m + d.row.cpu()).tolist())
+        # an edge id belongs to one of the directions that produced the pair
+        node = d.node.cpu()
+        for r, c, e in zip(b.row.cpu().tolist(), b.col.cpu().tolist(), b.edge.cpu().tolist()):
+            s_, t_ = int(ei[0, e]), int(ei[1, e])
+            assert (int(node[r]), int(node[c])) in ((s_, t_), (t_, s_))
+            if c * m + r in fwd:                            # sampled in this direction: its own id
+                assert (int(node[r]), int(node[c])) == (s_, t_)
+    with pytest.raises(NotImplementedError):
+        NeighborSampler(ei.to(dev), n, [2], subgraph_type='induced')
