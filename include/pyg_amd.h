@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 3
+#define PYGAMD_ABI_VERSION 4
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -243,6 +243,24 @@ PYGAMD_API int pygamd_spmm_csr_minmax_backward_arg(const void* rowptr, const voi
                                                    int64_t ldgo, int64_t n_rows, int64_t n_src,
                                                    int64_t F, int count_self, float* grad_x,
                                                    int64_t ldg, void* stream);
+/* The same gradient WITHOUT the N x F scattered atomics (round 3): the unique winners of `arg32`
+ * become one bit per (edge, feature) in `workspace` (pygamd_minmax_backward_src_workspace_bytes =
+ * nnz x ceil(F / 256) x 32 bytes, by-destination slot order), then a source-driven pass over the
+ * TRANSPOSED CSR (rowptr_t / col_t over the n_src sources; slot_map[e] = the by-destination slot of
+ * by-source slot e, cf. EdgeIndex.src_slot_to_dst_slot) sums, per source row and in registers, the
+ * grad_out entries whose bit is set and writes grad_x once (deterministic for the unique extrema;
+ * no memset).  Outputs marked -2 are then added by the two-pass tie kernel like in
+ * pygamd_spmm_csr_minmax_backward_arg.  Needs F % 4 == 0 and 16-byte aligned rows
+ * (PYGAMD_ERR_UNSUPPORTED otherwise: use _arg).  Reference semantics: utils/_scatter.py:84-100 +
+ * ATen's amax / amin backward (ties share the gradient evenly).                                  */
+PYGAMD_API size_t pygamd_minmax_backward_src_workspace_bytes(int64_t nnz, int64_t F);
+PYGAMD_API int pygamd_spmm_csr_minmax_backward_src(
+    const void* rowptr, const void* col, const void* rowptr_t, const void* col_t,
+    const void* slot_map, int idx_dtype, const int32_t* arg32, const float* x, int64_t ldx,
+    const float* out, int64_t ldo, const float* grad_out, int64_t ldgo, int64_t n_rows,
+    int64_t n_src, int64_t nnz, int64_t F, int count_self, void* workspace,
+    size_t workspace_bytes, float* grad_x, int64_t ldg, void* stream);
+
 
 /* ---- SDDMM: gradient w.r.t. edge weights ----------------------------------------------------
  * grad_w[e(k), h] = sum_{f in head h} grad_out[i, f] * x[col[k], f] * (src_scale? ...)  for k in

@@ -90,8 +90,16 @@ class SpmmFunction(Function):
                     ntie = _native.spmm_tie_count(fwd.ptr, fwd.idx, x2, out, count_self=True)
                     grad_x = _native.spmm_minmax_backward(bwd.ptr, bwd.idx, x2, out, g2, ntie)
                 else:
-                    grad_x = _native.spmm_minmax_backward_dst(fwd.ptr, fwd.idx, x2, out, g2,
-                                                              graph.num_src_nodes, arg32=arg32)
+                    grad_x = None
+                    if arg32 is not None and not graph.atomic_backward:
+                        # cached graph: winners as per-edge bit masks + a source-driven sum over
+                        # the transposed CSR instead of N x F scattered atomics
+                        grad_x = _native.spmm_minmax_backward_src(
+                            fwd, graph.by_src(), graph.src_slot_to_dst_slot(), x2, out, g2, arg32)
+                    if grad_x is None:
+                        grad_x = _native.spmm_minmax_backward_dst(fwd.ptr, fwd.idx, x2, out, g2,
+                                                                  graph.num_src_nodes,
+                                                                  arg32=arg32)
                 grad_x = grad_x.view(ctx.x_shape)
             return grad_x, None, None, None, None
         x2, w = ctx.saved_tensors

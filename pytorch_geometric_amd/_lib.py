@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 from . import _build
 
-ABI_VERSION = 3  # PYGAMD_ABI_VERSION of include/pyg_amd.h
+ABI_VERSION = 4  # PYGAMD_ABI_VERSION of include/pyg_amd.h
 IDX_I32, IDX_I64 = 0, 1
 SUM, MEAN, MIN, MAX, MUL, ANY = 0, 1, 2, 3, 4, 5
 REDUCE_IDS = {'sum': SUM, 'add': SUM, 'mean': MEAN, 'min': MIN, 'amin': MIN, 'max': MAX,
@@ -76,6 +76,11 @@ SIGNATURES = {
                                                     c_int64, _P]),
     'pygamd_multi_reduce_csr': (c_int, [_P, _P, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P,
                                         _P, c_int64, _P]),
+    'pygamd_minmax_backward_src_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'pygamd_spmm_csr_minmax_backward_src': (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P,
+                                                    c_int64, _P, c_int64, c_int64, c_int64,
+                                                    c_int64, c_int64, c_int, _P, c_size_t, _P,
+                                                    c_int64, _P]),
     'pygamd_spmm_csr_minmax_backward_arg': (c_int, [_P, _P, c_int, _P, _P, c_int64, _P, c_int64, _P,
                                                     c_int64, c_int64, c_int64, c_int64, c_int, _P,
                                                     c_int64, _P]),

@@ -331,6 +331,33 @@ def spmm_minmax_backward_dst(rowptr: Tensor, col: Optional[Tensor], x: Tensor, o
     return grad_x
 
 
+def spmm_minmax_backward_src(fwd, bwd, slot_map: Tensor, x: Tensor, out: Tensor,
+                             grad_out: Tensor, arg32: Tensor, count_self: bool = True
+                             ) -> Optional[Tensor]:
+    """The min/max gradient without the N x F scattered atomics (``pygamd_spmm_csr_minmax_backward_
+    src``): ``fwd`` / ``bwd`` = the destination- / source-sorted CSR of the graph, ``slot_map`` =
+    ``EdgeIndex.src_slot_to_dst_slot()``.  Returns ``None`` when the layout is not supported
+    (``F % 4``, alignment): the caller then takes :func:`spmm_minmax_backward_dst`."""
+    _require_device(fwd.ptr, fwd.idx, bwd.ptr, bwd.idx, slot_map, x, out, grad_out, arg32)
+    lib = _lib.load()
+    x2, o2, g2 = _f32_rows(x, 'x'), _f32_rows(out, 'out'), _f32_rows(grad_out, 'grad_out')
+    F, n_src, nnz = x2.size(1), bwd.ptr.numel() - 1, bwd.idx.numel()
+    if F % 4 or _ld(g2) % 4 or g2.data_ptr() % 16:
+        return None
+    grad_x = torch.empty(n_src, F, dtype=torch.float32, device=x.device)
+    nbytes = lib.pygamd_minmax_backward_src_workspace_bytes(nnz, F)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    a32 = arg32.contiguous()
+    rc = lib.pygamd_spmm_csr_minmax_backward_src(
+        _p(fwd.ptr), _p(fwd.idx), _p(bwd.ptr), _p(bwd.idx), _p(slot_map), _idx_dtype(fwd.ptr),
+        _p(a32), _p(x2), _ld(x2), _p(o2), _ld(o2), _p(g2), _ld(g2), fwd.ptr.numel() - 1, n_src,
+        nnz, F, int(count_self), _p(ws), nbytes, _p(grad_x), _ld(grad_x), _stream(x))
+    if rc == 2:  # PYGAMD_ERR_UNSUPPORTED
+        return None
+    check(rc, 'spmm_minmax_backward_src')
+    return grad_x
+
+
 def relu_backward_colsum(grad: Tensor, act: Tensor, want_colsum: bool = True):
     """(grad * (act > 0) as a new contiguous tensor, its column sums | None) in one pass; ``act``
     is the ReLU output.  Inputs may be row-strided views."""

@@ -359,6 +359,115 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- atomic-free fast half of the min/max backward (round 3) ------------------------------------
+// The one-atomic-per-output kernel above moves 4 bytes per atomic but a whole cache line per touched
+// source row segment: N x F scattered fp32 atomics = 30 ms at the products shape, F = 256 (the
+// forward takes 12.5).  Here the unique winners are first written as ONE BIT per (edge, feature):
+//   winner_masks   destination-driven, a wave per row i: lane l holds arg32[i, 4l .. 4l+3] and for
+//                  every slot s of the row four ballots (arg == s) give the 256 feature bits of that
+//                  edge, stored as 4 x uint64 in by-destination slot order (bit l of word c =
+//                  feature 4l + c of the 256-feature block);
+//   accumulate     source-driven over the transposed CSR, a wave per source j: for each out-edge it
+//                  reads the edge's 32-byte mask with scalar loads and ONLY the lanes whose bits are
+//                  set load their 16 bytes of grad_out[i]; sums stay in registers in by-source slot
+//                  order (deterministic) and grad_x[j] is written once — no atomics, no memset.
+// Per edge: 8 + 8 bytes of indices, 32 bytes of mask, and the cache lines of grad_out[i] that hold
+// a winner of this edge (deg ~25 and F = 256: ~10 winners, ~6 of the row's 8 lines).
+// Outputs marked -2 (ties / extremum 0) go to spmm_minmax_bwd_dst afterwards, as before.
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    minmax_winner_masks_kernel(const IdxT* __restrict__ rowptr, const int32_t* __restrict__ arg32,
+                               int64_t n_rows, int64_t F, int Q, uint64_t* __restrict__ masks) {
+  const int lane = lane_id();
+  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (row >= n_rows) return;
+  const int64_t start = rowptr[row];
+  const int64_t deg = static_cast<int64_t>(rowptr[row + 1]) - start;
+  for (int q = 0; q < Q; ++q) {
+    const int64_t f0 = static_cast<int64_t>(q) * 256 + 4 * lane;
+    int4 a = {-1, -1, -1, -1};
+    if (f0 < F) a = *reinterpret_cast<const int4*>(arg32 + row * F + f0);  // F % 4 == 0
+    for (int64_t s = 0; s < deg; ++s) {
+      const int32_t ss = static_cast<int32_t>(s);
+      const uint64_t b0 = __ballot(a.x == ss), b1 = __ballot(a.y == ss);
+      const uint64_t b2 = __ballot(a.z == ss), b3 = __ballot(a.w == ss);
+      if (lane < 4) {
+        const uint64_t w = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        masks[((start + s) * Q + q) * 4 + lane] = w;
+      }
+    }
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    minmax_bwd_src_kernel(const IdxT* __restrict__ rowptr_t, const IdxT* __restrict__ col_t,
+                          const IdxT* __restrict__ slot_map, const uint64_t* __restrict__ masks,
+                          const float* __restrict__ grad_out, int64_t ldgo, int64_t n_src,
+                          int64_t F, int Q, float* __restrict__ grad_x, int64_t ldg) {
+  const int lane = lane_id();
+  const int64_t j = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (j >= n_src) return;
+  const IdxT start = rowptr_t[j];
+  const IdxT end = rowptr_t[j + 1];
+  for (int q = 0; q < Q; ++q) {
+    const int64_t f0 = static_cast<int64_t>(q) * 256 + 4 * lane;
+    const bool fv = f0 < F;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (IdxT base = start; base < end; base += kWave) {
+      const IdxT rem = end - base;
+      const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+      IdxT my_dst = 0, my_slot = 0;
+      if (lane < cnt) {
+        my_dst = __builtin_nontemporal_load(&col_t[base + lane]);
+        my_slot = __builtin_nontemporal_load(&slot_map[base + lane]);
+      }
+      // U edges at a time: their masks (scalar loads), then the predicated grad_out loads of all
+      // of them, then the adds in slot order — one edge at a time leaves a wave with a single
+      // request in flight behind two dependent latencies
+      constexpr int U = 8;
+      for (int e = 0; e < cnt; e += U) {
+        uint64_t m[U][4];
+        int64_t di[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ee = e + u < cnt ? e + u : cnt - 1;
+          di[u] = static_cast<int64_t>(bcast_uniform(my_dst, ee));
+          const int64_t k = static_cast<int64_t>(bcast_uniform(my_slot, ee));
+          const uint64_t* __restrict__ mp = masks + (k * Q + q) * 4;  // wave-uniform address
+#pragma unroll
+          for (int c = 0; c < 4; ++c) m[u][c] = mp[c];
+        }
+        Vec<4> g[U];
+        bool hit[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint64_t any = (m[u][0] | m[u][1] | m[u][2] | m[u][3]) >> lane;
+          hit[u] = fv && (e + u < cnt) && (any & 1);
+          if (hit[u]) {
+            g[u] = load_vec<4>(grad_out + di[u] * ldgo + f0);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[u].v[c] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[c] += (hit[u] && ((m[u][c] >> lane) & 1)) ? g[u].v[c] : 0.f;
+        }
+      }
+    }
+    if (fv) {
+      Vec<4> o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o.v[c] = acc[c];
+      store_vec<4>(grad_x + j * ldg + f0, o);
+    }
+  }
+}
+
 // ---- one-pass multi-reduce (FusedAggregation, nn/aggr/fused.py:191-336) ----------------------
 // sum, sum of squares, min and max of the rows of a group in ONE read of the rows: the SpMM's lane
 // mapping with four accumulators per feature.  Outputs that are not requested are null; empty
@@ -1205,6 +1314,66 @@ int pygamd_spmm_csr_minmax_backward_arg(const void* rowptr, const void* col, int
   if (!arg32 && n_rows > 0 && F > 0) return PYGAMD_ERR_INVALID_ARG;
   return minmax_backward_common(rowptr, col, idx_dtype, arg32, x, ldx, out, ldo, grad_out, ldgo,
                                 n_rows, n_src, F, count_self, grad_x, ldg, stream);
+}
+
+size_t pygamd_minmax_backward_src_workspace_bytes(int64_t nnz, int64_t F) {
+  if (nnz <= 0 || F <= 0) return 0;
+  return static_cast<size_t>(nnz) * static_cast<size_t>((F + 255) / 256) * 32;
+}
+
+int pygamd_spmm_csr_minmax_backward_src(const void* rowptr, const void* col, const void* rowptr_t,
+                                        const void* col_t, const void* slot_map, int idx_dtype,
+                                        const int32_t* arg32, const float* x, int64_t ldx,
+                                        const float* out, int64_t ldo, const float* grad_out,
+                                        int64_t ldgo, int64_t n_rows, int64_t n_src, int64_t nnz,
+                                        int64_t F, int count_self, void* workspace,
+                                        size_t workspace_bytes, float* grad_x, int64_t ldg,
+                                        void* stream) {
+  if (n_rows < 0 || n_src < 0 || nnz < 0 || F < 0 || ldx < F || ldo < F || ldgo < F || ldg < F)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (n_src == 0 || F == 0) return PYGAMD_OK;
+  if (!grad_x || !rowptr_t) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows > 0 && (!rowptr || !x || !out || !grad_out || !arg32)) return PYGAMD_ERR_INVALID_ARG;
+  if (nnz > 0 && (!col_t || !slot_map)) return PYGAMD_ERR_INVALID_ARG;
+  // 16-byte accesses on arg32 / grad_out / grad_x rows
+  if ((F % 4) || (ldgo % 4) || (ldg % 4) || !aligned16(grad_out) || !aligned16(grad_x) ||
+      !aligned16(arg32))
+    return PYGAMD_ERR_UNSUPPORTED;
+  if (workspace_bytes < pygamd_minmax_backward_src_workspace_bytes(nnz, F) ||
+      (nnz > 0 && !workspace))
+    return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  const int Q = static_cast<int>((F + 255) / 256);
+  uint64_t* masks = static_cast<uint64_t*>(workspace);
+  int rc = PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    if (n_rows > 0 && nnz > 0) {
+      hipLaunchKernelGGL((minmax_winner_masks_kernel<IdxT>), dim3(wave_grid(n_rows)), dim3(kBlock),
+                         0, st, static_cast<const IdxT*>(rowptr), arg32, n_rows, F, Q, masks);
+      PYGAMD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((minmax_bwd_src_kernel<IdxT>), dim3(wave_grid(n_src)), dim3(kBlock), 0, st,
+                       static_cast<const IdxT*>(rowptr_t), static_cast<const IdxT*>(col_t),
+                       static_cast<const IdxT*>(slot_map), masks, grad_out, ldgo, n_src, F, Q,
+                       grad_x, ldg);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+  if (rc != PYGAMD_OK || n_rows == 0) return rc;
+  // outputs marked -2: the two-pass tie kernel adds their shares (fp32 atomics, rows without a
+  // mark leave after one read of their arg32 row)
+  pygamd_spmm_args probe = {};
+  probe.F = F;
+  probe.ldx = (ldx % 4 == 0) ? ldx : 1;
+  probe.ldo = ldo;
+  probe.x = x;
+  probe.out = const_cast<float*>(out);
+  probe.w_heads = 1;
+  probe.head_dim = static_cast<int>(F);
+  const Shape s = pick_shape(&probe);
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    return launch_minmax_bwd_dst<IdxT>(s, rowptr, col, x, ldx, out, ldo, grad_out, ldgo, n_rows,
+                                       F, count_self, arg32, grad_x, ldg, st);
+  });
 }
 
 int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int idx_dtype, const float* x,

@@ -888,3 +888,48 @@ def test_inplace_edit_of_a_saved_output_is_detected(dev):
             out.mul_(2.0)
             with pytest.raises(RuntimeError, match='modified by an inplace operation'):
                 out.sum().backward()
+
+
+@pytest.mark.parametrize('F', [4, 100, 256, 300, 520])
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_spmm_minmax_backward_without_atomics(dev, F, dtype):
+    """pygamd_spmm_csr_minmax_backward_src (winner bit masks + source-driven sum over the transposed
+    CSR) against the one-atomic-per-output kernel and the oracle: bipartite graph with hub rows, an
+    empty destination, a source without out-edges, data with ties and zeros (those outputs go to
+    the tie kernel in both paths), widths with one, two and three 256-feature blocks; the result
+    for the unique extrema is bit-identical run to run."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    n_src, n_dst = 500, 420
+    ei = random_graph(n_src, n_dst, 9000, seed=F + 3, skew=True)
+    ei[1][ei[1] == 9] = 10      # destination 9 is empty
+    ei[0][ei[0] == 33] = 34     # source 33 has no out-edges
+    g = gen(F + 41)
+    go = torch.randn(n_dst, F, generator=g)
+    h = pga.EdgeIndex(ei.to(dtype).to(dev), (n_src, n_dst))
+    fwd, bwd, smap = h.by_dst(), h.by_src(), h.src_slot_to_dst_slot()
+    for ties in (False, True):
+        x = torch.randn(n_src, F, generator=g)
+        if ties:
+            x[::3] = torch.randint(-1, 2, (len(range(0, n_src, 3)), F), generator=g).float()
+        for red in ('max', 'min'):
+            ref, (rg, ) = run_grad(lambda t: O.spmm(ei, t, n_dst, red), [x], go)
+            out, arg = _native.spmm_csr(fwd.ptr, fwd.idx, x.to(dev), red, n_rows=n_dst,
+                                        hub=fwd.hub, save_arg32=True)
+            a = _native.spmm_minmax_backward_dst(fwd.ptr, fwd.idx, x.to(dev), out, go.to(dev),
+                                                 n_src, arg32=arg)
+            b = _native.spmm_minmax_backward_src(fwd, bwd, smap, x.to(dev), out, go.to(dev), arg)
+            assert b is not None and b.shape == (n_src, F)
+            assert_close(b, rg, what=f'{red} F={F} ties={ties}: source-driven vs oracle')
+            assert_close(b, a, what=f'{red} F={F} ties={ties}: source-driven vs one-atomic kernel')
+            assert bool((b[33] == 0).all())
+            if not ties:
+                b2 = _native.spmm_minmax_backward_src(fwd, bwd, smap, x.to(dev), out, go.to(dev),
+                                                      arg)
+                assert torch.equal(b, b2)
+    # unsupported layout (F % 4): the wrapper says so and the autograd path falls back
+    x = torch.randn(n_src, 6, generator=g).to(dev)
+    out, arg = _native.spmm_csr(fwd.ptr, fwd.idx, x, 'max', n_rows=n_dst, hub=fwd.hub,
+                                save_arg32=True)
+    assert _native.spmm_minmax_backward_src(fwd, bwd, smap, x, out, go[:, :6].contiguous().to(dev),
+                                            arg) is None
