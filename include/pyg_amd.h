@@ -243,17 +243,19 @@ PYGAMD_API int pygamd_spmm_csr_minmax_backward_arg(const void* rowptr, const voi
                                                    int64_t ldgo, int64_t n_rows, int64_t n_src,
                                                    int64_t F, int count_self, float* grad_x,
                                                    int64_t ldg, void* stream);
-/* The same gradient WITHOUT the N x F scattered atomics (round 3): the unique winners of `arg32`
- * become one bit per (edge, feature) in `workspace` (pygamd_minmax_backward_src_workspace_bytes =
- * nnz x ceil(F / 256) x 32 bytes, by-destination slot order), then a source-driven pass over the
- * TRANSPOSED CSR (rowptr_t / col_t over the n_src sources; slot_map[e] = the by-destination slot of
- * by-source slot e, cf. EdgeIndex.src_slot_to_dst_slot) sums, per source row and in registers, the
- * grad_out entries whose bit is set and writes grad_x once (deterministic for the unique extrema;
- * no memset).  Outputs marked -2 are then added by the two-pass tie kernel like in
- * pygamd_spmm_csr_minmax_backward_arg.  Needs F % 4 == 0 and 16-byte aligned rows
- * (PYGAMD_ERR_UNSUPPORTED otherwise: use _arg).  Reference semantics: utils/_scatter.py:84-100 +
- * ATen's amax / amin backward (ties share the gradient evenly).                                  */
-PYGAMD_API size_t pygamd_minmax_backward_src_workspace_bytes(int64_t nnz, int64_t F);
+/* The same gradient WITHOUT the N x F scattered atomics (round 3).  Every output with a unique
+ * extremum has exactly one winning edge: a destination-driven pass regroups the (feature, value)
+ * pairs of grad_out by edge (`workspace`: n_rows x F pairs + one 32-bit (offset, count) word per
+ * edge, pygamd_minmax_backward_src_workspace_bytes), then a source-driven pass over the TRANSPOSED
+ * CSR (rowptr_t / col_t over the n_src sources; slot_map[e] = the by-destination slot of by-source
+ * slot e, cf. EdgeIndex.src_slot_to_dst_slot) reads each out-edge's pairs — contiguous — and
+ * sums them into the source's row in LDS, in slot order (deterministic for the unique extrema);
+ * grad_x is written once, no memset.  Outputs marked -2 are then added by the two-pass tie kernel
+ * like in pygamd_spmm_csr_minmax_backward_arg.  Needs F % 4 == 0, F <= 8192 and 16-byte aligned
+ * rows (PYGAMD_ERR_UNSUPPORTED otherwise: use _arg).  Reference semantics: utils/_scatter.py:84-100
+ * + ATen's amax / amin backward (ties share the gradient evenly).                               */
+PYGAMD_API size_t pygamd_minmax_backward_src_workspace_bytes(int64_t n_rows, int64_t nnz,
+                                                             int64_t F);
 PYGAMD_API int pygamd_spmm_csr_minmax_backward_src(
     const void* rowptr, const void* col, const void* rowptr_t, const void* col_t,
     const void* slot_map, int idx_dtype, const int32_t* arg32, const float* x, int64_t ldx,

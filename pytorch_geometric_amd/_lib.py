@@ -76,7 +76,7 @@ SIGNATURES = {
                                                     c_int64, _P]),
     'pygamd_multi_reduce_csr': (c_int, [_P, _P, c_int, _P, c_int64, c_int64, c_int64, _P, _P, _P,
                                         _P, c_int64, _P]),
-    'pygamd_minmax_backward_src_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'pygamd_minmax_backward_src_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64]),
     'pygamd_spmm_csr_minmax_backward_src': (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P,
                                                     c_int64, _P, c_int64, c_int64, c_int64,
                                                     c_int64, c_int64, c_int, _P, c_size_t, _P,

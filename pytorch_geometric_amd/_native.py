@@ -345,7 +345,7 @@ def spmm_minmax_backward_src(fwd, bwd, slot_map: Tensor, x: Tensor, out: Tensor,
     if F % 4 or _ld(g2) % 4 or g2.data_ptr() % 16:
         return None
     grad_x = torch.empty(n_src, F, dtype=torch.float32, device=x.device)
-    nbytes = lib.pygamd_minmax_backward_src_workspace_bytes(nnz, F)
+    nbytes = lib.pygamd_minmax_backward_src_workspace_bytes(fwd.ptr.numel() - 1, nnz, F)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
     a32 = arg32.contiguous()
     rc = lib.pygamd_spmm_csr_minmax_backward_src(

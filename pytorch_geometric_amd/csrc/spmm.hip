@@ -200,8 +200,13 @@ __global__ void __launch_bounds__(kBlock)
   const float init = IS_MAX ? -INFINITY : INFINITY;
   // per feature: the extremum, the slot OFFSET inside the row of its first occurrence (32 bits: a
   // row holds < 2^31 slots) and whether it was met more than once
+  // ... from a DIFFERENT source row: parallel edges (the same neighbour twice) attain the value
+  // together but send the whole gradient to one row, which is what the one-winner backward does
+  // (round 3: on a multigraph like the products-shaped one they were the bulk of the marked
+  // outputs and kept the tie kernel at 10 ms)
   float best[CH][VW];
   int32_t barg[CH][VW];
+  IdxT bsrc[CH][VW];
   bool tie[CH][VW];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
@@ -209,6 +214,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int i = 0; i < VW; ++i) {
       best[c][i] = init;
       barg[c][i] = -1;
+      bsrc[c][i] = 0;
       tie[c][i] = false;
     }
   }
@@ -227,6 +233,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < cnt; j += STEP) {
       Vec<VW> v[U][CH];
       bool ok[U];
+      IdxT cs[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = j + u * EPI + sub;
@@ -238,6 +245,7 @@ __global__ void __launch_bounds__(kBlock)
         } else {
           c = bcast_lane(myc, kk);
         }
+        cs[u] = c;
         const float* __restrict__ xr = a.x + static_cast<int64_t>(c) * a.ldx;
 #pragma unroll
         for (int c2 = 0; c2 < CH; ++c2) {
@@ -262,9 +270,11 @@ __global__ void __launch_bounds__(kBlock)
             const bool lt = better_val<IS_MAX>(best[c2][i], val);
             // the first valid slot always wins over the (arg == -1) initial state
             const bool take = ok[u] & (empty | gt);
-            tie[c2][i] = take ? false : (tie[c2][i] | (ok[u] & !empty & !lt));
+            const bool other_src = cs[u] != bsrc[c2][i];
+            tie[c2][i] = take ? false : (tie[c2][i] | (ok[u] & !empty & !lt & other_src));
             best[c2][i] = take ? val : best[c2][i];
             barg[c2][i] = take ? slot : barg[c2][i];
+            bsrc[c2][i] = take ? cs[u] : bsrc[c2][i];
           }
         }
       }
@@ -280,6 +290,7 @@ __global__ void __launch_bounds__(kBlock)
         const float ov = bcast_lane(best[c][i], lane ^ off);
         const int32_t oa = bcast_lane(barg[c][i], lane ^ off);
         const bool ot = bcast_lane(static_cast<int32_t>(tie[c][i]), lane ^ off) != 0;
+        const IdxT os = bcast_lane(bsrc[c][i], lane ^ off);
         // Branch-free on purpose: hipcc 7.2 drops the guarded assignment of the nested-if form
         // of this update for VW = 4 (found by tests/test_gpu_ops.py::test_spmm_minmax_vs_oracle).
         const bool other_valid = oa >= 0;
@@ -290,9 +301,10 @@ __global__ void __launch_bounds__(kBlock)
         const bool tie_earlier = equal & (oa < barg[c][i]);
         const bool take = other_valid & (mine_empty | other_better | tie_earlier);
         const bool take_tie = other_valid & (mine_empty | other_better);
-        tie[c][i] = equal ? true : (take_tie ? ot : tie[c][i]);
+        tie[c][i] = equal ? (tie[c][i] | ot | (os != bsrc[c][i])) : (take_tie ? ot : tie[c][i]);
         best[c][i] = take ? ov : best[c][i];
         barg[c][i] = take ? oa : barg[c][i];
+        bsrc[c][i] = take ? os : bsrc[c][i];
       }
     }
   }
@@ -362,110 +374,146 @@ __global__ void __launch_bounds__(kBlock)
 // ---- atomic-free fast half of the min/max backward (round 3) ------------------------------------
 // The one-atomic-per-output kernel above moves 4 bytes per atomic but a whole cache line per touched
 // source row segment: N x F scattered fp32 atomics = 30 ms at the products shape, F = 256 (the
-// forward takes 12.5).  Here the unique winners are first written as ONE BIT per (edge, feature):
-//   winner_masks   destination-driven, a wave per row i: lane l holds arg32[i, 4l .. 4l+3] and for
-//                  every slot s of the row four ballots (arg == s) give the 256 feature bits of that
-//                  edge, stored as 4 x uint64 in by-destination slot order (bit l of word c =
-//                  feature 4l + c of the 256-feature block);
-//   accumulate     source-driven over the transposed CSR, a wave per source j: for each out-edge it
-//                  reads the edge's 32-byte mask with scalar loads and ONLY the lanes whose bits are
-//                  set load their 16 bytes of grad_out[i]; sums stay in registers in by-source slot
-//                  order (deterministic) and grad_x[j] is written once — no atomics, no memset.
-// Per edge: 8 + 8 bytes of indices, 32 bytes of mask, and the cache lines of grad_out[i] that hold
-// a winner of this edge (deg ~25 and F = 256: ~10 winners, ~6 of the row's 8 lines).
+// forward takes 12).  Every output (i, f) with a unique extremum has exactly ONE winning edge, so
+// the N x F gradient values can be regrouped BY EDGE in one streaming pass and then read once:
+//   pack        destination-driven, a wave per row i: lane l holds arg32[i, 4l..4l+3] and
+//               grad_out[i, 4l..4l+3]; for every slot s of the row, ballots (arg == s) give each
+//               winner its rank, and the winners' (feature, value) pairs go to the row's own
+//               F-entry region of `entries` in slot order; seg[k] = (offset in the region << 16 |
+//               count) per edge.  No global scan: a row owns entries [i F, (i + 1) F).
+//   accumulate  source-driven over the transposed CSR, a wave per source j with an F-float row in
+//               LDS: for each out-edge (8 in flight) the lanes read the edge's packed pairs —
+//               one or two cache lines instead of the scattered grad_out row — and add them with
+//               ds_add_f32 (the features of one edge are distinct, edges are processed in slot
+//               order: deterministic); the row is written to grad_x once.  No atomics on global
+//               memory, no memset.
+// Per edge: 16 bytes of indices, 4 of seg, ~8 bytes x (F / deg) of pairs.  Two earlier forms were
+// measured at the products shape, F = 256: one bit per (edge, feature) + predicated 16-byte loads
+// from grad_out[i]: 3.5 ms (masks) + 16.3 ms (every edge still touches ~6 of the row's 8 lines).
 // Outputs marked -2 (ties / extremum 0) go to spmm_minmax_bwd_dst afterwards, as before.
+struct MinmaxEntry {
+  uint32_t f;
+  float v;
+};
+
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
-    minmax_winner_masks_kernel(const IdxT* __restrict__ rowptr, const int32_t* __restrict__ arg32,
-                               int64_t n_rows, int64_t F, int Q, uint64_t* __restrict__ masks) {
+    minmax_pack_kernel(const IdxT* __restrict__ rowptr, const int32_t* __restrict__ arg32,
+                       const float* __restrict__ grad_out, int64_t ldgo, int64_t n_rows, int64_t F,
+                       MinmaxEntry* __restrict__ entries, uint32_t* __restrict__ seg) {
   const int lane = lane_id();
   const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
   if (row >= n_rows) return;
   const int64_t start = rowptr[row];
   const int64_t deg = static_cast<int64_t>(rowptr[row + 1]) - start;
-  for (int q = 0; q < Q; ++q) {
-    const int64_t f0 = static_cast<int64_t>(q) * 256 + 4 * lane;
+  if (deg == 0) return;
+  const int Q = static_cast<int>((F + 255) / 256);
+  const uint64_t lt = (1ull << lane) - 1;  // lanes below this one
+  MinmaxEntry* __restrict__ reg = entries + row * F;
+  if (Q == 1) {  // the whole row in registers: one pass over the slots
+    const int64_t f0 = 4 * lane;
     int4 a = {-1, -1, -1, -1};
-    if (f0 < F) a = *reinterpret_cast<const int4*>(arg32 + row * F + f0);  // F % 4 == 0
+    Vec<4> g = {{0.f, 0.f, 0.f, 0.f}};
+    if (f0 < F) {
+      a = *reinterpret_cast<const int4*>(arg32 + row * F + f0);
+      g = load_vec<4>(grad_out + row * ldgo + f0);
+    }
+    uint32_t run = 0;
     for (int64_t s = 0; s < deg; ++s) {
       const int32_t ss = static_cast<int32_t>(s);
       const uint64_t b0 = __ballot(a.x == ss), b1 = __ballot(a.y == ss);
       const uint64_t b2 = __ballot(a.z == ss), b3 = __ballot(a.w == ss);
-      if (lane < 4) {
-        const uint64_t w = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-        masks[((start + s) * Q + q) * 4 + lane] = w;
-      }
+      const uint32_t n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+      if (a.x == ss) reg[run + __popcll(b0 & lt)] = {static_cast<uint32_t>(f0), g.v[0]};
+      if (a.y == ss) reg[run + n0 + __popcll(b1 & lt)] = {static_cast<uint32_t>(f0 + 1), g.v[1]};
+      if (a.z == ss)
+        reg[run + n0 + n1 + __popcll(b2 & lt)] = {static_cast<uint32_t>(f0 + 2), g.v[2]};
+      if (a.w == ss)
+        reg[run + n0 + n1 + n2 + __popcll(b3 & lt)] = {static_cast<uint32_t>(f0 + 3), g.v[3]};
+      const uint32_t n = n0 + n1 + n2 + n3;
+      if (lane == 0) seg[start + s] = (run << 16) | n;
+      run += n;
     }
+    return;
+  }
+  // wide rows: slot-major too, the feature blocks of a slot one after the other
+  uint32_t run = 0;
+  for (int64_t s = 0; s < deg; ++s) {
+    const int32_t ss = static_cast<int32_t>(s);
+    const uint32_t run0 = run;
+    for (int q = 0; q < Q; ++q) {
+      const int64_t f0 = static_cast<int64_t>(q) * 256 + 4 * lane;
+      int4 a = {-1, -1, -1, -1};
+      if (f0 < F) a = *reinterpret_cast<const int4*>(arg32 + row * F + f0);
+      const uint64_t b0 = __ballot(a.x == ss), b1 = __ballot(a.y == ss);
+      const uint64_t b2 = __ballot(a.z == ss), b3 = __ballot(a.w == ss);
+      const uint32_t n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+      const float* __restrict__ gp = grad_out + row * ldgo + f0;
+      if (a.x == ss) reg[run + __popcll(b0 & lt)] = {static_cast<uint32_t>(f0), gp[0]};
+      if (a.y == ss) reg[run + n0 + __popcll(b1 & lt)] = {static_cast<uint32_t>(f0 + 1), gp[1]};
+      if (a.z == ss) reg[run + n0 + n1 + __popcll(b2 & lt)] = {static_cast<uint32_t>(f0 + 2), gp[2]};
+      if (a.w == ss)
+        reg[run + n0 + n1 + n2 + __popcll(b3 & lt)] = {static_cast<uint32_t>(f0 + 3), gp[3]};
+      run += n0 + n1 + n2 + n3;
+    }
+    if (lane == 0) seg[start + s] = (run0 << 16) | (run - run0);
   }
 }
 
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
     minmax_bwd_src_kernel(const IdxT* __restrict__ rowptr_t, const IdxT* __restrict__ col_t,
-                          const IdxT* __restrict__ slot_map, const uint64_t* __restrict__ masks,
-                          const float* __restrict__ grad_out, int64_t ldgo, int64_t n_src,
-                          int64_t F, int Q, float* __restrict__ grad_x, int64_t ldg) {
+                          const IdxT* __restrict__ slot_map,
+                          const MinmaxEntry* __restrict__ entries, const uint32_t* __restrict__ seg,
+                          int64_t n_src, int64_t F, float* __restrict__ grad_x, int64_t ldg) {
+  extern __shared__ __align__(16) float rows_lds[];  // [waves per block][F]
   const int lane = lane_id();
   const int64_t j = xcd_logical_block() * kWavesPerBlock + wave_in_block();
   if (j >= n_src) return;
+  float* __restrict__ acc = rows_lds + static_cast<int64_t>(wave_in_block()) * F;
+  for (int64_t f = 4 * lane; f < F; f += 4 * kWave)
+    *reinterpret_cast<Vec<4>*>(acc + f) = Vec<4>{{0.f, 0.f, 0.f, 0.f}};
   const IdxT start = rowptr_t[j];
   const IdxT end = rowptr_t[j + 1];
-  for (int q = 0; q < Q; ++q) {
-    const int64_t f0 = static_cast<int64_t>(q) * 256 + 4 * lane;
-    const bool fv = f0 < F;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (IdxT base = start; base < end; base += kWave) {
-      const IdxT rem = end - base;
-      const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
-      IdxT my_dst = 0, my_slot = 0;
-      if (lane < cnt) {
-        my_dst = __builtin_nontemporal_load(&col_t[base + lane]);
-        my_slot = __builtin_nontemporal_load(&slot_map[base + lane]);
+  constexpr int U = 8;
+  for (IdxT base = start; base < end; base += kWave) {
+    const IdxT rem = end - base;
+    const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+    int64_t my_dst = 0;
+    uint32_t my_seg = 0;
+    if (lane < cnt) {
+      my_dst = static_cast<int64_t>(__builtin_nontemporal_load(&col_t[base + lane]));
+      my_seg = seg[__builtin_nontemporal_load(&slot_map[base + lane])];
+    }
+    for (int e = 0; e < cnt; e += U) {
+      // the pairs of U edges (first 64 of each) are requested before the first add
+      MinmaxEntry en[U];
+      int n[U];
+      const MinmaxEntry* ep[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ee = e + u < cnt ? e + u : cnt - 1;
+        const int64_t i = bcast_uniform(my_dst, ee);
+        const uint32_t sg = static_cast<uint32_t>(bcast_uniform(static_cast<int32_t>(my_seg), ee));
+        n[u] = e + u < cnt ? static_cast<int>(sg & 0xffffu) : 0;
+        ep[u] = entries + i * F + (sg >> 16);
+        en[u] = {0u, 0.f};
+        if (lane < n[u]) en[u] = ep[u][lane];
       }
-      // U edges at a time: their masks (scalar loads), then the predicated grad_out loads of all
-      // of them, then the adds in slot order — one edge at a time leaves a wave with a single
-      // request in flight behind two dependent latencies
-      constexpr int U = 8;
-      for (int e = 0; e < cnt; e += U) {
-        uint64_t m[U][4];
-        int64_t di[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ee = e + u < cnt ? e + u : cnt - 1;
-          di[u] = static_cast<int64_t>(bcast_uniform(my_dst, ee));
-          const int64_t k = static_cast<int64_t>(bcast_uniform(my_slot, ee));
-          const uint64_t* __restrict__ mp = masks + (k * Q + q) * 4;  // wave-uniform address
-#pragma unroll
-          for (int c = 0; c < 4; ++c) m[u][c] = mp[c];
-        }
-        Vec<4> g[U];
-        bool hit[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint64_t any = (m[u][0] | m[u][1] | m[u][2] | m[u][3]) >> lane;
-          hit[u] = fv && (e + u < cnt) && (any & 1);
-          if (hit[u]) {
-            g[u] = load_vec<4>(grad_out + di[u] * ldgo + f0);
-          } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) g[u].v[c] = 0.f;
+      for (int u = 0; u < U; ++u) {
+        if (lane < n[u]) atomicAdd(acc + en[u].f, en[u].v);  // ds_add_f32: features of an edge differ
+        for (int t = kWave; t < n[u]; t += kWave) {  // an edge with more than 64 winners (rare)
+          if (t + lane < n[u]) {
+            const MinmaxEntry x = ep[u][t + lane];
+            atomicAdd(acc + x.f, x.v);
           }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            acc[c] += (hit[u] && ((m[u][c] >> lane) & 1)) ? g[u].v[c] : 0.f;
-        }
       }
     }
-    if (fv) {
-      Vec<4> o;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) o.v[c] = acc[c];
-      store_vec<4>(grad_x + j * ldg + f0, o);
-    }
   }
+  for (int64_t f = 4 * lane; f < F; f += 4 * kWave)
+    store_vec<4>(grad_x + j * ldg + f, *reinterpret_cast<const Vec<4>*>(acc + f));
 }
 
 // ---- one-pass multi-reduce (FusedAggregation, nn/aggr/fused.py:191-336) ----------------------
@@ -1316,9 +1364,14 @@ int pygamd_spmm_csr_minmax_backward_arg(const void* rowptr, const void* col, int
                                 n_rows, n_src, F, count_self, grad_x, ldg, stream);
 }
 
-size_t pygamd_minmax_backward_src_workspace_bytes(int64_t nnz, int64_t F) {
-  if (nnz <= 0 || F <= 0) return 0;
-  return static_cast<size_t>(nnz) * static_cast<size_t>((F + 255) / 256) * 32;
+static size_t minmax_src_entries_bytes(int64_t n_rows, int64_t F) {
+  return (static_cast<size_t>(n_rows) * static_cast<size_t>(F) * sizeof(MinmaxEntry) + 255) &
+         ~static_cast<size_t>(255);
+}
+
+size_t pygamd_minmax_backward_src_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t F) {
+  if (n_rows <= 0 || nnz <= 0 || F <= 0) return 0;
+  return minmax_src_entries_bytes(n_rows, F) + static_cast<size_t>(nnz) * sizeof(uint32_t);
 }
 
 int pygamd_spmm_csr_minmax_backward_src(const void* rowptr, const void* col, const void* rowptr_t,
@@ -1335,26 +1388,34 @@ int pygamd_spmm_csr_minmax_backward_src(const void* rowptr, const void* col, con
   if (!grad_x || !rowptr_t) return PYGAMD_ERR_INVALID_ARG;
   if (n_rows > 0 && (!rowptr || !x || !out || !grad_out || !arg32)) return PYGAMD_ERR_INVALID_ARG;
   if (nnz > 0 && (!col_t || !slot_map)) return PYGAMD_ERR_INVALID_ARG;
-  // 16-byte accesses on arg32 / grad_out / grad_x rows
+  // 16-byte accesses on arg32 / grad_out / grad_x rows; seg packs (offset, count) in 16 + 16 bits;
+  // one LDS row per wave
   if ((F % 4) || (ldgo % 4) || (ldg % 4) || !aligned16(grad_out) || !aligned16(grad_x) ||
-      !aligned16(arg32))
+      !aligned16(arg32) || F > 8192)
     return PYGAMD_ERR_UNSUPPORTED;
-  if (workspace_bytes < pygamd_minmax_backward_src_workspace_bytes(nnz, F) ||
-      (nnz > 0 && !workspace))
+  if (workspace_bytes < pygamd_minmax_backward_src_workspace_bytes(n_rows, nnz, F) ||
+      (nnz > 0 && n_rows > 0 && !workspace))
     return PYGAMD_ERR_INVALID_ARG;
   hipStream_t st = as_stream(stream);
-  const int Q = static_cast<int>((F + 255) / 256);
-  uint64_t* masks = static_cast<uint64_t*>(workspace);
+  MinmaxEntry* entries = static_cast<MinmaxEntry*>(workspace);
+  uint32_t* seg = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) +
+                                              minmax_src_entries_bytes(n_rows, F));
   int rc = PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     if (n_rows > 0 && nnz > 0) {
-      hipLaunchKernelGGL((minmax_winner_masks_kernel<IdxT>), dim3(wave_grid(n_rows)), dim3(kBlock),
-                         0, st, static_cast<const IdxT*>(rowptr), arg32, n_rows, F, Q, masks);
+      hipLaunchKernelGGL((minmax_pack_kernel<IdxT>), dim3(wave_grid(n_rows)), dim3(kBlock), 0, st,
+                         static_cast<const IdxT*>(rowptr), arg32, grad_out, ldgo, n_rows, F,
+                         entries, seg);
       PYGAMD_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL((minmax_bwd_src_kernel<IdxT>), dim3(wave_grid(n_src)), dim3(kBlock), 0, st,
+    const size_t lds = sizeof(float) * kWavesPerBlock * static_cast<size_t>(F);
+    auto k = minmax_bwd_src_kernel<IdxT>;
+    if (lds > 48 * 1024)
+      PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds)));
+    hipLaunchKernelGGL(k, dim3(wave_grid(n_src)), dim3(kBlock), lds, st,
                        static_cast<const IdxT*>(rowptr_t), static_cast<const IdxT*>(col_t),
-                       static_cast<const IdxT*>(slot_map), masks, grad_out, ldgo, n_src, F, Q,
-                       grad_x, ldg);
+                       static_cast<const IdxT*>(slot_map), entries, seg, n_src, F, grad_x, ldg);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });
