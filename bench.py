@@ -301,10 +301,10 @@ def run_minibatch(args, rank, local_rank, world, dev):
                     num_sampled_edges_per_hop=b.num_sampled_edges)[:b.batch_size]
         loss = F.cross_entropy(out, b.y[:b.batch_size])
         loss.backward()
-        if world > 1:
+        if dist.is_initialized():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            bucket.all_reduce_mean()
+            bucket.all_reduce_mean(force=True)
             e1.record()
             ar_events.append((e0, e1))
         opt.step()
@@ -313,7 +313,7 @@ def run_minibatch(args, rank, local_rank, world, dev):
         return loss
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -330,7 +330,11 @@ def run_minibatch(args, rank, local_rank, world, dev):
     assert torch.isfinite(loss).item()
     it.close()  # stops the loader's prefetch thread
     t = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
-    if world > 1:
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    if dist.is_initialized():
+        every = [torch.zeros_like(t[:1]) for _ in range(world)]
+        dist.all_gather(every, t[:1].clone())
+        per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
         tm = t[:1].clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
@@ -353,7 +357,10 @@ def run_minibatch(args, rank, local_rank, world, dev):
                                       f'all-reduce/step)',
                        'allreduce_ms_per_step': round(
                            sum(a.elapsed_time(b) for a, b in ar_events)
-                           / max(len(ar_events), 1), 4) if world > 1 else 0.0,
+                           / max(len(ar_events), 1), 4) if ar_events else 0.0,
+                       'per_rank_ms_per_step': {'min': round(min(per_rank_ms), 3),
+                                                'max': round(max(per_rank_ms), 3),
+                                                'ranks': [round(v, 3) for v in per_rank_ms]},
                        'graph_build_s': round(t_gen, 1),
                        'hbm_gb_allocated': round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                        'gemm': gemm_desc(False)}}), flush=True)
@@ -407,9 +414,11 @@ def init_ranks(args):
     if not has_gpu and not args.dry_run:
         raise RuntimeError('bench.py needs a GPU (there is no CPU fallback); --dry-run only '
                            'checks the multi-rank launcher')
-    if world > 1:
+    if world > 1 or getattr(args, 'init_dist', False):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         if has_gpu:
             torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl' if has_gpu else 'gloo', rank=rank, world_size=world)
@@ -499,6 +508,10 @@ def main():
     ap.add_argument('--no-tuned-gemm', action='store_true',
                     help='use the default rocBLAS/hipBLASLt heuristics instead of the shipped '
                          'TunableOp table')
+    ap.add_argument('--init-dist', action='store_true',
+                    help='initialise torch.distributed (nccl = RCCL) also for ONE rank and run the '
+                         'broadcast / all-reduce / barrier collectives on it (exercises the '
+                         'multi-GPU code path on a single-GPU box)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -558,17 +571,18 @@ def main():
         out = model(x, ei)
         loss = F.cross_entropy(out[train_idx], y_train)
         loss.backward()
-        if world > 1:
+        if dist.is_initialized():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            bucket.all_reduce_mean()  # the current stream waits for RCCL's stream before e1
+            # (the current stream waits for RCCL's stream before e1)
+            bucket.all_reduce_mean(force=True)
             e1.record()
             ar_events.append((e0, e1))
         opt.step()
         return loss
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -588,14 +602,18 @@ def main():
     assert torch.isfinite(loss).item(), 'loss is not finite'
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    if dist.is_initialized():
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)  # each rank's own clock: a straggler shows up by name
+        per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = 3.0 * E * world / (elapsed / args.steps)
 
     allreduce_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1)
-                    if world > 1 else 0.0)
+                    if ar_events else 0.0)
     n_pg = dist.get_world_size() if dist.is_initialized() else 1
 
     # ---- roofline: every launch of this repo's kernels in the timed region carries HIP events
@@ -693,6 +711,10 @@ def main():
                 'edges_per_step_per_gpu': 3 * E, 'scale': args.scale,
                 'parallelism': f'dp{world} (graph replicas, one flat-bucket all-reduce/step)',
                 'allreduce_ms_per_step': round(allreduce_ms, 4),
+                'per_rank_ms_per_step': {'min': round(min(per_rank_ms), 3),
+                                         'max': round(max(per_rank_ms), 3),
+                                         'ranks': [round(v, 3) for v in per_rank_ms]},
+                'process_group': dist.get_backend() if dist.is_initialized() else None,
                 'graph_gen_s': round(t_gen, 1),
                 'gemm': gemm_desc(tuned),
                 'schedule': 'layers 1-2 forward AND layer 2 input gradient as ONE kernel each '

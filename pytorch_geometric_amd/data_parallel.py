@@ -45,10 +45,11 @@ class FlatGradBucket:
         hi = lo + self.flat.numel() * self.flat.element_size()
         return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params)
 
-    def all_reduce_mean(self, async_op: bool = False):
-        """Average the gradients over all ranks (DDP's AVG semantics): one collective."""
+    def all_reduce_mean(self, async_op: bool = False, force: bool = False):
+        """Average the gradients over all ranks (DDP's AVG semantics): one collective.  A group of
+        one rank needs none; ``force`` issues it anyway (exercises the collective path)."""
         ws = self.world_size
-        if ws == 1:
+        if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
             return None
         self.flat.div_(ws)
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group,

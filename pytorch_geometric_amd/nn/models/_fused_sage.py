@@ -130,7 +130,9 @@ class FusedSageStack(Function):
             Fi, Fo = dims[layer]
             last = layer == L - 1
             if last:
-                nbuf, dst = None, torch.empty(N, Fo, dtype=torch.float32, device=dev)
+                nbuf = None
+                dst = (None if modes[layer] == 'pre'
+                       else torch.empty(N, Fo, dtype=torch.float32, device=dev))
                 out = dst
             else:
                 nbuf, dst = new_input(layer + 1)
@@ -186,7 +188,10 @@ class FusedSageStack(Function):
                 # y = [x W_l^T | x W_r^T + b];  right += aggr(left)
                 _native.spmm_csr(fwd.ptr, fwd.idx, y[:, :Fp], aggr, n_rows=N, hub=fwd.hub,
                                  out=y[:, Fp:], accumulate=True)
-                dst.copy_(y[:, Fp:Fp + Fo])
+                if last:  # the result IS the right half of y: hand it out as a (row-strided) view
+                    out = dst = y[:, Fp:Fp + Fo]
+                else:
+                    dst.copy_(y[:, Fp:Fp + Fo])
             if not last and not relu_done:
                 dst.relu_()
             bufs.append(buf)
