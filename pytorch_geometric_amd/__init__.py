@@ -44,10 +44,20 @@ def check_index_errors() -> None:
 
 
 def build(force: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into ``lib/libpyg_amd.so`` (in-tree)."""
-    return _build.build_library(force=force)
+    """Compile the HIP sources for gfx950 into ``lib/libpyg_amd.so`` and the compiled PyTorch
+    binding (csrc/torch_binding.cpp) into ``lib/libpyg_amd_torch.so`` (both in-tree)."""
+    path = _build.build_library(force=force)
+    _build.build_torch_binding(force=force)
+    return path
+
+
+def binding_status() -> str:
+    """'compiled (<path>)' when ``torch.ops.pyg_amd_c`` (the TORCH_LIBRARY binding) carries the hot
+    entry points, 'ctypes (...)' when the ctypes route to the same C ABI is in use."""
+    from . import _compiled
+    return _compiled.status()
 
 
 __all__ = ['EdgeIndex', 'as_edge_index', 'clear_cache', 'set_cache_enabled', 'index2ptr',
            'ptr2index', 'utils', 'nn', 'build', 'load_library', 'lib_path', 'PygAmdError',
-           'set_gemm_mode', 'get_gemm_mode', 'check_index_errors']
+           'set_gemm_mode', 'get_gemm_mode', 'check_index_errors', 'binding_status']

@@ -1,7 +1,9 @@
-"""In-tree build of the C-ABI library ``lib/libpyg_amd.so`` (hipcc, gfx950 only).
+"""In-tree build of the C-ABI library ``lib/libpyg_amd.so`` (hipcc, gfx950 only) and of the compiled
+PyTorch binding ``lib/libpyg_amd_torch.so`` (csrc/torch_binding.cpp: host code only, links the C-ABI
+library and libtorch).
 
-The library is plain HIP + rocPRIM headers; it does not link against torch.  Objects go to
-``build/`` (git-ignored), the shared object stays in-tree next to the package so that it travels
+The C-ABI library is plain HIP + rocPRIM headers; it does not link against torch.  Objects go to
+``build/`` (git-ignored), the shared objects stay in-tree next to the package so that they travel
 with a repo snapshot to a GPU box (``*.so`` is git-ignored but not gpurun-ignored).
 """
 import os
@@ -30,11 +32,17 @@ def find_hipcc():
 STAMP_PATH = LIB_PATH + '.stamp'
 
 
+BINDING_SRC = os.path.join(CSRC_DIR, 'torch_binding.cpp')
+BINDING_PATH = os.path.join(LIB_DIR, 'libpyg_amd_torch.so')
+BINDING_STAMP = BINDING_PATH + '.stamp'
+
+
 def source_hash():
     """sha1 over every source the library is built from (mtimes do not survive a snapshot)."""
     import hashlib
     h = hashlib.sha1()
-    paths = sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR))
+    paths = sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)
+                   if f != os.path.basename(BINDING_SRC))
     paths.append(os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h'))
     for p in paths:
         if os.path.isfile(p):
@@ -94,5 +102,56 @@ def build_library(force=False, verbose=True):
     return LIB_PATH
 
 
+def binding_hash():
+    import hashlib
+    import torch
+    h = hashlib.sha1()
+    for p in (BINDING_SRC, os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h')):
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    return h.hexdigest()
+
+
+def binding_is_stale():
+    if not (os.path.exists(BINDING_PATH) and os.path.exists(BINDING_STAMP)):
+        return True
+    with open(BINDING_STAMP) as f:
+        return f.read().strip() != binding_hash()
+
+
+def build_torch_binding(force=False, verbose=True):
+    """hipcc (host C++ only) -> ``lib/libpyg_amd_torch.so``: TORCH_LIBRARY operators over the C ABI,
+    linked against libpyg_amd.so (found through ``$ORIGIN``) and libtorch.  Returns its path."""
+    if not force and not binding_is_stale():
+        return BINDING_PATH
+    import torch
+    from torch.utils import cpp_extension
+    hipcc = find_hipcc()
+    if hipcc is None:
+        raise RuntimeError('hipcc not found: cannot build libpyg_amd_torch.so')
+    build_library(verbose=verbose)  # the binding links the C-ABI library
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    inc = cpp_extension.include_paths(device_type='cuda')
+    tmp = BINDING_PATH + '.tmp'
+    cmd = [hipcc, '-x', 'c++', '-O2', '-std=c++17', '-fPIC', '-shared', '-fvisibility=hidden',
+           '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
+           f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}']
+    cmd += [f'-I{i}' for i in inc]
+    cmd += [BINDING_SRC, '-o', tmp, f'-L{tlib}', '-ltorch', '-ltorch_cpu', '-lc10', '-lc10_hip',
+            '-ltorch_hip', f'-L{LIB_DIR}', '-lpyg_amd', '-Wl,-rpath,$ORIGIN',
+            f'-Wl,-rpath,{tlib}']
+    if verbose:
+        print('[pyg_amd build]', ' '.join(cmd), file=sys.stderr, flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f'building the torch binding failed:\n{res.stdout}\n{res.stderr}')
+    os.replace(tmp, BINDING_PATH)
+    with open(BINDING_STAMP, 'w') as f:
+        f.write(binding_hash())
+    return BINDING_PATH
+
+
 if __name__ == '__main__':
     print(build_library(force='--force' in sys.argv))
+    print(build_torch_binding(force='--force' in sys.argv))

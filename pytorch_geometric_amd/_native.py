@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
-from . import _lib
+from . import _compiled, _lib
 from ._lib import REDUCE_IDS, PygAmdError, SpmmArgs, check
 
 # rows with more stored entries than this are split into chunks (see csrc/spmm.hip)
@@ -59,6 +59,23 @@ def _ld(t: Tensor) -> int:
     return t.stride(0) if (t.size(0) > 1 and t.size(1) > 0) else max(t.size(1), 1)
 
 
+def _plain(*tensors) -> bool:
+    """Every given tensor is a 2-D fp32 HIP tensor: the operands the compiled binding
+    (csrc/torch_binding.cpp, `torch.ops.pyg_amd_c`) takes as they are.  Anything else goes through
+    the Python path below, which raises this package's typed errors."""
+    for t in tensors:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+            return False
+    return True
+
+
+def _hub4(hub):
+    """(rows, chunk_ptr, n_hub, n_chunks) -> the same with Nones for 'no hub rows'"""
+    if hub is not None and hub[2] > 0:
+        return hub
+    return None, None, 0, 0
+
+
 # ---- integer side --------------------------------------------------------------------------------
 def index_sort(keys: Tensor, max_value: Optional[int] = None) -> Tuple[Tensor, Tensor]:
     _require_device(keys)
@@ -82,6 +99,9 @@ def index_sort(keys: Tensor, max_value: Optional[int] = None) -> Tuple[Tensor, T
 
 def index2ptr(index: Tensor, size: int) -> Tensor:
     _require_device(index)
+    C = _compiled.ops()
+    if C is not None and index.dtype in (torch.int32, torch.int64):
+        return C.index2ptr(index, size)
     index = index.contiguous()
     lib = _lib.load()
     ptr = torch.empty(size + 1, dtype=index.dtype, device=index.device)
@@ -92,6 +112,9 @@ def index2ptr(index: Tensor, size: int) -> Tensor:
 
 def ptr2index(ptr: Tensor, n: int) -> Tensor:
     _require_device(ptr)
+    C = _compiled.ops()
+    if C is not None and ptr.dtype in (torch.int32, torch.int64):
+        return C.ptr2index(ptr, n)
     ptr = ptr.contiguous()
     lib = _lib.load()
     out = torch.empty(n, dtype=ptr.dtype, device=ptr.device)
@@ -196,6 +219,31 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     _require_device(rowptr, col, x, eid, w, src_scale, relu_mask, relu_bits)
     if relu_mask is not None and relu_bits is not None:
         raise ValueError("pass at most one of 'relu_mask' / 'relu_bits'")
+    C = _compiled.ops()
+    if (C is not None and not return_arg and _plain(x, relu_mask)
+            and (w is None or (w.dtype == torch.float32 and
+                               (w.dim() == 1 or x.size(1) % max(w.size(1), 1) == 0)))
+            and rowptr.dtype in (torch.int32, torch.int64)):
+        nr = rowptr.numel() - 1 if n_rows is None else n_rows
+        F = x.size(1)
+        if relu_mask is None or tuple(relu_mask.shape) == (nr, F):
+            _check_bits(relu_bits, nr, F)
+            if out is None:
+                out = torch.empty(nr, F, dtype=torch.float32, device=x.device)
+            arg32 = None
+            if save_arg32 and reduce in ('min', 'max'):
+                arg32 = torch.empty(nr, F, dtype=torch.int32, device=x.device)
+            h_rows, h_cptr, n_hub, n_chunks = _hub4(hub)
+            with _timed({'n_rows': nr, 'n_src': x.size(0),
+                         'nnz': col.numel() if col is not None else x.size(0), 'F': F,
+                         'reduce': reduce, 'idx_bytes': rowptr.element_size(),
+                         'weighted': w is not None, 'src_scale': src_scale is not None,
+                         'accumulate': bool(accumulate), 'relu_mask': relu_mask is not None,
+                         'relu_bits': relu_bits is not None, 'n_hub': n_hub}, x):
+                C.spmm_csr(rowptr, col, x, REDUCE_IDS[reduce], nr, eid, w, src_scale, h_rows,
+                           h_cptr, n_hub, n_chunks, HUB_THRESHOLD, HUB_CHUNK, out, accumulate,
+                           hub_phase, arg32, relu_mask, relu_bits)
+            return (out, arg32) if save_arg32 else out
     lib = _lib.load()
     x2 = _f32_rows(x, 'x')
     n_rows = rowptr.numel() - 1 if n_rows is None else n_rows
@@ -402,6 +450,9 @@ def spmm_minmax_backward(rowptr_t, col_t, x, out, grad_out, ntie) -> Tensor:
 
 def sddmm_csr(rowptr, col, eid, grad_out, x, n_edges: int, w_heads: int) -> Tensor:
     _require_device(rowptr, col, eid, grad_out, x)
+    C = _compiled.ops()
+    if C is not None and _plain(grad_out, x):
+        return C.sddmm_csr(rowptr, col, eid, grad_out, x, n_edges, w_heads)
     lib = _lib.load()
     g2, x2 = _f32_rows(grad_out, 'grad_out'), _f32_rows(x, 'x')
     F = x2.size(1)
@@ -510,6 +561,10 @@ def _raise_if_flagged(err: Tensor, index: Tensor, size: int, what: str):
 
 def gather_rows(x: Tensor, index: Tensor, check_bounds: bool = False) -> Tensor:
     _require_device(x, index)
+    C = _compiled.ops()
+    if C is not None and not check_bounds and _plain(x) \
+            and index.dtype in (torch.int32, torch.int64):
+        return C.gather_rows(x, index)
     lib = _lib.load()
     x2 = _f32_rows(x, 'x')
     index = index.contiguous()
@@ -615,6 +670,9 @@ def scatter_argmax(src: Tensor, index: Tensor, dim_size: int) -> Tensor:
 # ---- softmax ---------------------------------------------------------------------------------
 def segment_softmax_forward(src: Tensor, ptr: Tensor) -> Tensor:
     _require_device(src, ptr)
+    C = _compiled.ops()
+    if C is not None and _plain(src):
+        return C.segment_softmax_forward(src, ptr)
     lib = _lib.load()
     s2 = src.contiguous()
     out = torch.empty_like(s2)
@@ -626,6 +684,9 @@ def segment_softmax_forward(src: Tensor, ptr: Tensor) -> Tensor:
 
 def segment_softmax_backward(out: Tensor, grad_out: Tensor, ptr: Tensor) -> Tensor:
     _require_device(out, grad_out, ptr)
+    C = _compiled.ops()
+    if C is not None and _plain(out, grad_out):
+        return C.segment_softmax_backward(out, grad_out, ptr)
     lib = _lib.load()
     o2, g2 = out.contiguous(), grad_out.contiguous()
     grad_src = torch.empty_like(o2)
@@ -690,6 +751,16 @@ def linear_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, relu: bo
     """``act(x @ w.T + bias)`` for row-strided fp32 ``x [M, K]``, ``w [N, K]``; ``out`` may be a
     row-strided view (e.g. one half of an ``[agg | x]`` buffer)."""
     _require_device(x, w, bias, out)
+    C = _compiled.ops()
+    if C is not None and _plain(x, w) and x.size(1) == w.size(1) \
+            and (out is None or (out.dtype == torch.float32 and out.shape == (x.size(0), w.size(0))
+                                 and (w.size(0) <= 1 or out.stride(1) == 1))):
+        if out is None:
+            out = torch.empty(x.size(0), w.size(0), dtype=torch.float32, device=x.device)
+        with _timed({'kind': 'gemm', 'op': 'forward', 'M': x.size(0), 'N': w.size(0),
+                     'K': x.size(1)}, x):
+            C.linear_forward(x, w, bias, relu, out, accumulate)
+        return out
     lib = _lib.load()
     x2, w2 = _f32_rows(x, 'x'), _f32_rows(w, 'weight')
     M, K = x2.shape
@@ -769,6 +840,33 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     as a second output (what the next such launch gathers)."""
     _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out, relu_bits, mask_bits,
                     row_scale, out_scaled)
+    C = _compiled.ops()
+    if C is not None and _plain(x_gather, x_root, w, agg, out, out_scaled):
+        n_rows, F, Fo = rowptr.numel() - 1, x_gather.size(1), w.size(0)
+        ok = (x_root.shape == (n_rows, F) and w.size(1) == 2 * F and agg.shape == (n_rows, F)
+              and out.shape == (n_rows, Fo)
+              and (out_scaled is None or (row_scale is not None and row_scale.numel() == n_rows
+                                          and row_scale.dtype == torch.float32
+                                          and out_scaled.shape == (n_rows, Fo)
+                                          and (Fo <= 1 or out_scaled.stride(1) == 1))))
+        if ok:
+            _check_bits(relu_bits, n_rows, Fo)
+            _check_bits(mask_bits, n_rows, Fo)
+            h_rows, h_cptr, n_hub, n_chunks = _hub4(hub)
+            with _timed({'n_rows': n_rows, 'n_src': x_gather.size(0), 'nnz': col.numel(), 'F': F,
+                         'reduce': reduce, 'idx_bytes': rowptr.element_size(), 'weighted': False,
+                         'src_scale': False, 'accumulate': False, 'n_hub': n_hub,
+                         'fused_gemm': {'Fo': Fo, 'K': 2 * F, 'save_agg': bool(save_agg),
+                                        'backward': mask_bits is not None,
+                                        'scaled_copy': out_scaled is not None}}, x_gather):
+                C.sage_layer_fused(
+                    rowptr, col, x_gather, x_root, w, bias, REDUCE_IDS[reduce], relu, agg, out,
+                    h_rows, h_cptr, n_hub, n_chunks,
+                    HUB_THRESHOLD if hub_threshold is None else hub_threshold,
+                    HUB_CHUNK if hub_chunk is None else hub_chunk, save_agg, relu_bits,
+                    mask_bits, row_scale, out_scaled,
+                    SAGE_FUSED_VARIANT if variant is None else variant, SAGE_FUSED_PROBE)
+            return out
     lib = _lib.load()
     xg, xr, w2 = _f32_rows(x_gather, 'x'), _f32_rows(x_root, 'x_root'), _f32_rows(w, 'weight')
     n_rows, F, Fo = rowptr.numel() - 1, xg.size(1), w2.size(0)
@@ -865,6 +963,23 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
     _require_device(g, w_t, row_scale, out, relu_mask, relu_bits, out_scaled)
     if relu_mask is not None and relu_bits is not None:
         raise ValueError("pass at most one of 'relu_mask' / 'relu_bits'")
+    C = _compiled.ops()
+    if C is not None and _plain(g, w_t, relu_mask, out, out_scaled) \
+            and g.size(1) == w_t.size(1):
+        M, K = g.size(0), w_t.size(0)
+        ok = ((out is None or (out.shape == (M, K) and (K <= 1 or out.stride(1) == 1)))
+              and (relu_mask is None or tuple(relu_mask.shape) == (M, K))
+              and (out_scaled is None or (row_scale is not None and not accumulate
+                                          and out_scaled.shape == (M, K)
+                                          and (K <= 1 or out_scaled.stride(1) == 1))))
+        if ok:
+            _check_bits(relu_bits, M, K)
+            if out is None:
+                out = torch.empty(M, K, dtype=torch.float32, device=g.device)
+            with _timed({'kind': 'gemm', 'op': 'dgrad', 'M': M, 'N': K, 'K': g.size(1)}, g):
+                C.linear_dgrad(g, w_t, row_scale, n_scaled, out, accumulate, relu_mask,
+                               relu_bits, out_scaled)
+            return out
     lib = _lib.load()
     g2, w2 = _f32_rows(g, 'grad'), _f32_rows(w_t, 'weight_t')
     M, N = g2.shape
@@ -908,6 +1023,17 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
     over ``g`` — as ``(grad_w, grad_b)``.  ``x2`` (``[M, K2]``): the gradient against
     ``[x | x2]`` -> ``[N, K + K2]`` without concatenating the two."""
     _require_device(g, x, out, x2)
+    C = _compiled.ops()
+    if C is not None and _plain(g, x, x2, out) and x.size(0) == g.size(0) \
+            and (x2 is None or (x2.size(0) == g.size(0) and x.size(1) > 0 and x2.size(1) > 0)):
+        N, K = g.size(1), x.size(1) + (0 if x2 is None else x2.size(1))
+        if K > 0 and (out is None or (out.shape == (N, K) and (K <= 1 or out.stride(1) == 1))):
+            if out is None:
+                out = torch.empty(N, K, dtype=torch.float32, device=g.device)
+            gb = torch.empty(N, dtype=torch.float32, device=g.device) if bias_grad else None
+            with _timed({'kind': 'gemm', 'op': 'wgrad', 'M': g.size(0), 'N': N, 'K': K}, g):
+                C.linear_wgrad(g, x, out, accumulate, wgs_per_cu, gb, x2)
+            return (out, gb) if bias_grad else out
     lib = _lib.load()
     second = None if x2 is None else _f32_rows(x2, 'x2')
     g2, first = _f32_rows(g, 'grad'), _f32_rows(x, 'x')
@@ -1044,6 +1170,13 @@ def gather_scatter_add(x: Tensor, gather_idx: Tensor, scatter_idx: Tensor, n_out
     """out[scatter_idx[e]] += scale[gather_idx[e]] * w[e] * x[gather_idx[e]]; ``out`` defaults to
     zeros, or accumulates into the given (row-strided) buffer."""
     _require_device(x, gather_idx, scatter_idx, scale, w, out)
+    C = _compiled.ops()
+    if C is not None and _plain(x, out) and gather_idx.dtype in (torch.int32, torch.int64) \
+            and (out is None or (out.size(1) == x.size(1) and (x.size(1) <= 1 or out.stride(1) == 1))):
+        if out is None:
+            out = torch.zeros(n_out, x.size(1), dtype=torch.float32, device=x.device)
+        C.gather_scatter_add(x, gather_idx, scatter_idx, scale, w, out)
+        return out
     lib = _lib.load()
     x2 = _f32_rows(x, 'x')
     F = x2.size(1)

@@ -160,3 +160,35 @@ def test_gemm_mode_python_api_and_relu_bits_checks():
     for bad in (bits[:, :3], bits.to(torch.int64), bits[:2], bits.transpose(0, 1)):
         with pytest.raises(ValueError):
             _native._check_bits(bad, 70, 100)
+
+
+def test_torch_binding_builds_loads_and_declares_its_operators():
+    """csrc/torch_binding.cpp: the TORCH_LIBRARY binding over the C ABI compiles with hipcc on a
+    CPU-only box, loads, reports the library's ABI version and registers every operator with the
+    `out=`-style schema (mutable arguments, no alias-or-not results) plus a fake kernel."""
+    import torch
+    from pytorch_geometric_amd import _build, _compiled, _lib
+    if _build.binding_is_stale() and _build.find_hipcc() is None:
+        pytest.skip('binding not built and no hipcc here')
+    ns = _compiled.ops()
+    assert ns is not None, _compiled.status()
+    assert int(ns.abi_version()) == _lib.ABI_VERSION
+    for name in _compiled.OPS:
+        schema = str(getattr(ns, name).default._schema)
+        assert '-> ()' in schema and '(a!)' in schema, schema
+    for name in _compiled.FUNCTIONAL_OPS:
+        schema = str(getattr(ns, name).default._schema)
+        assert '-> Tensor' in schema and '!' not in schema, schema
+    # CPU tensors: no kernel is registered for them (there is no CPU fallback)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ns.index2ptr(torch.tensor([0, 1, 1]), 3)
+    # fake tensors propagate shapes without running anything
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        x = torch.empty(10, 8, device='cuda')
+        idx = torch.empty(5, dtype=torch.int64, device='cuda')
+        assert ns.gather_rows(x, idx).shape == (5, 8)
+        assert ns.index2ptr(idx, 7).shape == (8, )
+        out = torch.empty(10, 4, device='cuda')
+        assert ns.linear_forward(x, torch.empty(4, 8, device='cuda'), None, False, out,
+                                 False) is None
