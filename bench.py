@@ -628,8 +628,10 @@ def main():
             lpr <<= 1
         it = 'long' if info['idx_bytes'] == 8 else 'int'
         if info.get('fused_gemm'):
-            name = ('sage_fused_fwd_kernel' if _native.SAGE_FUSED_VARIANT == 1
-                    else 'sage_fused_stream_kernel')
+            # (csrc/sage_fused.hip: variant 0 = the library default = 1, row-at-a-time gather)
+            name = {0: 'sage_fused_fwd_kernel', 1: 'sage_fused_fwd_kernel',
+                    2: 'sage_fused_stream_kernel'}.get(_native.SAGE_FUSED_VARIANT,
+                                                       'sage_fused_spec_kernel')
             return f'{name}<{it},{lpr}>'
         return f'spmm_sum_rows<{it},F={info["F"]}>'
 

@@ -395,12 +395,14 @@ struct MinmaxEntry {
   uint32_t f;
   float v;
 };
+constexpr int kPackCap = 1024;  // slots of a row counted in LDS (longer rows take the ballot loop)
 
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
     minmax_pack_kernel(const IdxT* __restrict__ rowptr, const int32_t* __restrict__ arg32,
                        const float* __restrict__ grad_out, int64_t ldgo, int64_t n_rows, int64_t F,
                        MinmaxEntry* __restrict__ entries, uint32_t* __restrict__ seg) {
+  __shared__ int pack_cnt[kWavesPerBlock * kPackCap];
   const int lane = lane_id();
   const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
   if (row >= n_rows) return;
@@ -410,7 +412,51 @@ __global__ void __launch_bounds__(kBlock)
   const int Q = static_cast<int>((F + 255) / 256);
   const uint64_t lt = (1ull << lane) - 1;  // lanes below this one
   MinmaxEntry* __restrict__ reg = entries + row * F;
-  if (Q == 1) {  // the whole row in registers: one pass over the slots
+  if (Q == 1 && deg <= kPackCap) {
+    // counting sort of the row's <= 256 winners by slot, in LDS: one ds_add_rtn per entry gives
+    // its rank inside its edge (the order inside an edge is free: its features are distinct), a
+    // wave scan over the deg counters gives the edge offsets; 4 global stores per lane and ROW.
+    // (A loop over the slots with four ballots + four conditional stores per slot — 250 M store
+    // instructions at the products shape — measured 7.5 ms for this kernel.)
+    int* __restrict__ cnt = pack_cnt + wave_in_block() * kPackCap;
+    for (int s = lane; s < deg; s += kWave) cnt[s] = 0;
+    const int64_t f0 = 4 * lane;
+    int4 a = {-1, -1, -1, -1};
+    Vec<4> g = {{0.f, 0.f, 0.f, 0.f}};
+    if (f0 < F) {
+      a = *reinterpret_cast<const int4*>(arg32 + row * F + f0);
+      g = load_vec<4>(grad_out + row * ldgo + f0);
+    }
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    if (a.x >= 0) r0 = atomicAdd(cnt + a.x, 1);
+    if (a.y >= 0) r1 = atomicAdd(cnt + a.y, 1);
+    if (a.z >= 0) r2 = atomicAdd(cnt + a.z, 1);
+    if (a.w >= 0) r3 = atomicAdd(cnt + a.w, 1);
+    // exclusive scan of cnt[0 .. deg) in place -> edge offsets; seg words written on the way
+    int carry = 0;
+    for (int s0 = 0; s0 < deg; s0 += kWave) {
+      const int s = s0 + lane;
+      const int c = s < deg ? cnt[s] : 0;
+      int inc = c;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int t = __shfl_up(inc, off, kWave);
+        if (lane >= off) inc += t;
+      }
+      const int excl = carry + inc - c;
+      if (s < deg) {
+        cnt[s] = excl;
+        seg[start + s] = (static_cast<uint32_t>(excl) << 16) | static_cast<uint32_t>(c);
+      }
+      carry += bcast_uniform(inc, kWave - 1);
+    }
+    if (a.x >= 0) reg[cnt[a.x] + r0] = {static_cast<uint32_t>(f0), g.v[0]};
+    if (a.y >= 0) reg[cnt[a.y] + r1] = {static_cast<uint32_t>(f0 + 1), g.v[1]};
+    if (a.z >= 0) reg[cnt[a.z] + r2] = {static_cast<uint32_t>(f0 + 2), g.v[2]};
+    if (a.w >= 0) reg[cnt[a.w] + r3] = {static_cast<uint32_t>(f0 + 3), g.v[3]};
+    return;
+  }
+  if (Q == 1) {  // a longer row: one pass over the slots, ballots give the ranks
     const int64_t f0 = 4 * lane;
     int4 a = {-1, -1, -1, -1};
     Vec<4> g = {{0.f, 0.f, 0.f, 0.f}};

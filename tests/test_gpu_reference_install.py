@@ -152,8 +152,13 @@ def test_reference_graphsage_model_runs_the_fused_stack(pyg, installed, launches
     ref_out, ref_gin, ref_gp = _fwd_bwd(model, (x, ei), go)
     dmodel = copy.deepcopy(model).to(dev)
     out, gin, gp = _fwd_bwd(dmodel, _to(dev, (x, ei)), go)
-    widths = [info['F'] for info, _, _ in launches['sink']]
-    assert sorted(widths) == [12, 12, 20, 20, 64, 64], widths  # fwd 20,64,12; bwd 12,64,20
+    # (the sink also carries the dense-transform launches, which have no 'F')
+    widths = sorted(info['F'] for info, _, _ in launches['sink'] if 'F' in info)
+    # six aggregation launches: forward at 20 / 64 / 12 (the 64 -> 10 layer re-ordered), backward
+    # at 12, 64 and — the layer-1 input gradient — 20 as a transposed SpMM or 64 as the one-kernel
+    # input gradient (which gathers at the layer's OUTPUT width)
+    assert len(widths) == 6 and widths.count(12) == 2 and widths.count(20) >= 1 \
+        and widths[-1] == 64, widths
     assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what='GraphSAGE out')
     assert_close_scaled(gin[0], ref_gin[0], tol=2e-5, what='GraphSAGE grad x')
     for a, b in zip(gp, ref_gp):
@@ -163,7 +168,7 @@ def test_reference_graphsage_model_runs_the_fused_stack(pyg, installed, launches
     dmodel.fuse_stack = False
     del launches['sink'][:]
     out2, _, _ = _fwd_bwd(dmodel, _to(dev, (x, ei)), go)
-    assert sorted(i['F'] for i, _, _ in launches['sink']) == [20, 20, 64, 64, 64, 64]
+    assert sorted(i['F'] for i, _, _ in launches['sink'] if 'F' in i) == [20, 20, 64, 64, 64, 64]
     assert_close(out2, ref_out, rtol=1e-5, atol=2e-5, what='GraphSAGE layer loop')
 
 
