@@ -282,6 +282,9 @@ def run_minibatch(args, rank, local_rank, world, dev):
     model = GraphSAGE(128, 256, num_layers=3, out_channels=172).to(dev)
     broadcast_parameters(model)
     bucket = FlatGradBucket(model)
+    if args.capture:
+        return run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, scale,
+                                      N, E, t_gen)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
     def batches():
@@ -364,6 +367,143 @@ def run_minibatch(args, rank, local_rank, world, dev):
                        'graph_build_s': round(t_gen, 1),
                        'hbm_gb_allocated': round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                        'gemm': gemm_desc(False)}}), flush=True)
+
+
+def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, scale, N, E, t_gen):
+    """BASELINE config 4 with the WHOLE batch step — device-side neighbour sampling at static
+    capacities, feature gather, the padded hop-aware GraphSAGE stack forward + backward, Adam — as
+    ONE captured hipGraph (the eager path is bound by ~145 launches per batch).
+    Only the seed ids change between replays (one device-to-device copy) plus a device-side RNG
+    word.  With a process group the gradient all-reduce and the optimizer step stay outside the
+    graph (fwd + bwd captured)."""
+    import torch.distributed as dist
+
+    from pytorch_geometric_amd.nn.models._fused_sage_hops import run_padded
+    use_dist = dist.is_initialized()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    B = loader.batch_size
+    seeds_buf = torch.zeros(B, dtype=torch.int64, device=dev)
+    rng_word = torch.zeros(1, dtype=torch.int64, device=dev)
+    hop_edges = torch.zeros(len(fan), dtype=torch.int64, device=dev)   # real edges per hop, summed
+    hop_nodes = torch.zeros(len(fan), dtype=torch.int64, device=dev)   # new nodes per hop, summed
+    loss_buf = torch.zeros((), device=dev)
+
+    def fwd_bwd():
+        rng_word.add_(1)
+        b = loader.collate_padded(seeds_buf, seed=17 + rank, seed_dev=rng_word)
+        bucket.zero_()
+        out = run_padded(model, b.x, b.hops)
+        loss = F.cross_entropy(out, b.y)
+        loss.backward()
+        hop_edges.add_(torch.cat(b.hops.n_edges))
+        hop_nodes.add_(torch.cat(b.hops.n_nodes))
+        loss_buf.copy_(loss.detach())
+
+    def whole_step():
+        fwd_bwd()
+        opt.step()
+
+    def plan():
+        while True:
+            for seeds, _ in loader._plan():
+                if seeds.numel() == B:
+                    yield seeds
+
+    it = plan()
+    seeds_buf.copy_(next(it))
+    from pytorch_geometric_amd.hipgraph import CapturedStep
+    captured = CapturedStep(fwd_bwd if use_dist else whole_step, warmup=3)
+    ar_events = []
+
+    def step():
+        seeds_buf.copy_(next(it))
+        captured()
+        if use_dist:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.all_reduce_mean(force=True)
+            e1.record()
+            ar_events.append((e0, e1))
+            opt.step()
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    hop_edges.zero_()
+    hop_nodes.zero_()
+    del ar_events[:]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(loss_buf).item()
+    ne = [int(v) for v in hop_edges.tolist()]
+    nn_ = [int(v) for v in hop_nodes.tolist()]
+    Lh = len(ne)
+    edges = sum(sum(ne[:Lh - l]) for l in range(Lh))   # layer l aggregates hops 0 .. L-1-l
+    # algorithmic HBM bytes of the aggregation + feature gather (SURVEY.md 8(d)): per aggregated
+    # edge one source row (4 F) + one index, per gathered node one 512-byte feature row
+    widths = [128, 256, 256]
+    agg_bytes = sum(sum(ne[:Lh - l]) * (4 * widths[l] + 8) for l in range(Lh))
+    gather_bytes = (B * args.steps + sum(nn_)) * 128 * 4
+    t = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    if use_dist:
+        every = [torch.zeros_like(t[:1]) for _ in range(world)]
+        dist.all_gather(every, t[:1].clone())
+        per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
+        tm = t[:1].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        t[0] = tm[0]
+    elapsed, total_edges = float(t[0]), float(t[1])
+    if rank == 0:
+        caps = [B]
+        for k in fan:
+            caps.append(caps[-1] * k)
+        print(json.dumps({
+            'metric': 'edges/sec (fwd+bwd) 3-layer SAGE + NeighborLoader [15,10,5], '
+                      'papers100M shape (BASELINE config 4, informational)',
+            'value': total_edges / elapsed, 'unit': 'edges/s',
+            'n_gpus': dist.get_world_size() if use_dist else 1,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'GraphSAGE(128->256->256->172) mini-batch training, batch '
+                                   f'{B} seeds/rank, fan-out {fan}, hop-aware (trim_to_layer) '
+                                   f'stack on STATIC-shape batches (block capacities {caps}), '
+                                   f'synthetic papers100M shape x {scale:g} (N={N}, E={E}) '
+                                   f'replicated per GPU',
+                       'captured': ('sampling + gather + forward + backward' +
+                                    ('' if use_dist else ' + Adam') + ' = one hipGraph per batch'),
+                       'parallelism': f'dp{world} (seed sharding, one flat-bucket '
+                                      f'all-reduce/step)',
+                       'allreduce_ms_per_step': round(
+                           sum(a.elapsed_time(b) for a, b in ar_events)
+                           / max(len(ar_events), 1), 4) if ar_events else 0.0,
+                       'per_rank_ms_per_step': {'min': round(min(per_rank_ms), 3),
+                                                'max': round(max(per_rank_ms), 3),
+                                                'ranks': [round(v, 3) for v in per_rank_ms]},
+                       'real_edges_per_batch_per_hop': [round(v / args.steps, 1) for v in ne],
+                       'new_nodes_per_batch_per_hop': [round(v / args.steps, 1) for v in nn_],
+                       'graph_build_s': round(t_gen, 1),
+                       'hbm_gb_allocated': round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                       'gemm': gemm_desc(False)},
+            'roofline': {'bound': 'hbm', 'unit': 'GB/s', 'peak': 8000.0,
+                         'achieved': round((agg_bytes + gather_bytes) / elapsed / 1e9, 1),
+                         'frac': round((agg_bytes + gather_bytes) / elapsed / 8e12, 4),
+                         'traffic': None,
+                         'kernel': 'whole captured batch step (aggregation + feature gather '
+                                   'bytes over the step time: the step is latency-bound, not '
+                                   'bandwidth-bound)',
+                         'algorithmic_bytes_per_batch': round(
+                             (agg_bytes + gather_bytes) / args.steps)}}), flush=True)
 
 
 def gemm_desc(tuned: bool) -> str:
@@ -508,6 +648,9 @@ def main():
     ap.add_argument('--no-tuned-gemm', action='store_true',
                     help='use the default rocBLAS/hipBLASLt heuristics instead of the shipped '
                          'TunableOp table')
+    ap.add_argument('--capture', action='store_true',
+                    help='minibatch mode: sampling + gather + forward + backward + Adam of a batch '
+                         'as ONE hipGraph on static-shape (padded) batches')
     ap.add_argument('--init-dist', action='store_true',
                     help='initialise torch.distributed (nccl = RCCL) also for ONE rank and run the '
                          'broadcast / all-reduce / barrier collectives on it (exercises the '

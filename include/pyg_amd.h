@@ -321,11 +321,14 @@ PYGAMD_API int pygamd_gather_rows(const float* x, int64_t ldx, int64_t n_src, co
 /* Fused gather -> scale -> scatter-add on an unsorted edge list (the COO
  * fallback of the SpMM for graphs used once, e.g. the backward of a sampled mini-batch):
  *   out[scatter_idx[e], :] += (scale ? scale[gather_idx[e]] : 1) * (w ? w[e] : 1) * x[gather_idx[e], :]
- * `out` must be initialised by the caller (usually zeros); fp32 atomics.                        */
+ * `out` must be initialised by the caller (usually zeros); fp32 atomics.  `n_valid` (device int64,
+ * may be NULL): only the first min(*n_valid, n_edges) entries of the fixed-capacity edge list are
+ * real (a sampled hop at its static capacity: no host read, hipGraph-capturable).               */
 PYGAMD_API int pygamd_gather_scatter_add(const float* x, int64_t ldx, const void* gather_idx,
                                          const void* scatter_idx, int idx_dtype,
                                          const float* scale, const float* w, int64_t n_edges,
-                                         int64_t F, float* out, int64_t ldo, void* stream);
+                                         const int64_t* n_valid, int64_t F, float* out,
+                                         int64_t ldo, void* stream);
 
 /* ---- a5: scatter (unsorted COO, atomics) ----------------------------------------------------
  * out[index[e], :] (reduce)= src[e, :]   (utils/_scatter.py:14-138).  `out` must be
@@ -437,13 +440,15 @@ PYGAMD_API int pygamd_gat_edge_softmax_backward(const void* rowptr, const void* 
  * flags bit 0 (the reference's `replace=True`, loader/neighbor_loader.py:209; needs a bounded
  * fan-out): every frontier node with at least one in-neighbour gets exactly k independent uniform
  * draws (offsets from pygamd_sample_counts with replace set).  flags bit 1: the draws of a node
- * depend on its position in the frontier as well (disjoint sampling: one tree per seed).       */
+ * depend on its position in the frontier as well (disjoint sampling: one tree per seed).
+ * seed_dev (device uint64, may be NULL) is added to `seed` on the device: a captured graph draws a
+ * fresh batch at every replay by bumping that word.                                            */
 PYGAMD_API int pygamd_sample_max_fanout(void);
 PYGAMD_API int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
                                        const void* frontier, int64_t n_frontier,
                                        const void* offsets, int64_t max_per_node, uint64_t seed,
-                                       int flags, void* src_out, void* dstpos_out,
-                                       void* slot_out, void* stream);
+                                       int flags, const uint64_t* seed_dev, void* src_out,
+                                       void* dstpos_out, void* slot_out, void* stream);
 
 /* cnt[f] = min(deg(frontier[f]), k) (k < 0: deg; replace != 0 and k >= 0: k wherever deg > 0, else
  * 0) — the per-node sample counts of one hop.

@@ -118,7 +118,7 @@ SIGNATURES = {
                                             c_int64, c_int64, c_int64, _P, _P]),
     'pygamd_sample_max_fanout': (c_int, []),
     'pygamd_sample_neighbors': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, c_uint64, c_int,
-                                        _P, _P, _P, _P]),
+                                        _P, _P, _P, _P, _P]),
     'pygamd_edge_key': (c_int, [_P, _P, c_int, c_int64, c_int64, c_int, _P, _P]),
     'pygamd_run_flags': (c_int, [_P, c_int64, _P, _P]),
     'pygamd_edge_unkey': (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P]),
@@ -126,8 +126,8 @@ SIGNATURES = {
     'pygamd_relabel': (c_int, [c_int, _P, c_int, c_int64, _P, _P, _P, c_int64, _P, _P, _P]),
     'pygamd_gather_rows': (c_int, [_P, c_int64, c_int64, _P, c_int, c_int64, c_int64, _P,
                                    c_int64, _P, _P]),
-    'pygamd_gather_scatter_add': (c_int, [_P, c_int64, _P, _P, c_int, _P, _P, c_int64, c_int64,
-                                          _P, c_int64, _P]),
+    'pygamd_gather_scatter_add': (c_int, [_P, c_int64, _P, _P, c_int, _P, _P, c_int64, _P,
+                                          c_int64, _P, c_int64, _P]),
     'pygamd_scatter_init': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
     'pygamd_scatter_rows': (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P, c_int64,
                                     c_int64, c_int, _P, _P, _P]),

@@ -1141,13 +1141,15 @@ def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int, blocks: int = 1
 # ---- neighbour sampling (one hop) ---------------------------------------------------------------
 def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Tensor, total: int,
                      max_per_node: int, seed: int, zero_fill: bool = False,
-                     replace: bool = False, salt_position: bool = False):
+                     replace: bool = False, salt_position: bool = False,
+                     seed_dev: Optional[Tensor] = None):
     """(src_global, dst_pos_in_frontier, csc_slot) for the sampled in-edges of `frontier`.
     ``total`` sizes the outputs; ``zero_fill`` for a static capacity larger than what the hop
     really samples (the tail then holds 0 = a valid node / slot id).  ``replace``: draws with
     replacement (``offsets`` from :func:`sample_counts` with the same flag).  ``salt_position``:
     the draws of a node also depend on its position in ``frontier`` (disjoint sampling: the same
-    node in two trees draws independently)."""
+    node in two trees draws independently).  ``seed_dev`` (int64 [1] on the device) is added to
+    ``seed`` on the device (a captured graph bumps it between replays)."""
     _require_device(colptr, row, frontier, offsets)
     lib = _lib.load()
     alloc = torch.zeros if zero_fill else torch.empty
@@ -1158,7 +1160,8 @@ def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Ten
         check(lib.pygamd_sample_neighbors(_p(colptr), _p(row), _idx_dtype(colptr), _p(frontier),
                                           frontier.numel(), _p(offsets), max_per_node,
                                           seed & 0xFFFFFFFFFFFFFFFF,
-                                          int(replace) | (2 if salt_position else 0), _p(src),
+                                          int(replace) | (2 if salt_position else 0),
+                                          _p(seed_dev), _p(src),
                                           _p(dstpos),
                                           _p(slot), _stream(colptr)), 'sample_neighbors')
     return src, dstpos, slot
@@ -1166,16 +1169,17 @@ def sample_neighbors(colptr: Tensor, row: Tensor, frontier: Tensor, offsets: Ten
 
 def gather_scatter_add(x: Tensor, gather_idx: Tensor, scatter_idx: Tensor, n_out: int,
                        scale: Optional[Tensor] = None, w: Optional[Tensor] = None,
-                       out: Optional[Tensor] = None) -> Tensor:
+                       out: Optional[Tensor] = None, n_valid: Optional[Tensor] = None) -> Tensor:
     """out[scatter_idx[e]] += scale[gather_idx[e]] * w[e] * x[gather_idx[e]]; ``out`` defaults to
-    zeros, or accumulates into the given (row-strided) buffer."""
+    zeros, or accumulates into the given (row-strided) buffer.  ``n_valid`` (int64 [1], device):
+    only that many leading entries of the fixed-capacity edge list are real."""
     _require_device(x, gather_idx, scatter_idx, scale, w, out)
     C = _compiled.ops()
     if C is not None and _plain(x, out) and gather_idx.dtype in (torch.int32, torch.int64) \
             and (out is None or (out.size(1) == x.size(1) and (x.size(1) <= 1 or out.stride(1) == 1))):
         if out is None:
             out = torch.zeros(n_out, x.size(1), dtype=torch.float32, device=x.device)
-        C.gather_scatter_add(x, gather_idx, scatter_idx, scale, w, out)
+        C.gather_scatter_add(x, gather_idx, scatter_idx, scale, w, out, n_valid)
         return out
     lib = _lib.load()
     x2 = _f32_rows(x, 'x')
@@ -1188,8 +1192,8 @@ def gather_scatter_add(x: Tensor, gather_idx: Tensor, scatter_idx: Tensor, n_out
     if w is not None:
         w = w.contiguous()
     check(lib.pygamd_gather_scatter_add(_p(x2), _ld(x2), _p(gi), _p(si), _idx_dtype(gi),
-                                        _p(scale), _p(w), gi.numel(), F, _p(out), _ld(out),
-                                        _stream(x)), 'gather_scatter_add')
+                                        _p(scale), _p(w), gi.numel(), _p(n_valid), F, _p(out),
+                                        _ld(out), _stream(x)), 'gather_scatter_add')
     return out
 
 

@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(kBlock)
     sample_neighbors_kernel(const IdxT* __restrict__ colptr, const IdxT* __restrict__ row,
                             const IdxT* __restrict__ frontier, int64_t n_frontier,
                             const IdxT* __restrict__ offsets, uint64_t seed, int flags,
+                            const uint64_t* __restrict__ seed_dev,
                             IdxT* __restrict__ src_out, IdxT* __restrict__ dstpos_out,
                             IdxT* __restrict__ slot_out) {
   const int lane = lane_id();
@@ -43,6 +44,7 @@ __global__ void __launch_bounds__(kBlock)
   const bool replace = (flags & 1) != 0;
   // flags & 2: the draws depend on the frontier position too (disjoint trees)
   const uint64_t salt = (flags & 2) ? mix64(0xD1B54A32D192ED03ull * static_cast<uint64_t>(f + 1)) : 0;
+  if (seed_dev) seed += *seed_dev;  // (a captured graph bumps this word between replays)
   const uint64_t key = mix64(seed ^ mix64(static_cast<uint64_t>(v)) ^ salt);
   if (replace) {  // cnt = k independent draws from the deg in-neighbours (deg > 0 here)
     if (lane < cnt) {
@@ -183,7 +185,8 @@ int pygamd_sample_max_fanout(void) { return kMaxFanout; }
 
 int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
                             const void* frontier, int64_t n_frontier, const void* offsets,
-                            int64_t max_per_node, uint64_t seed, int flags, void* src_out,
+                            int64_t max_per_node, uint64_t seed, int flags,
+                            const uint64_t* seed_dev, void* src_out,
                             void* dstpos_out, void* slot_out, void* stream) {
   if (n_frontier < 0) return PYGAMD_ERR_INVALID_ARG;
   if (n_frontier == 0) return PYGAMD_OK;
@@ -197,7 +200,7 @@ int pygamd_sample_neighbors(const void* colptr, const void* row, int idx_dtype,
     hipLaunchKernelGGL((sample_neighbors_kernel<IdxT>), dim3(grid), dim3(kBlock), 0,
                        as_stream(stream), static_cast<const IdxT*>(colptr),
                        static_cast<const IdxT*>(row), static_cast<const IdxT*>(frontier),
-                       n_frontier, static_cast<const IdxT*>(offsets), seed, flags,
+                       n_frontier, static_cast<const IdxT*>(offsets), seed, flags, seed_dev,
                        static_cast<IdxT*>(src_out), static_cast<IdxT*>(dstpos_out),
                        static_cast<IdxT*>(slot_out));
     PYGAMD_LAUNCH_CHECK();

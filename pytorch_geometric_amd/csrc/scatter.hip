@@ -227,8 +227,11 @@ __global__ void __launch_bounds__(kBlock)
                               const IdxT* __restrict__ gather_idx,
                               const IdxT* __restrict__ scatter_idx,
                               const float* __restrict__ scale, const float* __restrict__ w,
-                              int64_t n_edges, int64_t units, int64_t F, float* __restrict__ out,
-                              int64_t ldo) {
+                              int64_t n_edges, const int64_t* __restrict__ n_valid, int64_t units,
+                              int64_t F, float* __restrict__ out, int64_t ldo) {
+  // (n_valid: device-side count of the real entries of a fixed-capacity edge list — a sampled
+  // hop inside a captured graph)
+  if (n_valid && *n_valid < n_edges) n_edges = *n_valid;
   const int64_t total = n_edges * units;
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
        t += static_cast<int64_t>(gridDim.x) * kBlock) {
@@ -497,8 +500,8 @@ int pygamd_gather_rows(const float* x, int64_t ldx, int64_t n_src, const void* i
 
 int pygamd_gather_scatter_add(const float* x, int64_t ldx, const void* gather_idx,
                               const void* scatter_idx, int idx_dtype, const float* scale,
-                              const float* w, int64_t n_edges, int64_t F, float* out,
-                              int64_t ldo, void* stream) {
+                              const float* w, int64_t n_edges, const int64_t* n_valid, int64_t F,
+                              float* out, int64_t ldo, void* stream) {
   if (n_edges < 0 || F < 0 || ldx < F || ldo < F) return PYGAMD_ERR_INVALID_ARG;
   if (n_edges == 0 || F == 0) return PYGAMD_OK;
   if (!x || !gather_idx || !scatter_idx || !out) return PYGAMD_ERR_INVALID_ARG;
@@ -509,13 +512,14 @@ int pygamd_gather_scatter_add(const float* x, int64_t ldx, const void* gather_id
       hipLaunchKernelGGL((gather_scatter_add_kernel<IdxT, 4>), dim3(flat_grid(n_edges * units)),
                          dim3(kBlock), 0, as_stream(stream), x, ldx,
                          static_cast<const IdxT*>(gather_idx),
-                         static_cast<const IdxT*>(scatter_idx), scale, w, n_edges, units, F, out,
-                         ldo);
+                         static_cast<const IdxT*>(scatter_idx), scale, w, n_edges, n_valid, units,
+                         F, out, ldo);
     } else {
       hipLaunchKernelGGL((gather_scatter_add_kernel<IdxT, 1>), dim3(flat_grid(n_edges * F)),
                          dim3(kBlock), 0, as_stream(stream), x, ldx,
                          static_cast<const IdxT*>(gather_idx),
-                         static_cast<const IdxT*>(scatter_idx), scale, w, n_edges, F, F, out, ldo);
+                         static_cast<const IdxT*>(scatter_idx), scale, w, n_edges, n_valid, F, F,
+                         out, ldo);
     }
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;

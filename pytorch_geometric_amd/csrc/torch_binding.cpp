@@ -324,7 +324,8 @@ Tensor gather_rows(const Tensor& x, const Tensor& index) {
 }
 
 void gather_scatter_add(const Tensor& x, const Tensor& gather_idx, const Tensor& scatter_idx,
-                        const OptTensor& scale, const OptTensor& w, Tensor out) {
+                        const OptTensor& scale, const OptTensor& w, Tensor out,
+                        const OptTensor& n_valid) {
   const Tensor x2 = rows_f32(x, "x");
   const int64_t F = x2.size(1);
   TORCH_CHECK(out.dim() == 2 && out.size(1) == F && out.scalar_type() == at::kFloat &&
@@ -333,8 +334,8 @@ void gather_scatter_add(const Tensor& x, const Tensor& gather_idx, const Tensor&
   const Tensor gi = gather_idx.contiguous(), si = scatter_idx.contiguous();
   const Tensor sc = contig(scale), wc = contig(w);
   check(pygamd_gather_scatter_add(fptr(x2), ld(x2), ptr(gi), ptr(si), idx_dtype(gi), fptr(sc),
-                                  fptr(wc), gi.numel(), F, static_cast<float*>(ptr(out)), ld(out),
-                                  cur_stream(x2)),
+                                  fptr(wc), gi.numel(), static_cast<const int64_t*>(ptr(n_valid)),
+                                  F, static_cast<float*>(ptr(out)), ld(out), cur_stream(x2)),
         "gather_scatter_add");
 }
 
@@ -402,7 +403,7 @@ TORCH_LIBRARY(pyg_amd_c, m) {
   m.def("gather_rows(Tensor x, Tensor index) -> Tensor");
   m.def(
       "gather_scatter_add(Tensor x, Tensor gather_idx, Tensor scatter_idx, Tensor? scale, "
-      "Tensor? w, Tensor(a!) out) -> ()");
+      "Tensor? w, Tensor(a!) out, Tensor? n_valid) -> ()");
   m.def(
       "sddmm_csr(Tensor rowptr, Tensor? col, Tensor? eid, Tensor grad_out, Tensor x, "
       "int n_edges, int w_heads) -> Tensor");

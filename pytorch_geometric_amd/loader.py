@@ -40,6 +40,21 @@ class Batch:
         self.graph.record_stream(stream)
 
 
+@dataclass
+class PaddedBatch:
+    """A mini-batch at STATIC shapes (``NeighborLoader.collate_padded``): ``hops`` is the
+    sampler's padded-id output (block positions as node ids, per-hop CSR pointers, device-side
+    counts), ``x`` the features of all ``hops.bases[-1]`` padded rows (padding rows repeat node 0),
+    ``y`` the labels of the seeds.  Nothing in it depends on a host read: sampling, gather, the
+    padded hop stack (nn/models/_fused_sage_hops.py) and the optimizer step replay as one
+    hipGraph."""
+    x: Tensor
+    y: Optional[Tensor]
+    hops: object
+    n_id: Tensor
+    batch_size: int
+
+
 class NeighborLoader:
     r"""Iterates over mini-batches of ``batch_size`` seed nodes with their sampled ``k``-hop
     neighbourhoods.
@@ -96,6 +111,17 @@ class NeighborLoader:
                      e_id=out.edge, input_id=seeds if input_id is None else input_id,
                      batch_size=seeds.numel(), num_sampled_nodes=out.num_sampled_nodes,
                      num_sampled_edges=out.num_sampled_edges, batch=out.batch)
+
+    def collate_padded(self, seeds: Tensor, seed: int = 0,
+                       seed_dev: Optional[Tensor] = None) -> PaddedBatch:
+        """One batch at its static capacity, without any host synchronisation (bounded fan-outs,
+        directional, non-disjoint).  ``seed_dev`` (int64 [1], device) is added to the RNG seed on
+        the device: a captured step bumps it before every replay."""
+        p = self.sampler.sample_padded(seeds, seed=seed, padded_ids=True, seed_dev=seed_dev)
+        n_id = torch.cat([p.seeds] + p.new_nodes)
+        x = _native.gather_rows(self.x, n_id)  # filter_data: x[n_id]
+        y = None if self.y is None else self.y[seeds]
+        return PaddedBatch(x=x, y=y, hops=p, n_id=n_id, batch_size=seeds.numel())
 
     def _plan(self):
         n = self.input_nodes.numel()

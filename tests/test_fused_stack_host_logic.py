@@ -356,3 +356,87 @@ def test_fused_stack_steps_aside_for_lazy_or_foreign_parameters():
     assert not params_ready(Conv(w.double(), w), x)
     assert not params_ready(Conv(w, w, torch.nn.Parameter(torch.zeros(5, dtype=torch.float64))), x)
     assert not params_ready(Conv(w.to('meta'), w), x)
+
+
+@pytest.mark.parametrize('own', [False, True])
+@pytest.mark.parametrize('aggr', ['mean', 'sum'])
+def test_padded_hop_stack_wiring(fake_native, monkeypatch, own, aggr):
+    """FusedSagePaddedHopStack (the static-shape batch a captured training step runs on): node ids
+    are block positions with padding rows, each hop has its own CSR pointer over its destination
+    block and its real-edge count on the device.  Seed rows, parameter gradients and the input
+    gradient on the real rows must equal the full GraphSAGE on the compact sampled subgraph; padding
+    rows hold garbage on the way in and get exactly zero gradient."""
+    from types import SimpleNamespace
+
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    from pytorch_geometric_amd.nn.models._fused_sage_hops import FusedSagePaddedHopStack
+
+    def gather_scatter_add(x, gather_idx, scatter_idx, n_out, scale=None, w=None, out=None,
+                           n_valid=None):
+        assert w is None and n_valid is not None
+        n = int(n_valid)
+        gi, si = gather_idx[:n], scatter_idx[:n]
+        v = x[gi] if scale is None else x[gi] * scale[gi].view(-1, 1)
+        out.index_add_(0, si, v)
+        return out
+
+    monkeypatch.setattr(_native, 'gather_scatter_add', gather_scatter_add)
+    monkeypatch.setattr(_fused_sage, 'OWN_GEMM_MIN_ROWS', 0 if own else 1 << 30)
+    g = gen(23)
+    nodes_per_hop = [4, 7, 11, 16]                   # compact batch: seeds + 3 hops
+    ei, edges_per_hop = _sampled_batch(nodes_per_hop, 3, g)
+    L = 3
+    n, dims = sum(nodes_per_hop), (8, 12, 12, 5)
+    caps = [4, 9, 15, 21]                            # block capacities >= the real counts
+    bases = [0]
+    for c in caps:
+        bases.append(bases[-1] + c)
+    starts = [0]
+    for c in nodes_per_hop:
+        starts.append(starts[-1] + c)
+    # compact id -> padded id
+    pad_of = torch.empty(n, dtype=torch.long)
+    for b in range(L + 1):
+        pad_of[starts[b]:starts[b + 1]] = torch.arange(nodes_per_hop[b]) + bases[b]
+    ptrs, rows, cols, n_edges = [], [], [], []
+    e0 = 0
+    for h in range(L):
+        e1 = e0 + edges_per_hop[h]
+        src, dst = ei[0, e0:e1], ei[1, e0:e1]
+        deg = torch.bincount(dst - starts[h], minlength=caps[h])      # padding rows: degree 0
+        ptrs.append(torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)]))
+        cap_e = edges_per_hop[h] + 5                                   # zero-filled tail
+        r = torch.zeros(cap_e, dtype=torch.long)
+        c = torch.zeros(cap_e, dtype=torch.long)
+        r[:e1 - e0], c[:e1 - e0] = pad_of[src], pad_of[dst]
+        rows.append(r)
+        cols.append(c)
+        n_edges.append(torch.tensor([e1 - e0]))
+        e0 = e1
+    batch = SimpleNamespace(bases=bases, ptrs=ptrs, rows=rows, cols=cols, n_edges=n_edges)
+    x = torch.randn(n, dims[0], generator=g)
+    x_pad = torch.randn(bases[-1], dims[0], generator=g) * 50.0        # garbage in the padding
+    x_pad[pad_of] = x
+    params = [(torch.randn(fo, fi, generator=g) * 0.3, torch.randn(fo, generator=g),
+               torch.randn(fo, fi, generator=g) * 0.3) for fi, fo in zip(dims[:-1], dims[1:])]
+    seeds = nodes_per_hop[0]
+    go = torch.randn(seeds, dims[-1], generator=g)
+    # reference: the full model on the compact subgraph
+    xs = x.clone().requires_grad_(True)
+    ps = [tuple(t.clone().requires_grad_(True) for t in p) for p in params]
+    ref = O.graphsage(xs, ei, ps, aggr)
+    ref[:seeds].backward(go)
+    want = [ref[:seeds].detach(), xs.grad] + [t.grad for p in ps for t in p]
+    xp = x_pad.clone().requires_grad_(True)
+    pp = [tuple(t.clone().requires_grad_(True) for t in p) for p in params]
+    out = FusedSagePaddedHopStack.apply(xp, batch, aggr, *[t for p in pp for t in p])
+    assert out.shape == (bases[1], dims[-1])
+    out[:seeds].backward(go)
+    got = [out[:seeds].detach(), xp.grad[pad_of]] + [t.grad for p in pp for t in p]
+    for a, b in zip(want, got):
+        assert_close(b, a, rtol=1e-4, atol=2e-4, what=f'padded hop stack (own={own})')
+    padding = torch.ones(bases[-1], dtype=torch.bool)
+    padding[pad_of] = False
+    assert bool((xp.grad[padding] == 0).all())
+    assert bool([e for e in fake_native if e[0] == 'wgrad']) == own
