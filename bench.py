@@ -412,7 +412,12 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
     it = plan()
     seeds_buf.copy_(next(it))
     from pytorch_geometric_amd.hipgraph import CapturedStep
-    captured = CapturedStep(fwd_bwd if use_dist else whole_step, warmup=3)
+    if os.environ.get('PYGAMD_CAPTURE', '1') == '0':  # the same static-shape step, eagerly
+        captured = fwd_bwd if use_dist else whole_step   # (per-kernel times for a profile)
+        for _ in range(3):
+            captured()
+    else:
+        captured = CapturedStep(fwd_bwd if use_dist else whole_step, warmup=3)
     ar_events = []
 
     def step():

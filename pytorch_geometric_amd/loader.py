@@ -117,7 +117,8 @@ class NeighborLoader:
         """One batch at its static capacity, without any host synchronisation (bounded fan-outs,
         directional, non-disjoint).  ``seed_dev`` (int64 [1], device) is added to the RNG seed on
         the device: a captured step bumps it before every replay."""
-        p = self.sampler.sample_padded(seeds, seed=seed, padded_ids=True, seed_dev=seed_dev)
+        p = self.sampler.sample_padded(seeds, seed=seed, padded_ids=True, seed_dev=seed_dev,
+                                       want_edge_ids=False)
         n_id = torch.cat([p.seeds] + p.new_nodes)
         x = _native.gather_rows(self.x, n_id)  # filter_data: x[n_id]
         y = None if self.y is None else self.y[seeds]

@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--scale', type=float, default=1.0)
 ap.add_argument('--widths', default='256,100')
 ap.add_argument('--only-spec', action='store_true', help='only the producer/consumer variants')
+ap.add_argument('--sq-only', action='store_true',
+                help='a few launches of v1 and v3 with phases on/off (for a rocprofv3 --pmc pass)')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 x0, _, ei, _ = products_like(seed=1, scale=args.scale)
@@ -61,6 +63,13 @@ for F in [int(v) for v in args.widths.split(',')]:
                                              hub=fwd.hub, out=buf[:, :F]))
     t_gemm = timeit(lambda: _native.linear_forward(buf, w, b, relu=True, out=ref))
     print(f'F={F} Fo={Fo}: SpMM {t_spmm:.3f} ms, GEMM {t_gemm:.3f} ms', flush=True)
+    if args.sq_only:
+        for variant in (1, 3):
+            for probe in (0, 1, 2):   # full / gather skipped / MFMA skipped: told apart by order
+                for _ in range(3):
+                    one(variant, probe)
+        torch.cuda.synchronize()
+        continue
     for variant in (3, 4):
         out.fill_(float('nan'))
         one(variant)
