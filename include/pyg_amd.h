@@ -386,6 +386,19 @@ PYGAMD_API int pygamd_segment_softmax_backward(const float* out, const float* gr
                                                const void* ptr, int idx_dtype, int64_t n_seg,
                                                int64_t H, float* grad_src, void* stream);
 
+/* The same softmax over an UNSORTED `index` ([n], values in [0, N)) — the index branch of
+ * utils/_softmax.py:82-88 (scatter-max, gather, exp, scatter-sum, gather, div) as four launches:
+ * group maxima (atomic float max), exp + group sums (fp32 atomics), normalisation.  `workspace`:
+ * 2 x N x H floats (forward), N x H floats (backward).  Rows whose index is out of range are
+ * skipped (their output is left untouched by the forward, their gradient is 0).               */
+PYGAMD_API int pygamd_softmax_index_forward(const float* src, const void* index, int idx_dtype,
+                                            int64_t n, int64_t H, int64_t N, float* workspace,
+                                            float* out, void* stream);
+PYGAMD_API int pygamd_softmax_index_backward(const float* out, const float* grad_out,
+                                             const void* index, int idx_dtype, int64_t n,
+                                             int64_t H, int64_t N, float* workspace,
+                                             float* grad_src, void* stream);
+
 /* segment_logsumexp (utils/_segment.py:53-80): out[s,h] = log(sum_{k in s} exp(src[k,h])),
  * evaluated with the segment maximum subtracted; an empty segment gives 0.  src is [n, H]
  * contiguous, out [n_seg, H].  Backward: grad_src[k,h] = exp(src[k,h] - out[s,h]) * grad_out[s,h]. */

@@ -300,6 +300,27 @@ class SegmentSoftmaxFunction(Function):
         return g.view(ctx.src_shape), None
 
 
+class IndexSoftmaxFunction(Function):
+    """Softmax within the groups of an UNSORTED ``index`` (utils/_softmax.py:82-88: the maximum is
+    taken on the detached input, ``1e-16`` joins the denominator) as dedicated kernels instead of
+    the six-pass scatter / gather composition; backward = the softmax Jacobian,
+    ``out * (g - sum_group(out * g))``."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, index: Tensor, num_groups: int):
+        res = _shaped(_native.softmax_index_forward(_rows(src), index, num_groups), src.shape)
+        ctx.save_for_backward(res, index)
+        ctx.num_groups = num_groups
+        return res
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        out, index = ctx.saved_tensors
+        o2 = _rows(out)
+        g = _native.softmax_index_backward(o2, grad_out.reshape(o2.shape), index, ctx.num_groups)
+        return g.view(out.shape), None, None
+
+
 class SegmentLogSumExpFunction(Function):
     """``segment_logsumexp(src, ptr, dim=0)`` (utils/_segment.py:53-80) for 2-D ``src``; the total
     derivative through the subtracted maximum is the in-segment softmax."""

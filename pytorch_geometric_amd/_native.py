@@ -696,6 +696,33 @@ def segment_softmax_backward(out: Tensor, grad_out: Tensor, ptr: Tensor) -> Tens
     return grad_src
 
 
+def softmax_index_forward(src: Tensor, index: Tensor, num_groups: int) -> Tensor:
+    """Softmax of ``src [n, H]`` within the groups of an unsorted ``index`` (4 launches)."""
+    _require_device(src, index)
+    lib = _lib.load()
+    s2, idx = src.contiguous(), index.contiguous()
+    n, H = s2.shape
+    out = torch.zeros_like(s2)
+    ws = torch.empty(2 * max(num_groups, 1) * max(H, 1), dtype=torch.float32, device=src.device)
+    check(lib.pygamd_softmax_index_forward(_p(s2), _p(idx), _idx_dtype(idx), n, H, num_groups,
+                                           _p(ws), _p(out), _stream(src)), 'softmax_index_forward')
+    return out
+
+
+def softmax_index_backward(out: Tensor, grad_out: Tensor, index: Tensor,
+                           num_groups: int) -> Tensor:
+    _require_device(out, grad_out, index)
+    lib = _lib.load()
+    o2, g2, idx = out.contiguous(), grad_out.contiguous(), index.contiguous()
+    n, H = o2.shape
+    grad_src = torch.empty_like(o2)
+    ws = torch.empty(max(num_groups, 1) * max(H, 1), dtype=torch.float32, device=out.device)
+    check(lib.pygamd_softmax_index_backward(_p(o2), _p(g2), _p(idx), _idx_dtype(idx), n, H,
+                                            num_groups, _p(ws), _p(grad_src), _stream(out)),
+          'softmax_index_backward')
+    return grad_src
+
+
 def segment_logsumexp_forward(src: Tensor, ptr: Tensor) -> Tensor:
     _require_device(src, ptr)
     lib = _lib.load()

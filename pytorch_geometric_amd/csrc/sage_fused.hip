@@ -301,6 +301,10 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArg
     }
   }
   __syncthreads();  // next_row armed
+  // (probe bit 11: the gather phase at raised issue priority, the transform phase at 0 — VALU /
+  // VMEM issue on a SIMD is arbitrated by priority, then age, and a wave issuing dependent MFMAs
+  // back to back otherwise wins every slot it asks for)
+  if (a.probe & 2048) __builtin_amdgcn_s_setprio(2);
   for (; !(a.probe & 1);) {  // rows are handed out one by one: long and short rows balance over
     int r = 0;               // the 8 waves
     if (lane == 0) r = atomicAdd(&next_row, 1);
@@ -309,6 +313,7 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArg
     fused_gather_row<IdxT, 4, LPR>(a, row0 + r, agg + r * agg_ld, lane);
   }
 
+  if (a.probe & 2048) __builtin_amdgcn_s_setprio(0);
   __syncthreads();  // phase 1 complete: both tiles visible to every wave
   fused_transform<IdxT, 1>(a, agg, xr, agg_ld, row0, wave, lane);
 }
@@ -759,6 +764,7 @@ __global__ void __launch_bounds__(kSBlock) sage_fused_spec_kernel(SageFusedArgs<
 
   if (m < 0) {
     // ---- gather waves
+    if (a.probe & 2048) __builtin_amdgcn_s_setprio(2);
     for (;;) {
       const int t = __builtin_amdgcn_readfirstlane(lds_counter_add(&ticket, sink, lane));
       const int lt = t >> 5, r = t & 31;

@@ -277,6 +277,52 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- softmax over an UNSORTED index (utils/_softmax.py:82-88) ---------------------------------------
+// The reference's index branch is scatter-max (detached) -> gather -> exp -> scatter-sum -> gather ->
+// div: six passes over the [n, H] values (ten launches with the scatter prologues / epilogues).  Here:
+//   init      gmax = -inf, gsum = 0                                   [N, H] each (workspace)
+//   max       atomic float max of src[k, h] into gmax[index[k], h]
+//   exp_sum   e = exp(src - gmax[index]); out = e; atomicAdd(gsum[index], e)
+//   div       out /= gsum[index] + 1e-16
+// and for the backward  s = scatter_sum(out * g);  grad = out * (g - s[index])  as init + 2 passes.
+// One thread per (k, h) element; the group statistics are N x H floats (L2-resident for the
+// attention shapes this serves).  Sums use fp32 atomics (order-dependent rounding, like the
+// reference's scatter_add_ on a GPU).
+__global__ void __launch_bounds__(kBlock)
+    softmax_index_init_kernel(float* __restrict__ gmax, float* __restrict__ gsum, int64_t total) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= total) return;
+  if (gmax) gmax[t] = -INFINITY;
+  gsum[t] = 0.f;
+}
+
+template <typename IdxT, int PHASE>
+__global__ void __launch_bounds__(kBlock)
+    softmax_index_kernel(const float* __restrict__ src, const IdxT* __restrict__ index, int64_t n,
+                         int64_t H, int64_t N, float* __restrict__ gmax, float* __restrict__ gsum,
+                         float* __restrict__ out, const float* __restrict__ grad_out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= n * H) return;
+  const int64_t k = t / H;
+  const int64_t h = t - k * H;
+  const int64_t g = static_cast<int64_t>(index[k]);
+  if (g < 0 || g >= N) return;  // (out of range: skipped, like the scatter kernels)
+  const int64_t s = g * H + h;
+  if constexpr (PHASE == 0) {         // group maxima
+    atomic_max_f32(gmax + s, src[t]);
+  } else if constexpr (PHASE == 1) {  // exp + group sums
+    const float e = expf(src[t] - gmax[s]);
+    out[t] = e;
+    atomicAdd(gsum + s, e);
+  } else if constexpr (PHASE == 2) {  // normalise
+    out[t] = out[t] / (gsum[s] + 1e-16f);
+  } else if constexpr (PHASE == 3) {  // backward: group sums of out * g
+    atomicAdd(gsum + s, src[t] * grad_out[t]);
+  } else {                            // backward: grad = out * (g - sum)
+    out[t] = src[t] * (grad_out[t] - gsum[s]);
+  }
+}
+
 }  // namespace pygamd
 
 using namespace pygamd;
@@ -312,6 +358,62 @@ int pygamd_segment_softmax_backward(const float* out, const float* grad_out, con
                        dim3(kBlock), 0, as_stream(stream), out, grad_out,
                        static_cast<const IdxT*>(ptr), n_seg, H, grad_src, none,
                        static_cast<float*>(nullptr), static_cast<float*>(nullptr));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_softmax_index_forward(const float* src, const void* index, int idx_dtype, int64_t n,
+                                 int64_t H, int64_t N, float* workspace, float* out,
+                                 void* stream) {
+  if (n < 0 || H < 0 || N < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0 || H == 0) return PYGAMD_OK;
+  if (!src || !index || !out || (N > 0 && !workspace)) return PYGAMD_ERR_INVALID_ARG;
+  if (N == 0) return PYGAMD_OK;
+  hipStream_t st = as_stream(stream);
+  float* gmax = workspace;
+  float* gsum = workspace + N * H;
+  const dim3 ginit(static_cast<unsigned>(ceil_div(N * H, kBlock)));
+  const dim3 grid(static_cast<unsigned>(ceil_div(n * H, kBlock)));
+  hipLaunchKernelGGL(softmax_index_init_kernel, ginit, dim3(kBlock), 0, st, gmax, gsum, N * H);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const IdxT* idx = static_cast<const IdxT*>(index);
+    hipLaunchKernelGGL((softmax_index_kernel<IdxT, 0>), grid, dim3(kBlock), 0, st, src, idx, n, H,
+                       N, gmax, gsum, out, static_cast<const float*>(nullptr));
+    hipLaunchKernelGGL((softmax_index_kernel<IdxT, 1>), grid, dim3(kBlock), 0, st, src, idx, n, H,
+                       N, gmax, gsum, out, static_cast<const float*>(nullptr));
+    hipLaunchKernelGGL((softmax_index_kernel<IdxT, 2>), grid, dim3(kBlock), 0, st, src, idx, n, H,
+                       N, gmax, gsum, out, static_cast<const float*>(nullptr));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_softmax_index_backward(const float* out, const float* grad_out, const void* index,
+                                  int idx_dtype, int64_t n, int64_t H, int64_t N,
+                                  float* workspace, float* grad_src, void* stream) {
+  if (n < 0 || H < 0 || N < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0 || H == 0) return PYGAMD_OK;
+  if (!out || !grad_out || !index || !grad_src || (N > 0 && !workspace))
+    return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  if (N == 0) {  // every index is out of range: zero gradient
+    PYGAMD_HIP_CHECK(hipMemsetAsync(grad_src, 0, sizeof(float) * n * H, st));
+    return PYGAMD_OK;
+  }
+  const dim3 ginit(static_cast<unsigned>(ceil_div(N * H, kBlock)));
+  const dim3 grid(static_cast<unsigned>(ceil_div(n * H, kBlock)));
+  PYGAMD_HIP_CHECK(hipMemsetAsync(grad_src, 0, sizeof(float) * n * H, st));  // skipped rows: 0
+  hipLaunchKernelGGL(softmax_index_init_kernel, ginit, dim3(kBlock), 0, st,
+                     static_cast<float*>(nullptr), workspace, N * H);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    const IdxT* idx = static_cast<const IdxT*>(index);
+    hipLaunchKernelGGL((softmax_index_kernel<IdxT, 3>), grid, dim3(kBlock), 0, st, out, idx, n, H,
+                       N, static_cast<float*>(nullptr), workspace, grad_src, grad_out);
+    hipLaunchKernelGGL((softmax_index_kernel<IdxT, 4>), grid, dim3(kBlock), 0, st, out, idx, n, H,
+                       N, static_cast<float*>(nullptr), workspace, grad_src, grad_out);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });

@@ -3,8 +3,8 @@ from typing import Optional
 from torch import Tensor
 
 from .. import _native
-from .._functions import GatherFunction, SegmentSoftmaxFunction
-from ._scatter import _require_fp32, scatter
+from .._functions import IndexSoftmaxFunction, SegmentSoftmaxFunction
+from ._scatter import _require_fp32
 from .num_nodes import maybe_num_nodes
 
 
@@ -22,11 +22,12 @@ def softmax(src: Tensor, index: Optional[Tensor] = None, ptr: Optional[Tensor] =
         index = _native.ptr2index(ptr, src.size(dim))
     if index is None:
         raise NotImplementedError("'softmax' requires 'index' to be specified")
-    # index branch (:82-88): scatter-max (detached) -> gather -> exp -> scatter-sum -> gather
+    # index branch (:82-88: scatter-max (detached) -> gather -> exp -> scatter-sum -> gather -> div)
+    # as one operator: group maxima, exp + group sums, normalisation (csrc/softmax.hip)
     N = maybe_num_nodes(index, num_nodes)
     if dim != 0:
         return softmax(src.movedim(dim, 0).contiguous(), index, None, N, 0).movedim(0, dim)
-    src_max = scatter(src.detach(), index, 0, dim_size=N, reduce='max')
-    out = (src - GatherFunction.apply(src_max, index, False)).exp()
-    out_sum = scatter(out, index, 0, dim_size=N, reduce='sum') + 1e-16
-    return out / GatherFunction.apply(out_sum, index, False)
+    if index.dim() != 1 or index.numel() != src.size(0):
+        raise ValueError(f"'index' must hold one group id per entry of dimension {dim} of 'src' "
+                         f"({src.size(0)}), got {tuple(index.shape)}")
+    return IndexSoftmaxFunction.apply(src, index, N)

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--scale', type=float, default=1.0)
 ap.add_argument('--widths', default='256,100')
 ap.add_argument('--only-spec', action='store_true', help='only the producer/consumer variants')
+ap.add_argument('--prio', action='store_true', help='A/B of the issue-priority scheme')
 ap.add_argument('--sq-only', action='store_true',
                 help='a few launches of v1 and v3 with phases on/off (for a rocprofv3 --pmc pass)')
 args = ap.parse_args()
@@ -63,6 +64,13 @@ for F in [int(v) for v in args.widths.split(',')]:
                                              hub=fwd.hub, out=buf[:, :F]))
     t_gemm = timeit(lambda: _native.linear_forward(buf, w, b, relu=True, out=ref))
     print(f'F={F} Fo={Fo}: SpMM {t_spmm:.3f} ms, GEMM {t_gemm:.3f} ms', flush=True)
+    if args.prio:
+        for variant in (1, 3, 4):
+            print(f'  v{variant}: default {timeit(lambda: one(variant)):.3f} ms, gather at s_setprio 2 '
+                  f'{timeit(lambda: one(variant, 2048)):.3f} ms; MFMA skipped '
+                  f'{timeit(lambda: one(variant, 2)):.3f} / {timeit(lambda: one(variant, 2048 | 2)):.3f}'
+                  f' ms', flush=True)
+        continue
     if args.sq_only:
         for variant in (1, 3):
             for probe in (0, 1, 2):   # full / gather skipped / MFMA skipped: told apart by order
