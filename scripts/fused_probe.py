@@ -18,6 +18,7 @@ ap.add_argument('--scale', type=float, default=1.0)
 ap.add_argument('--widths', default='256,100')
 ap.add_argument('--only-spec', action='store_true', help='only the producer/consumer variants')
 ap.add_argument('--prio', action='store_true', help='A/B of the issue-priority scheme')
+ap.add_argument('--pitch', action='store_true', help='F = 100 rows at a 128-float pitch')
 ap.add_argument('--sq-only', action='store_true',
                 help='a few launches of v1 and v3 with phases on/off (for a rocprofv3 --pmc pass)')
 args = ap.parse_args()
@@ -64,6 +65,25 @@ for F in [int(v) for v in args.widths.split(',')]:
                                              hub=fwd.hub, out=buf[:, :F]))
     t_gemm = timeit(lambda: _native.linear_forward(buf, w, b, relu=True, out=ref))
     print(f'F={F} Fo={Fo}: SpMM {t_spmm:.3f} ms, GEMM {t_gemm:.3f} ms', flush=True)
+    if args.pitch and F == 100:
+        # layer 1's rows are 400 bytes: 3.125 lines each, straddling — against the same rows stored
+        # at a 512-byte pitch (whole lines, 28 % more bytes)
+        wide = torch.zeros(N, 128, device=dev)
+        wide[:, :F] = xsrc
+        xw = wide[:, :F]
+
+        def one_wide(variant=1, probe=0):
+            _native.SAGE_FUSED_PROBE = probe
+            _native.sage_layer_forward(fwd.ptr, fwd.idx, xw, xw, w, b, 'mean', True, buf[:, :F], out,
+                                       hub=fwd.hub, save_agg=True, variant=variant)
+            _native.SAGE_FUSED_PROBE = 0
+
+        print(f'  F=100, v1: 400-byte pitch {timeit(lambda: one(1)):.3f} ms (MFMA skipped '
+              f'{timeit(lambda: one(1, 2)):.3f}); 512-byte pitch {timeit(one_wide):.3f} ms (MFMA '
+              f'skipped {timeit(lambda: one_wide(1, 2)):.3f}); stand-alone SpMM 400 / 512: '
+              f'{t_spmm:.3f} / ' + f'''{timeit(lambda: _native.spmm_csr(fwd.ptr, fwd.idx, xw, 'mean', n_rows=N, hub=fwd.hub, out=buf[:, :F])):.3f} ms''',
+              flush=True)
+        continue
     if args.prio:
         for variant in (1, 3, 4):
             print(f'  v{variant}: default {timeit(lambda: one(variant)):.3f} ms, gather at s_setprio 2 '
