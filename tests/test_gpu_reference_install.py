@@ -325,3 +325,48 @@ def test_reference_node_loader_drives_the_gpu_sampler(pyg, installed, dev):
     out = model(batch.x, batch.edge_index, num_sampled_nodes_per_hop=batch.num_sampled_nodes,
                 num_sampled_edges_per_hop=batch.num_sampled_edges)
     assert out.shape[1] == 5 and bool(torch.isfinite(out).all())
+
+
+def test_reference_node_loader_with_sampler_options(pyg, installed, dev):
+    """The options NeighborLoader forwards to its sampler (loader/neighbor_loader.py:209-233), on
+    the BaseSampler adapter, driven by the reference's NodeLoader: `disjoint=True` fills
+    `batch.batch` (the reference's filter_data copies SamplerOutput.batch), `replace=True` gives
+    exactly k edges per seed with an in-neighbour, `subgraph_type='bidirectional'` (string or the
+    reference's SubgraphType) returns symmetric edges without hop counts."""
+    from torch_geometric.data import Data
+    from torch_geometric.loader import NodeLoader
+    from torch_geometric.sampler.base import SubgraphType
+    g = gen(33)
+    N = 1200
+    ei = torch.randint(0, N, (2, 15000), generator=g)
+    x = torch.randn(N, 6, generator=g)
+    data = Data(x=x, edge_index=ei, num_nodes=N).to(dev)
+    seeds = torch.randperm(N, generator=g)[:96]
+    deg = torch.bincount(ei[1], minlength=N)
+
+    def batches(**opts):
+        sampler = installed.neighbor_sampler(data, [4, 2], seed=3, **opts)
+        return list(NodeLoader(data, node_sampler=sampler, input_nodes=seeds, batch_size=32,
+                               shuffle=False))
+
+    for b in batches(disjoint=True):
+        tree = b.batch.cpu()
+        n_id, loc = b.n_id.cpu(), b.edge_index.cpu()
+        assert torch.equal(tree[:32], torch.arange(32)) and tree.numel() == n_id.numel()
+        assert torch.equal(tree[loc[0]], tree[loc[1]])             # edges stay inside their tree
+        assert (tree * N + n_id).unique().numel() == n_id.numel()
+        assert torch.equal(b.x.cpu(), x[n_id])
+    for i, b in enumerate(batches(replace=True)):
+        s = seeds[i * 32:(i + 1) * 32]
+        first_hop = b.edge_index.cpu()[1][:b.num_sampled_edges[0]]
+        got = torch.bincount(first_hop, minlength=32)[:32]
+        assert torch.equal(got, torch.where(deg[s] > 0, torch.full_like(deg[s], 4), deg[s]))
+    for kind in ('bidirectional', SubgraphType.bidirectional):
+        for b in batches(subgraph_type=kind):
+            loc = b.edge_index.cpu()
+            m = b.n_id.numel()
+            fwd_keys = set((loc[1] * m + loc[0]).tolist())
+            assert fwd_keys == set((loc[0] * m + loc[1]).tolist())  # every edge has its reverse
+            assert b.num_sampled_edges is None or 'num_sampled_edges' not in b
+    with pytest.raises(NotImplementedError):
+        installed.neighbor_sampler(data, [4, 2], subgraph_type='induced')
