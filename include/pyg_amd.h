@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 4
+#define PYGAMD_ABI_VERSION 5
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -192,7 +192,33 @@ typedef struct {
                                 one of relu_mask / relu_bits.                                      */
   int64_t ld_bits;           /* column blocks per row tile, >= ceil(F / 32); the array holds
                                 ceil(n_rows / 32) * ld_bits * 32 words                             */
+  const uint32_t* src_bits;  /* SUM/MEAN without w / src_scale, col != NULL; NULL or one bit per
+                                SOURCE row (bit j & 31 of word j >> 5, ceil(n_src / 32) words):
+                                a clear bit promises that x[j, :] is all zero, and the row is not
+                                read.  What pygamd_rows_pack writes.  The case: the gradient of a
+                                loss taken on a training split (`out[train_idx]`, 8 % of the rows
+                                of ogbn-products) entering the transposed aggregation of the last
+                                layer — the reference gathers every zero row
+                                (index_select on the full [E] index, message_passing.py:283-292)   */
+  const int64_t* src_bits_set; /* NULL or a DEVICE counter of the set bits: with more than half of
+                                the n_src rows live the kernel ignores src_bits (the lookup then
+                                costs more than it saves) — decided on the device, no host sync    */
 } pygamd_spmm_args;
+
+/* Row-sparsity of a gradient block, found in the pass that lays it out for the backward of a
+ * transform-then-aggregate layer: for every row i < n_rows of g ([n_rows, ldg], F columns)
+ *   row_bits bit i   = [g[i, :] has an entry != 0]  (NaN counts; ceil(n_rows / 32) words, the
+ *                      bits past n_rows are clear);
+ *   scaled[i, f]     = g[i, f] * row_scale[i] (row_scale NULL: 1) for f < F, 0 for F <= f <
+ *                      F_scaled (scaled NULL: skipped);
+ *   copy[i, f]       = g[i, f] for f < F, 0 for F <= f < F_copy (copy NULL: skipped);
+ *   *n_set           = the number of set bits (device int64, NULL: skipped; zeroed here).
+ * `scaled` / `copy` may not alias g.  One read of g; replaces aten::mul + aten::copy_ + two fills
+ * in the backward of the 256 -> 47 output layer and feeds pygamd_spmm_args.src_bits.             */
+PYGAMD_API int pygamd_rows_pack(const float* g, int64_t ldg, int64_t n_rows, int64_t F,
+                                const float* row_scale, float* scaled, int64_t ld_scaled,
+                                int64_t F_scaled, float* copy, int64_t ld_copy, int64_t F_copy,
+                                uint32_t* row_bits, int64_t* n_set, void* stream);
 
 PYGAMD_API int pygamd_spmm_csr_workspace_bytes(const pygamd_spmm_args* args, size_t* bytes);
 PYGAMD_API int pygamd_spmm_csr(const pygamd_spmm_args* args, void* workspace,

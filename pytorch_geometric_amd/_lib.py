@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 from . import _build
 
-ABI_VERSION = 4  # PYGAMD_ABI_VERSION of include/pyg_amd.h
+ABI_VERSION = 5  # PYGAMD_ABI_VERSION of include/pyg_amd.h
 IDX_I32, IDX_I64 = 0, 1
 SUM, MEAN, MIN, MAX, MUL, ANY = 0, 1, 2, 3, 4, 5
 REDUCE_IDS = {'sum': SUM, 'add': SUM, 'mean': MEAN, 'min': MIN, 'amin': MIN, 'max': MAX,
@@ -32,7 +32,8 @@ class SpmmArgs(Structure):
         ('n_hub', c_int64), ('n_chunks', c_int64), ('hub_threshold', c_int64),
         ('hub_chunk', c_int64), ('accumulate', c_int32), ('hub_phase', c_int32),
         ('arg32_out', c_void_p), ('relu_mask', c_void_p), ('ld_mask', c_int64),
-        ('relu_bits', c_void_p), ('ld_bits', c_int64),
+        ('relu_bits', c_void_p), ('ld_bits', c_int64), ('src_bits', c_void_p),
+        ('src_bits_set', c_void_p),
     ]
 
 
@@ -65,6 +66,8 @@ SIGNATURES = {
     'pygamd_hub_plan_workspace_bytes': (c_int, [c_int, c_int64, POINTER(c_size_t)]),
     'pygamd_hub_plan': (c_int, [_P, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64,
                                 POINTER(c_int64), POINTER(c_int64), _P, c_size_t, _P]),
+    'pygamd_rows_pack': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, c_int64, _P,
+                                 c_int64, c_int64, _P, _P, _P]),
     'pygamd_spmm_csr_workspace_bytes': (c_int, [POINTER(SpmmArgs), POINTER(c_size_t)]),
     'pygamd_spmm_csr': (c_int, [POINTER(SpmmArgs), _P, c_size_t, _P]),
     'pygamd_spmm_csr_tie_count': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, c_int64,

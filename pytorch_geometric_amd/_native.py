@@ -214,13 +214,26 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
              w: Optional[Tensor] = None, src_scale: Optional[Tensor] = None,
              hub=None, out: Optional[Tensor] = None, return_arg: bool = False,
              accumulate: bool = False, hub_phase: int = 0, save_arg32: bool = False,
-             relu_mask: Optional[Tensor] = None, relu_bits: Optional[Tensor] = None):
-    """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h."""
-    _require_device(rowptr, col, x, eid, w, src_scale, relu_mask, relu_bits)
+             relu_mask: Optional[Tensor] = None, relu_bits: Optional[Tensor] = None,
+             src_bits: Optional[Tensor] = None, src_bits_set: Optional[Tensor] = None):
+    """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h.
+    ``src_bits`` (from :func:`rows_pack`): one bit per row of ``x``, clear = the row is all zero
+    and is not read; ``src_bits_set``: the device counter of set bits (dense inputs then ignore the
+    bits)."""
+    _require_device(rowptr, col, x, eid, w, src_scale, relu_mask, relu_bits, src_bits,
+                    src_bits_set)
     if relu_mask is not None and relu_bits is not None:
         raise ValueError("pass at most one of 'relu_mask' / 'relu_bits'")
+    if src_bits is not None:
+        if (src_bits.dtype != torch.int32 or not src_bits.is_contiguous()
+                or src_bits.numel() < (x.size(0) + 31) // 32):
+            raise ValueError(f"'src_bits' must be contiguous int32 with one bit per row of x "
+                             f'({(x.size(0) + 31) // 32} words)')
+        if src_bits_set is not None and (src_bits_set.dtype != torch.int64
+                                         or src_bits_set.numel() != 1):
+            raise ValueError("'src_bits_set' must be one int64")
     C = _compiled.ops()
-    if (C is not None and not return_arg and _plain(x, relu_mask)
+    if (C is not None and not return_arg and src_bits is None and _plain(x, relu_mask)
             and (w is None or (w.dtype == torch.float32 and
                                (w.dim() == 1 or x.size(1) % max(w.size(1), 1) == 0)))
             and rowptr.dtype in (torch.int32, torch.int64)):
@@ -293,6 +306,9 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     if relu_bits is not None:
         _check_bits(relu_bits, n_rows, F)
         a.relu_bits, a.ld_bits = relu_bits.data_ptr(), relu_bits.size(1)
+    if src_bits is not None:
+        a.src_bits = src_bits.data_ptr()
+        a.src_bits_set = 0 if src_bits_set is None else src_bits_set.data_ptr()
     ws, ws_bytes = None, 0
     if hub is not None and hub[2] > 0:
         hub_rows, hub_cptr, n_hub, n_chunks = hub
@@ -316,11 +332,45 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
                       'reduce': reduce, 'idx_bytes': rowptr.element_size(),
                       'weighted': w is not None, 'src_scale': src_scale is not None,
                       'accumulate': bool(accumulate), 'relu_mask': relu_mask is not None,
-                      'relu_bits': relu_bits is not None,
+                      'relu_bits': relu_bits is not None, 'src_bits': src_bits is not None,
                       'n_hub': a.n_hub}, ev0, ev1))
     if save_arg32:
         return out, arg32
     return (out, arg) if return_arg else out
+
+
+def rows_pack(g: Tensor, row_scale: Optional[Tensor] = None, *, scaled: Optional[Tensor] = None,
+              copy: Optional[Tensor] = None, count: bool = True):
+    """(row_bits, n_set) of ``g`` ([n, F], unit column stride): bit i of ``row_bits`` (int32 words)
+    = row i has a non-zero entry; ``n_set`` = one device int64 with the number of such rows (None
+    with ``count=False``).  In the same pass: ``scaled[:, :F] = g * row_scale[:, None]`` and
+    ``copy[:, :F] = g``, both zero-filled up to their own width (``pygamd_rows_pack``)."""
+    _require_device(g, row_scale, scaled, copy)
+    if g.dim() != 2 or g.dtype != torch.float32 or (g.size(1) > 1 and g.stride(1) != 1):
+        raise ValueError("'g' must be a float32 matrix with unit column stride")
+    n, F = g.shape
+    for name, t in (('scaled', scaled), ('copy', copy)):
+        if t is None:
+            continue
+        if (t.dim() != 2 or t.dtype != torch.float32 or t.size(0) != n or t.size(1) < F
+                or (t.size(1) > 1 and t.stride(1) != 1)):
+            raise ValueError(f"'{name}' must be float32 [{n}, >= {F}] with unit column stride")
+        if t.data_ptr() == g.data_ptr() and n * F > 0:
+            raise ValueError(f"'{name}' may not be 'g' itself")
+    if row_scale is not None:
+        if row_scale.dtype != torch.float32 or row_scale.numel() != n:
+            raise ValueError(f"'row_scale' must be {n} float32 values")
+        row_scale = row_scale.contiguous()
+    bits = torch.empty((n + 31) // 32, dtype=torch.int32, device=g.device)
+    n_set = torch.empty(1, dtype=torch.int64, device=g.device) if count else None
+    lib = _lib.load()
+    check(lib.pygamd_rows_pack(_p(g), _ld(g), n, F, _p(row_scale), _p(scaled),
+                               0 if scaled is None else _ld(scaled),
+                               0 if scaled is None else scaled.size(1), _p(copy),
+                               0 if copy is None else _ld(copy),
+                               0 if copy is None else copy.size(1), _p(bits), _p(n_set),
+                               _stream(g)), 'rows_pack')
+    return bits, n_set
 
 
 def multi_reduce_csr(rowptr: Tensor, perm: Optional[Tensor], x: Tensor, want):

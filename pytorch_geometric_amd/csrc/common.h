@@ -79,6 +79,17 @@ __device__ __forceinline__ int64_t bcast_lane(int64_t v, int k) {
 }
 __device__ __forceinline__ float bcast_lane(float v, int k) { return __shfl(v, k, kWave); }
 
+// The inverse of bcast_lane: lane l's value lands in lane `to` (ds_permute, a push through the
+// LDS crossbar).  `to` must be a permutation of 0..63 over the wave.
+__device__ __forceinline__ int32_t push_lane(int32_t v, int to) {
+  return __builtin_amdgcn_ds_permute(to << 2, v);
+}
+__device__ __forceinline__ int64_t push_lane(int64_t v, int to) {
+  const int32_t lo = __builtin_amdgcn_ds_permute(to << 2, static_cast<int32_t>(v));
+  const int32_t hi = __builtin_amdgcn_ds_permute(to << 2, static_cast<int32_t>(v >> 32));
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+
 template <int VW>
 struct Vec;
 template <>

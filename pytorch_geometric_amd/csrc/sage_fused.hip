@@ -939,6 +939,9 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
     a.g.ldm = 0;
     a.g.relu_bits = nullptr;
     a.g.ldb = 0;
+    a.g.src_bits = nullptr;
+    a.g.src_bits_set = nullptr;
+    a.g.n_src = graph->n_src;
     a.g.n_rows = graph->n_rows;
     a.g.F = F;
     a.g.ldx = graph->ldx;

@@ -990,6 +990,9 @@ static SpmmDev<IdxT> make_dev(const pygamd_spmm_args* p) {
   a.ldm = p->ld_mask;
   a.relu_bits = p->relu_bits;
   a.ldb = p->ld_bits;
+  a.src_bits = p->src_bits;
+  a.src_bits_set = p->src_bits_set;
+  a.n_src = p->n_src;
   a.n_rows = p->n_rows;
   a.F = p->F;
   a.ldx = p->ldx;
@@ -1060,6 +1063,9 @@ static int launch_sum_w(const pygamd_spmm_args* p, const Shape& s, float* partia
   if (has_w && p->w_heads > 1)
     return launch_sum<IdxT, VW, LPR, CH, 2, IDENT>(p, s, partial, st);
   if (has_w || has_scale) return launch_sum<IdxT, VW, LPR, CH, 1, IDENT>(p, s, partial, st);
+  if constexpr (!IDENT) {
+    if (p->src_bits) return launch_sum<IdxT, VW, LPR, CH, 3, IDENT>(p, s, partial, st);
+  }
   return launch_sum<IdxT, VW, LPR, CH, 0, IDENT>(p, s, partial, st);
 }
 
@@ -1268,7 +1274,49 @@ static int validate(const pygamd_spmm_args* p) {
                        p->hub_threshold < 1 || p->n_chunks < p->n_hub))
     return PYGAMD_ERR_INVALID_ARG;
   if (p->hub_phase < 0 || p->hub_phase > 2) return PYGAMD_ERR_INVALID_ARG;
+  if (p->src_bits && (mm || p->w || p->src_scale || !p->col)) return PYGAMD_ERR_UNSUPPORTED;
+  if (p->src_bits_set && !p->src_bits) return PYGAMD_ERR_INVALID_ARG;
   return PYGAMD_OK;
+}
+
+// One wave per 32 rows (= one word of the row bitmap), 2^lshift lanes per row: copies of a row
+// block with a 1/deg-style row factor and zero padding, and [row has a non-zero entry] per row.
+__global__ void __launch_bounds__(kBlock)
+    rows_pack_kernel(const float* __restrict__ g, int64_t ldg, int64_t n_rows, int F, int lshift,
+                     const float* __restrict__ row_scale, float* __restrict__ scaled,
+                     int64_t lds, int Fs, float* __restrict__ copy, int64_t ldc, int Fc,
+                     uint32_t* __restrict__ bits, unsigned long long* __restrict__ n_set) {
+  const int lane = lane_id();
+  const int64_t word = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  if (word * 32 >= n_rows) return;
+  const int L = 1 << lshift;
+  const int rpi = kWave >> lshift;  // rows per iteration
+  const int sub = lane >> lshift;
+  const int lir = lane & (L - 1);
+  const int fmax = Fs > Fc ? (Fs > F ? Fs : F) : (Fc > F ? Fc : F);
+  const uint64_t group = L == kWave ? ~0ull : ((1ull << L) - 1ull);
+  uint32_t w = 0;
+  for (int it = 0; it < 32 / rpi; ++it) {
+    const int64_t row = word * 32 + it * rpi + sub;
+    bool nz = false;
+    if (row < n_rows) {
+      const float sc = row_scale ? row_scale[row] : 1.f;
+      for (int f = lir; f < fmax; f += L) {
+        const float v = f < F ? g[row * ldg + f] : 0.f;
+        nz |= (__float_as_uint(v) << 1) != 0u;  // anything but +-0 (NaN and subnormals count)
+        if (scaled && f < Fs) scaled[row * lds + f] = v * sc;
+        if (copy && f < Fc) copy[row * ldc + f] = v;
+      }
+    }
+    const uint64_t m = __ballot(nz);
+    for (int r = 0; r < rpi; ++r) {
+      if ((m >> (r << lshift)) & group) w |= 1u << (it * rpi + r);
+    }
+  }
+  if (lane == 0) {
+    bits[word] = w;
+    if (n_set && w) atomicAdd(n_set, static_cast<unsigned long long>(__popc(w)));
+  }
 }
 
 }  // namespace pygamd
@@ -1301,6 +1349,34 @@ int pygamd_spmm_csr(const pygamd_spmm_args* args, void* workspace, size_t worksp
     return s.vw == 4 ? launch_vw<IdxT, 4>(args, s, partial, st)
                      : launch_vw<IdxT, 1>(args, s, partial, st);
   });
+}
+
+int pygamd_rows_pack(const float* g, int64_t ldg, int64_t n_rows, int64_t F,
+                     const float* row_scale, float* scaled, int64_t ld_scaled, int64_t F_scaled,
+                     float* copy, int64_t ld_copy, int64_t F_copy, uint32_t* row_bits,
+                     int64_t* n_set, void* stream) {
+  if (n_rows < 0 || F < 0 || F > (1 << 20) || ldg < F || (n_rows > 0 && !row_bits))
+    return PYGAMD_ERR_INVALID_ARG;
+  if (scaled && (F_scaled < F || ld_scaled < F_scaled)) return PYGAMD_ERR_INVALID_ARG;
+  if (copy && (F_copy < F || ld_copy < F_copy)) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows > 0 && F > 0 && !g) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  if (n_set) PYGAMD_HIP_CHECK(hipMemsetAsync(n_set, 0, sizeof(int64_t), st));
+  if (n_rows == 0) return PYGAMD_OK;
+  int64_t fmax = F;
+  if (scaled && F_scaled > fmax) fmax = F_scaled;
+  if (copy && F_copy > fmax) fmax = F_copy;
+  int lshift = 2;
+  while (lshift < 6 && (1 << lshift) < fmax) ++lshift;
+  const int64_t words = ceil_div(n_rows, static_cast<int64_t>(32));
+  dim3 grid(static_cast<unsigned>(ceil_div(words, static_cast<int64_t>(kWavesPerBlock))));
+  hipLaunchKernelGGL(rows_pack_kernel, grid, dim3(kBlock), 0, st, g, ldg, n_rows,
+                     static_cast<int>(F), lshift, row_scale, scaled, ld_scaled,
+                     static_cast<int>(scaled ? F_scaled : 0), copy, ld_copy,
+                     static_cast<int>(copy ? F_copy : 0), row_bits,
+                     reinterpret_cast<unsigned long long*>(n_set));
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
 }
 
 int pygamd_spmm_csr_tie_count(const void* rowptr, const void* col, int idx_dtype, const float* x,

@@ -22,6 +22,13 @@ struct SpmmDev {
   int64_t ldm;
   const uint32_t* __restrict__ relu_bits;  // the same mask, one bit per element (or null)
   int64_t ldb;
+  // null, or one bit per SOURCE row (bit j & 31 of src_bits[j >> 5]): rows whose bit is clear are
+  // all-zero and are not read (plain sums only).  src_bits_set (or null): how many bits are set,
+  // on the device — with more than half of the n_src rows live the lookup costs more than it
+  // saves and the kernel ignores the bits.
+  const uint32_t* __restrict__ src_bits;
+  const int64_t* __restrict__ src_bits_set;
+  int64_t n_src;
   int64_t n_rows, F, ldx, ldo;
   int w_heads, head_dim;
   int mean;
@@ -37,7 +44,9 @@ constexpr int spmm_unroll() {
 }
 
 // WMODE: 0 = plain sum; 1 = one staged multiplier per slot (w with one head and/or src_scale);
-//        2 = per-head weights fetched per slot (+ optional staged src_scale).
+//        2 = per-head weights fetched per slot (+ optional staged src_scale);
+//        3 = plain sum over the source rows whose bit in a.src_bits is set (the others are known
+//            to be all-zero and are not read).
 template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, bool FULL, int UF = 0>
 __device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cnt, int sub,
                                            IdxT myc, IdxT mye, float mym, const int (&fo)[CH],
@@ -59,7 +68,7 @@ __device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cn
     } else {
       c = bcast_lane(myc, kk);
     }
-    if constexpr (WMODE != 0) {
+    if constexpr (WMODE == 1 || WMODE == 2) {
       float mm;
       if constexpr (EPI == 1) {
         mm = bcast_uniform(mym, kk);
@@ -98,7 +107,7 @@ __device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cn
     for (int c2 = 0; c2 < CH; ++c2) {
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
-        if constexpr (WMODE == 0) {
+        if constexpr (WMODE == 0 || WMODE == 3) {
           acc[c2][i] += v[u][c2].v[i];
         } else if constexpr (WMODE == 1) {
           acc[c2][i] = fmaf(v[u][c2].v[i], m[u], acc[c2][i]);
@@ -121,9 +130,13 @@ __device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT sta
   constexpr int U = UF > 0 ? UF : spmm_unroll<LPR, CH>();
   constexpr int STEP = EPI * U;
   const int sub = lane / LPR;
+  bool sparse_src = false;
+  if constexpr (WMODE == 3) {
+    sparse_src = a.src_bits_set == nullptr || 2 * *a.src_bits_set < a.n_src;
+  }
   for (IdxT base = start; base < end; base += kWave) {
     const IdxT rem = end - base;
-    const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+    int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
     IdxT myc = 0, mye = 0;
     float mym = 1.f;
     if (lane < cnt) {
@@ -133,12 +146,25 @@ __device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT sta
       } else {
         myc = __builtin_nontemporal_load(&a.col[k]);  // streamed once: keep L2 for feature rows
       }
-      if constexpr (WMODE != 0) {
+      if constexpr (WMODE == 1 || WMODE == 2) {
         mye = a.eid ? a.eid[k] : k;
         if (a.src_scale) mym = a.src_scale[myc];
         if constexpr (WMODE == 1) {
           if (a.w) mym *= a.w[mye];
         }
+      }
+    }
+    if constexpr (WMODE == 3) {
+      if (sparse_src) {
+        // keep the slots whose source row is live, packed into the low lanes in slot order (an
+        // all-zero row adds +0.0 to every sum: dropping it changes no result)
+        const bool keep =
+            lane < cnt && ((a.src_bits[static_cast<int64_t>(myc) >> 5] >> (myc & 31)) & 1u) != 0;
+        const uint64_t m = __ballot(keep);
+        const int before = __builtin_amdgcn_mbcnt_hi(
+            static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+        cnt = __popcll(m);
+        myc = push_lane(myc, keep ? before : cnt + lane - before);
       }
     }
     int j = 0;

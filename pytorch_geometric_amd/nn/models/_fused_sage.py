@@ -57,6 +57,9 @@ FUSE_BWD = os.environ.get('PYGAMD_FUSE_BWD', '1') != '0'
 # matrix cores idle).  0 = everything on one stream.  (Round 1 measured the same idea with a
 # library GEMM that takes every wave slot: slower.  The own kernel's footprint is a parameter.)
 OVERLAP_WGRAD = os.environ.get('PYGAMD_OVERLAP_WGRAD', '0') != '0'
+# backward of a 'pre' layer: find the all-zero rows of the incoming gradient in the pass that lays
+# it out and skip them in the transposed aggregation (PYGAMD_SPARSE_GRAD=0: read every row)
+SPARSE_GRAD = os.environ.get('PYGAMD_SPARSE_GRAD', '1') != '0'
 _side_streams = {}
 # below this many rows a launch of the own row-tiled kernels has fewer tiles than the chip has CUs
 # (cf. nn/dense/linear.py): small sampled batches keep the library GEMM
@@ -333,22 +336,36 @@ class FusedSageStack(Function):
             else:
                 Fp = _pad4(Fo)
                 gy = torch.empty(N, 2 * Fp, dtype=torch.float32, device=g.device)
-                if Fp != Fo:
-                    gy[:, Fp + Fo:].zero_()
-                gy[:, Fp:Fp + Fo].copy_(g)
                 # grad wrt (x W_l^T) = A^T (g / deg);  grad wrt (x W_r^T) = g.  The 1/deg factor
                 # is applied ONCE per row into a dense [N, Fp] copy instead of once per gathered
                 # slot inside the SpMM (a random 4-byte read per edge, 64-byte sectors: the scaled
-                # F = 48 launch ran at 0.50 of HBM peak against 0.73 for its unscaled twin)
-                if scale is not None:
-                    gsrc = torch.empty(N, Fp, dtype=torch.float32, device=g.device)
-                    if Fp != Fo:
-                        gsrc[:, Fo:].zero_()
-                    torch.mul(g, scale.view(-1, 1), out=gsrc[:, :Fo])
+                # F = 48 launch ran at 0.50 of HBM peak against 0.73 for its unscaled twin).
+                # One pass over `g` writes that copy, the root half of `gy`, the zero padding of
+                # both and one bit per row "has a non-zero entry": the gradient of a loss taken on
+                # `out[train_idx]` is zero outside the training split (92 % of the rows of the
+                # products workload), and the transposed aggregation below does not read rows
+                # whose bit is clear (decided on the device from the count of set bits, so a dense
+                # gradient costs nothing).
+                if SPARSE_GRAD:
+                    gsrc = (torch.empty(N, Fp, dtype=torch.float32, device=g.device)
+                            if scale is not None else None)
+                    row_bits, n_set = _native.rows_pack(g, scale, scaled=gsrc, copy=gy[:, Fp:])
+                    if gsrc is None:
+                        gsrc = gy[:, Fp:]
                 else:
-                    gsrc = gy[:, Fp:]
+                    row_bits = n_set = None
+                    if Fp != Fo:
+                        gy[:, Fp + Fo:].zero_()
+                    gy[:, Fp:Fp + Fo].copy_(g)
+                    if scale is not None:
+                        gsrc = torch.empty(N, Fp, dtype=torch.float32, device=g.device)
+                        if Fp != Fo:
+                            gsrc[:, Fo:].zero_()
+                        torch.mul(g, scale.view(-1, 1), out=gsrc[:, :Fo])
+                    else:
+                        gsrc = gy[:, Fp:]
                 _native.spmm_csr(bwd.ptr, bwd.idx, gsrc, 'sum', n_rows=N, hub=bwd.hub,
-                                 out=gy[:, :Fp])
+                                 out=gy[:, :Fp], src_bits=row_bits, src_bits_set=n_set)
                 x_in = buf
                 # [2 Fp, Fi]
                 if own and OVERLAP_WGRAD and not torch.cuda.is_current_stream_capturing():

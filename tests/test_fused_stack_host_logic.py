@@ -62,9 +62,16 @@ def fake_native(monkeypatch):
     log = []
 
     def spmm_csr(ptr, idx, x, reduce, *, n_rows=None, hub=None, out=None, accumulate=False,
-                 src_scale=None, relu_mask=None, relu_bits=None, **kw):
+                 src_scale=None, relu_mask=None, relu_bits=None, src_bits=None,
+                 src_bits_set=None, **kw):
         assert not kw, kw
         xs = x if src_scale is None else x * src_scale.view(-1, 1)
+        if src_bits is not None:  # only the rows whose bit is set are read
+            assert src_scale is None and reduce in ('sum', 'mean')
+            live = torch.tensor([(int(src_bits[i >> 5]) >> (i & 31)) & 1
+                                 for i in range(x.size(0))], dtype=torch.bool)
+            assert int(src_bits_set) == int(live.sum())
+            assert bool((xs[~live] == 0).all()), 'a row with a clear bit is not all-zero'
         res = _aggregate(ptr, idx, xs, reduce)
         if accumulate:
             res = res + out
@@ -73,7 +80,8 @@ def fake_native(monkeypatch):
             res = torch.where(relu_mask > 0, res, torch.zeros_like(res))
         if relu_bits is not None:
             res = torch.where(_unpack_bits(relu_bits, *res.shape), res, torch.zeros_like(res))
-        log.append(('spmm', reduce, accumulate, relu_mask is not None, relu_bits is not None))
+        log.append(('spmm', reduce, accumulate, relu_mask is not None, relu_bits is not None)
+                   + (('src_bits', ) if src_bits is not None else ()))
         if out is None:
             return res
         out.copy_(res)
@@ -104,6 +112,20 @@ def fake_native(monkeypatch):
                    if not (mask_bits is not None or not save_agg) else
                    ('fused_layer_bwd', mask_bits is not None, out_scaled is not None))
         return out
+
+    def rows_pack(g, row_scale=None, *, scaled=None, copy=None, count=True):
+        live = (g != 0).any(dim=1) | g.isnan().any(dim=1)
+        words = torch.zeros((g.size(0) + 31) // 32, dtype=torch.int64)
+        for i in torch.nonzero(live).flatten().tolist():
+            words[i >> 5] |= 1 << (i & 31)
+        if scaled is not None:
+            scaled.zero_()
+            scaled[:, :g.size(1)] = g if row_scale is None else g * row_scale.view(-1, 1)
+        if copy is not None:
+            copy.zero_()
+            copy[:, :g.size(1)] = g
+        log.append(('rows_pack', scaled is not None, copy is not None))
+        return words, (live.sum().view(1) if count else None)
 
     def linear_forward(x, w, bias=None, relu=False, out=None, accumulate=False):
         y = x @ w.t()
@@ -138,6 +160,7 @@ def fake_native(monkeypatch):
         return (gw, g.sum(0)) if bias_grad else gw
 
     for name, fn in dict(spmm_csr=spmm_csr, sage_layer_forward=sage_layer_forward,
+                         rows_pack=rows_pack,
                          linear_forward=linear_forward, linear_dgrad=linear_dgrad,
                          linear_wgrad=linear_wgrad).items():
         monkeypatch.setattr(_native, name, fn)
@@ -178,6 +201,8 @@ def test_fused_stack_wiring_against_the_oracle(fake_native, monkeypatch, dims, a
                        torch.randn(fo, generator=g) if bias else None,
                        torch.randn(fo, fi, generator=g) * 0.3))
     go = torch.randn(n, dims[-1], generator=g)
+    if dims[-1] == 47:  # a loss on a training split: most rows of the incoming gradient are zero
+        go[torch.rand(n, generator=g) < 0.85] = 0
 
     def leaves():
         xs = x.clone().requires_grad_(x_grad)
@@ -210,6 +235,11 @@ def test_fused_stack_wiring_against_the_oracle(fake_native, monkeypatch, dims, a
         if e[0] == 'wgrad':
             assert e[1] == bias          # the bias gradient rides on the weight gradient
     if dims == (100, 256, 256, 47):
+        # the output layer's backward lays its gradient out in one pass that also finds the live
+        # rows, and its transposed aggregation takes their bitmap
+        assert [e for e in fake_native if e[0] == 'rows_pack'] == [('rows_pack', True, True)]
+        assert [e for e in fake_native if e[0] == 'spmm' and e[-1] == 'src_bits'] == [
+            ('spmm', 'sum', False, False, False, 'src_bits')]
         fused = [e for e in fake_native if e[0] == 'fused_layer']
         assert [e[1] for e in fused] == [True, False]   # layer 1 roots on x itself (no copy)
         assert ('wgrad', bias, True) in fake_native      # ... and its wgrad takes [agg | x] apart

@@ -238,6 +238,54 @@ def test_fused_sage_stack_matches_layer_loop_and_oracle(dev):
     assert_close(out, ref.detach(), atol=2e-5)
 
 
+@pytest.mark.parametrize('aggr', ['mean', 'sum'])
+def test_fused_sage_stack_with_a_loss_on_a_training_split(dev, aggr, monkeypatch):
+    """`out[train_idx]` leaves most rows of the incoming gradient zero: the backward of the
+    transform-first output layer finds them (rows_pack) and its transposed aggregation skips them
+    (src_bits).  Same gradients as the oracle and as the path that reads every row."""
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd.nn import GraphSAGE
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    from tests._util import assert_close_scaled, random_graph
+    g = gen(33)
+    n = 1500
+    ei = random_graph(n, n, 30_000, seed=33, skew=True)
+    x = torch.randn(n, 24, generator=g)
+    train = torch.randperm(n, generator=g)[:n // 12]
+    y = torch.randint(0, 7, (n, ), generator=g)
+    torch.manual_seed(6)
+    model = GraphSAGE(24, 32, num_layers=3, out_channels=7, aggr=aggr)
+    st = model.state_dict()
+    params = [(st[f'convs.{i}.lin_l.weight'].clone().requires_grad_(True),
+               st[f'convs.{i}.lin_l.bias'].clone().requires_grad_(True),
+               st[f'convs.{i}.lin_r.weight'].clone().requires_grad_(True)) for i in range(3)]
+    xr = x.clone().requires_grad_(True)
+    ref = O.graphsage(xr, ei, params, aggr=aggr)
+    torch.nn.functional.cross_entropy(ref[train], y[train]).backward()
+    model = model.to(dev)
+    results = {}
+    for sparse in (True, False):
+        monkeypatch.setattr(_fused_sage, 'SPARSE_GRAD', sparse)
+        model.zero_grad()
+        xg = x.to(dev).requires_grad_(True)
+        sink = []
+        monkeypatch.setattr(_native, 'timing_sink', sink)
+        out = model(xg, ei.to(dev))
+        torch.nn.functional.cross_entropy(out[train.to(dev)], y[train].to(dev)).backward()
+        monkeypatch.setattr(_native, 'timing_sink', None)
+        used = [info for info, *_ in sink if info.get('src_bits')]
+        assert (len(used) == 1 and used[0]['F'] == 8) if sparse else not used
+        results[sparse] = (xg.grad.cpu(), [p.grad.detach().cpu().clone()
+                                           for p in model.parameters()])
+    flat_ref = [t.grad for layer in params for t in layer]
+    for sparse in (True, False):
+        gx, gp = results[sparse]
+        assert_close_scaled(gx, xr.grad, what=f'sparse={sparse} grad_x')
+        for got, want in zip(gp, flat_ref):
+            assert_close_scaled(got, want, what=f'sparse={sparse} param grad')
+
+
 def test_rgcn_conv_golden(dev, golden):
     """config 5 (a16): per-relation mean + W_r, incl. basis and block-diagonal decompositions."""
     from pytorch_geometric_amd.nn import RGCNConv
@@ -290,7 +338,7 @@ def test_rgcn_conv_vs_oracle_skewed_relations(dev):
     """FB15k-237-like relation histogram (Zipf), empty relations, int32 indices, sum aggregation."""
     from oracle import pyg_oracle as O
     from pytorch_geometric_amd.nn import RGCNConv
-    from tests._util import random_graph
+    from tests._util import assert_close_scaled, random_graph
     g = gen(33)
     n, e, R = 300, 6000, 40
     ei = random_graph(n, n, e, seed=33, skew=True)

@@ -938,3 +938,102 @@ def test_spmm_minmax_backward_without_atomics(dev, F, dtype):
                                 save_arg32=True)
     assert _native.spmm_minmax_backward_src(fwd, bwd, smap, x, out, go[:, :6].contiguous().to(dev),
                                             arg) is None
+
+
+@pytest.mark.parametrize('F,Fs,Fc', [(47, 48, 48), (1, 4, 1), (5, 5, 8), (64, 64, 64),
+                                     (100, 104, 100), (256, 256, 260)])
+def test_rows_pack(dev, F, Fs, Fc):
+    """pygamd_rows_pack: the non-zero-row bitmap (+ its device count), the row-scaled copy and the
+    plain copy, both zero-filled to their own width, in one pass over a strided block."""
+    from pytorch_geometric_amd import _native
+    n = 1000 + F  # not a multiple of 32
+    g = gen(F)
+    wide = torch.randn(n, F + 9, generator=g)
+    live = torch.rand(n, generator=g) < 0.1
+    wide[~live] = 0
+    wide[7, 2 + 3 % F] = float('nan')  # a NaN row is a live row
+    wide[9] = 0
+    wide[9, 2 + F - 1] = -0.0  # all (signed) zeros: not live
+    wide[11] = 0
+    wide[11, 2 + F - 1] = 1e-40  # a subnormal is not zero
+    scale = torch.rand(n, generator=g) + 0.5
+    src = wide.to(dev)[:, 2:2 + F]  # row stride F + 9
+    ref = wide[:, 2:2 + F]
+    scaled = torch.full((n, Fs + 3), 7.0, device=dev)[:, :Fs]
+    copy = torch.full((n, Fc), 7.0, device=dev)
+    bits, n_set = _native.rows_pack(src, scale.to(dev), scaled=scaled, copy=copy)
+    want = (ref != 0).any(dim=1)
+    words = bits.cpu().numpy().view('uint32')
+    got = torch.tensor([(int(words[i >> 5]) >> (i & 31)) & 1 for i in range(32 * len(words))],
+                       dtype=torch.bool)
+    assert torch.equal(got[:n], want) and not bool(got[n:].any())
+    assert bool(want[7]) and not bool(want[9]) and bool(want[11])
+    assert int(n_set.item()) == int(want.sum())
+    assert torch.equal(copy[:, :F].cpu().nan_to_num(nan=123.), ref.nan_to_num(nan=123.))
+    assert bool((copy[:, F:] == 0).all())
+    exp = ref * scale.view(-1, 1)
+    assert torch.equal(scaled[:, :F].cpu().nan_to_num(nan=123.), exp.nan_to_num(nan=123.))
+    assert bool((scaled[:, F:] == 0).all())
+    # bits alone, no count
+    b2, none = _native.rows_pack(src, count=False)
+    assert none is None and torch.equal(b2, bits)
+    # nothing live / empty
+    b3, c3 = _native.rows_pack(torch.zeros(70, F, device=dev))
+    assert int(c3.item()) == 0 and not bool(b3.any())
+    b4, c4 = _native.rows_pack(torch.zeros(0, F, device=dev))
+    assert b4.numel() == 0 and int(c4.item()) == 0
+    with pytest.raises(ValueError):
+        _native.rows_pack(src, copy=torch.empty(n, F - 1 if F > 1 else 0, device=dev))
+    with pytest.raises(ValueError):
+        _native.rows_pack(src.double())
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+@pytest.mark.parametrize('F', [1, 4, 47, 48, 100, 256, 520])
+def test_spmm_skips_zero_source_rows(dev, dtype, F, monkeypatch):
+    """`src_bits`: the sum over the live source rows only equals the sum over all of them (hub rows
+    and chunks of more than 64 slots included), whatever the density says about using the bits."""
+    from pytorch_geometric_amd import _native
+    import pytorch_geometric_amd as pga
+    monkeypatch.setattr(_native, 'HUB_THRESHOLD', 200)
+    monkeypatch.setattr(_native, 'HUB_CHUNK', 96)
+    orig = _native.hub_plan
+    monkeypatch.setattr(_native, 'hub_plan', lambda ptr, threshold=None, chunk=None: orig(
+        ptr, 200, 96))
+    n_src, n_dst = 3000, 500
+    ei = random_graph(n_src, n_dst, 40_000, seed=F + 3, dtype=dtype, skew=True)
+    h = pga.EdgeIndex(ei.to(dev), (n_src, n_dst)).by_dst()
+    assert h.hub[2] > 0
+    for frac in (0.08, 0.0, 0.9):
+        g = gen(F + int(100 * frac))
+        x = torch.randn(n_src, F, generator=g)
+        x[torch.rand(n_src, generator=g) >= frac] = 0
+        xd = x.to(dev)
+        bits, n_set = _native.rows_pack(xd)
+        ex = O.spmm(ei.long(), x.double(), n_dst, 'sum')
+        ref = O.spmm(ei.long(), x, n_dst, 'sum')
+        plain = _native.spmm_csr(h.ptr, h.idx, xd, 'sum', n_rows=n_dst, hub=h.hub)
+        for counter in (n_set, None):  # None: the bits are used even at 90 % density
+            for red in ('sum', 'mean'):
+                out = _native.spmm_csr(h.ptr, h.idx, xd, red, n_rows=n_dst, hub=h.hub,
+                                       src_bits=bits, src_bits_set=counter)
+                if red == 'mean':
+                    e2 = O.spmm(ei.long(), x.double(), n_dst, 'mean')
+                    r2 = O.spmm(ei.long(), x, n_dst, 'mean')
+                    assert_sum_close(out, r2, e2, what=f'sparse-source mean F={F} p={frac}')
+                else:
+                    assert_sum_close(out, ref, ex, what=f'sparse-source sum F={F} p={frac}')
+                    # a row with no live source is exactly zero either way
+                    dead = (plain == 0).all(dim=1)
+                    assert bool((out[dead] == 0).all())
+        # accumulate + strided output keep working with the bits
+        buf = torch.ones(n_dst, F + 4, device=dev)
+        _native.spmm_csr(h.ptr, h.idx, xd, 'sum', n_rows=n_dst, hub=h.hub, out=buf[:, :F],
+                         accumulate=True, src_bits=bits, src_bits_set=n_set)
+        assert_sum_close(buf[:, :F] - 1, ref, ex, atol=1e-4, what='sparse-source accumulate')
+        assert bool((buf[:, F:] == 1).all())
+    with pytest.raises(ValueError):
+        _native.spmm_csr(h.ptr, h.idx, xd, 'sum', n_rows=n_dst, hub=h.hub, src_bits=bits[:5])
+    with pytest.raises(Exception):  # not with per-edge weights
+        _native.spmm_csr(h.ptr, h.idx, xd, 'sum', n_rows=n_dst, hub=h.hub, src_bits=bits,
+                         w=torch.ones(ei.size(1), device=dev))

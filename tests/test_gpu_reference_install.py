@@ -367,6 +367,6 @@ def test_reference_node_loader_with_sampler_options(pyg, installed, dev):
             m = b.n_id.numel()
             fwd_keys = set((loc[1] * m + loc[0]).tolist())
             assert fwd_keys == set((loc[0] * m + loc[1]).tolist())  # every edge has its reverse
-            assert b.num_sampled_edges is None or 'num_sampled_edges' not in b
+            assert 'num_sampled_edges' not in b or b.num_sampled_edges is None
     with pytest.raises(NotImplementedError):
         installed.neighbor_sampler(data, [4, 2], subgraph_type='induced')
