@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 5
+#define PYGAMD_ABI_VERSION 6
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -41,6 +41,9 @@ typedef enum {
 } pygamd_status;
 
 typedef enum { PYGAMD_IDX_I32 = 0, PYGAMD_IDX_I64 = 1 } pygamd_idx_dtype;
+
+/* layout of the gathered block of an aggregation (pygamd_spmm_args.x_format) */
+typedef enum { PYGAMD_X_DENSE = 0, PYGAMD_X_COMPRESSED = 1 } pygamd_x_format;
 
 /* reduce ids follow torch_geometric/utils/_scatter.py:14-138 */
 typedef enum {
@@ -192,7 +195,8 @@ typedef struct {
                                 one of relu_mask / relu_bits.                                      */
   int64_t ld_bits;           /* column blocks per row tile, >= ceil(F / 32); the array holds
                                 ceil(n_rows / 32) * ld_bits * 32 words                             */
-  const uint32_t* src_bits;  /* SUM/MEAN without w / src_scale, col != NULL; NULL or one bit per
+  const uint32_t* src_bits;  /* SUM/MEAN without w / src_scale (ignored with col == NULL, where
+                                every row is read once anyway); NULL or one bit per
                                 SOURCE row (bit j & 31 of word j >> 5, ceil(n_src / 32) words):
                                 a clear bit promises that x[j, :] is all zero, and the row is not
                                 read.  What pygamd_rows_pack writes.  The case: the gradient of a
@@ -203,7 +207,26 @@ typedef struct {
   const int64_t* src_bits_set; /* NULL or a DEVICE counter of the set bits: with more than half of
                                 the n_src rows live the kernel ignores src_bits (the lookup then
                                 costs more than it saves) — decided on the device, no host sync    */
+  int32_t x_format;          /* PYGAMD_X_DENSE (0), or PYGAMD_X_COMPRESSED: `x` is the block written
+                                by pygamd_rows_compress / pygamd_sage_layer_fused.compressed_out
+                                ([n_src, ldx] 32-bit words, F <= 256, F % 4 == 0, ldx >= F + 12);
+                                SUM/MEAN without w / src_scale / src_bits; same sums, bit for bit,
+                                as the dense rows                                                 */
+  int32_t reserved0;         /* 0 */
 } pygamd_spmm_args;
+
+/* Lossless compression of a [n_rows, F <= 256] block with many exact zeros (the output of a ReLU)
+ * for the row GATHER of the next aggregation, whose cost on this chip is proportional to the
+ * 128-byte lines a row touches (scripts/gather_lines_probe.py): row i of `out` (32-bit words, row
+ * pitch ld_out >= F + 12; 288 for F = 256) = [8 mask words | the kept values in column order],
+ * bit (c & 31) of mask word (c >> 5) set where x[i, c] is kept = has a bit pattern other than
+ * +0.0 (-0.0 and NaN are kept).  Words past the last kept value are unspecified.  A half-empty
+ * 256-float row then occupies 4.4 lines instead of 8.  Consumed by pygamd_spmm_csr /
+ * pygamd_sage_layer_fused with x_format = PYGAMD_X_COMPRESSED; pygamd_sage_layer_fused writes the
+ * same format from its epilogue (compressed_out).  The reference keeps activations dense
+ * (nn/models/basic_gnn.py:262-263).                                                              */
+PYGAMD_API int pygamd_rows_compress(const float* x, int64_t ldx, int64_t n_rows, int64_t F,
+                                    uint32_t* out, int64_t ld_out, void* stream);
 
 /* Row-sparsity of a gradient block, found in the pass that lays it out for the backward of a
  * transform-then-aggregate layer: for every row i < n_rows of g ([n_rows, ldg], F columns)
@@ -647,6 +670,12 @@ typedef struct pygamd_sage_fused_args {
   int64_t ldy_scaled;
   int32_t variant;
   int32_t reserved;          /* 0 (timing probes of scripts/fused_probe.py only) */
+  uint32_t* compressed_out;  /* NULL or [n_rows, ld_compressed] words: y once more, in the format
+                                of pygamd_rows_compress (the next layer's gather source).  Needs
+                                Fo % 32 == 0 and variant 1.  With graph->x_format =
+                                PYGAMD_X_COMPRESSED the gather source itself is such a block
+                                (variant 1, F % 4 == 0, F <= 256).                             */
+  int64_t ld_compressed;
 } pygamd_sage_fused_args;
 PYGAMD_API int pygamd_sage_layer_fused(const pygamd_spmm_args* graph,
                                        const pygamd_sage_fused_args* f, void* workspace,

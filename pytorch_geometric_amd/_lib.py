@@ -10,7 +10,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 from . import _build
 
-ABI_VERSION = 5  # PYGAMD_ABI_VERSION of include/pyg_amd.h
+ABI_VERSION = 6
+X_DENSE, X_COMPRESSED = 0, 1  # pygamd_x_format  # PYGAMD_ABI_VERSION of include/pyg_amd.h
 IDX_I32, IDX_I64 = 0, 1
 SUM, MEAN, MIN, MAX, MUL, ANY = 0, 1, 2, 3, 4, 5
 REDUCE_IDS = {'sum': SUM, 'add': SUM, 'mean': MEAN, 'min': MIN, 'amin': MIN, 'max': MAX,
@@ -33,7 +34,7 @@ class SpmmArgs(Structure):
         ('hub_chunk', c_int64), ('accumulate', c_int32), ('hub_phase', c_int32),
         ('arg32_out', c_void_p), ('relu_mask', c_void_p), ('ld_mask', c_int64),
         ('relu_bits', c_void_p), ('ld_bits', c_int64), ('src_bits', c_void_p),
-        ('src_bits_set', c_void_p),
+        ('src_bits_set', c_void_p), ('x_format', c_int32), ('reserved0', c_int32),
     ]
 
 
@@ -45,7 +46,7 @@ class SageFusedArgs(Structure):
         ('y', c_void_p), ('ldy', c_int64), ('relu_bits_out', c_void_p), ('ld_bits_out', c_int64),
         ('mask_bits', c_void_p), ('ld_mask_bits', c_int64), ('row_scale', c_void_p),
         ('y_scaled', c_void_p), ('ldy_scaled', c_int64), ('variant', c_int32),
-        ('reserved', c_int32),
+        ('reserved', c_int32), ('compressed_out', c_void_p), ('ld_compressed', c_int64),
     ]
 
 
@@ -66,6 +67,7 @@ SIGNATURES = {
     'pygamd_hub_plan_workspace_bytes': (c_int, [c_int, c_int64, POINTER(c_size_t)]),
     'pygamd_hub_plan': (c_int, [_P, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64,
                                 POINTER(c_int64), POINTER(c_int64), _P, c_size_t, _P]),
+    'pygamd_rows_compress': (c_int, [_P, c_int64, c_int64, c_int64, _P, c_int64, _P]),
     'pygamd_rows_pack': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_int64, c_int64, _P,
                                  c_int64, c_int64, _P, _P, _P]),
     'pygamd_spmm_csr_workspace_bytes': (c_int, [POINTER(SpmmArgs), POINTER(c_size_t)]),

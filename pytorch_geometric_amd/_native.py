@@ -215,8 +215,11 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
              hub=None, out: Optional[Tensor] = None, return_arg: bool = False,
              accumulate: bool = False, hub_phase: int = 0, save_arg32: bool = False,
              relu_mask: Optional[Tensor] = None, relu_bits: Optional[Tensor] = None,
-             src_bits: Optional[Tensor] = None, src_bits_set: Optional[Tensor] = None):
+             src_bits: Optional[Tensor] = None, src_bits_set: Optional[Tensor] = None,
+             compressed_width: Optional[int] = None):
     """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h.
+    ``compressed_width=F``: ``x`` is the int32 block of :func:`rows_compress` holding ``F`` columns
+    per row (sum / mean only; the same sums bit for bit).
     ``src_bits`` (from :func:`rows_pack`): one bit per row of ``x``, clear = the row is all zero
     and is not read; ``src_bits_set``: the device counter of set bits (dense inputs then ignore the
     bits)."""
@@ -232,6 +235,9 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
         if src_bits_set is not None and (src_bits_set.dtype != torch.int64
                                          or src_bits_set.numel() != 1):
             raise ValueError("'src_bits_set' must be one int64")
+    if compressed_width is not None:
+        return _spmm_csr_compressed(rowptr, col, x, reduce, compressed_width, n_rows, hub, out,
+                                    hub_phase)
     C = _compiled.ops()
     if (C is not None and not return_arg and src_bits is None and _plain(x, relu_mask)
             and (w is None or (w.dtype == torch.float32 and
@@ -337,6 +343,79 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     if save_arg32:
         return out, arg32
     return (out, arg) if return_arg else out
+
+
+def compressed_pitch(F: int) -> int:
+    """Row pitch (32-bit words) of a compressed block of ``F`` columns: 8 mask words + F values + 4
+    words of slack for the 16-byte value loads, rounded up to 128-byte lines (288 for F = 256)."""
+    return (8 + F + 4 + 31) // 32 * 32
+
+
+def _check_compressed(z: Tensor, F: int, name: str):
+    if (z.dim() != 2 or z.dtype != torch.int32 or (z.size(0) > 1 and z.stride(0) < F + 12)
+            or (z.size(1) > 1 and z.stride(1) != 1) or z.size(1) < F + 12):
+        raise ValueError(f"'{name}' must be an int32 [n, >= {F + 12}] block of compressed rows")
+    if F > 256 or F % 4 != 0:
+        raise ValueError('compressed rows hold at most 256 columns, a multiple of 4')
+
+
+def rows_compress(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """``x`` ([n, F <= 256] float32) as compressed rows ``[8 mask words | kept values]`` — the
+    lossless zero-skipping layout the row gathers read (``pygamd_rows_compress``)."""
+    _require_device(x, out)
+    x2 = _f32_rows(x, 'x')
+    n, F = x2.shape
+    if F > 256:
+        raise ValueError('compressed rows hold at most 256 columns')
+    if out is None:
+        out = torch.empty(n, compressed_pitch(F), dtype=torch.int32, device=x.device)
+    elif (out.dim() != 2 or out.dtype != torch.int32 or out.size(0) != n or out.size(1) < F + 12
+          or (out.size(1) > 1 and out.stride(1) != 1)):
+        raise ValueError(f"'out' must be int32 [{n}, >= {F + 12}]")
+    check(_lib.load().pygamd_rows_compress(_p(x2), _ld(x2), n, F, _p(out), _ld(out), _stream(x)),
+          'rows_compress')
+    return out
+
+
+def _spmm_csr_compressed(rowptr, col, z, reduce, F, n_rows, hub, out, hub_phase):
+    _require_device(rowptr, col, z, out)
+    _check_compressed(z, F, 'x')
+    if reduce not in ('sum', 'mean'):
+        raise ValueError("compressed rows: reduce must be 'sum' or 'mean'")
+    n_rows = rowptr.numel() - 1 if n_rows is None else n_rows
+    if out is None:
+        out = torch.empty(n_rows, F, dtype=torch.float32, device=z.device)
+    a = SpmmArgs()
+    a.rowptr = rowptr.data_ptr()
+    a.col = 0 if col is None else col.data_ptr()
+    a.x, a.out = z.data_ptr(), out.data_ptr()
+    a.n_rows, a.n_src, a.F = n_rows, z.size(0), F
+    a.ldx, a.ldo = _ld(z), _ld(out)
+    a.idx_dtype, a.reduce = _idx_dtype(rowptr), REDUCE_IDS[reduce]
+    a.w_heads, a.head_dim = 1, max(F, 1)
+    a.hub_phase = hub_phase
+    a.x_format = _lib.X_COMPRESSED
+    ws, ws_bytes = None, 0
+    if hub is not None and hub[2] > 0:
+        hub_rows, hub_cptr, n_hub, n_chunks = hub
+        a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), hub_cptr.data_ptr()
+        a.n_hub, a.n_chunks = n_hub, n_chunks
+        a.hub_threshold, a.hub_chunk = HUB_THRESHOLD, HUB_CHUNK
+        if hub_phase != 1:
+            ws_bytes = n_chunks * F * 4
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=z.device)
+    sink = timing_sink
+    if sink is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(z.device))
+    check(_lib.load().pygamd_spmm_csr(ctypes.byref(a), _p(ws), ws_bytes, _stream(z)), 'spmm_csr')
+    if sink is not None:
+        ev1.record(torch.cuda.current_stream(z.device))
+        sink.append(({'n_rows': n_rows, 'n_src': z.size(0), 'nnz': col.numel(), 'F': F,
+                      'reduce': reduce, 'idx_bytes': rowptr.element_size(), 'weighted': False,
+                      'src_scale': False, 'accumulate': False, 'compressed_src': True,
+                      'n_hub': a.n_hub}, ev0, ev1))
+    return out
 
 
 def rows_pack(g: Tensor, row_scale: Optional[Tensor] = None, *, scaled: Optional[Tensor] = None,
@@ -905,7 +984,9 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
                        hub=None, save_agg: bool = True, hub_threshold: int = None,
                        hub_chunk: int = None, relu_bits: Optional[Tensor] = None,
                        mask_bits: Optional[Tensor] = None, row_scale: Optional[Tensor] = None,
-                       out_scaled: Optional[Tensor] = None, variant: Optional[int] = None) -> Tensor:
+                       out_scaled: Optional[Tensor] = None, variant: Optional[int] = None,
+                       gather_width: Optional[int] = None,
+                       compressed_out: Optional[Tensor] = None) -> Tensor:
     """``out = act([aggr(x_gather) | x_root] @ w.T + bias)`` in ONE kernel (csrc/sage_fused.hip);
     ``agg`` ([n_rows, F] view, may be a half of a wider buffer) receives the aggregated rows when
     ``save_agg`` (hub rows always).  ``relu_bits`` (from :func:`relu_bits_like`, needs
@@ -914,11 +995,14 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     graph, the degree-scaled gradient rows as ``x_gather``, the unscaled ones as ``x_root`` and
     ``w = [W_l^T | W_r^T]`` the launch is the layer's INPUT GRADIENT (dgrad GEMM + transposed
     aggregation + ReLU backward in one pass).  ``out_scaled`` receives ``out * row_scale[:, None]``
-    as a second output (what the next such launch gathers)."""
+    as a second output (what the next such launch gathers).  ``gather_width=F``: ``x_gather`` is
+    an int32 block of compressed rows (:func:`rows_compress`) of ``F`` columns; ``compressed_out``
+    (int32 ``[n_rows, compressed_pitch(Fo)]``) receives ``out`` once more in that layout."""
     _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out, relu_bits, mask_bits,
-                    row_scale, out_scaled)
+                    row_scale, out_scaled, compressed_out)
     C = _compiled.ops()
-    if C is not None and _plain(x_gather, x_root, w, agg, out, out_scaled):
+    if (C is not None and gather_width is None and compressed_out is None
+            and _plain(x_gather, x_root, w, agg, out, out_scaled)):
         n_rows, F, Fo = rowptr.numel() - 1, x_gather.size(1), w.size(0)
         ok = (x_root.shape == (n_rows, F) and w.size(1) == 2 * F and agg.shape == (n_rows, F)
               and out.shape == (n_rows, Fo)
@@ -945,8 +1029,14 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
                     SAGE_FUSED_VARIANT if variant is None else variant, SAGE_FUSED_PROBE)
             return out
     lib = _lib.load()
-    xg, xr, w2 = _f32_rows(x_gather, 'x'), _f32_rows(x_root, 'x_root'), _f32_rows(w, 'weight')
-    n_rows, F, Fo = rowptr.numel() - 1, xg.size(1), w2.size(0)
+    xr, w2 = _f32_rows(x_root, 'x_root'), _f32_rows(w, 'weight')
+    if gather_width is None:
+        xg = _f32_rows(x_gather, 'x')
+        F = xg.size(1)
+    else:
+        _check_compressed(x_gather, gather_width, 'x_gather')
+        xg, F = x_gather, gather_width
+    n_rows, Fo = rowptr.numel() - 1, w2.size(0)
     if xr.shape != (n_rows, F) or w2.size(1) != 2 * F or agg.shape != (n_rows, F) \
             or out.shape != (n_rows, Fo):
         raise ValueError('shape mismatch in sage_layer_forward')
@@ -957,6 +1047,8 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     a.ldx, a.ldo = _ld(xg), _ld(agg)
     a.idx_dtype, a.reduce = _idx_dtype(rowptr), REDUCE_IDS[reduce]
     a.w_heads, a.head_dim = 1, F
+    if gather_width is not None:
+        a.x_format = _lib.X_COMPRESSED
     ws, ws_bytes = None, 0
     if hub is not None and hub[2] > 0:
         hub_rows, hub_cptr, n_hub, n_chunks = hub
@@ -992,6 +1084,11 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
         f.y_scaled, f.ldy_scaled = out_scaled.data_ptr(), _ld(out_scaled)
     f.variant = SAGE_FUSED_VARIANT if variant is None else variant
     f.reserved = SAGE_FUSED_PROBE
+    if compressed_out is not None:
+        _check_compressed(compressed_out, Fo, 'compressed_out')
+        if compressed_out.size(0) != n_rows or Fo % 32 != 0:
+            raise ValueError("'compressed_out' needs one row per output row and Fo % 32 == 0")
+        f.compressed_out, f.ld_compressed = compressed_out.data_ptr(), _ld(compressed_out)
     sink = timing_sink
     if sink is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1003,9 +1100,11 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
         sink.append(({'n_rows': n_rows, 'n_src': xg.size(0), 'nnz': col.numel(), 'F': F,
                       'reduce': reduce, 'idx_bytes': rowptr.element_size(), 'weighted': False,
                       'src_scale': False, 'accumulate': False, 'n_hub': a.n_hub,
+                      'compressed_src': gather_width is not None,
                       'fused_gemm': {'Fo': Fo, 'K': 2 * F, 'save_agg': bool(save_agg),
                                      'backward': mask_bits is not None,
-                                     'scaled_copy': out_scaled is not None}}, ev0, ev1))
+                                     'scaled_copy': out_scaled is not None,
+                                     'compressed_out': compressed_out is not None}}, ev0, ev1))
     return out
 
 

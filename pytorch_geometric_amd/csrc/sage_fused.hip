@@ -68,6 +68,8 @@ struct SageFusedArgs {
   const float* __restrict__ row_scale;     // with y2: y2[i, :] = y[i, :] * row_scale[i]
   float* __restrict__ y2;                  // null or a second, row-scaled copy of the output
   int64_t ldy2;
+  uint32_t* __restrict__ zout;             // null or the output once more as compressed rows
+  int64_t ldz;                             // (spmm_device.h), the next layer's gather source
   int nbuf;   // specialised kernel: aggregated-tile buffers in LDS
   int probe;  // timing probes only (scripts/fused_probe.py): bit 0 = skip the gather loop (the
               // aggregated tile stays undefined), bit 1 = skip the MFMA loop, bits 2-3 = weight
@@ -80,7 +82,8 @@ struct SageFusedArgs {
 // C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31].
 template <typename IdxT>
 __device__ __forceinline__ void fused_epilogue(const SageFusedArgs<IdxT>& a, const f32x16& acc,
-                                               int64_t row0, int wave_col0, int lane) {
+                                               int64_t row0, int wave_col0, int lane,
+                                               f32x16& vout) {
   const int li = lane & 31, lh = lane >> 5;
   const int col = wave_col0 + li;
   const bool col_ok = col < a.Fo;
@@ -104,6 +107,7 @@ __device__ __forceinline__ void fused_epilogue(const SageFusedArgs<IdxT>& a, con
       v = ((mw >> li) & 1u) ? v : 0.f;
     }
     const bool ok = col_ok && rbase + roff < a.g.n_rows;
+    vout[e] = v;
     if (ok) yp[roff * a.ldy] = v;
     if (yp2 && ok) yp2[roff * a.ldy2] = v * a.row_scale[rbase + roff];
     if (a.bits) {  // uniform.  One ballot = this 32-column block of two rows (lane halves)
@@ -120,13 +124,59 @@ __device__ __forceinline__ void fused_epilogue(const SageFusedArgs<IdxT>& a, con
   }
 }
 
+// ---- the output tile once more as compressed rows (spmm_device.h): [8 mask words | kept values].
+// Wave w holds the 32 x 32 block of columns [32 w, 32 w + 32) in the accumulator layout above; the
+// offset of its values inside a row is the number of kept values in the blocks before it, which the
+// waves exchange through `zw` ([8][32] mask words in LDS).  EVERY wave of the workgroup calls this
+// (one barrier inside); waves without a column block pass active = false.
+template <typename IdxT>
+__device__ __forceinline__ void fused_compress_tile(const SageFusedArgs<IdxT>& a, const f32x16& v,
+                                                    uint32_t* __restrict__ zw, int64_t row0,
+                                                    int wave, int lane, bool active) {
+  const int li = lane & 31, lh = lane >> 5;
+  const bool col_ok = active && wave * 32 + li < a.Fo;
+  uint32_t my_word = 0;  // lane e < 16: row (e & 3) + 8 (e >> 2); lane 16 + e: that row + 4
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint64_t m = __ballot(col_ok && __float_as_uint(v[e]) != 0u);
+    if (lane == e) my_word = static_cast<uint32_t>(m);
+    if (lane == 16 + e) my_word = static_cast<uint32_t>(m >> 32);
+  }
+  if (lane < 32) {
+    const int e = lane & 15;
+    zw[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 4)] = my_word;
+  }
+  __syncthreads();
+  // kept values of row li in the column blocks before this wave's
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += __popc(zw[w * 32 + li]);
+  // the mask words of rows 4 wave .. 4 wave + 3: 32 contiguous bytes per row
+  if (lane < 32) {
+    const int r = 4 * wave + (lane >> 3);
+    if (row0 + r < a.g.n_rows) a.zout[(row0 + r) * a.ldz + (lane & 7)] = zw[(lane & 7) * 32 + r];
+  }
+  if (!active) return;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+    const bool keep = col_ok && __float_as_uint(v[e]) != 0u;
+    const uint64_t m = __ballot(keep);
+    const uint32_t half = lh ? static_cast<uint32_t>(m >> 32) : static_cast<uint32_t>(m);
+    const int rank = __popc(half & ((1u << li) - 1u));
+    const int pre = __shfl(before, r, kWave);
+    if (keep && row0 + r < a.g.n_rows)
+      a.zout[(row0 + r) * a.ldz + kZrowHdr + pre + rank] = __float_as_uint(v[e]);
+  }
+}
+
 // ---- phase 2 + epilogue, shared by both kernels: [32 x Fo] = [agg | x_root] @ w^T from the two
 // LDS tiles.  The caller has closed phase 1 with a barrier (both tiles visible to every wave).
 template <typename IdxT, int PF>
 __device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
                                                 const float* __restrict__ agg,
                                                 const float* __restrict__ xr, int agg_ld,
-                                                int64_t row0, int wave, int lane) {
+                                                int64_t row0, int wave, int lane,
+                                                uint32_t* __restrict__ zw = nullptr) {
   const int F = static_cast<int>(a.g.F);
   // ---- phase 2: [32 x Fo] = [agg | x_root] @ w^T.  No staging and no barrier: wave w owns the
   // output columns [32 w, 32 w + 32), so of every weight chunk it needs exactly its own 32 rows x
@@ -135,7 +185,15 @@ __device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
   // go global -> registers directly, one chunk ahead of the MFMAs (every weight byte once per
   // workgroup); both halves of A come from the LDS tiles.
   const int wave_col0 = wave * 32;
-  if (wave_col0 >= a.Fo) return;
+  if (wave_col0 >= a.Fo) {
+    if (zw) {  // (only the row-at-a-time kernel passes zw: all of its waves come through here)
+      f32x16 none;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) none[e] = 0.f;
+      fused_compress_tile<IdxT>(a, none, zw, row0, wave, lane, false);
+    }
+    return;
+  }
   const int li = lane & 31, lh = lane >> 5;
   const int n_half = a.f_pad / kFK;  // chunks per half (aggregated / root)
   const int n_chunks = 2 * n_half;
@@ -217,11 +275,13 @@ __device__ __forceinline__ void fused_transform(const SageFusedArgs<IdxT>& a,
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
   }
-  fused_epilogue<IdxT>(a, acc, row0, wave_col0, lane);
+  f32x16 vout;
+  fused_epilogue<IdxT>(a, acc, row0, wave_col0, lane, vout);
+  if (zw) fused_compress_tile<IdxT>(a, vout, zw, row0, wave, lane, true);
 }
 
 // aggregated row -> LDS tile (+ global agg buffer); lanes < LPR hold VW features per CH
-template <typename IdxT, int VW, int LPR>
+template <typename IdxT, int VW, int LPR, bool ZSRC = false>
 __device__ __forceinline__ void fused_gather_row(const SageFusedArgs<IdxT>& a, int64_t row,
                                                  float* __restrict__ agg_row, int lane) {
   constexpr int CH = 1;
@@ -249,7 +309,8 @@ __device__ __forceinline__ void fused_gather_row(const SageFusedArgs<IdxT>& a, i
     return;
   }
   // (16 instead of 8 row loads in flight per lane was measured slower here: 14.4 / 7.5 ms)
-  spmm_accumulate<IdxT, VW, LPR, CH, 0, false>(a.g, start, end, lane, fo, fv, head, acc);
+  spmm_accumulate<IdxT, VW, LPR, CH, ZSRC ? 4 : 0, false>(a.g, start, end, lane, fo, fv, head,
+                                                          acc);
   combine_subgroups<VW, LPR, CH>(acc);
   if (lane < LPR && fv[0]) {
     const float cntf = static_cast<float>(deg > 0 ? deg : 1);
@@ -265,10 +326,15 @@ __device__ __forceinline__ void fused_gather_row(const SageFusedArgs<IdxT>& a, i
   }
 }
 
-template <typename IdxT, int LPR>
-__global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArgs<IdxT> a) {
+// ZSRC: the gather source is a block of compressed rows (64 lanes x 4 columns per row, two
+// dependent loads per source row: more registers, two workgroups per CU — what the LDS tiles of
+// F = 256 allow anyway)
+template <typename IdxT, int LPR, bool ZSRC = false>
+__global__ void __launch_bounds__(kFBlock, 4)
+    sage_fused_fwd_kernel(SageFusedArgs<IdxT> a) {
   extern __shared__ __align__(16) float smem[];
   __shared__ int next_row;
+  __shared__ uint32_t zw[kFWaves * 32];
   const int agg_ld = a.f_pad + 4;
   float* agg = smem;                    // [32][f_pad + 4]  aggregated rows
   float* xr = smem + kFTile * agg_ld;   // [32][f_pad + 4]  root rows of the tile
@@ -310,12 +376,12 @@ __global__ void __launch_bounds__(kFBlock, 4) sage_fused_fwd_kernel(SageFusedArg
     if (lane == 0) r = atomicAdd(&next_row, 1);
     r = __builtin_amdgcn_readfirstlane(r);
     if (r >= kFTile) break;
-    fused_gather_row<IdxT, 4, LPR>(a, row0 + r, agg + r * agg_ld, lane);
+    fused_gather_row<IdxT, 4, LPR, ZSRC>(a, row0 + r, agg + r * agg_ld, lane);
   }
 
   if (a.probe & 2048) __builtin_amdgcn_s_setprio(0);
   __syncthreads();  // phase 1 complete: both tiles visible to every wave
-  fused_transform<IdxT, 1>(a, agg, xr, agg_ld, row0, wave, lane);
+  fused_transform<IdxT, 1>(a, agg, xr, agg_ld, row0, wave, lane, a.zout ? zw : nullptr);
 }
 
 // ---- v2: the gather phase as a software-pipelined stream ------------------------------------------
@@ -816,7 +882,10 @@ __global__ void __launch_bounds__(kSBlock) sage_fused_spec_kernel(SageFusedArgs<
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
       const int col0 = (m * NB + blk) * 32;
-      if (col0 < a.Fo && !(a.probe & 128)) fused_epilogue<IdxT>(a, acc[blk], row0, col0, lane);
+      if (col0 < a.Fo && !(a.probe & 128)) {
+        f32x16 unused;
+        fused_epilogue<IdxT>(a, acc[blk], row0, col0, lane, unused);
+      }
     }
   }
 }
@@ -847,13 +916,19 @@ static int launch_spec(SageFusedArgs<IdxT> a, int nm, hipStream_t st) {
 static bool aligned16f(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename IdxT, int LPR>
-static int launch_fused(const SageFusedArgs<IdxT>& a, bool streamed, hipStream_t st) {
+static int launch_fused(const SageFusedArgs<IdxT>& a, bool streamed, hipStream_t st,
+                        bool zsrc = false) {
   size_t lds = sizeof(float) * 2 * kFTile * (a.f_pad + 4);
   if (streamed) lds += sizeof(int32_t) * kFCap;
   if (a.probe & 64) lds = 100 * 1024;  // timing probe: one workgroup per CU
   // (probe bits 2-3: weight-prefetch depth of the transform phase, for A/B timing)
   const int pf = (a.probe >> 2) & 3;
-  auto k = !streamed ? sage_fused_fwd_kernel<IdxT, LPR>
+  void (*k)(SageFusedArgs<IdxT>) = nullptr;
+  if constexpr (LPR == kWave) {
+    if (zsrc) k = sage_fused_fwd_kernel<IdxT, LPR, true>;
+  }
+  if (!k)
+    k = !streamed ? sage_fused_fwd_kernel<IdxT, LPR, false>
            : pf == 1 ? sage_fused_stream_kernel<IdxT, LPR, 1>
            : pf == 3 ? sage_fused_stream_kernel<IdxT, LPR, 3>
                      : sage_fused_stream_kernel<IdxT, LPR, 2>;
@@ -897,6 +972,13 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
   if (f->mask_bits && f->ld_mask_bits < words) return PYGAMD_ERR_INVALID_ARG;
   if (f->y_scaled && (!f->row_scale || f->ldy_scaled < Fo)) return PYGAMD_ERR_INVALID_ARG;
   if (f->variant < 0 || f->variant > 4) return PYGAMD_ERR_INVALID_ARG;
+  const bool zsrc = graph->x_format == PYGAMD_X_COMPRESSED;
+  if (graph->x_format != PYGAMD_X_DENSE && !zsrc) return PYGAMD_ERR_INVALID_ARG;
+  // compressed rows in / out: the row-at-a-time kernel only
+  if ((zsrc || f->compressed_out) && f->variant > 1) return PYGAMD_ERR_UNSUPPORTED;
+  if (zsrc && (graph->ldx < F + 12 || graph->src_bits)) return PYGAMD_ERR_INVALID_ARG;
+  if (f->compressed_out && (Fo % 32 != 0 || f->ld_compressed < Fo + 12))
+    return PYGAMD_ERR_INVALID_ARG;
   if (graph->n_rows == 0) return PYGAMD_OK;
   if (!graph->rowptr || !graph->x || !graph->out || !f->x_root || !f->w || !f->y)
     return PYGAMD_ERR_INVALID_ARG;
@@ -924,6 +1006,7 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
   const int spec_nm = f->variant == 3 ? 4 : f->variant == 4 ? 8 : 0;
   int lpr = 4;
   while (lpr < 64 && lpr * 4 < F) lpr <<= 1;
+  if (zsrc) lpr = 64;  // a compressed row is decoded by a whole wave
   return PYGAMD_DISPATCH_IDX(graph->idx_dtype, [&]() -> int {
     SageFusedArgs<IdxT> a;
     a.g.rowptr = static_cast<const IdxT*>(graph->rowptr);
@@ -969,6 +1052,8 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
     a.row_scale = f->row_scale;
     a.y2 = f->y_scaled;
     a.ldy2 = f->ldy_scaled;
+    a.zout = f->compressed_out;
+    a.ldz = f->ld_compressed;
     a.probe = f->reserved;
     a.nbuf = 0;
     if (spec_nm) {
@@ -985,7 +1070,7 @@ int pygamd_sage_layer_fused(const pygamd_spmm_args* graph, const pygamd_sage_fus
       case 8: return launch_fused<IdxT, 8>(a, streamed, st);
       case 16: return launch_fused<IdxT, 16>(a, streamed, st);
       case 32: return launch_fused<IdxT, 32>(a, streamed, st);
-      default: return launch_fused<IdxT, 64>(a, streamed, st);
+      default: return launch_fused<IdxT, 64>(a, streamed, st, zsrc);
     }
   });
 }

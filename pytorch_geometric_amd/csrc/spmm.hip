@@ -85,6 +85,130 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
   }
 }
 
+// Sparse-source variant of spmm_sum_rows (a.src_bits given, plain sum / mean, no epilogue
+// operands): one wave owns R consecutive rows.  With 8 % of the source rows live a row's work is
+// three dependent round trips (its column ids, their bits, the two or three live rows) and almost
+// no bytes; the one-row kernel then runs at the latency of 3 trips per 8 waves per SIMD (1.0 ms for
+// the products graph).  Here the R index loads, then the R bit lookups, are in flight together.
+template <typename IdxT, int VW, int LPR, int CH, int R>
+__global__ void __launch_bounds__(kBlock) spmm_sum_rows_sparse(SpmmDev<IdxT> a) {
+  const int lane = lane_id();
+  const int64_t row0 = (xcd_logical_block() * kWavesPerBlock + wave_in_block()) * R;
+  if (row0 >= a.n_rows) return;
+  const bool use_bits = a.src_bits_set == nullptr || 2 * *a.src_bits_set < a.n_src;
+  int fo[CH], head[CH];
+  bool fv[CH];
+  feature_slots<VW, LPR, CH>(lane, a.F, a.head_dim, fo, fv, head);
+  // rowptr[row0 .. row0 + R], clamped to the last entry: rows past the end come out empty
+  IdxT myptr = 0;
+  if (lane <= R) {
+    const int64_t r = row0 + lane;
+    myptr = a.rowptr[r < a.n_rows ? r : a.n_rows];
+  }
+  IdxT start[R], end[R], myc[R];
+  int cnt[R];
+  bool hub[R];
+  // (loads are unconditional on clamped addresses and selected afterwards: a load inside a
+  // divergent `if` is waited for at the end of its block, one round trip per row again)
+  IdxT nnz = a.rowptr[a.n_rows];
+  const IdxT* __restrict__ colp = a.col;
+  const uint32_t* __restrict__ bitp = a.src_bits;
+  if (nnz == 0) {  // nothing stored: every load below reads slot 0 of a one-word stand-in
+    nnz = 1;
+    colp = reinterpret_cast<const IdxT*>(a.rowptr);  // rowptr[0] == 0: a valid column id
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    start[r] = bcast_uniform(myptr, r);
+    end[r] = bcast_uniform(myptr, r + 1);
+    const IdxT deg = end[r] - start[r];
+    hub[r] = a.hub_threshold > 0 && deg > a.hub_threshold;  // owned by the hub path
+    cnt[r] = hub[r] ? 0 : (deg < kWave ? static_cast<int>(deg) : kWave);
+    IdxT slot = start[r] + lane;
+    slot = slot < nnz ? slot : nnz - 1;
+    myc[r] = __builtin_nontemporal_load(&colp[slot]);
+  }
+  bool keep[R];
+  if (use_bits) {
+    uint32_t wbits[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      wbits[r] = bitp[static_cast<int64_t>(myc[r]) >> 5];
+#pragma unroll
+    for (int r = 0; r < R; ++r) keep[r] = lane < cnt[r] && ((wbits[r] >> (myc[r] & 31)) & 1u) != 0;
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) keep[r] = lane < cnt[r];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t m = __ballot(keep[r]);
+    const int before = __builtin_amdgcn_mbcnt_hi(
+        static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+    const int live = __popcll(m);
+    myc[r] = push_lane(myc[r], keep[r] ? before : live + lane - before);
+    cnt[r] = live;
+  }
+  constexpr int EPI = kWave / LPR;
+  constexpr int STEP = EPI * spmm_unroll<LPR, CH>();
+  const int sub = lane / LPR;
+  // the first EPI live slots of every row (with 8 % of the sources live: usually all of them),
+  // R loads in flight; the address is always that of a stored column (slot 0 when there is none)
+  Vec<VW> v0[R][CH];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    IdxT c;
+    if constexpr (EPI == 1) {
+      c = bcast_uniform(myc[r], 0);
+    } else {
+      c = bcast_lane(myc[r], sub < cnt[r] ? sub : 0);
+    }
+    const float* __restrict__ xr = a.x + static_cast<int64_t>(c) * a.ldx;
+#pragma unroll
+    for (int c2 = 0; c2 < CH; ++c2) v0[r][c2] = load_vec<VW>(xr + (fv[c2] ? fo[c2] : 0));
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= a.n_rows || hub[r]) continue;
+    float acc[CH][VW];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) acc[c][i] = (sub < cnt[r] && fv[c]) ? v0[r][c].v[i] : 0.f;
+    }
+    int j = EPI;
+    for (; j + STEP <= cnt[r]; j += STEP) {
+      spmm_batch<IdxT, VW, LPR, CH, 0, false, true>(a, j, cnt[r], sub, myc[r], IdxT(0), 1.f, fo,
+                                                    fv, head, acc);
+    }
+    if (j < cnt[r]) {
+      spmm_batch<IdxT, VW, LPR, CH, 0, false, false>(a, j, cnt[r], sub, myc[r], IdxT(0), 1.f, fo,
+                                                     fv, head, acc);
+    }
+    if (end[r] - start[r] > kWave) {  // the slots past the first 64, one chunk at a time
+      spmm_accumulate<IdxT, VW, LPR, CH, 3, false>(a, start[r] + kWave, end[r], lane, fo, fv,
+                                                    head, acc);
+    }
+    combine_subgroups<VW, LPR, CH>(acc);
+    if (lane < LPR) {
+      const IdxT deg = end[r] - start[r];
+      const float cntf = static_cast<float>(deg > 0 ? deg : 1);
+      float* __restrict__ orow = a.out + row * a.ldo;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (fv[c]) {
+#pragma unroll
+          for (int i = 0; i < VW; ++i) {
+            const float o = a.mean ? acc[c][i] / cntf : acc[c][i];
+            __builtin_nontemporal_store(o, orow + fo[c] + i);
+          }
+        }
+      }
+    }
+  }
+}
+
 // One wave per hub chunk: partial[ck, :] = sum over the chunk's slots (no post-scale).
 template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
 __global__ void __launch_bounds__(kBlock)
@@ -1033,9 +1157,21 @@ static int launch_sum(const pygamd_spmm_args* p, const Shape& s, float* partial,
                       hipStream_t st) {
   SpmmDev<IdxT> a = make_dev<IdxT>(p);
   if (p->hub_phase != 2) {
-    dim3 grid(wave_grid(p->n_rows), s.tiles);
-    hipLaunchKernelGGL((spmm_sum_rows<IdxT, VW, LPR, CH, WMODE, IDENT>), grid, dim3(kBlock), 0,
-                       st, a);
+    bool done = false;
+    if constexpr (WMODE == 3) {
+      if (!p->accumulate && !p->relu_mask && !p->relu_bits && p->n_src > 0) {
+        constexpr int R = 4;
+        dim3 grid(wave_grid(ceil_div(p->n_rows, static_cast<int64_t>(R))), s.tiles);
+        hipLaunchKernelGGL((spmm_sum_rows_sparse<IdxT, VW, LPR, CH, R>), grid, dim3(kBlock), 0,
+                           st, a);
+        done = true;
+      }
+    }
+    if (!done) {
+      dim3 grid(wave_grid(p->n_rows), s.tiles);
+      hipLaunchKernelGGL((spmm_sum_rows<IdxT, VW, LPR, CH, WMODE, IDENT>), grid, dim3(kBlock), 0,
+                         st, a);
+    }
     PYGAMD_LAUNCH_CHECK();
   }
   if (p->n_hub > 0 && p->hub_phase != 1) {
@@ -1274,48 +1410,125 @@ static int validate(const pygamd_spmm_args* p) {
                        p->hub_threshold < 1 || p->n_chunks < p->n_hub))
     return PYGAMD_ERR_INVALID_ARG;
   if (p->hub_phase < 0 || p->hub_phase > 2) return PYGAMD_ERR_INVALID_ARG;
-  if (p->src_bits && (mm || p->w || p->src_scale || !p->col)) return PYGAMD_ERR_UNSUPPORTED;
+  if (p->src_bits && (mm || p->w || p->src_scale)) return PYGAMD_ERR_UNSUPPORTED;
   if (p->src_bits_set && !p->src_bits) return PYGAMD_ERR_INVALID_ARG;
+  if (p->x_format != PYGAMD_X_DENSE && p->x_format != PYGAMD_X_COMPRESSED)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (p->x_format == PYGAMD_X_COMPRESSED) {
+    if (mm || p->w || p->src_scale || p->src_bits || !p->col) return PYGAMD_ERR_UNSUPPORTED;
+    if (p->F > 256 || p->F % 4 != 0 || p->ldx < p->F + 12 || p->ldo % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(p->out) & 15u) != 0)
+      return PYGAMD_ERR_UNSUPPORTED;
+  }
   return PYGAMD_OK;
 }
 
 // One wave per 32 rows (= one word of the row bitmap), 2^lshift lanes per row: copies of a row
 // block with a 1/deg-style row factor and zero padding, and [row has a non-zero entry] per row.
+// The loads of kPackRows row groups are issued before the first one is consumed (one row group at
+// a time leaves a wave with a single 188-byte request in flight: 0.99 ms for the [2.45 M, 47] block
+// of the products step, against 0.3 ms of traffic).
+constexpr int kPackRows = 8;
 __global__ void __launch_bounds__(kBlock)
     rows_pack_kernel(const float* __restrict__ g, int64_t ldg, int64_t n_rows, int F, int lshift,
                      const float* __restrict__ row_scale, float* __restrict__ scaled,
                      int64_t lds, int Fs, float* __restrict__ copy, int64_t ldc, int Fc,
-                     uint32_t* __restrict__ bits, unsigned long long* __restrict__ n_set) {
+                     uint32_t* __restrict__ bits) {
   const int lane = lane_id();
   const int64_t word = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
   if (word * 32 >= n_rows) return;
   const int L = 1 << lshift;
-  const int rpi = kWave >> lshift;  // rows per iteration
+  const int rpi = kWave >> lshift;  // rows per row group
+  const int iters = 32 / rpi;
   const int sub = lane >> lshift;
   const int lir = lane & (L - 1);
   const int fmax = Fs > Fc ? (Fs > F ? Fs : F) : (Fc > F ? Fc : F);
   const uint64_t group = L == kWave ? ~0ull : ((1ull << L) - 1ull);
   uint32_t w = 0;
-  for (int it = 0; it < 32 / rpi; ++it) {
-    const int64_t row = word * 32 + it * rpi + sub;
-    bool nz = false;
-    if (row < n_rows) {
-      const float sc = row_scale ? row_scale[row] : 1.f;
-      for (int f = lir; f < fmax; f += L) {
-        const float v = f < F ? g[row * ldg + f] : 0.f;
-        nz |= (__float_as_uint(v) << 1) != 0u;  // anything but +-0 (NaN and subnormals count)
-        if (scaled && f < Fs) scaled[row * lds + f] = v * sc;
-        if (copy && f < Fc) copy[row * ldc + f] = v;
+  for (int it0 = 0; it0 < iters; it0 += kPackRows) {
+    int64_t row[kPackRows];
+    bool live[kPackRows], nz[kPackRows];
+    float sc[kPackRows];
+#pragma unroll
+    for (int u = 0; u < kPackRows; ++u) {
+      row[u] = word * 32 + static_cast<int64_t>(it0 + u) * rpi + sub;
+      live[u] = it0 + u < iters && row[u] < n_rows;
+      row[u] = live[u] ? row[u] : n_rows - 1;  // (clamped: the load below is unconditional)
+      nz[u] = false;
+      sc[u] = row_scale ? row_scale[row[u]] : 1.f;
+    }
+    for (int f0 = 0; f0 < fmax; f0 += L) {
+      const int f = f0 + lir;
+      const int fc = f < F ? f : F - 1;
+      float v[kPackRows];
+#pragma unroll
+      for (int u = 0; u < kPackRows; ++u) v[u] = F > 0 ? g[row[u] * ldg + fc] : 0.f;
+#pragma unroll
+      for (int u = 0; u < kPackRows; ++u) {
+        const float x = (live[u] && f < F) ? v[u] : 0.f;
+        nz[u] |= (__float_as_uint(x) << 1) != 0u;  // anything but +-0 (NaN, subnormals count)
+        if (live[u]) {
+          if (scaled && f < Fs) scaled[row[u] * lds + f] = x * sc[u];
+          if (copy && f < Fc) copy[row[u] * ldc + f] = x;
+        }
       }
     }
-    const uint64_t m = __ballot(nz);
-    for (int r = 0; r < rpi; ++r) {
-      if ((m >> (r << lshift)) & group) w |= 1u << (it * rpi + r);
+#pragma unroll
+    for (int u = 0; u < kPackRows; ++u) {
+      const uint64_t m = __ballot(nz[u]);
+      for (int r = 0; r < rpi; ++r) {
+        if ((m >> (r << lshift)) & group) w |= 1u << ((it0 + u) * rpi + r);
+      }
     }
   }
-  if (lane == 0) {
-    bits[word] = w;
-    if (n_set && w) atomicAdd(n_set, static_cast<unsigned long long>(__popc(w)));
+  if (lane == 0) bits[word] = w;
+}
+
+// *n_set = number of set bits, one workgroup (the bitmap of 2.45 M rows is 300 KiB; one atomic per
+// word from the kernel above — 70 k of them on one address — cost 0.6 ms)
+__global__ void __launch_bounds__(1024)
+    bits_count_kernel(const uint32_t* __restrict__ bits, int64_t words, int64_t* __restrict__ n_set) {
+  __shared__ unsigned long long part[16];
+  unsigned long long c = 0;
+  for (int64_t i = threadIdx.x; i < words; i += 1024) c += __popc(bits[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 16; ++i) t += part[i];
+    *n_set = static_cast<int64_t>(t);
+  }
+}
+
+// One wave per row: x[row, :F] (F <= 256) -> the compressed row [8 mask words | kept values] of
+// spmm_device.h ("compressed rows").  Kept = bit pattern other than +0.0.
+__global__ void __launch_bounds__(kBlock)
+    rows_compress_kernel(const float* __restrict__ x, int64_t ldx, int64_t n_rows, int F,
+                         uint32_t* __restrict__ out, int64_t ldo) {
+  const int lane = lane_id();
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
+  if (row >= n_rows) return;
+  uint32_t v[4];
+  uint32_t nib = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 * lane + i;
+    v[i] = c < F ? __float_as_uint(x[row * ldx + c]) : 0u;
+    nib |= (v[i] != 0u ? 1u : 0u) << i;
+  }
+  uint32_t word = nib << (4 * (lane & 7));
+  word |= __shfl_xor(word, 1, kWave);
+  word |= __shfl_xor(word, 2, kWave);
+  word |= __shfl_xor(word, 4, kWave);
+  uint32_t nib2;
+  int off = zrow_lane_offset(word, lane, nib2);
+  uint32_t* __restrict__ orow = out + row * ldo;
+  if ((lane & 7) == 0) orow[lane >> 3] = word;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (nib & (1u << i)) orow[kZrowHdr + off++] = v[i];
   }
 }
 
@@ -1342,13 +1555,32 @@ int pygamd_spmm_csr(const pygamd_spmm_args* args, void* workspace, size_t worksp
   size_t need = 0;
   pygamd_spmm_csr_workspace_bytes(args, &need);
   if (need > 0 && (!workspace || workspace_bytes < need)) return PYGAMD_ERR_WORKSPACE;
-  const Shape s = pick_shape(args);
   hipStream_t st = as_stream(stream);
   float* partial = static_cast<float*>(workspace);
+  if (args->x_format == PYGAMD_X_COMPRESSED) {  // one wave per row, 64 lanes x 4 columns
+    Shape cs;
+    cs.vw = 4; cs.lpr = 64; cs.ch = 1; cs.tiles = 1;
+    return PYGAMD_DISPATCH_IDX(args->idx_dtype, [&]() -> int {
+      return launch_sum<IdxT, 4, 64, 1, 4, false>(args, cs, partial, st);
+    });
+  }
+  const Shape s = pick_shape(args);
   return PYGAMD_DISPATCH_IDX(args->idx_dtype, [&]() -> int {
     return s.vw == 4 ? launch_vw<IdxT, 4>(args, s, partial, st)
                      : launch_vw<IdxT, 1>(args, s, partial, st);
   });
+}
+
+int pygamd_rows_compress(const float* x, int64_t ldx, int64_t n_rows, int64_t F, uint32_t* out,
+                         int64_t ld_out, void* stream) {
+  if (n_rows < 0 || F < 0 || F > 256 || ldx < F || ld_out < F + 12) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows == 0) return PYGAMD_OK;
+  if (!out || (F > 0 && !x)) return PYGAMD_ERR_INVALID_ARG;
+  dim3 grid(static_cast<unsigned>(ceil_div(n_rows, static_cast<int64_t>(kWavesPerBlock))));
+  hipLaunchKernelGGL(rows_compress_kernel, grid, dim3(kBlock), 0, as_stream(stream), x, ldx,
+                     n_rows, static_cast<int>(F), out, ld_out);
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
 }
 
 int pygamd_rows_pack(const float* g, int64_t ldg, int64_t n_rows, int64_t F,
@@ -1361,8 +1593,10 @@ int pygamd_rows_pack(const float* g, int64_t ldg, int64_t n_rows, int64_t F,
   if (copy && (F_copy < F || ld_copy < F_copy)) return PYGAMD_ERR_INVALID_ARG;
   if (n_rows > 0 && F > 0 && !g) return PYGAMD_ERR_INVALID_ARG;
   hipStream_t st = as_stream(stream);
-  if (n_set) PYGAMD_HIP_CHECK(hipMemsetAsync(n_set, 0, sizeof(int64_t), st));
-  if (n_rows == 0) return PYGAMD_OK;
+  if (n_rows == 0) {
+    if (n_set) PYGAMD_HIP_CHECK(hipMemsetAsync(n_set, 0, sizeof(int64_t), st));
+    return PYGAMD_OK;
+  }
   int64_t fmax = F;
   if (scaled && F_scaled > fmax) fmax = F_scaled;
   if (copy && F_copy > fmax) fmax = F_copy;
@@ -1373,9 +1607,12 @@ int pygamd_rows_pack(const float* g, int64_t ldg, int64_t n_rows, int64_t F,
   hipLaunchKernelGGL(rows_pack_kernel, grid, dim3(kBlock), 0, st, g, ldg, n_rows,
                      static_cast<int>(F), lshift, row_scale, scaled, ld_scaled,
                      static_cast<int>(scaled ? F_scaled : 0), copy, ld_copy,
-                     static_cast<int>(copy ? F_copy : 0), row_bits,
-                     reinterpret_cast<unsigned long long*>(n_set));
+                     static_cast<int>(copy ? F_copy : 0), row_bits);
   PYGAMD_LAUNCH_CHECK();
+  if (n_set) {
+    hipLaunchKernelGGL(bits_count_kernel, dim3(1), dim3(1024), 0, st, row_bits, words, n_set);
+    PYGAMD_LAUNCH_CHECK();
+  }
   return PYGAMD_OK;
 }
 

@@ -46,7 +46,9 @@ constexpr int spmm_unroll() {
 // WMODE: 0 = plain sum; 1 = one staged multiplier per slot (w with one head and/or src_scale);
 //        2 = per-head weights fetched per slot (+ optional staged src_scale);
 //        3 = plain sum over the source rows whose bit in a.src_bits is set (the others are known
-//            to be all-zero and are not read).
+//            to be all-zero and are not read);
+//        4 = plain sum over COMPRESSED source rows (a.x = the compressed block, a.ldx its pitch in words;
+//            see "compressed rows" below).
 template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, bool FULL, int UF = 0>
 __device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cnt, int sub,
                                            IdxT myc, IdxT mye, float mym, const int (&fo)[CH],
@@ -119,6 +121,83 @@ __device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cn
   }
 }
 
+// ---- compressed rows ------------------------------------------------------------------------------------
+// A [n, F <= 256] activation block with many exact zeros (a ReLU output: half of it) stored row by
+// row as  [8 mask words | the kept values in column order]  at a fixed row pitch (ld words, a
+// multiple of 32 = 128 bytes, >= F + 12): bit (c & 31) of word (c >> 5) is set where element c is
+// kept (its bit pattern is not +0.0).  A gather then touches 32 + 4 nnz bytes of a row instead of
+// 4 F — 4.4 instead of 8 lines of 128 bytes for a half-empty 256-float row — and the cost of a
+// row gather on this chip is proportional to the lines it touches (scripts/gather_lines_probe.py:
+// 10.1 ms for 8 lines per row, 6.0 ms for 5, 4.6 ms for 4 at the products shape).  Lossless: the
+// sums below add the same values in the same order as the dense gather (a dropped +0.0 changes no
+// sum).  Lane l of the wave that reads a row owns columns 4 l .. 4 l + 3: its mask nibble is bits
+// 4 (l & 7) .. + 3 of word l >> 3, its values start at (kept in the words below) + (kept in the
+// lower nibbles of its word).
+constexpr int kZrowHdr = 8;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// exclusive prefix over the eight 8-lane groups of a wave of a value `t` that is equal inside each
+// group (three DPP adds: the other half of the 16-lane row, then row 0 -> 1 / 2 -> 3, then the
+// lower half -> rows 2, 3)
+__device__ __forceinline__ int group8_exclusive_prefix(int t) {
+  const int a1 = t + __builtin_amdgcn_update_dpp(0, t, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+  const int a2 = a1 + __builtin_amdgcn_update_dpp(0, a1, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+  const int a3 = a2 + __builtin_amdgcn_update_dpp(0, a2, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+  return a3 - t;
+}
+
+// (offset of the lane's first kept value, its mask nibble) from the lane's mask word
+__device__ __forceinline__ int zrow_lane_offset(uint32_t hw, int lane, uint32_t& nib) {
+  const int sh = (lane & 7) * 4;
+  nib = (hw >> sh) & 15u;
+  const int below = __popc(hw & ((1u << sh) - 1u));
+  return group8_exclusive_prefix(__popc(hw)) + below;
+}
+
+// the lane's four columns from its (up to four) kept values p[0..]
+__device__ __forceinline__ void zrow_expand(uint32_t nib, const f32x4u& p, float (&o)[4]) {
+  const bool b0 = nib & 1u, b1 = nib & 2u, b2 = nib & 4u, b3 = nib & 8u;
+  const int r2 = (b0 ? 1 : 0) + (b1 ? 1 : 0);
+  const int r3 = r2 + (b2 ? 1 : 0);
+  o[0] = b0 ? p[0] : 0.f;
+  o[1] = b1 ? (b0 ? p[1] : p[0]) : 0.f;
+  o[2] = b2 ? (r2 == 0 ? p[0] : (r2 == 1 ? p[1] : p[2])) : 0.f;
+  o[3] = b3 ? (r3 == 0 ? p[0] : (r3 == 1 ? p[1] : (r3 == 2 ? p[2] : p[3]))) : 0.f;
+}
+
+// U source rows of a compressed block into acc (one wave per destination row, 64 lanes x 4 columns):
+// the U mask words are in flight together, then the U value loads.
+template <typename IdxT, bool FULL, int U>
+__device__ __forceinline__ void spmm_batch_zrows(const SpmmDev<IdxT>& a, int j, int cnt, IdxT myc,
+                                                  int lane, float (&acc)[1][4]) {
+  const uint32_t* __restrict__ rows = reinterpret_cast<const uint32_t*>(a.x);
+  const uint32_t* base[U];
+  uint32_t hw[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = j + u;
+    const int kk = FULL ? k : (k < cnt ? k : cnt - 1);
+    const IdxT c = bcast_uniform(myc, kk);
+    base[u] = rows + static_cast<int64_t>(c) * a.ldx;
+    hw[u] = base[u][lane >> 3];
+  }
+  f32x4u v[U];
+  uint32_t nib[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int off = zrow_lane_offset(hw[u], lane, nib[u]);
+    if (!FULL && j + u >= cnt) nib[u] = 0u;
+    v[u] = *reinterpret_cast<const f32x4u*>(base[u] + kZrowHdr + off);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float o[4];
+    zrow_expand(nib[u], v[u], o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[0][i] += o[i];
+  }
+}
+
 // UF > 0 overrides the number of row loads in flight per lane (a kernel with few resident waves
 // needs more memory-level parallelism per wave)
 template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, int UF = 0>
@@ -168,14 +247,19 @@ __device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT sta
       }
     }
     int j = 0;
-    for (; j + STEP <= cnt; j += STEP) {
-      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, true, UF>(a, j, cnt, sub, myc, mye, mym, fo, fv,
-                                                        head, acc);
-    }
-    if (j < cnt) {
-      spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, false, UF>(a, j, cnt, sub, myc, mye, mym, fo,
-                                                             fv,
-                                                         head, acc);
+    if constexpr (WMODE == 4) {
+      static_assert(LPR == kWave && VW == 4 && CH == 1 && !IDENT, "compressed rows: 64 lanes x 4");
+      for (; j + U <= cnt; j += U) spmm_batch_zrows<IdxT, true, U>(a, j, cnt, myc, lane, acc);
+      if (j < cnt) spmm_batch_zrows<IdxT, false, U>(a, j, cnt, myc, lane, acc);
+    } else {
+      for (; j + STEP <= cnt; j += STEP) {
+        spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, true, UF>(a, j, cnt, sub, myc, mye, mym, fo,
+                                                              fv, head, acc);
+      }
+      if (j < cnt) {
+        spmm_batch<IdxT, VW, LPR, CH, WMODE, IDENT, false, UF>(a, j, cnt, sub, myc, mye, mym, fo,
+                                                               fv, head, acc);
+      }
     }
   }
 }

@@ -57,6 +57,16 @@ FUSE_BWD = os.environ.get('PYGAMD_FUSE_BWD', '1') != '0'
 # matrix cores idle).  0 = everything on one stream.  (Round 1 measured the same idea with a
 # library GEMM that takes every wave slot: slower.  The own kernel's footprint is a parameter.)
 OVERLAP_WGRAD = os.environ.get('PYGAMD_OVERLAP_WGRAD', '0') != '0'
+# OPT-IN (PYGAMD_COMPRESS_ROWS=1): a one-kernel layer with a ReLU writes its output a second time
+# as compressed rows (8 mask words + the non-zero values, csrc/spmm_device.h) and the next layer
+# gathers those: a row gather costs what the 128-byte lines it touches cost (10.1 ms for 8 lines per
+# row, 6.0 ms for 5: scripts/gather_lines_probe.py) and half of a ReLU output is exact zeros.
+# Lossless, same sums bit for bit — but NOT faster inside the one-kernel layer on this chip
+# (products shape: 16.8 ms against 12.9 ms for the layer that gathers, +0.8 ms for the layer that
+# writes): decoding a row is ~35 VALU instructions per lane against 4 adds, and the mask word has to
+# arrive before the values can be addressed (two dependent loads per source row with 4 waves per
+# SIMD).  DESIGN.md §5a.
+COMPRESS_ROWS = os.environ.get('PYGAMD_COMPRESS_ROWS', '0') != '0'
 # backward of a 'pre' layer: find the all-zero rows of the incoming gradient in the pass that lays
 # it out and skip them in the transposed aggregation (PYGAMD_SPARSE_GRAD=0: read every row)
 SPARSE_GRAD = os.environ.get('PYGAMD_SPARSE_GRAD', '1') != '0'
@@ -128,6 +138,12 @@ class FusedSageStack(Function):
         # forward next to the activation (the backward's ReLU epilogues then read 1/32 of it)
         bits: List[Optional[Tensor]] = [None] * L
         out = None
+        zsrc = None  # the current layer's input once more, as compressed rows (or None)
+
+        def one_kernel_post(k):
+            return (k < L and modes[k] == 'post' and FUSE_LAYER and GEMM_BACKEND == 'own'
+                    and _native.sage_layer_forward_supported(dims[k][0], dims[k][1], aggr))
+
         for layer in range(L):
             W_l, b, W_r = params[3 * layer:3 * layer + 3]
             Fi, Fo = dims[layer]
@@ -147,15 +163,23 @@ class FusedSageStack(Function):
                 one_kernel = lone or (FUSE_LAYER and GEMM_BACKEND == 'own'
                                       and _native.sage_layer_forward_supported(Fi, Fo, aggr)
                                       and src.stride(0) % 4 == 0 and buf.stride(0) % 4 == 0)
+                znext = None
                 if one_kernel:
                     if not last:
                         bits[layer + 1] = _native.relu_bits_like(N, Fo, dev)
+                        if (COMPRESS_ROWS and Fo % 32 == 0 and _native.SAGE_FUSED_VARIANT <= 1
+                                and one_kernel_post(layer + 1)):
+                            znext = torch.empty(N, _native.compressed_pitch(Fo),
+                                                dtype=torch.int32, device=dev)
                     # the aggregated rows are stored once (write-only) for the weight gradient
-                    _native.sage_layer_forward(fwd.ptr, fwd.idx, src, inp if lone else buf[:, Fi:],
+                    _native.sage_layer_forward(fwd.ptr, fwd.idx, src if zsrc is None else zsrc,
+                                               inp if lone else buf[:, Fi:],
                                                wmat, b, aggr, not last,
                                                buf if lone else buf[:, :Fi], dst, hub=fwd.hub,
                                                save_agg=True,
-                                               relu_bits=None if last else bits[layer + 1])
+                                               relu_bits=None if last else bits[layer + 1],
+                                               gather_width=None if zsrc is None else Fi,
+                                               compressed_out=znext)
                     relu_done = True
                 else:
                     _native.spmm_csr(fwd.ptr, fwd.idx, src, aggr, n_rows=N, hub=fwd.hub,
@@ -200,6 +224,7 @@ class FusedSageStack(Function):
             bufs.append(buf)
             wmats.append(wmat)
             buf, inp = nbuf, dst
+            zsrc = znext if modes[layer] == 'post' else None
         ctx.graph, ctx.aggr, ctx.L, ctx.dims, ctx.modes = graph, aggr, L, dims, modes
         ctx.has_bias = [params[3 * i + 1] is not None for i in range(L)]
         ctx.has_bits = [t is not None for t in bits]

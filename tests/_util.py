@@ -88,3 +88,18 @@ def assert_close_outliers(got, ref, tol=2e-5, max_outlier_frac=2e-3, what=''):
     frac = float(bad.float().mean())
     assert frac <= max_outlier_frac, f'{what}: {frac:.2e} of the elements differ by > {tol:g}'
     assert float((got - ref).abs().max()) <= 0.05 * scale, f'{what}: gross mismatch'
+
+
+def decompress_rows(z, F):
+    """CPU reading of the compressed-row layout (include/pyg_amd.h, pygamd_rows_compress): int32
+    [n, ld] -> (float32 [n, F], kept mask [n, F]); row = 8 mask words + kept values in order."""
+    import numpy as np
+    zz = z.detach().cpu().numpy().view(np.uint32)
+    n = zz.shape[0]
+    cols = np.arange(F)
+    mask = ((zz[:, cols >> 5] >> (cols & 31).astype(np.uint32)) & 1).astype(bool)
+    out = np.zeros((n, F), dtype=np.uint32)
+    for i in range(n):
+        k = int(mask[i].sum())
+        out[i, mask[i]] = zz[i, 8:8 + k]
+    return torch.from_numpy(out.view(np.float32)), torch.from_numpy(mask)

@@ -60,6 +60,7 @@ def fake_native(monkeypatch):
     from pytorch_geometric_amd import _native
     from pytorch_geometric_amd.nn.models import _fused_sage
     log = []
+    zstore = {}
 
     def spmm_csr(ptr, idx, x, reduce, *, n_rows=None, hub=None, out=None, accumulate=False,
                  src_scale=None, relu_mask=None, relu_bits=None, src_bits=None,
@@ -89,8 +90,12 @@ def fake_native(monkeypatch):
 
     def sage_layer_forward(ptr, idx, x_gather, x_root, w, bias, reduce, relu, agg, out, hub=None,
                            save_agg=True, relu_bits=None, mask_bits=None, row_scale=None,
-                           out_scaled=None, **kw):
+                           out_scaled=None, gather_width=None, compressed_out=None, **kw):
         assert not kw, kw
+        if gather_width is not None:  # the previous layer's compressed copy of its output
+            assert x_gather.dtype == torch.int32
+            x_gather = zstore[x_gather.data_ptr()]
+            assert x_gather.size(1) == gather_width and torch.equal(x_gather, x_root)
         a = _aggregate(ptr, idx, x_gather, reduce)
         y = torch.cat([a, x_root], 1) @ w.t()
         if bias is not None:
@@ -105,10 +110,16 @@ def fake_native(monkeypatch):
             assert relu
             relu_bits.copy_(_native.pack_relu_bits(y))
         out.copy_(y)
+        if compressed_out is not None:
+            assert relu and compressed_out.dtype == torch.int32
+            assert compressed_out.shape == (y.size(0), _native.compressed_pitch(y.size(1)))
+            zstore[compressed_out.data_ptr()] = y.clone()
         if out_scaled is not None:
             out_scaled.copy_(y * row_scale.view(-1, 1))
         # (root rows read from a dense tensor = the layer input itself, not a half of [agg | x])
         log.append(('fused_layer', x_root.is_contiguous(), relu_bits is not None)
+                   + (('z_in', ) if gather_width is not None else ())
+                   + (('z_out', ) if compressed_out is not None else ())
                    if not (mask_bits is not None or not save_agg) else
                    ('fused_layer_bwd', mask_bits is not None, out_scaled is not None))
         return out
@@ -190,6 +201,7 @@ def test_fused_stack_wiring_against_the_oracle(fake_native, monkeypatch, dims, a
     from pytorch_geometric_amd.nn.models import _fused_sage
     from pytorch_geometric_amd.nn.models._fused_sage import FusedSageStack
     monkeypatch.setattr(_fused_sage, 'FUSE_BWD', fuse_bwd)
+    monkeypatch.setattr(_fused_sage, 'COMPRESS_ROWS', True)  # (opt-in: the wiring is checked)
     n = 75  # three 32-row bit tiles, the last one partial
     g = gen(sum(dims) + n)
     ei = random_graph(n, n, 600, seed=dims[0], skew=True)
@@ -242,6 +254,8 @@ def test_fused_stack_wiring_against_the_oracle(fake_native, monkeypatch, dims, a
             ('spmm', 'sum', False, False, False, 'src_bits')]
         fused = [e for e in fake_native if e[0] == 'fused_layer']
         assert [e[1] for e in fused] == [True, False]   # layer 1 roots on x itself (no copy)
+        # layer 1 writes its ReLU output once more as compressed rows; layer 2 gathers those
+        assert fused[0][3:] == ('z_out', ) and fused[1][3:] == ('z_in', )
         assert ('wgrad', bias, True) in fake_native      # ... and its wgrad takes [agg | x] apart
         # ReLU backward of h1 and h2 in the epilogues of the kernels producing their gradients,
         # and never from the float activations: both came out of the one-kernel layer forward

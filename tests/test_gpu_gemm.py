@@ -259,6 +259,66 @@ def test_sage_layer_streamed_gather_is_bitwise_the_spmm(dev, F, Fo):
     assert not bool(torch.isnan(res[1][1]).any())
 
 
+@pytest.mark.parametrize('F,Fo', [(256, 256), (64, 128), (100, 96), (32, 32), (192, 64)])
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_sage_layer_with_compressed_rows_in_and_out(dev, F, Fo, dtype):
+    """The one-kernel layer gathers COMPRESSED source rows (x_format) and writes its own output a
+    second time in that layout (compressed_out): for F > 128 bitwise the dense launch — output,
+    saved aggregated rows, ReLU bits (narrower rows: equal to fp32 rounding, the dense gather then
+    adds several slots side by side) — and compressed_out decodes to exactly the launch's own dense
+    output.  Hub rows, empty rows, a partial last tile; the source is a ReLU output (half
+    zeros)."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    from tests._util import assert_close_scaled, decompress_rows, random_graph
+    n = 1037
+    g = gen(5 * F + Fo)
+    ei = random_graph(n, n, 30000, seed=F + 2 * Fo, skew=True).to(dtype)
+    ei = ei[:, (ei[1] != 5) & (ei[1] != 77)]
+    x = torch.randn(n, F, generator=g).relu().to(dev)
+    x[9] = 0
+    w = (torch.randn(Fo, 2 * F, generator=g) * 0.1).to(dev)
+    b = torch.randn(Fo, generator=g).to(dev)
+    fwd = pga.EdgeIndex(ei.to(dev), (n, n)).by_dst()
+    assert fwd.hub[2] > 0
+    z = _native.rows_compress(x)
+    res = []
+    for zin in (None, z):
+        agg = torch.full((n, F), float('nan'), device=dev)
+        out = torch.full((n, Fo), float('nan'), device=dev)
+        bits = _native.relu_bits_like(n, Fo, dev).fill_(-1)
+        zout = torch.full((n, _native.compressed_pitch(Fo)), -1, dtype=torch.int32, device=dev)
+        _native.sage_layer_forward(fwd.ptr, fwd.idx, x if zin is None else zin, x, w, b, 'mean',
+                                   True, agg, out, hub=fwd.hub, save_agg=True, relu_bits=bits,
+                                   gather_width=None if zin is None else F,
+                                   compressed_out=zout, variant=1)
+        res.append((agg, out, bits))
+        dec, mask = decompress_rows(zout, Fo)
+        assert torch.equal(dec.view(torch.int32), out.cpu().view(torch.int32)), \
+            'compressed_out does not decode to the dense output'
+        assert torch.equal(mask, out.cpu() > 0)
+    for a, c, what in zip(res[0], res[1], ('aggregated rows', 'output', 'ReLU bits')):
+        if F > 128:
+            assert torch.equal(a, c), f'{what}: compressed gather differs from the dense gather'
+        elif what != 'ReLU bits':
+            assert_close_scaled(a, c, what=what)
+    assert not bool(torch.isnan(res[1][1]).any()) and 0 < int((res[1][1] > 0).sum())
+    # no ReLU, no bias, a signed output (everything kept but exact zeros), compressed in only
+    out_d, out_z = torch.empty(n, Fo, device=dev), torch.empty(n, Fo, device=dev)
+    agg = torch.empty(n, F, device=dev)
+    _native.sage_layer_forward(fwd.ptr, fwd.idx, x, x, w, None, 'sum', False, agg, out_d,
+                               hub=fwd.hub, save_agg=False, variant=1)
+    _native.sage_layer_forward(fwd.ptr, fwd.idx, z, x, w, None, 'sum', False, agg, out_z,
+                               hub=fwd.hub, save_agg=False, gather_width=F, variant=1)
+    if F > 128:
+        assert torch.equal(out_d, out_z)
+    else:
+        assert_close_scaled(out_z, out_d, what='signed output')
+    with pytest.raises(Exception):  # the other schedules do not take compressed rows
+        _native.sage_layer_forward(fwd.ptr, fwd.idx, z, x, w, None, 'sum', False, agg, out_z,
+                                   hub=fwd.hub, save_agg=False, gather_width=F, variant=3)
+
+
 @pytest.mark.parametrize('Fi,Fo', [(256, 256), (64, 128), (100, 40)])
 @pytest.mark.parametrize('reduce', ['mean', 'sum'])
 @pytest.mark.parametrize('variant', [1, 2, 3, 4])

@@ -267,6 +267,8 @@ def test_fused_sage_stack_with_a_loss_on_a_training_split(dev, aggr, monkeypatch
     results = {}
     for sparse in (True, False):
         monkeypatch.setattr(_fused_sage, 'SPARSE_GRAD', sparse)
+        # (the opt-in compressed copy of the hidden activations rides along on one of the runs)
+        monkeypatch.setattr(_fused_sage, 'COMPRESS_ROWS', sparse)
         model.zero_grad()
         xg = x.to(dev).requires_grad_(True)
         sink = []

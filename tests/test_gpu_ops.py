@@ -1032,8 +1032,93 @@ def test_spmm_skips_zero_source_rows(dev, dtype, F, monkeypatch):
                          accumulate=True, src_bits=bits, src_bits_set=n_set)
         assert_sum_close(buf[:, :F] - 1, ref, ex, atol=1e-4, what='sparse-source accumulate')
         assert bool((buf[:, F:] == 1).all())
+    # no stored entries at all; rows past the last full group of four
+    for n_empty in (1, 4, 7):
+        e = pga.EdgeIndex(torch.empty(2, 0, dtype=dtype, device=dev), (n_src, n_empty)).by_dst()
+        out = _native.spmm_csr(e.ptr, e.idx, xd, 'sum', n_rows=n_empty, hub=e.hub, src_bits=bits,
+                               src_bits_set=n_set,
+                               out=torch.full((n_empty, F), 3.0, device=dev))
+        assert bool((out == 0).all())
     with pytest.raises(ValueError):
         _native.spmm_csr(h.ptr, h.idx, xd, 'sum', n_rows=n_dst, hub=h.hub, src_bits=bits[:5])
     with pytest.raises(Exception):  # not with per-edge weights
         _native.spmm_csr(h.ptr, h.idx, xd, 'sum', n_rows=n_dst, hub=h.hub, src_bits=bits,
                          w=torch.ones(ei.size(1), device=dev))
+
+
+def _with_zeros(n, F, density, seed):
+    g = gen(seed)
+    x = torch.randn(n, F, generator=g)
+    x[torch.rand(n, F, generator=g) >= density] = 0
+    return x
+
+
+@pytest.mark.parametrize('F', [4, 32, 36, 100, 128, 256])
+def test_rows_compress_layout(dev, F):
+    """pygamd_rows_compress: 8 mask words + the kept values in column order; kept = any bit pattern
+    but +0.0 (so -0.0, NaN and subnormals survive): lossless."""
+    from pytorch_geometric_amd import _native
+    from tests._util import decompress_rows
+    n = 517
+    x = _with_zeros(n, F, 0.5, F)
+    x[3] = 0                      # an empty row
+    x[4] = torch.arange(1, F + 1)  # a full row
+    x[5, 0] = -0.0
+    x[5, F - 1] = float('nan')
+    x[6] = 0
+    x[6, F - 1] = 1e-42
+    wide = torch.zeros(n, F + 5)
+    wide[:, 1:1 + F] = x
+    z = _native.rows_compress(wide.to(dev)[:, 1:1 + F])  # a strided, unaligned source
+    assert z.dtype == torch.int32 and z.shape == (n, _native.compressed_pitch(F))
+    got, mask = decompress_rows(z, F)
+    want_mask = x.view(torch.int32) != 0
+    assert torch.equal(mask, want_mask)
+    assert torch.equal(got.view(torch.int32), x.view(torch.int32))
+    # the mask words past F are clear
+    import numpy as np
+    zz = z.cpu().numpy().view(np.uint32)
+    for c in range(F, 256):
+        assert not ((zz[:, c >> 5] >> np.uint32(c & 31)) & 1).any()
+    with pytest.raises(ValueError):
+        _native.rows_compress(torch.zeros(4, 260, device=dev))
+    assert _native.rows_compress(torch.zeros(0, F, device=dev)).shape[0] == 0
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+@pytest.mark.parametrize('F', [4, 64, 100, 132, 256])
+def test_spmm_from_compressed_rows_is_bit_exact(dev, dtype, F, monkeypatch):
+    """The aggregation reads compressed source rows (x_format = PYGAMD_X_COMPRESSED).  A whole wave
+    decodes one source row, slot after slot: for F > 128, where the dense kernel walks the slots the
+    same way, the sums are the same bit for bit (same values, same order; a dropped +0.0 changes no
+    sum); narrower rows (the dense kernel then adds several slots side by side) agree to fp32
+    rounding.  Hub rows and rows with more than 64 / 8 k + r slots included."""
+    from pytorch_geometric_amd import _native
+    import pytorch_geometric_amd as pga
+    monkeypatch.setattr(_native, 'HUB_THRESHOLD', 200)
+    monkeypatch.setattr(_native, 'HUB_CHUNK', 96)
+    orig = _native.hub_plan
+    monkeypatch.setattr(_native, 'hub_plan', lambda ptr, threshold=None, chunk=None: orig(
+        ptr, 200, 96))
+    n_src, n_dst = 2000, 700
+    ei = random_graph(n_src, n_dst, 30_000, seed=F + 11, dtype=dtype, skew=True)
+    h = pga.EdgeIndex(ei.to(dev), (n_src, n_dst)).by_dst()
+    assert h.hub[2] > 0
+    for density in (0.5, 0.0, 1.0, 0.03):
+        x = _with_zeros(n_src, F, density, F + int(density * 100)).to(dev)
+        z = _native.rows_compress(x)
+        for red in ('sum', 'mean'):
+            dense = _native.spmm_csr(h.ptr, h.idx, x, red, n_rows=n_dst, hub=h.hub)
+            out = _native.spmm_csr(h.ptr, h.idx, z, red, n_rows=n_dst, hub=h.hub,
+                                   compressed_width=F)
+            if F > 128:
+                assert torch.equal(out.view(torch.int32), dense.view(torch.int32)), \
+                    f'{red} F={F} density={density}: {(out - dense).abs().max().item():.3e}'
+            else:
+                ex = O.spmm(ei.long(), x.cpu().double(), n_dst, red)
+                assert_sum_close(out, dense, ex, what=f'compressed {red} F={F} p={density}')
+    with pytest.raises(ValueError):
+        _native.spmm_csr(h.ptr, h.idx, z, 'max', n_rows=n_dst, hub=h.hub, compressed_width=F)
+    with pytest.raises(ValueError):
+        _native.spmm_csr(h.ptr, h.idx, z[:, :F], 'sum', n_rows=n_dst, hub=h.hub,
+                         compressed_width=F)
