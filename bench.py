@@ -41,7 +41,13 @@ def spmm_algorithmic_bytes(info) -> float:
     epilogue reads a ReLU output — or, 32 x smaller, its one-bit-per-element mask — to apply
     that activation's backward)."""
     b, Fw = info['idx_bytes'], info['F']
-    total = info['nnz'] * (4 * Fw + b) + (info['n_rows'] + 1) * b + info['n_rows'] * 4 * Fw
+    # (src_bits: only the source rows with a non-zero entry are read — `live_nnz` stored entries
+    # point at one — plus one bit per source row; every index still is)
+    rows_read = info.get('live_nnz', info['nnz']) if info.get('src_bits') else info['nnz']
+    total = (rows_read * 4 * Fw + info['nnz'] * b + (info['n_rows'] + 1) * b
+             + info['n_rows'] * 4 * Fw)
+    if info.get('src_bits'):
+        total += info['n_src'] / 8
     if info['src_scale']:
         total += info['n_src'] * 4
     if info['weighted']:
@@ -711,6 +717,9 @@ def main():
     g = torch.Generator().manual_seed(7 + rank)
     train_idx = torch.randperm(N, generator=g)[:max(int(0.0803 * N), 1)].to(dev)
     y_train = y[train_idx]
+    # stored entries that point at a training node: the rows of the loss gradient the transposed
+    # aggregation of the output layer has to read (the others are zero and skipped, src_bits)
+    live_nnz = int(torch.bincount(ei[1].long(), minlength=N)[train_idx].sum().item())
 
     ar_events = []  # (start, end) HIP events around the gradient all-reduce, timed steps only
 
@@ -781,9 +790,13 @@ def main():
                     2: 'sage_fused_stream_kernel'}.get(_native.SAGE_FUSED_VARIANT,
                                                        'sage_fused_spec_kernel')
             return f'{name}<{it},{lpr}>'
+        if info.get('src_bits'):
+            return f'spmm_sum_rows_sparse<{it},F={info["F"]}>'
         return f'spmm_sum_rows<{it},F={info["F"]}>'
 
     def alg_bytes(info):
+        if info.get('src_bits'):
+            info = dict(info, live_nnz=live_nnz)
         return (fused_algorithmic_bytes(info) if info.get('fused_gemm')
                 else spmm_algorithmic_bytes(info))
 

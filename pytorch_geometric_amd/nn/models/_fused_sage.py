@@ -57,6 +57,7 @@ FUSE_BWD = os.environ.get('PYGAMD_FUSE_BWD', '1') != '0'
 # matrix cores idle).  0 = everything on one stream.  (Round 1 measured the same idea with a
 # library GEMM that takes every wave slot: slower.  The own kernel's footprint is a parameter.)
 OVERLAP_WGRAD = os.environ.get('PYGAMD_OVERLAP_WGRAD', '0') != '0'
+OVERLAP_WGS = int(os.environ.get('PYGAMD_OVERLAP_WGS', '1'))  # workgroups per CU of that launch
 # OPT-IN (PYGAMD_COMPRESS_ROWS=1): a one-kernel layer with a ReLU writes its output a second time
 # as compressed rows (8 mask words + the non-zero values, csrc/spmm_device.h) and the next layer
 # gathers those: a row gather costs what the 128-byte lines it touches cost (10.1 ms for 8 lines per
@@ -292,7 +293,24 @@ class FusedSageStack(Function):
                 overlap = (own and OVERLAP_WGRAD and need_input_grad and not one_launch
                            and not torch.cuda.is_current_stream_capturing())
                 lone_x = x0 if layer == 0 else None  # [agg | x] as two operands side by side
-                if not overlap:
+                # the same idea with the one-launch input gradient: its gather phase leaves the
+                # matrix cores about half idle, the weight gradient is pure MFMA work that nobody
+                # waits for before the optimizer step
+                overlap_one = (own and OVERLAP_WGRAD and one_launch
+                               and not torch.cuda.is_current_stream_capturing())
+                if overlap_one:
+                    cur = torch.cuda.current_stream(g.device)
+                    side = _side_stream(g.device)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        gw = _native.linear_wgrad(g, buf, wgs_per_cu=OVERLAP_WGS, bias_grad=want_b,
+                                                  x2=lone_x)
+                        if want_b:
+                            gw, grads[3 * layer + 1] = gw
+                    for t in (g, buf) + ((lone_x, ) if lone_x is not None else ()):
+                        t.record_stream(side)
+                    pending.append(side)
+                elif not overlap:
                     if own:
                         gw = _native.linear_wgrad(g, buf, bias_grad=want_b, x2=lone_x)
                         if want_b:

@@ -23,3 +23,11 @@ except Exception as e:
 PY
 timeout 300 python bench.py --uniform --steps 20 --warmup 5 --no-cpu-baseline > $O/z_bench_uniform.json 2> $O/z_bench_uniform.err
 echo "uniform rc=$?"; cut -c1-330 $O/z_bench_uniform.json
+# kernel stats of the bench line as it stands at the end of the round
+OUT=$O/prof_final; rm -rf $OUT; mkdir -p $OUT
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o bench --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stdout.log 2>&1)
+echo "prof rc=$?"
+python scripts/summarize_profile.py $(find $OUT -name "*kernel_stats.csv" | head -1) $O/z_bench_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (round 3, end of round; 7 steps, MI355X)" 7
+cp $(find $OUT -name "*kernel_stats.csv" | head -1) $O/z_bench_kernel_stats.csv
+head -16 $O/z_bench_kernel_stats.md | cut -c1-170
+find $OUT -name "*.csv" -size +8M -delete
