@@ -55,14 +55,19 @@ if fetch and write:
         'workload': {'scale': 1.0, 'index_dtype': 'int64', 'graph': 'power-law', 'N': N, 'E': E},
         'units': 'FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE '
                  'on gfx950 reports exactly half of the bytes of a wide (16 B/lane) coalesced '
-                 'read, so it is doubled.  The correction is calibrated for >= 1 KiB rows only: the '
-                 'F = 100 (400-byte rows) and F = 48 (192-byte rows) figures are upper bounds.',
+                 'read, so it is doubled.  Calibrated on a known byte count at 1024 / 400 / 192-byte '
+                 'row pitches (profiles/r03_fetch_size_calibration.txt): the doubled figure is the '
+                 'line-granular (128-byte) traffic within +2...4 % at every pitch.',
         'per_launch': {},
     }
     for key, sub in (('sage_fused_fwd_F256 (layer-2 forward AND layer-2 input gradient)',
-                      'sage_fused_fwd_kernel<long, 64>'),
-                     ('sage_fused_fwd_F100 (layer-1 forward)', 'sage_fused_fwd_kernel<long, 32>'),
-                     ('spmm_sum_rows_F48', 'spmm_sum_rows<long, 4, 16, 1, 0'),
+                      'sage_fused_fwd_kernel<long, 64'),
+                     ('sage_fused_fwd_F100 (layer-1 forward)', 'sage_fused_fwd_kernel<long, 32'),
+                     ('spmm_sum_rows_F48 (layer-3 forward)', 'spmm_sum_rows<long, 4, 16, 1, 0'),
+                     ('spmm_sum_rows_sparse_F48 (layer-3 backward: zero rows of the loss '
+                      'gradient skipped)', 'spmm_sum_rows_sparse<long, 4, 16, 1'),
+                     ('rows_pack (layout pass of the loss gradient + live-row bitmap)',
+                      'rows_pack_kernel'),
                      ('gemm_tn_wgrad', 'gemm_tn_kernel<true, false>'),
                      ('gemm_nt_128x128', 'gemm_nt_kernel<2, 2, 2, 2, true, false>')):
         f, w = pick(fetch, sub), pick(write, sub)
@@ -82,9 +87,10 @@ if fetch and write:
         json.dump(res, f, indent=1)
     # the same numbers keyed by bench.py's kernel symbols (bench.py `pmc_traffic`)
     by_symbol = {}
-    for sym, sub in (('sage_fused_fwd_kernel<long,64>', 'sage_fused_fwd_kernel<long, 64>'),
-                     ('sage_fused_fwd_kernel<long,32>', 'sage_fused_fwd_kernel<long, 32>'),
-                     ('spmm_sum_rows<long,F=48>', 'spmm_sum_rows<long, 4, 16, 1, 0')):
+    for sym, sub in (('sage_fused_fwd_kernel<long,64>', 'sage_fused_fwd_kernel<long, 64'),
+                     ('sage_fused_fwd_kernel<long,32>', 'sage_fused_fwd_kernel<long, 32'),
+                     ('spmm_sum_rows<long,F=48>', 'spmm_sum_rows<long, 4, 16, 1, 0'),
+                     ('spmm_sum_rows_sparse<long,F=48>', 'spmm_sum_rows_sparse<long, 4, 16, 1')):
         fv, wv = pick(fetch, sub), pick(write, sub)
         if fv is not None and wv is not None:
             by_symbol[sym] = (2 * fv + wv) * 1024

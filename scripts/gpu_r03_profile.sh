@@ -39,12 +39,19 @@ with open('$OUT/dispatches.txt', 'w') as out:  # every dispatch, in order (phase
 PY
   find $OUT -name "*.csv" -size +8M -delete
 }
+# ONLY=traffic: just the two HBM-traffic passes (the rest of the visit costs 8 GPU-minutes)
+want() { [[ -z "${ONLY:-}" || "$ONLY" == "$1" ]]; }
+if want stats; then
 echo "== kernel stats: bench"
 prof bench python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
+fi
+if want traffic; then
 echo "== PMC FETCH_SIZE"
-pmc fetch FETCH_SIZE 'spmm_sum_rows|sage_fused|gemm_' python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+pmc fetch FETCH_SIZE 'spmm_sum_rows|sage_fused|gemm_|rows_pack' python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
 echo "== PMC WRITE_SIZE"
-pmc write WRITE_SIZE 'spmm_sum_rows|sage_fused|gemm_' python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+pmc write WRITE_SIZE 'spmm_sum_rows|sage_fused|gemm_|rows_pack' python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+fi
+[[ -n "${ONLY:-}" ]] && exit 0
 echo "== PMC SQ counters: fused layer variants"
 pmc sq_fused "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" 'sage_fused|spmm_sum_rows|gemm_nt' python $R/scripts/fused_probe.py --widths 256 --sq-only
 echo "== kernel stats: min/max probe"
