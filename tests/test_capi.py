@@ -192,3 +192,50 @@ def test_torch_binding_builds_loads_and_declares_its_operators():
         out = torch.empty(10, 4, device='cuda')
         assert ns.linear_forward(x, torch.empty(4, 8, device='cuda'), None, False, out,
                                  False) is None
+
+
+def test_struct_mirrors_match_the_header_field_for_field(tmp_path):
+    """`_lib.SpmmArgs` / `_lib.SageFusedArgs` are hand-written mirrors of the two argument structs of
+    include/pyg_amd.h.  Compile the header with gcc and compare size and every field offset: a field
+    added on one side only would silently shift everything behind it."""
+    import ctypes
+    import re
+    import subprocess
+    from pytorch_geometric_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'pyg_amd.h')).read()
+
+    def c_fields(struct_body):
+        body = re.sub(r'/\*.*?\*/', '', struct_body, flags=re.S)
+        names = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if decl:
+                names.append(re.split(r'[\s\*]+', decl)[-1])
+        return names
+
+    m1 = re.search(r'typedef struct \{(.*?)\} pygamd_spmm_args;', header, flags=re.S)
+    m2 = re.search(r'typedef struct pygamd_sage_fused_args \{(.*?)\} pygamd_sage_fused_args;',
+                   header, flags=re.S)
+    assert m1 and m2
+    structs = {'pygamd_spmm_args': (c_fields(m1.group(1)), _lib.SpmmArgs),
+               'pygamd_sage_fused_args': (c_fields(m2.group(1)), _lib.SageFusedArgs)}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pyg_amd.h"', 'int main(void) {']
+    for name, (fields, _) in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for f in fields:
+            lines.append(f'  printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)],
+                   check=True)
+    got = dict(line.rsplit(' ', 1) for line in
+               subprocess.run([str(exe)], check=True, capture_output=True,
+                              text=True).stdout.strip().splitlines())
+    for name, (fields, mirror) in structs.items():
+        assert [f for f, _ in mirror._fields_] == fields, f'{name}: field names / order differ'
+        assert int(got[name]) == ctypes.sizeof(mirror), f'{name}: size'
+        for f in fields:
+            assert int(got[f'{name}.{f}']) == getattr(mirror, f).offset, f'{name}.{f}: offset'
