@@ -40,3 +40,19 @@ for pitch in (256, 288):
         lines = (W * 4 + 127) // 128
         print(f'pitch {pitch * 4:5d} B, first {W:3d} floats ({lines} lines / row): {t:6.2f} ms '
               f'({E * lines * 128 / t / 1e9:5.2f} TB/s of lines, {E / t / 1e6:6.2f} G rows/s)')
+
+# the same aggregation from COMPRESSED rows (pygamd_rows_compress): a ReLU-like block, half zeros
+for density in (0.5, 0.25):
+    h = torch.randn(N, 256, device=dev)
+    h[torch.rand(N, 256, device=dev) >= density] = 0
+    z = _native.rows_compress(h)
+    out = torch.empty(N, 256, device=dev)
+    td = timeit(lambda: _native.spmm_csr(g.ptr, g.idx, h, 'sum', n_rows=N, hub=g.hub, out=out))
+    tz = timeit(lambda: _native.spmm_csr(g.ptr, g.idx, z, 'sum', n_rows=N, hub=g.hub, out=out,
+                                         compressed_width=256))
+    tc = timeit(lambda: _native.rows_compress(h, out=z))
+    lines = (32 + 4 * 256 * density) / 128
+    print(f'stand-alone aggregation, F = 256, {density:.0%} non-zero: dense rows {td:6.2f} ms, '
+          f'compressed rows {tz:6.2f} ms ({lines:.1f} lines / row on average), compressing the '
+          f'block {tc:5.2f} ms')
+    del h, z, out
