@@ -63,15 +63,21 @@ def spmm_algorithmic_bytes(info) -> float:
 
 def pmc_traffic(args, N, E, kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this very command
-    (profiles/r03_pmc_bench.json: FETCH_SIZE and WRITE_SIZE in separate passes, converted as
+    (profiles/r04_pmc_bench.json, r03_pmc_bench.json: FETCH_SIZE and WRITE_SIZE in separate passes, converted as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; collected by scripts/gpu_r03_profile.sh).
     Counters cannot be read from inside this process, so a number is only reported when this run is
     the workload the counters were collected on; otherwise null."""
-    path = os.path.join(ROOT, 'profiles', 'r03_pmc_bench.json')
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except (OSError, ValueError):
+    d = None
+    for name in ('r04_pmc_bench.json', 'r03_pmc_bench.json'):  # newest file that knows the kernel
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                cand = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if kernel in cand.get('traffic_bytes_per_launch', {}):
+            d = cand
+            break
+    if d is None:
         return None
     w = d.get('workload', {})
     same = (w.get('N') == N and w.get('E') == E and not args.uniform
@@ -245,8 +251,64 @@ def parity_at_cpu_scale(sample, dev):
     errs['worst_param'] = worst
     errs['n_param_tensors'] = len(gpu64)
     errs['tol'] = {'loss': 1e-5, 'out': 1e-5,
-                   'param_grad': 'gpu_vs_fp64 <= max(2 x ref_vs_fp64, 2e-5) per tensor'}
+                   'param_grad': 'NOT north_star\'s 1e-5: gpu_vs_fp64 <= max(2 x ref_vs_fp64, '
+                                 '2e-5) per tensor (sums over N rows; the reference\'s own fp32 '
+                                 'distance to fp64 is reported beside it)'}
     errs['against'] = sample['kind']
+    errs['ok'] = bool(errs['loss'] <= 1e-5 and errs['out'] <= 1e-5
+                      and all(gpu64[k] <= max(2 * ref64[k], 2e-5) for k in gpu64))
+    return {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in errs.items()}
+
+
+def parity_cached(dev):
+    """`parity_at_cpu_scale` without a live CPU run: the GPU stack on the committed sample
+    (tests/golden/golden_bench_sample_v1.pt, made by tests/golden/make_golden_bench_sample.py from
+    the real reference at 1/128 of the products shape; inputs are regenerated from their seeds and
+    checked against the stored checksums).  What rank 0 reports when world > 1."""
+    from pytorch_geometric_amd.datasets import products_like
+    from pytorch_geometric_amd.nn import GraphSAGE
+    path = os.path.join(ROOT, 'tests', 'golden', 'golden_bench_sample_v1.pt')
+    if not os.path.exists(path):
+        return {'ok': None, 'against': 'no cached sample in this snapshot'}
+    blob = torch.load(path, map_location='cpu', weights_only=False)
+    x, y, ei, c = products_like(seed=1, scale=blob['scale'])
+    g = torch.Generator().manual_seed(7)
+    train_idx = torch.randperm(x.size(0), generator=g)[:max(int(0.0803 * x.size(0)), 1)]
+    torch.manual_seed(0)
+    model = GraphSAGE(100, 256, num_layers=3, out_channels=c)
+    cs = {'x': float(x.double().abs().sum()), 'ei': float(ei.double().sum()),
+          'state': sum(float(v.double().abs().sum()) for v in model.state_dict().values())}
+    if any(abs(cs[k] - blob['checksums'][k]) > 1e-9 * abs(blob['checksums'][k]) for k in cs):
+        return {'ok': None, 'against': 'cached sample: regenerated inputs differ (checksums)'}
+    model = model.to(dev)
+    ti = train_idx.to(dev)
+    out = model(x.to(dev), ei.to(dev))
+    loss = F.cross_entropy(out[ti], y.to(dev)[ti])
+    loss.backward()
+    torch.cuda.synchronize(dev)
+
+    def rel(got, ref, scale):
+        got = got.detach().cpu().double()
+        if not bool(torch.isfinite(got).all()):
+            return float('inf')
+        return float((got - ref.double()).abs().max() / max(scale, 1e-30))
+
+    errs = {'loss': rel(loss, blob['loss'], float(blob['loss'].abs())),
+            'out': rel(out[blob['rows'].to(dev)], blob['out_rows'], blob['out_absmax'])}
+    g64 = blob['grads64_as_f32']
+    gpu64 = {k: rel(p.grad, g64[k], float(g64[k].abs().max()))
+             for k, p in model.named_parameters()}
+    ref64 = blob['ref_vs_fp64']
+    errs['param_grad_gpu_vs_fp64'] = max(gpu64.values())
+    errs['param_grad_ref_vs_fp64'] = max(ref64.values())
+    errs['worst_param'] = max(gpu64, key=lambda k: gpu64[k] / max(2 * ref64[k], 2e-5))
+    errs['tol'] = {'loss': 1e-5, 'out': 1e-5,
+                   'param_grad': 'NOT north_star\'s 1e-5: gpu_vs_fp64 <= max(2 x ref_vs_fp64, '
+                                 '2e-5) per tensor (sums over N rows; the reference\'s own fp32 '
+                                 'distance to fp64 is reported beside it)'}
+    errs['against'] = (f'cached reference sample, {blob["scale"]:g} x products shape '
+                       f'(N={blob["n"]}, E={blob["e"]}; 1024 output rows, every parameter '
+                       f'gradient): tests/golden/golden_bench_sample_v1.pt')
     errs['ok'] = bool(errs['loss'] <= 1e-5 and errs['out'] <= 1e-5
                       and all(gpu64[k] <= max(2 * ref64[k], 2e-5) for k in gpu64))
     return {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in errs.items()}
@@ -522,11 +584,13 @@ def gemm_desc(tuned: bool) -> str:
     if _fused_sage.GEMM_BACKEND == 'own':
         from pytorch_geometric_amd import get_gemm_mode
         if get_gemm_mode() == 'split':
-            return ('pytorch_geometric_amd/csrc/gemm.hip, PYGAMD_GEMM_MODE=split (NOT the '
-                    'default): '
-                    'fp32 operands as 3 bf16 terms each, 6 v_mfma_f32_32x32x16_bf16 products, '
-                    'fp32 accumulation, in the stand-alone forward / dgrad / wgrad kernels; the '
-                    'one-kernel layer forward stays on the fp32 instruction')
+            return ('pytorch_geometric_amd/csrc/gemm.hip + sage_fused.hip, arithmetic "split" '
+                    '(the default since round 4): every fp32 operand as the exact sum of 3 bf16 '
+                    'terms, the 6 leading cross products on v_mfma_f32_32x32x16_bf16, fp32 '
+                    'accumulation — fp32 inputs and outputs, error vs fp64 <= the fp32 '
+                    'instruction\'s on the same inputs (tests/test_gpu_split_accept.py, '
+                    'tests/test_gpu_gemm.py); stand-alone forward / dgrad / wgrad kernels AND the '
+                    'transform phase of the one-kernel layers')
         return ('pytorch_geometric_amd/csrc/gemm.hip: hand-written fp32 MFMA '
                 '(v_mfma_f32_32x32x2_f32) forward (+bias+ReLU epilogue), dgrad (+1/deg row '
                 'scale and ReLU-backward epilogues) and split-reduction wgrad (+bias gradient) '
@@ -656,6 +720,14 @@ def main():
                     help='fraction of the products shape the CPU baseline is timed on '
                          '(BASELINE.md 3.5: s in {1 .. 1/16})')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--arith', choices=['split', 'fp32'], default=None,
+                    help="arithmetic of the dense transforms (default: the library's, 'split' "
+                         "unless PYGAMD_GEMM_MODE says otherwise): 'split' = 3 x bf16 terms per "
+                         "fp32 operand, 6 bf16 matrix products, fp32 accumulation; 'fp32' = the "
+                         "exact fp32 matrix instruction")
+    ap.add_argument('--no-side-figures', action='store_true',
+                    help='full-batch mode: skip the short re-timings printed beside the headline '
+                         '(exact fp32 instruction, dense loss)')
     ap.add_argument('--no-tuned-gemm', action='store_true',
                     help='use the default rocBLAS/hipBLASLt heuristics instead of the shipped '
                          'TunableOp table')
@@ -686,8 +758,12 @@ def main():
     if world > 1:  # the ranks build their synthetic graphs on the host at the same time
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     pga.load_library()  # fail loudly if the HIP library is missing
+    if args.arith is not None:
+        pga.set_gemm_mode(args.arith)
     tuned = False
-    if not args.no_tuned_gemm:
+    # (TunableOp serves the library GEMMs of the sampled-batch stack's small blocks only: the
+    # full-batch step launches no library GEMM)
+    if not args.no_tuned_gemm and args.mode == 'minibatch':
         from pytorch_geometric_amd.tuning import enable_tuned_gemms
         tuned = enable_tuned_gemms()
 
@@ -785,10 +861,13 @@ def main():
             lpr <<= 1
         it = 'long' if info['idx_bytes'] == 8 else 'int'
         if info.get('fused_gemm'):
-            # (csrc/sage_fused.hip: variant 0 = the library default = 1, row-at-a-time gather)
-            name = {0: 'sage_fused_fwd_kernel', 1: 'sage_fused_fwd_kernel',
-                    2: 'sage_fused_stream_kernel'}.get(_native.SAGE_FUSED_VARIANT,
-                                                       'sage_fused_spec_kernel')
+            # (csrc/sage_fused.hip: the production kernel of the current arithmetic; the lab
+            # schedules of include/pyg_amd_lab.h when PYGAMD_FUSED_VARIANT asks for one)
+            prod = ('sage_fused_split_kernel' if pga.get_gemm_mode() == 'split'
+                    else 'sage_fused_fwd_kernel')
+            name = {0: prod, 1: 'sage_fused_probe_kernel', 2: 'sage_fused_stream_kernel',
+                    5: 'sage_fused_split_kernel', 6: 'sage_fused_fwd_kernel'}.get(
+                        _native.SAGE_FUSED_VARIANT, 'sage_fused_spec_kernel')
             return f'{name}<{it},{lpr}>'
         if info.get('src_bits'):
             return f'spmm_sum_rows_sparse<{it},F={info["F"]}>'
@@ -860,12 +939,48 @@ def main():
         'GFLOP_inside_fused_layers': round(fused_flop / 1e9, 1),
         'other_ms': round(ms_per_step - agg_ms - gemm_ms, 3)}
 
+    # ---- figures printed BESIDE the headline (never the headline): the same step with the exact
+    # fp32 matrix instruction everywhere, and with the loss gradient treated as dense (no zero-row
+    # skipping in the output layer's transposed aggregation).  Every rank runs them (the step
+    # contains the all-reduce); short: 2 + 5 steps each.
+    def quick_ms(n_warm=2, n=5):
+        for _ in range(n_warm):
+            step()
+        fence()
+        q0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        fence()
+        return (time.perf_counter() - q0) / n * 1e3
+
+    side = {}
+    if not args.no_side_figures:
+        from pytorch_geometric_amd.nn.models import _fused_sage
+        mode = pga.get_gemm_mode()
+        if mode != 'fp32':
+            pga.set_gemm_mode('fp32')
+            side['ms_per_step_exact_fp32_instruction'] = round(quick_ms(), 3)
+            pga.set_gemm_mode(mode)
+        if _fused_sage.SPARSE_GRAD:
+            _fused_sage.SPARSE_GRAD = False
+            side['dense_loss_ms_per_step'] = round(quick_ms(), 3)
+            _fused_sage.SPARSE_GRAD = True
+
+    arithmetic = (
+        'fp32 in / fp32 out; products as 3 x bf16 split (x = x1 + x2 + x3 exactly), the 6 leading '
+        'cross terms on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs fp64 <= the exact '
+        'fp32 instruction\'s on the same inputs at the headline shapes '
+        '(tests/test_gpu_split_accept.py); ms_per_step_exact_fp32_instruction = the same step on '
+        'v_mfma_f32_32x32x2_f32' if pga.get_gemm_mode() == 'split'
+        else 'v_mfma_f32_32x32x2_f32 (exact fp32 products and sums, bitwise an fmaf chain)')
+
     if rank == 0:
         result = {
             'metric': 'edges/sec (fwd+bwd) 3-layer SAGE, ogbn-products shape',
             'value': value, 'unit': 'edges/s', 'n_gpus': n_pg, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'arithmetic': arithmetic, **side,
             'config': {
                 'workload': (f'GraphSAGE(100->256->256->{num_classes}, mean aggr) full-batch '
                              f'fwd+bwd(CE on an 8% train split)+Adam on a synthetic ogbn-products-shaped graph per GPU '
@@ -881,7 +996,7 @@ def main():
                 'graph_gen_s': round(t_gen, 1),
                 'gemm': gemm_desc(tuned),
                 'schedule': 'layers 1-2 forward AND layer 2 input gradient as ONE kernel each '
-                            '(gather -> LDS -> fp32 MFMA); 256->47 layer transforms first, '
+                            '(gather -> LDS -> MFMA); 256->47 layer transforms first, '
                             'aggregates at width 48; ReLU backward / bias grads / 1/deg in '
                             'epilogues',
             },
@@ -890,6 +1005,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'], sample = cpu_baseline(args.cpu_scale)
             result['parity_at_cpu_scale'] = parity_at_cpu_scale(sample, dev)
+        elif not args.no_cpu_baseline:
+            # N > 1: no live CPU run of the reference (rank 0 only, the other ranks wait at the
+            # barrier below); the GPU leg against the committed reference sample
+            result['cpu_baseline'] = None
+            result['parity_at_cpu_scale'] = parity_cached(dev)
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.barrier()

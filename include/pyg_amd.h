@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 6
+#define PYGAMD_ABI_VERSION 7
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -626,7 +626,8 @@ PYGAMD_API int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x,
  * one bit per element in the tiled layout of pygamd_spmm_args.relu_bits — the form of the ReLU mask
  * that the backward's pygamd_spmm_csr / pygamd_linear_dgrad epilogues take
  * (ld_bits >= ceil(Fo / 32)).
- * Workspace: pygamd_spmm_csr_workspace_bytes(graph).                                              */
+ * Workspace: pygamd_sage_layer_fused_workspace_bytes (pygamd_spmm_csr_workspace_bytes(graph)
+ * suffices in PYGAMD_GEMM_FP32 mode).                                                              */
 PYGAMD_API int pygamd_sage_layer_forward_supported(int64_t F, int64_t Fo, int reduce);
 PYGAMD_API int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const float* x_root,
                                          int64_t ld_root, const float* w, int64_t ldw,
@@ -645,11 +646,13 @@ PYGAMD_API int pygamd_sage_layer_forward(const pygamd_spmm_args* graph, const fl
  *    by W_l), i.e. pygamd_linear_dgrad + the transposed pygamd_spmm_csr in one pass over the graph.
  *  - y_scaled / row_scale: a second copy y * row_scale[row] of the output (the next such launch
  *    gathers the 1/deg-scaled rows and takes the unscaled ones as its root operand).
- *  - variant: 0 = default (1), 1 = row-at-a-time gather phase (round 2), 2 = streamed gather phase
- *    (column indices of the tile staged in LDS, row loads software-pipelined across rows; needs
- *    n_src < 2^31) — 1 and 2 give the same results bit for bit; 3 / 4 = one persistent workgroup
- *    per CU whose gather waves feed 4 / 8 transform waves through LDS tiles (the two phases overlap
- *    by construction; sums run root half first: equal to rounding, not bitwise).                  */
+ *  - arithmetic: the transform phase follows pygamd_set_gemm_mode.  PYGAMD_GEMM_SPLIT_BF16 runs
+ *    the split schedule (csrc/sage_fused.hip (B): every operand element converted to three bf16
+ *    terms ONCE where it is produced, the weight by a pre-pass into the workspace) for dense rows
+ *    in and out; it needs the workspace of pygamd_sage_layer_fused_workspace_bytes
+ *    (PYGAMD_ERR_WORKSPACE otherwise).
+ * (The schedules that were measured and not adopted, and the kernels' timing probes, are reachable
+ * through include/pyg_amd_lab.h only — not part of this boundary.)                                */
 typedef struct pygamd_sage_fused_args {
   const float* x_root;       /* [n_rows, F] root rows                   */
   int64_t ld_root;
@@ -668,15 +671,18 @@ typedef struct pygamd_sage_fused_args {
   const float* row_scale;    /* [n_rows], with y_scaled                 */
   float* y_scaled;           /* NULL or [n_rows, Fo]                    */
   int64_t ldy_scaled;
-  int32_t variant;
-  int32_t reserved;          /* 0 (timing probes of scripts/fused_probe.py only) */
   uint32_t* compressed_out;  /* NULL or [n_rows, ld_compressed] words: y once more, in the format
                                 of pygamd_rows_compress (the next layer's gather source).  Needs
-                                Fo % 32 == 0 and variant 1.  With graph->x_format =
-                                PYGAMD_X_COMPRESSED the gather source itself is such a block
-                                (variant 1, F % 4 == 0, F <= 256).                             */
+                                Fo % 32 == 0.  With graph->x_format = PYGAMD_X_COMPRESSED the
+                                gather source itself is such a block (F % 4 == 0, F <= 256).
+                                Both run the fp32-instruction schedule whatever the mode.      */
   int64_t ld_compressed;
 } pygamd_sage_fused_args;
+/* hub partials (pygamd_spmm_csr_workspace_bytes) + the weight's bf16 term planes of the split
+ * schedule (6 bytes per padded weight element; 768 KiB at F = Fo = 256)                          */
+PYGAMD_API int pygamd_sage_layer_fused_workspace_bytes(const pygamd_spmm_args* graph,
+                                                       const pygamd_sage_fused_args* f,
+                                                       size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_sage_layer_fused(const pygamd_spmm_args* graph,
                                        const pygamd_sage_fused_args* f, void* workspace,
                                        size_t workspace_bytes, void* stream);

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(PKG_DIR, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpyg_amd.so')
 BUILD_DIR = os.path.join(os.path.dirname(PKG_DIR), 'build', 'pyg_amd')
 SOURCES = ['capi.hip', 'graph.hip', 'spmm.hip', 'scatter.hip', 'softmax.hip', 'segmm.hip',
-           'sample.hip', 'gemm.hip', 'sage_fused.hip']
+           'sample.hip', 'gemm.hip', 'sage_fused.hip', 'sage_fused_lab.hip']
 ARCH = 'gfx950'
 FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
@@ -44,6 +44,7 @@ def source_hash():
     paths = sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)
                    if f != os.path.basename(BINDING_SRC))
     paths.append(os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h'))
+    paths.append(os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd_lab.h'))
     for p in paths:
         if os.path.isfile(p):
             h.update(os.path.basename(p).encode())
@@ -71,6 +72,7 @@ def build_library(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h'))
+    headers.append(os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd_lab.h'))
     headers_mtime = max(os.path.getmtime(h) for h in headers)
 
     def compile_one(src):
@@ -106,7 +108,8 @@ def binding_hash():
     import hashlib
     import torch
     h = hashlib.sha1()
-    for p in (BINDING_SRC, os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h')):
+    for p in (BINDING_SRC, os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h'),
+              os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd_lab.h')):
         with open(p, 'rb') as f:
             h.update(f.read())
     h.update(torch.__version__.encode())

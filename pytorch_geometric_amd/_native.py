@@ -972,9 +972,11 @@ def sage_layer_forward_supported(F: int, Fo: int, reduce: str) -> bool:
     return bool(_lib.load().pygamd_sage_layer_forward_supported(F, Fo, REDUCE_IDS[reduce]))
 
 
-# schedule of the one-kernel layer: 0 = library default (1), 1 = row-at-a-time gather
-# phase (round 2), 2 = streamed gather phase, 3 / 4 = persistent producer / consumer waves (4 / 8
-# transform waves); the env switch exists for A/B timing on the device
+# schedule of the one-kernel layer: 0 / None = the production entry point (arithmetic per
+# set_gemm_mode); 1..6 = include/pyg_amd_lab.h (1 = production fp32 schedule with probe bits,
+# 2 = streamed gather phase, 3 / 4 = persistent producer / consumer waves with 4 / 8 transform
+# waves, 5 / 6 = the production split / fp32 kernels whatever the mode); the env switch exists for
+# A/B timing on the device
 SAGE_FUSED_VARIANT = int(os.environ.get('PYGAMD_FUSED_VARIANT', '0'))
 SAGE_FUSED_PROBE = 0  # scripts/fused_probe.py: skip the gather (1) / MFMA (2) loop of the kernel
 
@@ -1049,15 +1051,12 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     a.w_heads, a.head_dim = 1, F
     if gather_width is not None:
         a.x_format = _lib.X_COMPRESSED
-    ws, ws_bytes = None, 0
     if hub is not None and hub[2] > 0:
         hub_rows, hub_cptr, n_hub, n_chunks = hub
         a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), hub_cptr.data_ptr()
         a.n_hub, a.n_chunks = n_hub, n_chunks
         a.hub_threshold = HUB_THRESHOLD if hub_threshold is None else hub_threshold
         a.hub_chunk = HUB_CHUNK if hub_chunk is None else hub_chunk
-        ws_bytes = n_chunks * F * 4
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xg.device)
     if bias is not None:
         bias = bias.contiguous()
     _check_bits(relu_bits, n_rows, Fo)
@@ -1082,8 +1081,6 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
         row_scale = row_scale.contiguous()
         f.row_scale = row_scale.data_ptr()
         f.y_scaled, f.ldy_scaled = out_scaled.data_ptr(), _ld(out_scaled)
-    f.variant = SAGE_FUSED_VARIANT if variant is None else variant
-    f.reserved = SAGE_FUSED_PROBE
     if compressed_out is not None:
         _check_compressed(compressed_out, Fo, 'compressed_out')
         if compressed_out.size(0) != n_rows or Fo % 32 != 0:
@@ -1093,8 +1090,19 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     if sink is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(xg.device))
-    check(lib.pygamd_sage_layer_fused(ctypes.byref(a), ctypes.byref(f), _p(ws), ws_bytes,
-                                      _stream(xg)), 'sage_layer_forward')
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_sage_layer_fused_workspace_bytes(ctypes.byref(a), ctypes.byref(f),
+                                                      ctypes.byref(nbytes)))
+    ws_bytes = nbytes.value
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xg.device) if ws_bytes else None
+    variant = SAGE_FUSED_VARIANT if variant is None else variant
+    if variant or SAGE_FUSED_PROBE:
+        check(lib.pygamd_lab_sage_layer_fused(ctypes.byref(a), ctypes.byref(f), variant or 1,
+                                              SAGE_FUSED_PROBE, _p(ws), ws_bytes, _stream(xg)),
+              'sage_layer_forward (lab schedule)')
+    else:
+        check(lib.pygamd_sage_layer_fused(ctypes.byref(a), ctypes.byref(f), _p(ws), ws_bytes,
+                                          _stream(xg)), 'sage_layer_forward')
     if sink is not None:
         ev1.record(torch.cuda.current_stream(xg.device))
         sink.append(({'n_rows': n_rows, 'n_src': xg.size(0), 'nnz': col.numel(), 'F': F,

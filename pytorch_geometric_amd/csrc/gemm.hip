@@ -28,37 +28,18 @@
 // Splits write their partial tiles to a slab; a second kernel adds the slabs in split order
 // (deterministic, no atomics).  Workgroups of one split are adjacent on one XCD: each row of g and
 // x leaves HBM once.
-#include "common.h"
+#include "split_bf16.h"
 
 namespace pygamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// ---- "split" mode: fp32 operands as sums of three bf16 terms --------------------------------------
-// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (both residuals are
-// exact in fp32; three 8-bit significands cover the 24 of an fp32 value).  A product a * b is then
-// the sum of the six cross terms of weight >= 2^-16 (a1 b3, a3 b1, a2 b2, a1 b2, a2 b1, a1 b1 — the
-// three dropped ones are below 2^-24 of the product), each an EXACT bf16 x bf16 product summed in
-// the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  Six instructions of 32 cycles replace eight
-// fp32 instructions of 64 cycles for the same 16 k values.  Measured error against fp64
-// (profiles/r02_split_bf16_accuracy_probe.txt): at or below that of the fp32 fmaf chain for
-// K = 256 .. 2048 on normal, all-positive and wide-dynamic-range inputs.  Differences from the
-// exact mode: results are not bitwise those of an fmaf chain, and an Inf operand gives NaN
-// (Inf - Inf in the residual) where IEEE arithmetic would give Inf.  Opt-in
-// (pygamd_set_gemm_mode), the default stays the exact fp32 instruction.
+// ---- "split" mode: fp32 operands as sums of three bf16 terms (split_bf16.h).  Opt-in
+// (pygamd_set_gemm_mode); the default is the exact fp32 instruction.
 struct SplitFrag {
   bf16x8 p[3];
 };
-
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32
-}
 
 // eight consecutive k values of one row (two 16-byte LDS reads) -> three bf16x8 operands
 __device__ __forceinline__ SplitFrag split_frag(const f32x4& v0, const f32x4& v1) {
@@ -67,15 +48,11 @@ __device__ __forceinline__ SplitFrag split_frag(const f32x4& v0, const f32x4& v1
   for (int q = 0; q < 4; ++q) {
     const float x0 = q < 2 ? v0[2 * q] : v1[2 * q - 4];
     const float x1 = q < 2 ? v0[2 * q + 1] : v1[2 * q - 3];
-    const uint32_t a = pack_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(a << 16);
-    const float r1 = x1 - __uint_as_float(a & 0xffff0000u);
-    const uint32_t b = pack_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(b << 16);
-    const float s1 = r1 - __uint_as_float(b & 0xffff0000u);
-    w[0][q] = a;
-    w[1][q] = b;
-    w[2][q] = pack_bf16(s0, s1);
+    uint32_t t[3];
+    split_pair(x0, x1, t);
+    w[0][q] = t[0];
+    w[1][q] = t[1];
+    w[2][q] = t[2];
   }
   SplitFrag f;
 #pragma unroll
@@ -83,17 +60,13 @@ __device__ __forceinline__ SplitFrag split_frag(const f32x4& v0, const f32x4& v1
   return f;
 }
 
-// The six cross terms in the order they are accumulated (small ones first): term t multiplies
-// part kSplitA[t] of a with part kSplitB[t] of b.  Callers walk the terms in the OUTER loop and
-// their 32 x 32 blocks in the inner one: consecutive instructions then write different
-// accumulators (six back-to-back instructions on one accumulator, with the conversion VALU work
-// scheduled in between, leave the matrix pipe idle waiting on the dependency — measured 31 % busy).
-constexpr int kSplitTerms = 6;
+// Callers walk the six terms in the OUTER loop and their 32 x 32 blocks in the inner one:
+// consecutive instructions then write different accumulators (six back-to-back instructions on
+// one accumulator, with the conversion VALU work scheduled in between, leave the matrix pipe idle
+// waiting on the dependency — measured 31 % busy).
 __device__ __forceinline__ void split_term(int t, const SplitFrag& a, const SplitFrag& b,
                                            f32x16& acc) {
-  constexpr int ta[kSplitTerms] = {0, 2, 1, 0, 1, 0};
-  constexpr int tb[kSplitTerms] = {2, 0, 1, 1, 0, 0};
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[ta[t]], b.p[tb[t]], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[kSplitTa[t]], b.p[kSplitTb[t]], acc, 0, 0, 0);
 }
 
 constexpr int kGK = 32;        // k chunk

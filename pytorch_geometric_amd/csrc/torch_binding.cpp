@@ -19,6 +19,7 @@
 #include <torch/library.h>
 
 #include "../../include/pyg_amd.h"
+#include "../../include/pyg_amd_lab.h"
 
 namespace {
 
@@ -248,8 +249,6 @@ void sage_layer_fused(const Tensor& rowptr, const OptTensor& col, const Tensor& 
   a.reduce = static_cast<int32_t>(reduce);
   a.w_heads = 1;
   a.head_dim = static_cast<int32_t>(F);
-  Tensor ws;
-  size_t ws_bytes = 0;
   if (n_hub > 0 && has(hub_rows) && has(hub_cptr)) {
     a.hub_rows = ptr(hub_rows);
     a.hub_chunk_ptr = ptr(hub_cptr);
@@ -257,8 +256,6 @@ void sage_layer_fused(const Tensor& rowptr, const OptTensor& col, const Tensor& 
     a.n_chunks = n_chunks;
     a.hub_threshold = hub_threshold;
     a.hub_chunk = hub_chunk;
-    ws_bytes = static_cast<size_t>(n_chunks) * static_cast<size_t>(F) * 4;
-    ws = at::empty({static_cast<int64_t>(ws_bytes)}, xg.options().dtype(at::kByte));
   }
   const Tensor b = contig(bias), rs = contig(row_scale);
   pygamd_sage_fused_args f = {};
@@ -291,8 +288,18 @@ void sage_layer_fused(const Tensor& rowptr, const OptTensor& col, const Tensor& 
     f.y_scaled = static_cast<float*>(ptr(out_scaled));
     f.ldy_scaled = ld(*out_scaled);
   }
-  f.variant = static_cast<int32_t>(variant);
-  f.reserved = static_cast<int32_t>(probe);
+  // hub partials + (split arithmetic) the weight's bf16 term planes
+  size_t ws_bytes = 0;
+  check(pygamd_sage_layer_fused_workspace_bytes(&a, &f, &ws_bytes), "sage_layer_forward");
+  Tensor ws;
+  if (ws_bytes > 0)
+    ws = at::empty({static_cast<int64_t>(ws_bytes)}, xg.options().dtype(at::kByte));
+  if (variant != 0 || probe != 0) {  // include/pyg_amd_lab.h: not the boundary
+    check(pygamd_lab_sage_layer_fused(&a, &f, variant != 0 ? static_cast<int>(variant) : 1,
+                                      static_cast<int>(probe), ptr(ws), ws_bytes, cur_stream(xg)),
+          "sage_layer_forward (lab schedule)");
+    return;
+  }
   check(pygamd_sage_layer_fused(&a, &f, ptr(ws), ws_bytes, cur_stream(xg)), "sage_layer_forward");
 }
 

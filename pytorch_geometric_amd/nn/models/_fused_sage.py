@@ -251,7 +251,11 @@ class FusedSageStack(Function):
         scale = graph.by_dst().inv_degree() if aggr == 'mean' else None
         N = grad_out.size(0)
         grads: List[Optional[Tensor]] = [None] * (3 * L)
-        g = grad_out if grad_out.stride(1) == 1 else grad_out.contiguous()
+        # rows must be addressable with one leading dimension >= the width: an expanded gradient
+        # (`out.sum(0)` / `out.mean(0)` upstream hand over strides (0, 1)) is materialised
+        g = grad_out
+        if g.dim() != 2 or g.stride(1) != 1 or (g.size(0) > 1 and g.stride(0) < g.size(1)):
+            g = g.contiguous()
         grad_x = None
         pending = []  # side streams with weight-gradient launches in flight
         own = GEMM_BACKEND == 'own'

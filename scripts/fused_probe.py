@@ -19,6 +19,8 @@ ap.add_argument('--widths', default='256,100')
 ap.add_argument('--only-spec', action='store_true', help='only the producer/consumer variants')
 ap.add_argument('--prio', action='store_true', help='A/B of the issue-priority scheme')
 ap.add_argument('--pitch', action='store_true', help='F = 100 rows at a 128-float pitch')
+ap.add_argument('--split', action='store_true',
+                help='only: production fp32 kernel (6) vs production split kernel (5) + its phases')
 ap.add_argument('--sq-only', action='store_true',
                 help='a few launches of v1 and v3 with phases on/off (for a rocprofv3 --pmc pass)')
 args = ap.parse_args()
@@ -65,6 +67,20 @@ for F in [int(v) for v in args.widths.split(',')]:
                                              hub=fwd.hub, out=buf[:, :F]))
     t_gemm = timeit(lambda: _native.linear_forward(buf, w, b, relu=True, out=ref))
     print(f'F={F} Fo={Fo}: SpMM {t_spmm:.3f} ms, GEMM {t_gemm:.3f} ms', flush=True)
+    if args.split:
+        one(6)
+        err6 = float((out - ref).abs().max() / ref.abs().max())
+        one(5)
+        err5 = float((out - ref).abs().max() / ref.abs().max())
+        print(f'  fp32 kernel {timeit(lambda: one(6)):.3f} ms (max rel diff vs GEMM {err6:.1e}); '
+              f'split kernel {timeit(lambda: one(5)):.3f} ms ({err5:.1e}); split: gather skipped '
+              f'{timeit(lambda: one(5, 1)):.3f} ms, matrix loop skipped '
+              f'{timeit(lambda: one(5, 2)):.3f} ms, both {timeit(lambda: one(5, 3)):.3f} ms; '
+              f'agg not stored {timeit(lambda: one(5, 0, False)):.3f} ms; three workgroups per '
+              f'CU (two-pass kernel, ring of 2) {timeit(lambda: one(5, 16)):.3f} ms; fp32 v1 gather skipped '
+              f'{timeit(lambda: one(1, 1)):.3f} ms, MFMA skipped {timeit(lambda: one(1, 2)):.3f} ms',
+              flush=True)
+        continue
     if args.pitch and F == 100:
         # layer 1's rows are 400 bytes: 3.125 lines each, straddling — against the same rows stored
         # at a 512-byte pitch (whole lines, 28 % more bytes)

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, 'include', 'pyg_amd.h')).read()
+def declared_symbols(header='pyg_amd.h'):
+    text = open(os.path.join(ROOT, 'include', header)).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'PYGAMD_API\s+[\w\s\*]+?\b(pygamd_\w+)\s*\(', text)))
 
@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     if _build.is_stale() and _build.find_hipcc() is None:
         pytest.skip('library not built and no hipcc here')
     lib = _lib.load()
-    assert lib.pygamd_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.pygamd_abi_version() == _lib.ABI_VERSION == 7
     assert lib.pygamd_build_arch() == b'gfx950'
     assert lib.pygamd_status_string(0) == b'ok'
     assert lib.pygamd_status_string(3) == b'workspace too small'
@@ -39,7 +39,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     out = subprocess.run(['nm', '-D', '--defined-only', _lib.lib_path()], capture_output=True,
                          text=True).stdout
     exported = sorted(set(re.findall(r' T (pygamd_\w+)', out)))
-    assert exported == declared, 'exported symbols differ from the header'
+    # the laboratory entry points (schedules not adopted, timing probes) live in their own header
+    # and carry their own prefix: nothing of them may leak into the boundary, and vice versa
+    lab = declared_symbols('pyg_amd_lab.h')
+    assert lab and all(n.startswith('pygamd_lab_') for n in lab)
+    assert not any(n.startswith('pygamd_lab_') for n in declared)
+    assert sorted(_lib.LAB_SIGNATURES) == lab
+    assert exported == sorted(declared + lab), 'exported symbols differ from the headers'
 
 
 def test_code_object_is_gfx950_only():

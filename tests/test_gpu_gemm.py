@@ -291,7 +291,7 @@ def test_sage_layer_with_compressed_rows_in_and_out(dev, F, Fo, dtype):
         _native.sage_layer_forward(fwd.ptr, fwd.idx, x if zin is None else zin, x, w, b, 'mean',
                                    True, agg, out, hub=fwd.hub, save_agg=True, relu_bits=bits,
                                    gather_width=None if zin is None else F,
-                                   compressed_out=zout, variant=1)
+                                   compressed_out=zout)
         res.append((agg, out, bits))
         dec, mask = decompress_rows(zout, Fo)
         assert torch.equal(dec.view(torch.int32), out.cpu().view(torch.int32)), \
@@ -307,9 +307,9 @@ def test_sage_layer_with_compressed_rows_in_and_out(dev, F, Fo, dtype):
     out_d, out_z = torch.empty(n, Fo, device=dev), torch.empty(n, Fo, device=dev)
     agg = torch.empty(n, F, device=dev)
     _native.sage_layer_forward(fwd.ptr, fwd.idx, x, x, w, None, 'sum', False, agg, out_d,
-                               hub=fwd.hub, save_agg=False, variant=1)
+                               hub=fwd.hub, save_agg=False)
     _native.sage_layer_forward(fwd.ptr, fwd.idx, z, x, w, None, 'sum', False, agg, out_z,
-                               hub=fwd.hub, save_agg=False, gather_width=F, variant=1)
+                               hub=fwd.hub, save_agg=False, gather_width=F)
     if F > 128:
         assert torch.equal(out_d, out_z)
     else:

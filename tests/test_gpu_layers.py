@@ -238,6 +238,42 @@ def test_fused_sage_stack_matches_layer_loop_and_oracle(dev):
     assert_close(out, ref.detach(), atol=2e-5)
 
 
+def test_fused_sage_stack_takes_an_expanded_gradient(dev):
+    """A graph-level readout (`out.sum(0)`, `out.mean(0)`) hands the stack's backward a gradient
+    with strides (0, 1): every row is the same memory.  The output layer here is transform-first
+    ('pre'), whose backward packs the gradient rows (rows_pack) — it must see real rows (ADVICE r3:
+    the expanded tensor reached the C entry with a leading dimension of 0)."""
+    from oracle import pyg_oracle as O
+    from pytorch_geometric_amd.nn import GraphSAGE
+    from tests._util import assert_close_scaled, random_graph
+    g = gen(91)
+    n = 700
+    ei = random_graph(n, n, 9_000, seed=91, skew=True)
+    x = torch.randn(n, 24, generator=g)
+    torch.manual_seed(8)
+    model = GraphSAGE(24, 32, num_layers=2, out_channels=5)   # 32 -> 5: transform first
+    st = model.state_dict()
+    params = [(st[f'convs.{i}.lin_l.weight'].clone().requires_grad_(True),
+               st[f'convs.{i}.lin_l.bias'].clone().requires_grad_(True),
+               st[f'convs.{i}.lin_r.weight'].clone().requires_grad_(True)) for i in range(2)]
+    w = torch.randn(5, generator=g)
+    for readout in ('sum', 'mean'):
+        for p in (t for layer in params for t in layer):
+            p.grad = None
+        xr = x.clone().requires_grad_(True)
+        ref = O.graphsage(xr, ei, params)
+        (getattr(ref, readout)(0) * w).sum().backward()
+        md = model.to(dev)
+        md.zero_grad()
+        xg = x.to(dev).requires_grad_(True)
+        out = md(xg, ei.to(dev))
+        (getattr(out, readout)(0) * w.to(dev)).sum().backward()
+        assert_close_scaled(xg.grad, xr.grad, what=f'{readout} readout grad_x')
+        flat_ref = [t.grad for layer in params for t in layer]
+        for got, want in zip((p.grad for p in md.parameters()), flat_ref):
+            assert_close_scaled(got, want, what=f'{readout} readout param grad')
+
+
 @pytest.mark.parametrize('aggr', ['mean', 'sum'])
 def test_fused_sage_stack_with_a_loss_on_a_training_split(dev, aggr, monkeypatch):
     """`out[train_idx]` leaves most rows of the incoming gradient zero: the backward of the
