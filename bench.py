@@ -250,6 +250,8 @@ def parity_at_cpu_scale(sample, dev):
     errs['param_grad_gpu_vs_ref'] = max(gpuref.values())
     errs['worst_param'] = worst
     errs['n_param_tensors'] = len(gpu64)
+    errs['per_tensor_gpu_vs_fp64__ref_vs_fp64'] = {
+        k: [float(f'{gpu64[k]:.2e}'), float(f'{ref64[k]:.2e}')] for k in gpu64}
     errs['tol'] = {'loss': 1e-5, 'out': 1e-5,
                    'param_grad': 'NOT north_star\'s 1e-5: gpu_vs_fp64 <= max(2 x ref_vs_fp64, '
                                  '2e-5) per tensor (sums over N rows; the reference\'s own fp32 '

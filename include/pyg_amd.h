@@ -577,9 +577,17 @@ PYGAMD_API int pygamd_multi_reduce_csr(const void* rowptr, const void* perm, int
 #define PYGAMD_GEMM_SPLIT_BF16 1
 PYGAMD_API int pygamd_set_gemm_mode(int mode);
 PYGAMD_API int pygamd_get_gemm_mode(void);
+/* Workspace of the forward / dgrad2 entry points (both are one "NT" product out[M, N_out] over a
+ * reduction of K_red columns): 0 when the output has enough row tiles to fill the chip (every
+ * full-batch layer); for few rows (sampled blocks of 1 k .. 16 k rows, Cora-sized inputs) room for
+ * the partial tiles of a split over the reduction, combined in slice order by a second pass
+ * (deterministic).  Without it (NULL) the launch runs unsliced: same result, fewer workgroups.  */
+PYGAMD_API int pygamd_linear_nt_workspace_bytes(int64_t M, int64_t N_out, int64_t K_red,
+                                                size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
                                      const float* bias, int64_t M, int64_t K, int64_t N, int relu,
-                                     int accumulate, float* out, int64_t ldo, void* stream);
+                                     int accumulate, float* out, int64_t ldo, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 PYGAMD_API int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
                                    const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
                                    int64_t K, int accumulate, const float* relu_mask,
@@ -594,7 +602,7 @@ PYGAMD_API int pygamd_linear_dgrad2(const float* g, int64_t ldg, const float* w_
                                     int64_t N, int64_t K, int accumulate, const float* relu_mask,
                                     int64_t ld_mask, const uint32_t* relu_bits, int64_t ld_bits,
                                     float* out, int64_t ldo, float* out_scaled, int64_t ld_scaled,
-                                    void* stream);
+                                    void* workspace, size_t workspace_bytes, void* stream);
 PYGAMD_API int pygamd_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K,
                                                    size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_linear_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx,

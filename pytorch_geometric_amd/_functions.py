@@ -423,3 +423,23 @@ class LinearFunction(Function):
         elif need_b:
             gb = _native.colsum(g2)
         return gx, gw, gb
+
+
+# Below this many rows the library GEMM stays (F.linear): a Python-side autograd Function per call
+# costs more than such a product.  From here up the own kernels fill the chip: 128-row tiles for
+# the full-batch layers, 64 x 64 tiles + a deterministic split over the reduction for sampled
+# blocks and Cora-sized inputs (csrc/gemm.hip nt_shape; round 3 drew this line at 16,384 rows).
+OWN_GEMM_MIN_ROWS = 1024
+
+
+def own_linear_eligible(x: Tensor, weight: Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.dim() >= 2 and x.numel() // max(x.size(-1), 1) >= OWN_GEMM_MIN_ROWS
+            and not torch.jit.is_scripting() and not torch.is_autocast_enabled())
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """``F.linear`` semantics (``weight [out, in]``); large float32 HIP inputs run on csrc/gemm.hip."""
+    if own_linear_eligible(x, weight):
+        return LinearFunction.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)

@@ -102,15 +102,16 @@ SIGNATURES = {
                                         _P]),
     'pygamd_sage_layer_fused_workspace_bytes': (c_int, [POINTER(SpmmArgs), POINTER(SageFusedArgs),
                                                         POINTER(c_size_t)]),
+    'pygamd_linear_nt_workspace_bytes': (c_int, [c_int64, c_int64, c_int64, POINTER(c_size_t)]),
     'pygamd_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
-                                      c_int, c_int, _P, c_int64, _P]),
+                                      c_int, c_int, _P, c_int64, _P, c_size_t, _P]),
     'pygamd_set_gemm_mode': (c_int, [c_int]),
     'pygamd_get_gemm_mode': (c_int, []),
     'pygamd_linear_dgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                     c_int64, c_int, _P, c_int64, _P, c_int64, _P, c_int64, _P]),
     'pygamd_linear_dgrad2': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                      c_int64, c_int, _P, c_int64, _P, c_int64, _P, c_int64, _P,
-                                     c_int64, _P]),
+                                     c_int64, _P, c_size_t, _P]),
     'pygamd_linear_wgrad_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
                                                     POINTER(c_size_t)]),
     'pygamd_linear_wgrad': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int,

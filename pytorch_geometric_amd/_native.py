@@ -902,6 +902,16 @@ def gat_edge_softmax_backward(rowptr, col, alpha_src, alpha_dst, alpha, grad_alp
 
 
 # ---- dense feature transform (fp32 MFMA GEMM, csrc/gemm.hip) -------------------------------------
+def _nt_workspace(lib, M: int, n_out: int, k_red: int, device):
+    """Partial-tile slabs of a launch split over its reduction (few row tiles: sampled blocks,
+    Cora-sized inputs); ``(None, 0)`` when the rows alone fill the chip."""
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_linear_nt_workspace_bytes(M, n_out, k_red, ctypes.byref(nbytes)))
+    if nbytes.value == 0:
+        return None, 0
+    return torch.empty(nbytes.value, dtype=torch.uint8, device=device), nbytes.value
+
+
 def linear_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
                    out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     """``act(x @ w.T + bias)`` for row-strided fp32 ``x [M, K]``, ``w [N, K]``; ``out`` may be a
@@ -929,10 +939,11 @@ def linear_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, relu: bo
         raise ValueError("'out' must be a float32 [M, N] tensor with unit inner stride")
     if bias is not None:
         bias = bias.contiguous()
+    ws, ws_bytes = _nt_workspace(lib, M, N, K, x.device)
     with _timed({'kind': 'gemm', 'op': 'forward', 'M': M, 'N': N, 'K': K}, x):
         check(lib.pygamd_linear_forward(_p(x2), _ld(x2), _p(w2), _ld(w2), _p(bias), M, K, N,
-                                        int(relu), int(accumulate), _p(out), _ld(out),
-                                        _stream(x)), 'linear_forward')
+                                        int(relu), int(accumulate), _p(out), _ld(out), _p(ws),
+                                        ws_bytes, _stream(x)), 'linear_forward')
     return out
 
 
@@ -1186,6 +1197,7 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
         m2 = _f32_rows(relu_mask, 'relu_mask')
         if tuple(m2.shape) != (M, K):
             raise ValueError(f"'relu_mask' must be [{M}, {K}], got {tuple(m2.shape)}")
+    ws, ws_bytes = _nt_workspace(lib, M, K, N, g.device)
     with _timed({'kind': 'gemm', 'op': 'dgrad', 'M': M, 'N': K, 'K': N}, g):
         check(lib.pygamd_linear_dgrad2(_p(g2), _ld(g2), _p(w2), _ld(w2), _p(row_scale),
                                        n_scaled if row_scale is not None else 0, M, N, K,
@@ -1194,7 +1206,7 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
                                        relu_bits.size(1) if relu_bits is not None else 0,
                                        _p(out), _ld(out), _p(out_scaled),
                                        _ld(out_scaled) if out_scaled is not None else 0,
-                                       _stream(g)), 'linear_dgrad')
+                                       _p(ws), ws_bytes, _stream(g)), 'linear_dgrad')
     return out
 
 

@@ -90,6 +90,12 @@ struct GemmNT {
   int accumulate; // c += result
   int tiles_m, tiles_n;
   int split;      // 3 x bf16 operand split instead of the fp32 instruction
+  // split-K (few row tiles: sampled blocks, Cora-sized inputs): grid.y = ksplits slices of
+  // k_per_split (a multiple of the chunk) reduction columns each; a slice writes its raw partial
+  // tile to partial[slice][M][N] and gemm_nt_splitk_epilogue sums the slices in order and applies
+  // every epilogue of this struct (deterministic, no atomics)
+  int ksplits, k_per_split;
+  float* __restrict__ partial;
 };
 
 // Tile numbering: hardware block b runs on XCD b % 8.  Logical order inside an XCD: for each row
@@ -119,6 +125,9 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
+  // this workgroup's slice of the reduction: [kb, ke) (the whole of K without split-K)
+  const int kb = p.ksplits > 1 ? static_cast<int>(blockIdx.y) * p.k_per_split : 0;
+  const int ke = p.ksplits > 1 ? (kb + p.k_per_split < p.K ? kb + p.k_per_split : p.K) : p.K;
 
   // ---- global -> register staging map: thread -> (row r0 + 32 q, 16-byte column kq).  Row
   // pointers are fixed for the whole K walk; rows past M / N are clamped (never stored / zeroed).
@@ -147,7 +156,7 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
   auto load_chunk = [&](int k0) {
     const int k = k0 + 4 * kq;
     if (VEC) {
-      const int kc = k < p.K ? k : 0;  // column 0 exists whenever a chunk is loaded (K > 0)
+      const int kc = k < ke ? k : 0;  // column 0 exists whenever a chunk is loaded (K > 0)
 #pragma unroll
       for (int q = 0; q < A_LD4; ++q) ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + kc);
 #pragma unroll
@@ -156,11 +165,11 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int q = 0; q < A_LD4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ra[q][e] = pa[q][k + e < p.K ? k + e : 0];
+        for (int e = 0; e < 4; ++e) ra[q][e] = pa[q][k + e < ke ? k + e : 0];
 #pragma unroll
       for (int q = 0; q < B_LD4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rb[q][e] = pb[q][k + e < p.K ? k + e : 0];
+        for (int e = 0; e < 4; ++e) rb[q][e] = pb[q][k + e < ke ? k + e : 0];
     }
   };
   auto store_chunk = [&](int buf, int k0) {
@@ -172,7 +181,7 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
     for (int q = 0; q < A_LD4; ++q) {
       f32x4 v = ra[q];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (k + e < p.K) ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = (k + e < ke) ? v[e] : 0.f;
       *reinterpret_cast<f32x4*>(as + 32 * q * kGLD) = v;
     }
 #pragma unroll
@@ -180,7 +189,7 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
       if (BN % 32 == 0 || r0 + 32 * q < BN) {
         f32x4 v = rb[q];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (okb[q] && k + e < p.K) ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = (okb[q] && k + e < ke) ? v[e] : 0.f;
         *reinterpret_cast<f32x4*>(bs + 32 * q * kGLD) = v;
       }
     }
@@ -248,13 +257,13 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
   //                 barrier;  MFMA(f0, steps 4-7);  f0 <- LDS[c+1] lower half;  MFMA(f1).
   // The barrier orders (a) the stores of chunk c+1 before anybody's reads of it and (b) every
   // wave's reads of LDS[c] before the stores of chunk c+2 into the same buffer next iteration.
-  const int n_chunks = (p.K + kGK - 1) / kGK;
+  const int n_chunks = (ke - kb + kGK - 1) / kGK;
   Frag f0, f1;
   if (n_chunks > 0) {
-    load_chunk(0);
-    store_chunk(0, 0);
+    load_chunk(kb);
+    store_chunk(0, kb);
   }
-  if (n_chunks > 1) load_chunk(kGK);
+  if (n_chunks > 1) load_chunk(kb + kGK);
   __syncthreads();
   if (n_chunks > 0) read_frag(f0, 0, 0);
   if constexpr (SPLIT) {
@@ -269,8 +278,8 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
     if (n_chunks > 0) split_all(f0, ca, cb);
     for (int c = 0; c < n_chunks; ++c) {
       const int buf = c & 1;
-      if (c + 1 < n_chunks) store_chunk(buf ^ 1, (c + 1) * kGK);
-      if (c + 2 < n_chunks) load_chunk((c + 2) * kGK);
+      if (c + 1 < n_chunks) store_chunk(buf ^ 1, kb + (c + 1) * kGK);
+      if (c + 2 < n_chunks) load_chunk(kb + (c + 2) * kGK);
       __builtin_amdgcn_sched_barrier(0);
       read_frag(f1, buf, 1);
       split_all(f1, na, nb);
@@ -300,8 +309,8 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
   } else {
     for (int c = 0; c < n_chunks; ++c) {
       const int buf = c & 1;
-      if (c + 1 < n_chunks) store_chunk(buf ^ 1, (c + 1) * kGK);
-      if (c + 2 < n_chunks) load_chunk((c + 2) * kGK);
+      if (c + 1 < n_chunks) store_chunk(buf ^ 1, kb + (c + 1) * kGK);
+      if (c + 2 < n_chunks) load_chunk(kb + (c + 2) * kGK);
       read_frag(f1, buf, 1);
       mma_steps(f0, 0, 4);
       // keep the barrier in the MIDDLE of the MFMA stream (hipcc hoists it to the top otherwise:
@@ -312,11 +321,29 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
       mma_steps(f0, 4, 8);
       if (c + 1 < n_chunks) read_frag(f0, buf ^ 1, 0);
       // a K tail of <= 8 leaves the upper 8 steps all zero in both lane halves: skip them
-      if (p.K - c * kGK > 8) mma_steps(f1, 0, 8);
+      if (ke - kb - c * kGK > 8) mma_steps(f1, 0, 8);
     }
   }
 
   // ---- epilogue: reg e of lane l is C[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
+  if (p.ksplits > 1) {  // raw partial tile of this K slice; the epilogue runs in the combine pass
+    float* __restrict__ slab = p.partial + static_cast<int64_t>(blockIdx.y) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + li;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
+          if (row < p.M) slab[row * p.N + col] = acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
   const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
   const bool wave_scaled = p.n_scaled > n0 + wn * TN * 32;  // wave-uniform
   if (full && !p.accumulate) {
@@ -400,6 +427,29 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_nt_kernel(GemmNT p) {
       }
     }
   }
+}
+
+// split-K combine: c = epilogue(sum over slices, in slice order) — one thread per output element
+__global__ void __launch_bounds__(kBlock) gemm_nt_splitk_epilogue(GemmNT p) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t MN = p.M * p.N;
+  if (t >= MN) return;
+  const int64_t row = t / p.N;
+  const int col = static_cast<int>(t - row * p.N);
+  float v = 0.f;
+  for (int sp = 0; sp < p.ksplits; ++sp) v += p.partial[sp * MN + t];
+  if (p.bias) v += p.bias[col];
+  if (col < p.n_scaled) v *= p.row_scale[row];
+  if (p.relu) v = (v > 0.f || v != v) ? v : 0.f;
+  float* dst = p.c + row * p.ldc + col;
+  if (p.accumulate) v += *dst;
+  if (p.mask) v = p.mask[row * p.ldm + col] > 0.f ? v : 0.f;
+  if (p.mask_bits)
+    v = ((p.mask_bits[((row >> 5) * p.ldmb + (col >> 5)) * 32 + (row & 31)] >> (col & 31)) & 1u)
+            ? v
+            : 0.f;
+  *dst = v;
+  if (p.c2) p.c2[row * p.ldc2 + col] = v * p.row_scale[row];
 }
 
 // ---- TN: out[N, K] = g[M, N]^T @ x[M, K], split over M -------------------------------------------
@@ -723,24 +773,77 @@ static int launch_nt(GemmNT p, bool vec, hipStream_t st) {
   PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));
-  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, st, p);
+  const unsigned gy = static_cast<unsigned>(p.ksplits > 1 ? p.ksplits : 1);
+  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(blocks), gy), dim3(kBlock), lds, st, p);
   PYGAMD_LAUNCH_CHECK();
+  if (p.ksplits > 1) {
+    const int64_t MN = p.M * p.N;
+    hipLaunchKernelGGL(gemm_nt_splitk_epilogue, dim3(static_cast<unsigned>(ceil_div(MN, kBlock))),
+                       dim3(kBlock), 0, st, p);
+    PYGAMD_LAUNCH_CHECK();
+  }
   return PYGAMD_OK;
 }
 
 static int g_gemm_mode = 0;  // pygamd_set_gemm_mode
 
-static int run_nt(GemmNT p, hipStream_t st) {
+// Shape of an NT launch: the tile and the number of K slices.  Outputs with >= kFillTiles tiles of
+// the large shape fill the chip by their rows alone (the full-batch layers); below that — sampled
+// blocks of 1 k .. 16 k rows, Cora-sized inputs — smaller tiles and, if the workspace allows,
+// slices of the reduction bring the launch back to about one workgroup per CU.
+constexpr int kFillTiles = 128;
+struct NtShape {
+  int tile;     // 0: 128x128, 1: 128x96, 2: 128x64, 3: 128x32, 4: 64x64
+  int ksplits;
+  int k_per_split;
+};
+static NtShape nt_shape(int64_t M, int N, int K, bool allow_splitk) {
+  NtShape s;
+  s.tile = N > 96 ? 0 : N > 64 ? 1 : N > 32 ? 2 : 3;
+  s.ksplits = 1;
+  s.k_per_split = K;
+  const int bn[5] = {128, 96, 64, 32, 64};
+  int64_t tiles = ceil_div(M, 128) * ceil_div(N, bn[s.tile]);
+  if (tiles >= kFillTiles) return s;
+  if (N > 32) {  // 64 x 64: four waves, one 32 x 32 block each
+    s.tile = 4;
+    tiles = ceil_div(M, 64) * ceil_div(N, 64);
+  }
+  if (allow_splitk && tiles < kFillTiles && K >= 128) {
+    int want = static_cast<int>(ceil_div(2 * kFillTiles, tiles));
+    const int most = K / 64;  // a slice walks at least two chunks
+    want = want < most ? want : most;
+    want = want < 32 ? want : 32;
+    if (want > 1) {
+      s.k_per_split = static_cast<int>(round_up(ceil_div(K, want), kGK));
+      s.ksplits = static_cast<int>(ceil_div(K, s.k_per_split));
+    }
+  }
+  return s;
+}
+
+static int run_nt(GemmNT p, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (p.M == 0 || p.N == 0) return PYGAMD_OK;
   p.split = g_gemm_mode == PYGAMD_GEMM_SPLIT_BF16 ? 1 : 0;
   const bool vec = (p.K % 4 == 0) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) && aligned16p(p.a) &&
                    aligned16p(p.b);
   // tile shape by output width: wide outputs 128 x 128; 65..96 columns one 128 x 96 tile row;
-  // narrow outputs 128 x 64 / 128 x 32 tiles (all four waves stacked along M)
-  if (p.N > 96) return launch_nt<2, 2, 2, 2>(p, vec, st);
-  if (p.N > 64) return launch_nt<4, 1, 1, 3>(p, vec, st);
-  if (p.N > 32) return launch_nt<4, 1, 1, 2>(p, vec, st);
-  return launch_nt<4, 1, 1, 1>(p, vec, st);
+  // narrow outputs 128 x 64 / 128 x 32 tiles (all four waves stacked along M); few tiles: 64 x 64
+  // and slices of K (nt_shape).  Without a workspace for the slices the launch runs unsliced.
+  NtShape sh = nt_shape(p.M, p.N, p.K, workspace != nullptr);
+  if (sh.ksplits > 1 &&
+      workspace_bytes < static_cast<size_t>(sh.ksplits) * p.M * p.N * sizeof(float))
+    sh = nt_shape(p.M, p.N, p.K, false);
+  p.ksplits = sh.ksplits;
+  p.k_per_split = sh.k_per_split;
+  p.partial = sh.ksplits > 1 ? static_cast<float*>(workspace) : nullptr;
+  switch (sh.tile) {
+    case 0: return launch_nt<2, 2, 2, 2>(p, vec, st);
+    case 1: return launch_nt<4, 1, 1, 3>(p, vec, st);
+    case 2: return launch_nt<4, 1, 1, 2>(p, vec, st);
+    case 3: return launch_nt<4, 1, 1, 1>(p, vec, st);
+    default: return launch_nt<2, 2, 1, 1>(p, vec, st);
+  }
 }
 
 }  // namespace pygamd
@@ -759,7 +862,8 @@ int pygamd_get_gemm_mode(void) { return g_gemm_mode; }
 
 int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
                           const float* bias, int64_t M, int64_t K, int64_t N, int relu,
-                          int accumulate, float* out, int64_t ldo, void* stream) {
+                          int accumulate, float* out, int64_t ldo, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldx < K || ldw < K ||
       ldo < N)
     return PYGAMD_ERR_INVALID_ARG;
@@ -770,14 +874,15 @@ int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t l
   p.M = M; p.lda = ldx; p.ldb = ldw; p.ldc = ldo; p.ldm = 0;
   p.N = static_cast<int>(N); p.K = static_cast<int>(K);
   p.relu = relu ? 1 : 0; p.n_scaled = 0; p.accumulate = accumulate ? 1 : 0;
-  return run_nt(p, as_stream(stream));
+  return run_nt(p, workspace, workspace_bytes, as_stream(stream));
 }
 
 int pygamd_linear_dgrad2(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
                          const float* row_scale, int64_t n_scaled, int64_t M, int64_t N,
                          int64_t K, int accumulate, const float* relu_mask, int64_t ld_mask,
                          const uint32_t* relu_bits, int64_t ld_bits, float* out, int64_t ldo,
-                         float* out_scaled, int64_t ld_scaled, void* stream) {
+                         float* out_scaled, int64_t ld_scaled, void* workspace,
+                         size_t workspace_bytes, void* stream) {
   // out[M, K] = g[M, N] @ w[N, K], with w given TRANSPOSED as w_t[K, N]: the same NT kernel
   if (M < 0 || K < 0 || N < 0 || K > INT32_MAX || N > INT32_MAX || ldg < N || ldwt < N ||
       ldo < K || n_scaled < 0 || n_scaled > K || (relu_mask && ld_mask < K) ||
@@ -795,7 +900,7 @@ int pygamd_linear_dgrad2(const float* g, int64_t ldg, const float* w_t, int64_t 
   p.mask_bits = relu_bits; p.ldmb = ld_bits;
   p.N = static_cast<int>(K); p.K = static_cast<int>(N);
   p.relu = 0; p.n_scaled = static_cast<int>(n_scaled); p.accumulate = accumulate ? 1 : 0;
-  return run_nt(p, as_stream(stream));
+  return run_nt(p, workspace, workspace_bytes, as_stream(stream));
 }
 
 int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t ldwt,
@@ -804,16 +909,27 @@ int pygamd_linear_dgrad(const float* g, int64_t ldg, const float* w_t, int64_t l
                         const uint32_t* relu_bits, int64_t ld_bits, float* out, int64_t ldo,
                         void* stream) {
   return pygamd_linear_dgrad2(g, ldg, w_t, ldwt, row_scale, n_scaled, M, N, K, accumulate,
-                              relu_mask, ld_mask, relu_bits, ld_bits, out, ldo, nullptr, 0, stream);
+                              relu_mask, ld_mask, relu_bits, ld_bits, out, ldo, nullptr, 0, nullptr,
+                              0, stream);
+}
+
+int pygamd_linear_nt_workspace_bytes(int64_t M, int64_t N_out, int64_t K_red, size_t* bytes) {
+  if (!bytes || M < 0 || N_out < 0 || K_red < 0 || N_out > INT32_MAX || K_red > INT32_MAX)
+    return PYGAMD_ERR_INVALID_ARG;
+  const NtShape sh = nt_shape(M, static_cast<int>(N_out), static_cast<int>(K_red), true);
+  *bytes = sh.ksplits > 1 ? static_cast<size_t>(sh.ksplits) * M * N_out * sizeof(float) : 0;
+  return PYGAMD_OK;
 }
 
 static int64_t wgrad_splits(int64_t M, int64_t tiles, int wgs_per_cu = 2) {
   // two workgroups per CU (the LDS ring allows no more) = one full wave of workgroups, every
-  // split a multiple of 32 rows and at least 2048 rows.  wgs_per_cu = 1: half the footprint — the
+  // split a multiple of 32 rows and at least 2048 rows (256 below 64 k rows).  wgs_per_cu = 1: half the footprint — the
   // launch then shares the chip with a bandwidth-bound kernel on another stream (the matrix cores
   // are idle under an SpMM) instead of taking every wave slot.
   int64_t s = ceil_div(256 * (wgs_per_cu == 1 ? 1 : 2), tiles < 1 ? 1 : tiles);
-  const int64_t max_s = ceil_div(M, 2048);
+  // (sampled blocks of a few thousand rows: splits of 256 rows keep the chip busy; their slabs
+  // are a few MB)
+  const int64_t max_s = ceil_div(M, M >= 65536 ? 2048 : 256);
   s = s > max_s ? max_s : s;
   return s < 1 ? 1 : s;
 }

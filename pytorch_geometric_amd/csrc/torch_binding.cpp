@@ -151,9 +151,13 @@ void linear_forward(const Tensor& x, const Tensor& w, const OptTensor& bias, boo
                   (N <= 1 || out.stride(1) == 1),
               "'out' must be a float32 [M, N] tensor with unit inner stride");
   const Tensor b = contig(bias);
+  size_t ws_bytes = 0;  // split over the reduction when the output has few row tiles
+  check(pygamd_linear_nt_workspace_bytes(M, N, K, &ws_bytes), "linear_forward");
+  Tensor ws;
+  if (ws_bytes > 0) ws = at::empty({static_cast<int64_t>(ws_bytes)}, x2.options().dtype(at::kByte));
   check(pygamd_linear_forward(fptr(x2), ld(x2), fptr(w2), ld(w2), fptr(b), M, K, N, relu ? 1 : 0,
-                              accumulate ? 1 : 0, static_cast<float*>(ptr(out)), ld(out),
-                              cur_stream(x2)),
+                              accumulate ? 1 : 0, static_cast<float*>(ptr(out)), ld(out), ptr(ws),
+                              ws_bytes, cur_stream(x2)),
         "linear_forward");
 }
 
@@ -180,12 +184,16 @@ void linear_dgrad(const Tensor& g, const Tensor& w_t, const OptTensor& row_scale
     m2 = rows_f32(*relu_mask, "relu_mask");
     TORCH_CHECK(m2.size(0) == M && m2.size(1) == K, "'relu_mask' must be [M, K]");
   }
+  size_t ws_bytes = 0;
+  check(pygamd_linear_nt_workspace_bytes(M, K, N, &ws_bytes), "linear_dgrad");
+  Tensor ws;
+  if (ws_bytes > 0) ws = at::empty({static_cast<int64_t>(ws_bytes)}, g2.options().dtype(at::kByte));
   check(pygamd_linear_dgrad2(
             fptr(g2), ld(g2), fptr(w2), ld(w2), fptr(rs), rs.defined() ? n_scaled : 0, M, N, K,
             accumulate ? 1 : 0, fptr(m2), m2.defined() ? ld(m2) : 0,
             static_cast<const uint32_t*>(ptr(relu_bits)), has(relu_bits) ? relu_bits->size(1) : 0,
             static_cast<float*>(ptr(out)), ld(out), static_cast<float*>(ptr(out_scaled)),
-            has(out_scaled) ? ld(*out_scaled) : 0, cur_stream(g2)),
+            has(out_scaled) ? ld(*out_scaled) : 0, ptr(ws), ws_bytes, cur_stream(g2)),
         "linear_dgrad");
 }
 

@@ -6,7 +6,7 @@ from torch import Tensor
 from torch.nn import Parameter
 
 from ... import _native
-from ..._functions import GatherFunction, SpmmFunction
+from ..._functions import GatherFunction, SpmmFunction, linear
 from ...edge_index import EdgeIndex
 from ...utils._segment_matmul import block_segment_matmul, segment_matmul
 from ..inits import glorot, zeros
@@ -196,7 +196,7 @@ class RGCNConv(MessagePassing):
             if not torch.is_floating_point(x_r):
                 out = out + root[x_r]
             else:
-                out = out + x_r @ root
+                out = out + linear(x_r, root.t())
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -255,7 +255,8 @@ class FastRGCNConv(RGCNConv):
                 self.num_relations, self.in_channels_l, self.out_channels)
         out = self._index_inputs(x_l, x_r, edge_index, edge_type, weight, by_node_id=True)
         if self.root is not None:
-            out = out + (self.root[x_r] if not torch.is_floating_point(x_r) else x_r @ self.root)
+            out = out + (self.root[x_r] if not torch.is_floating_point(x_r)
+                         else linear(x_r, self.root.t()))
         if self.bias is not None:
             out = out + self.bias
         return out

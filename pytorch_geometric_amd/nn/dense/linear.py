@@ -56,19 +56,15 @@ class Linear(torch.nn.Module):
                 raise RuntimeError(f"Linear layer bias initializer "
                                    f"'{self.bias_initializer}' is not supported")
 
-    # The own kernels tile the ROWS over the chip (128-row tiles, no split over K in the forward):
-    # below ~16 k rows there are fewer tiles than CUs and the library's split-K solutions win
-    # (GCN on the Cora shape, 2,708 rows x 1,433 features: 0.12 ms/step captured with the library,
-    # 0.38 ms with the 22-workgroup launch of the own kernel).
-    OWN_GEMM_MIN_ROWS = 16384
+    # From this many rows up the own kernels run (csrc/gemm.hip): 128-row tiles when the rows alone
+    # fill the chip, otherwise 64 x 64 tiles and a deterministic split over the reduction (GCN on
+    # the Cora shape, 2,708 rows x 1,433 features: 264 workgroups instead of the 22 of round 3's
+    # row-tiled launch).  Below it: F.linear.
+    from ..._functions import OWN_GEMM_MIN_ROWS
 
     def forward(self, x: Tensor) -> Tensor:
-        if (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32
-                and x.dim() >= 2 and x.numel() // max(x.size(-1), 1) >= self.OWN_GEMM_MIN_ROWS
-                and not torch.jit.is_scripting() and not torch.is_autocast_enabled()):
-            from ..._functions import LinearFunction
-            return LinearFunction.apply(x, self.weight, self.bias)
-        return F.linear(x, self.weight, self.bias)
+        from ..._functions import linear
+        return linear(x, self.weight, self.bias)
 
     def __repr__(self) -> str:
         return (f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, '

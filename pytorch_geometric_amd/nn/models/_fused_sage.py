@@ -72,9 +72,9 @@ COMPRESS_ROWS = os.environ.get('PYGAMD_COMPRESS_ROWS', '0') != '0'
 # it out and skip them in the transposed aggregation (PYGAMD_SPARSE_GRAD=0: read every row)
 SPARSE_GRAD = os.environ.get('PYGAMD_SPARSE_GRAD', '1') != '0'
 _side_streams = {}
-# below this many rows a launch of the own row-tiled kernels has fewer tiles than the chip has CUs
-# (cf. nn/dense/linear.py): small sampled batches keep the library GEMM
-OWN_GEMM_MIN_ROWS = int(os.environ.get('PYGAMD_OWN_GEMM_MIN_ROWS', '16384'))
+# below this many rows the library GEMM stays (cf. _functions.OWN_GEMM_MIN_ROWS: from 1 k rows up
+# the own kernels fill the chip with 64 x 64 tiles and a split over the reduction)
+OWN_GEMM_MIN_ROWS = int(os.environ.get('PYGAMD_OWN_GEMM_MIN_ROWS', '1024'))
 
 
 def own_gemm(rows: int) -> bool:
