@@ -213,6 +213,14 @@ typedef struct {
                                 SUM/MEAN without w / src_scale / src_bits; same sums, bit for bit,
                                 as the dense rows                                                 */
   int32_t reserved0;         /* 0 */
+  const void* rowend;        /* NULL, or [n_rows]: the slots of row r are [rowptr[r], rowend[r])
+                                instead of [rowptr[r], rowptr[r + 1]) — rows that own fixed-stride,
+                                partly filled slot blocks (a sampled batch at its static fan-out
+                                capacity: pygamd_sample_slots).  SUM / MEAN without hubs, dense
+                                rows; also honoured by pygamd_sage_layer_fused.                  */
+  int64_t accumulate_rows;   /* with accumulate: only rows < accumulate_rows have an old value, the
+                                others start from 0 (0 = every row) — the root gradient of a
+                                sampled layer exists for its destination rows only.  No hubs.   */
 } pygamd_spmm_args;
 
 /* Lossless compression of a [n_rows, F <= 256] block with many exact zeros (the output of a ReLU)
@@ -620,6 +628,55 @@ PYGAMD_API int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x,
                                     int64_t M, int64_t N, int accumulate, int wgs_per_cu,
                                     float* out, int64_t ldo, float* bias_grad, void* workspace,
                                     size_t workspace_bytes, void* stream);
+
+/* ---- f1b: static-shape ("slot") sampled batches — csrc/minibatch.hip ---------------------------------
+ * The sampling contract of pygamd_sample_neighbors (sampler/neighbor_sampler.py:550-577: per
+ * frontier node a uniform min(deg, k)-subset of its in-neighbours, no replacement) with an output
+ * layout in which a whole training step has the same shapes and row ranges every batch and reads
+ * nothing back to the host.  Batch-local node ids are BLOCK POSITIONS: block 0 = the B seeds,
+ * block h + 1 = the fanout[h] slots of every position of block h; bases[b] = first id of block b
+ * (bases[hops + 1] = all rows R); slot e (global slot index, hop by hop) is row B + e.
+ *   node_g  [R]   int64  graph node held by row r, -1 = hole (a duplicate, or nothing sampled)
+ *   src_g   [R-B] int64  graph node sampled into slot e, -1 = slot not filled
+ *   src_id  [R-B] int32  row that holds the features of slot e's source (the earliest occurrence)
+ *   row_end [bases[hops]] int32  row r's slots are [row_begin[r], row_end[r]) with the static
+ *           row_begin[r] = (bases[b + 1] - B) + (r - bases[b]) * fanout[b] for r in block b:
+ *           pass them as pygamd_spmm_args.rowptr / .rowend with col = src_id
+ *   inv_cnt [bases[hops]] float  1 / max(row_end - row_begin, 1)
+ *   local_map [num_nodes] int64, zero-initialised ONCE: duplicates resolve through atomicMax of
+ *           epoch << 32 | (2^32 - 1 - row) — never reset; *epoch_dev (device int64, >= 1) must
+ *           grow from batch to batch and also salts the draws.
+ * Call order per batch: seed, then per hop sample + resolve (resolve also counts, per source row,
+ * the entries of the transposed CSRs the hop belongs to: counts[c], c < n_counts), then transpose
+ * (one scan launch + one fill launch for all n_csr transposed CSRs; CSR c covers the slots
+ * [0, n_slots[c]) with sources in rows [0, n_src_rows[c]); counts / cursor zeroed by the caller),
+ * then gather (x[node_g] -> out, holes = zero rows).                                               */
+PYGAMD_API int pygamd_slots_max_fanout(void);
+PYGAMD_API int pygamd_slots_max_hops(void);
+PYGAMD_API int pygamd_slots_seed(const void* seeds, int idx_dtype, int64_t B,
+                                 const int64_t* epoch_dev, int64_t* local_map, int64_t* node_g,
+                                 void* stream);
+PYGAMD_API int pygamd_slots_sample(const void* colptr, const void* row, int idx_dtype,
+                                   const int64_t* node_g, int64_t frontier_base,
+                                   int64_t n_frontier, int fanout, int64_t slot_base, int64_t B,
+                                   uint64_t seed, int hop, const int64_t* epoch_dev,
+                                   int64_t* local_map, int64_t* src_g, int32_t* row_end,
+                                   float* inv_cnt, void* stream);
+PYGAMD_API int pygamd_slots_resolve(const int64_t* src_g, int64_t slot_base, int64_t n_slots,
+                                    int64_t B, const int64_t* local_map, int32_t* src_id,
+                                    int64_t* node_g, int32_t* const* counts /*[host]*/,
+                                    int n_counts, void* stream);
+PYGAMD_API int pygamd_slots_gather(const float* x, int64_t ldx, int64_t F, const int64_t* node_g,
+                                   int64_t n_rows, float* out, int64_t ldo, void* stream);
+PYGAMD_API int pygamd_slots_transpose(const int64_t* src_g, const int32_t* src_id, int hops,
+                                      const int32_t* fanout /*[host]*/,
+                                      const int64_t* bases /*[host, hops + 2]*/, int n_csr,
+                                      const int64_t* n_slots /*[host]*/,
+                                      const int64_t* n_src_rows /*[host]*/,
+                                      int32_t* const* counts /*[host]*/,
+                                      int32_t* const* cursor /*[host]*/,
+                                      int32_t* const* ptr /*[host]*/,
+                                      int32_t* const* col /*[host]*/, void* stream);
 
 /* ---- f3: SAGEConv layer forward in one kernel ----------------------------------------------------
  * y[i, :] = act([aggr_{j->i} x[j] | x_root[i]] @ w[Fo, 2F]^T + bias) — `propagate` + `lin_l(agg)

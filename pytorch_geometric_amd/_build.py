@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(PKG_DIR, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpyg_amd.so')
 BUILD_DIR = os.path.join(os.path.dirname(PKG_DIR), 'build', 'pyg_amd')
 SOURCES = ['capi.hip', 'graph.hip', 'spmm.hip', 'scatter.hip', 'softmax.hip', 'segmm.hip',
-           'sample.hip', 'gemm.hip', 'sage_fused.hip', 'sage_fused_lab.hip']
+           'sample.hip', 'minibatch.hip', 'gemm.hip', 'sage_fused.hip', 'sage_fused_lab.hip']
 ARCH = 'gfx950'
 FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']

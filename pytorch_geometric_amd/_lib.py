@@ -35,6 +35,7 @@ class SpmmArgs(Structure):
         ('arg32_out', c_void_p), ('relu_mask', c_void_p), ('ld_mask', c_int64),
         ('relu_bits', c_void_p), ('ld_bits', c_int64), ('src_bits', c_void_p),
         ('src_bits_set', c_void_p), ('x_format', c_int32), ('reserved0', c_int32),
+        ('rowend', c_void_p), ('accumulate_rows', c_int64),
     ]
 
 
@@ -127,6 +128,14 @@ SIGNATURES = {
     'pygamd_sample_max_fanout': (c_int, []),
     'pygamd_sample_neighbors': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, c_uint64, c_int,
                                         _P, _P, _P, _P, _P]),
+    'pygamd_slots_max_fanout': (c_int, []),
+    'pygamd_slots_max_hops': (c_int, []),
+    'pygamd_slots_seed': (c_int, [_P, c_int, c_int64, _P, _P, _P, _P]),
+    'pygamd_slots_sample': (c_int, [_P, _P, c_int, _P, c_int64, c_int64, c_int, c_int64, c_int64,
+                                    c_uint64, c_int, _P, _P, _P, _P, _P, _P]),
+    'pygamd_slots_resolve': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_int, _P]),
+    'pygamd_slots_gather': (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
+    'pygamd_slots_transpose': (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     'pygamd_edge_key': (c_int, [_P, _P, c_int, c_int64, c_int64, c_int, _P, _P]),
     'pygamd_run_flags': (c_int, [_P, c_int64, _P, _P]),
     'pygamd_edge_unkey': (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P]),

@@ -216,8 +216,12 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
              accumulate: bool = False, hub_phase: int = 0, save_arg32: bool = False,
              relu_mask: Optional[Tensor] = None, relu_bits: Optional[Tensor] = None,
              src_bits: Optional[Tensor] = None, src_bits_set: Optional[Tensor] = None,
-             compressed_width: Optional[int] = None):
+             compressed_width: Optional[int] = None, rowend: Optional[Tensor] = None,
+             accumulate_rows: int = 0):
     """out[i] = reduce_k m(k) * x[col[k]] — see pygamd_spmm_csr in include/pyg_amd.h.
+    ``rowend`` ([n_rows], dtype of ``rowptr``): row ``r`` owns the slots ``[rowptr[r], rowend[r])``
+    (fixed-stride slot blocks of a static-shape sampled batch; ``rowptr`` then has ``n_rows``
+    entries).  ``accumulate_rows``: with ``accumulate``, only rows below it have an old value.
     ``compressed_width=F``: ``x`` is the int32 block of :func:`rows_compress` holding ``F`` columns
     per row (sum / mean only; the same sums bit for bit).
     ``src_bits`` (from :func:`rows_pack`): one bit per row of ``x``, clear = the row is all zero
@@ -238,8 +242,14 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     if compressed_width is not None:
         return _spmm_csr_compressed(rowptr, col, x, reduce, compressed_width, n_rows, hub, out,
                                     hub_phase)
+    if rowend is not None:
+        _require_device(rowend)
+        if rowend.dtype != rowptr.dtype or not rowend.is_contiguous() or n_rows is None \
+                or rowend.numel() < n_rows or rowptr.numel() < n_rows:
+            raise ValueError("'rowend' needs 'n_rows', the dtype of 'rowptr' and one entry per row")
     C = _compiled.ops()
     if (C is not None and not return_arg and src_bits is None and _plain(x, relu_mask)
+            and rowend is None and accumulate_rows == 0
             and (w is None or (w.dtype == torch.float32 and
                                (w.dim() == 1 or x.size(1) % max(w.size(1), 1) == 0)))
             and rowptr.dtype in (torch.int32, torch.int64)):
@@ -304,6 +314,9 @@ def spmm_csr(rowptr: Tensor, col: Optional[Tensor], x: Tensor, reduce: str, *,
     a.w_heads, a.head_dim = w_heads, head_dim
     a.accumulate = 1 if accumulate else 0
     a.hub_phase = hub_phase
+    if rowend is not None:
+        a.rowend = rowend.data_ptr()
+    a.accumulate_rows = int(accumulate_rows)
     if relu_mask is not None:
         m2 = _f32_rows(relu_mask, 'relu_mask')
         if tuple(m2.shape) != (n_rows, F):
@@ -999,7 +1012,8 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
                        mask_bits: Optional[Tensor] = None, row_scale: Optional[Tensor] = None,
                        out_scaled: Optional[Tensor] = None, variant: Optional[int] = None,
                        gather_width: Optional[int] = None,
-                       compressed_out: Optional[Tensor] = None) -> Tensor:
+                       compressed_out: Optional[Tensor] = None,
+                       rowend: Optional[Tensor] = None) -> Tensor:
     """``out = act([aggr(x_gather) | x_root] @ w.T + bias)`` in ONE kernel (csrc/sage_fused.hip);
     ``agg`` ([n_rows, F] view, may be a half of a wider buffer) receives the aggregated rows when
     ``save_agg`` (hub rows always).  ``relu_bits`` (from :func:`relu_bits_like`, needs
@@ -1014,7 +1028,7 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out, relu_bits, mask_bits,
                     row_scale, out_scaled, compressed_out)
     C = _compiled.ops()
-    if (C is not None and gather_width is None and compressed_out is None
+    if (C is not None and gather_width is None and compressed_out is None and rowend is None
             and _plain(x_gather, x_root, w, agg, out, out_scaled)):
         n_rows, F, Fo = rowptr.numel() - 1, x_gather.size(1), w.size(0)
         ok = (x_root.shape == (n_rows, F) and w.size(1) == 2 * F and agg.shape == (n_rows, F)
@@ -1050,11 +1064,19 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
         _check_compressed(x_gather, gather_width, 'x_gather')
         xg, F = x_gather, gather_width
     n_rows, Fo = rowptr.numel() - 1, w2.size(0)
+    if rowend is not None:  # rows own fixed slot blocks [rowptr[r], rowend[r]) (sampled batches)
+        _require_device(rowend)
+        n_rows = xr.size(0)
+        if rowend.dtype != rowptr.dtype or not rowend.is_contiguous() \
+                or rowend.numel() < n_rows or rowptr.numel() < n_rows:
+            raise ValueError("'rowend' needs the dtype of 'rowptr' and one entry per row")
     if xr.shape != (n_rows, F) or w2.size(1) != 2 * F or agg.shape != (n_rows, F) \
             or out.shape != (n_rows, Fo):
         raise ValueError('shape mismatch in sage_layer_forward')
     a = SpmmArgs()
     a.rowptr, a.col = rowptr.data_ptr(), col.data_ptr()
+    if rowend is not None:
+        a.rowend = rowend.data_ptr()
     a.x, a.out = xg.data_ptr(), agg.data_ptr()
     a.n_rows, a.n_src, a.F = n_rows, xg.size(0), F
     a.ldx, a.ldo = _ld(xg), _ld(agg)

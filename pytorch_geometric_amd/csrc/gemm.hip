@@ -927,9 +927,9 @@ static int64_t wgrad_splits(int64_t M, int64_t tiles, int wgs_per_cu = 2) {
   // launch then shares the chip with a bandwidth-bound kernel on another stream (the matrix cores
   // are idle under an SpMM) instead of taking every wave slot.
   int64_t s = ceil_div(256 * (wgs_per_cu == 1 ? 1 : 2), tiles < 1 ? 1 : tiles);
-  // (sampled blocks of a few thousand rows: splits of 256 rows keep the chip busy; their slabs
-  // are a few MB)
-  const int64_t max_s = ceil_div(M, M >= 65536 ? 2048 : 256);
+  // (sampled blocks of a few thousand rows: splits of 256 / 64 rows keep the chip busy; their
+  // slabs are a few MB)
+  const int64_t max_s = ceil_div(M, M >= 65536 ? 2048 : M >= 8192 ? 256 : 64);
   s = s > max_s ? max_s : s;
   return s < 1 ? 1 : s;
 }

@@ -171,7 +171,7 @@ __device__ __forceinline__ void split_gather_row(const SageFusedArgs<IdxT>& a, i
   IdxT start = 0, end = 0;
   if (row < a.g.n_rows) {
     start = a.g.rowptr[row];
-    end = a.g.rowptr[row + 1];
+    end = spmm_row_end(a.g, row);
   }
   const IdxT deg = end - start;
   const bool hub = a.g.hub_threshold > 0 && deg > a.g.hub_threshold;

@@ -270,7 +270,7 @@ __device__ __forceinline__ void fused_gather_row(const SageFusedArgs<IdxT>& a, i
   IdxT start = 0, end = 0;
   if (row < a.g.n_rows) {
     start = a.g.rowptr[row];
-    end = a.g.rowptr[row + 1];
+    end = spmm_row_end(a.g, row);
   }
   const IdxT deg = end - start;
   const bool hub = a.g.hub_threshold > 0 && deg > a.g.hub_threshold;
@@ -352,6 +352,8 @@ inline int sage_fused_validate(const pygamd_spmm_args* graph, const pygamd_sage_
   if (f->y_scaled && (!f->row_scale || f->ldy_scaled < Fo)) return PYGAMD_ERR_INVALID_ARG;
   const bool zsrc = graph->x_format == PYGAMD_X_COMPRESSED;
   if (graph->x_format != PYGAMD_X_DENSE && !zsrc) return PYGAMD_ERR_INVALID_ARG;
+  if (graph->rowend && (graph->n_hub > 0 || zsrc)) return PYGAMD_ERR_UNSUPPORTED;
+  if (graph->accumulate_rows != 0) return PYGAMD_ERR_INVALID_ARG;
   if (zsrc && (graph->ldx < F + 12 || graph->src_bits)) return PYGAMD_ERR_INVALID_ARG;
   if (f->compressed_out && (Fo % 32 != 0 || f->ld_compressed < Fo + 12))
     return PYGAMD_ERR_INVALID_ARG;
@@ -409,6 +411,8 @@ inline SageFusedArgs<IdxT> sage_fused_fill(const pygamd_spmm_args* graph,
   a.g.mean = (graph->reduce == PYGAMD_MEAN);
   a.g.accumulate = 0;
   a.g.hub_threshold = graph->n_hub > 0 ? graph->hub_threshold : 0;
+  a.g.rowend = static_cast<const IdxT*>(graph->rowend);
+  a.g.accumulate_rows = 0;
   a.x_root = f->x_root;
   a.ld_root = f->ld_root;
   a.w = f->w;

@@ -617,6 +617,8 @@ extern "C" int pygamd_lab_sage_layer_fused(const pygamd_spmm_args* graph,
   if (variant == 6) return sage_layer_fused_run(graph, f, false, 0, workspace, workspace_bytes, stream);
   // compressed rows in / out: the production kernel only
   if (graph->x_format != PYGAMD_X_DENSE || f->compressed_out) return PYGAMD_ERR_UNSUPPORTED;
+  // (the streamed / producer-consumer schedules read rowptr[row + 1] themselves)
+  if (graph->rowend && variant != 5 && variant != 6 && variant != 1) return PYGAMD_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
   rc = sage_fused_hub_pass(graph, workspace, workspace_bytes, stream);
   if (rc != PYGAMD_OK) return rc;

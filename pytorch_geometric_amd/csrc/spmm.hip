@@ -30,9 +30,10 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
   const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
   if (row >= a.n_rows) return;
   const IdxT start = a.rowptr[row];
-  const IdxT end = a.rowptr[row + 1];
+  const IdxT end = spmm_row_end(a, row);
   const IdxT deg = end - start;
   if (a.hub_threshold > 0 && deg > a.hub_threshold) return;  // owned by the hub path
+  const bool has_old = a.accumulate && (a.accumulate_rows <= 0 || row < a.accumulate_rows);
   int fo[CH], head[CH];
   bool fv[CH];
   feature_slots<VW, LPR, CH>(lane, a.F, a.head_dim, fo, fv, head);
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
       maskv[c].v[i] = 1.f;
     }
     if (lane < LPR && fv[c]) {
-      if (a.accumulate) oldv[c] = load_vec_streamed<VW>(orow + fo[c]);
+      if (has_old) oldv[c] = load_vec_streamed<VW>(orow + fo[c]);
       if (a.relu_mask) maskv[c] = load_vec_streamed<VW>(a.relu_mask + row * a.ldm + fo[c]);
       if (a.relu_bits) {  // VW divides 32 and fo[c] is a multiple of VW: one word holds the bits
         const uint32_t w =
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
 #pragma unroll
         for (int i = 0; i < VW; ++i) {
           float o = a.mean ? acc[c][i] / cntf : acc[c][i];
-          if (a.accumulate) o += oldv[c].v[i];  // (not "+ 0": -0.0 sums stay -0.0)
+          if (has_old) o += oldv[c].v[i];  // (not "+ 0": -0.0 sums stay -0.0)
           o = maskv[c].v[i] > 0.f ? o : 0.f;
           __builtin_nontemporal_store(o, orow + fo[c] + i);
         }
@@ -1126,6 +1127,8 @@ static SpmmDev<IdxT> make_dev(const pygamd_spmm_args* p) {
   a.mean = (p->reduce == PYGAMD_MEAN);
   a.accumulate = p->accumulate;
   a.hub_threshold = (p->n_hub > 0) ? p->hub_threshold : 0;
+  a.rowend = static_cast<const IdxT*>(p->rowend);
+  a.accumulate_rows = p->accumulate_rows;
   return a;
 }
 
@@ -1413,6 +1416,12 @@ static int validate(const pygamd_spmm_args* p) {
   if (p->src_bits && (mm || p->w || p->src_scale)) return PYGAMD_ERR_UNSUPPORTED;
   if (p->src_bits_set && !p->src_bits) return PYGAMD_ERR_INVALID_ARG;
   if (p->x_format != PYGAMD_X_DENSE && p->x_format != PYGAMD_X_COMPRESSED)
+    return PYGAMD_ERR_INVALID_ARG;
+  // fixed-stride slot blocks / a row limit on `accumulate`: the plain and weighted sum kernels of
+  // rows without hubs (what a sampled batch needs)
+  if (p->rowend && (mm || p->n_hub > 0 || p->src_bits || p->x_format != PYGAMD_X_DENSE))
+    return PYGAMD_ERR_UNSUPPORTED;
+  if (p->accumulate_rows < 0 || (p->accumulate_rows > 0 && (!p->accumulate || p->n_hub > 0)))
     return PYGAMD_ERR_INVALID_ARG;
   if (p->x_format == PYGAMD_X_COMPRESSED) {
     if (mm || p->w || p->src_scale || p->src_bits || !p->col) return PYGAMD_ERR_UNSUPPORTED;

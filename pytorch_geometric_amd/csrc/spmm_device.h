@@ -34,7 +34,17 @@ struct SpmmDev {
   int mean;
   int accumulate;  // out[i] += result instead of out[i] = result
   int64_t hub_threshold;
+  // null, or [n_rows]: the slots of row r are [rowptr[r], rowend[r]) instead of [rowptr[r],
+  // rowptr[r + 1]) — rows own fixed-stride slot blocks that are only partly filled (sampled batches
+  // at their static fan-out capacity, csrc/minibatch.hip)
+  const IdxT* __restrict__ rowend;
+  int64_t accumulate_rows;  // with accumulate: rows >= this start from 0 (0 = every row has an old value)
 };
+
+template <typename IdxT>
+__device__ __forceinline__ IdxT spmm_row_end(const SpmmDev<IdxT>& a, int64_t row) {
+  return a.rowend ? a.rowend[row] : a.rowptr[row + 1];
+}
 
 // Independent row loads issued per lane before the first add.  A staged index chunk holds 64
 // slots, so EPI * U never needs to exceed 64 (U <= LPR).

@@ -83,6 +83,7 @@ class NeighborLoader:
                  subgraph_type: str = 'directional'):
         self.prefetch = int(prefetch)
         self._side = None
+        self._slots = None  # the static-shape sampler of `collate_slots`, built on first use
         self.x, self.y = x, y
         self.num_nodes = x.size(0)
         self.sampler = NeighborSampler(edge_index, self.num_nodes, num_neighbors, seed=seed,
@@ -123,6 +124,27 @@ class NeighborLoader:
         x = _native.gather_rows(self.x, n_id)  # filter_data: x[n_id]
         y = None if self.y is None else self.y[seeds]
         return PaddedBatch(x=x, y=y, hops=p, n_id=n_id, batch_size=seeds.numel())
+
+    def collate_slots(self, seeds: Tensor, epoch_dev: Tensor):
+        """One batch in the static-shape SLOT layout (:mod:`pytorch_geometric_amd.slots`; bounded
+        fan-outs, directional, non-disjoint, without replacement): 1 + 2 launches per hop for the
+        sampling, 3 for the transposed CSRs of the backward, 1 for the feature gather, no host
+        synchronisation.  ``epoch_dev``: int64 [1] on the device, >= 1, growing from batch to batch
+        (a captured step bumps it before every replay).  Returns a ``SlotBatch`` with ``x`` = the
+        gathered ``[R, 2 F]`` buffer and ``y`` = the seeds' labels."""
+        from .slots import SlotPlan, SlotSampler
+        smp = self.sampler
+        if smp.replace or smp.disjoint or smp.subgraph_type != 'directional' \
+                or any(k < 1 for k in smp.num_neighbors):
+            raise ValueError("'collate_slots' covers bounded fan-outs, directional, non-disjoint, "
+                             "without replacement")
+        if self._slots is None or self._slots.plan.B != seeds.numel():
+            plan = SlotPlan(seeds.numel(), smp.num_neighbors, self.x.device)
+            self._slots = SlotSampler(smp.colptr, smp.row, self.num_nodes, plan, seed=smp.seed)
+        b = self._slots.sample(seeds, epoch_dev)
+        b.x = self._slots.gather(self.x, b)
+        b.y = None if self.y is None else self.y[seeds]
+        return b
 
     def _plan(self):
         n = self.input_nodes.numel()

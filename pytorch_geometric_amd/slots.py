@@ -1,0 +1,277 @@
+"""Static-shape ("slot") neighbour-sampled batches and the GraphSAGE stack that trains on them
+(BASELINE config 4) — the host side of ``csrc/minibatch.hip``.
+
+What the reference does per batch (``examples/multi_gpu/distributed_sampling.py:64-115``):
+``NeighborLoader`` samples ``[15, 10, 5]`` neighbours around 1024 seeds, gathers ``x[n_id]``, and the
+model runs layer by layer on the sampled subgraph (``trim_to_layer``,
+``utils/_trim_to_layer.py:167-215``: layer ``l`` only needs the rows the next layer consumes).  Here
+the same computation is laid out so that every tensor shape and every row range is a function of
+(batch size, fan-outs) only and nothing is read back to the host — the whole step captures into one
+hipGraph — with as few, as fat kernels as the path allows (round 3: 181 kernels / 3.0 ms per batch):
+
+* sampling: 1 launch for the seeds + 2 per hop (``SlotSampler.sample``); the duplicate-resolving
+  node map is never reset (epoch-stamped claims);
+* feature gather: 1 launch, straight into the right half of the first ``[agg | x]`` buffer;
+* forward: ONE launch per layer — the one-kernel SAGE layer (gather -> LDS -> MFMA, bias + ReLU +
+  ReLU bits in the epilogue) over all destination blocks of the layer at once (``rowptr`` =
+  the static ``row_begin``, ``rowend`` = the sampler's ``row_end``);
+* backward: per layer the weight gradient (+ bias gradient from the same pass), two half-width
+  dgrad GEMMs (``g W_l`` scaled by 1/deg in the epilogue -> the rows to scatter; ``g W_r`` straight
+  into the destination rows of the input gradient) and ONE transposed SpMM over the batch's
+  transposed CSR (built by 3 launches per batch) that accumulates onto the root gradient and applies
+  the ReLU mask bits — no atomics, no zero-fill, no stand-alone ReLU-backward / column-sum pass.
+Padding rows (holes) hold finite values forward (zero features, or an aggregation of nothing) and
+receive exactly zero gradient backward: no entry of a transposed CSR points at them."""
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib, _native
+from ._lib import check
+
+
+def _i64p(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class SlotPlan:
+    """Everything static about a batch of ``batch_size`` seeds and bounded fan-outs ``fanouts``."""
+
+    def __init__(self, batch_size: int, fanouts: List[int], device):
+        lib = _lib.load()
+        if not fanouts or len(fanouts) > lib.pygamd_slots_max_hops():
+            raise ValueError(f'1 .. {lib.pygamd_slots_max_hops()} hops')
+        if any(k < 1 or k > lib.pygamd_slots_max_fanout() for k in fanouts):
+            raise ValueError(f'fan-outs must be in 1 .. {lib.pygamd_slots_max_fanout()} '
+                             f'(slot batches need bounded fan-outs)')
+        self.B, self.fanouts, self.L = int(batch_size), [int(k) for k in fanouts], len(fanouts)
+        self.device = torch.device(device)
+        cap = [self.B]
+        for k in self.fanouts:
+            cap.append(cap[-1] * k)
+        self.cap = cap
+        self.bases = [0]
+        for c in cap:
+            self.bases.append(self.bases[-1] + c)          # len L + 2
+        self.R = self.bases[-1]                              # all rows
+        self.R_dst = self.bases[self.L]                      # rows that are ever a destination
+        self.S = self.R - self.B                             # all slots
+        if self.R >= 2 ** 31:
+            raise ValueError('batch too large for 32-bit batch-local ids')
+        begin = [(self.bases[b + 1] - self.B) + torch.arange(cap[b], dtype=torch.int64) * k
+                 for b, k in enumerate(self.fanouts)]
+        self.row_begin = torch.cat(begin).to(torch.int32).to(self.device)
+        # transposed CSR c serves the backward of layer c + 1: hops 0 .. L - c - 2
+        self.n_csr = self.L - 1
+        self.t_slots = [self.bases[self.L - c] - self.B for c in range(self.n_csr)]
+        self.t_rows = [self.bases[self.L - c] for c in range(self.n_csr)]
+
+    def ebase(self, h: int) -> int:
+        return self.bases[h + 1] - self.B
+
+
+@dataclass
+class SlotBatch:
+    plan: SlotPlan
+    node_g: Tensor      # [R] int64: graph node of a row, -1 = hole
+    src_g: Tensor       # [S] int64: graph node sampled into a slot, -1 = empty
+    src_id: Tensor      # [S] int32: row holding the slot's source
+    row_end: Tensor     # [R_dst] int32
+    inv_cnt: Tensor     # [R_dst] float32
+    t_ptr: List[Tensor]  # per transposed CSR: [rows + 1] int32
+    t_col: List[Tensor]  # per transposed CSR: [slots] int32 (filled prefix = ptr[-1])
+    x: Optional[Tensor] = None   # [R, 2 F] = [ (aggregation target) | x[node_g] ]
+    y: Optional[Tensor] = None
+
+
+class SlotSampler:
+    """Device-side k-hop sampler over the destination-sorted (CSC) form of a graph that writes
+    :class:`SlotBatch` es.  ``colptr`` / ``row`` as in :class:`pytorch_geometric_amd.sampler.
+    NeighborSampler` (``graph.by_dst()``)."""
+
+    def __init__(self, colptr: Tensor, row: Tensor, num_nodes: int, plan: SlotPlan,
+                 seed: int = 0):
+        _native._require_device(colptr, row)
+        if colptr.dtype != row.dtype or colptr.dtype not in (torch.int32, torch.int64):
+            raise ValueError("'colptr' / 'row' must share an int32 / int64 dtype")
+        self.colptr, self.row, self.plan, self.seed = colptr, row, plan, int(seed)
+        dev = colptr.device
+        p = plan
+        # the claim map: zero = "never claimed"; epochs >= 1 always beat it — never reset
+        self.local = torch.zeros(num_nodes, dtype=torch.int64, device=dev)
+        self.node_g = torch.empty(p.R, dtype=torch.int64, device=dev)
+        self.src_g = torch.empty(p.S, dtype=torch.int64, device=dev)
+        self.src_id = torch.empty(p.S, dtype=torch.int32, device=dev)
+        self.row_end = torch.empty(p.R_dst, dtype=torch.int32, device=dev)
+        self.inv_cnt = torch.empty(p.R_dst, dtype=torch.float32, device=dev)
+        # counts and cursors of every transposed CSR in ONE buffer (one memset per batch)
+        self._tbuf = torch.zeros(max(2 * sum(p.t_rows), 1), dtype=torch.int32, device=dev)
+        self.t_counts, self.t_cursor, off = [], [], 0
+        for n in p.t_rows:
+            self.t_counts.append(self._tbuf[off:off + n])
+            self.t_cursor.append(self._tbuf[off + n:off + 2 * n])
+            off += 2 * n
+        self.t_ptr = [torch.empty(n + 1, dtype=torch.int32, device=dev) for n in p.t_rows]
+        self.t_col = [torch.zeros(max(n, 1), dtype=torch.int32, device=dev) for n in p.t_slots]
+        self._fan_host = (ctypes.c_int32 * p.L)(*p.fanouts)
+        self._bases_host = (ctypes.c_int64 * (p.L + 2))(*p.bases)
+        self._slots_host = (ctypes.c_int64 * max(p.n_csr, 1))(*p.t_slots)
+        self._rows_host = (ctypes.c_int64 * max(p.n_csr, 1))(*p.t_rows)
+
+        def ptrs(ts):
+            return (ctypes.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
+        self._counts_host, self._cursor_host = ptrs(self.t_counts), ptrs(self.t_cursor)
+        self._ptr_host, self._col_host = ptrs(self.t_ptr), ptrs(self.t_col)
+
+    @torch.no_grad()
+    def sample(self, seeds: Tensor, epoch_dev: Tensor) -> SlotBatch:
+        """``seeds`` [B] graph node ids (device, dtype of ``colptr``); ``epoch_dev`` int64 [1] on the
+        device, >= 1 and larger than for every earlier batch of this sampler (a captured step bumps
+        it before every replay).  No host synchronisation; the returned tensors are the sampler's
+        own buffers (valid until the next call)."""
+        p, lib = self.plan, _lib.load()
+        if seeds.numel() != p.B or seeds.dtype != self.colptr.dtype or not seeds.is_contiguous():
+            raise ValueError(f"'seeds' must be {p.B} contiguous {self.colptr.dtype} node ids")
+        if epoch_dev.dtype != torch.int64 or epoch_dev.numel() != 1 or not epoch_dev.is_cuda:
+            raise ValueError("'epoch_dev' must be one int64 on the device")
+        st = _native._stream(seeds)
+        idt = _native._idx_dtype(self.colptr)
+        ep = _i64p(epoch_dev)
+        self._tbuf.zero_()
+        check(lib.pygamd_slots_seed(_i64p(seeds), idt, p.B, ep, _i64p(self.local),
+                                    _i64p(self.node_g), st), 'slots_seed')
+        for h, k in enumerate(p.fanouts):
+            check(lib.pygamd_slots_sample(
+                _i64p(self.colptr), _i64p(self.row), idt, _i64p(self.node_g), p.bases[h],
+                p.cap[h], k, p.ebase(h), p.B, self.seed & 0xFFFFFFFFFFFFFFFF, h, ep,
+                _i64p(self.local), _i64p(self.src_g), _i64p(self.row_end), _i64p(self.inv_cnt),
+                st), 'slots_sample')
+            n_counts = max(p.L - 1 - h, 0)   # transposed CSRs c = 0 .. L - 2 - h contain hop h
+            check(lib.pygamd_slots_resolve(
+                _i64p(self.src_g), p.ebase(h), p.cap[h + 1], p.B, _i64p(self.local),
+                _i64p(self.src_id), _i64p(self.node_g), self._counts_host, n_counts, st),
+                'slots_resolve')
+        if p.n_csr > 0:
+            check(lib.pygamd_slots_transpose(
+                _i64p(self.src_g), _i64p(self.src_id), p.L, self._fan_host, self._bases_host,
+                p.n_csr, self._slots_host, self._rows_host, self._counts_host, self._cursor_host,
+                self._ptr_host, self._col_host, st), 'slots_transpose')
+        return SlotBatch(p, self.node_g, self.src_g, self.src_id, self.row_end, self.inv_cnt,
+                         self.t_ptr, self.t_col)
+
+    @torch.no_grad()
+    def gather(self, x: Tensor, batch: SlotBatch, out: Optional[Tensor] = None) -> Tensor:
+        """``[R, 2 F]`` with ``x[node_g]`` in the right half (holes: zero rows); the left half is
+        where layer 0 stores its aggregated rows."""
+        p = self.plan
+        F = x.size(1)
+        if out is None:
+            out = torch.empty(p.R, 2 * F, dtype=torch.float32, device=x.device)
+        check(_lib.load().pygamd_slots_gather(
+            _i64p(x), _native._ld(x), F, _i64p(batch.node_g), p.R,
+            ctypes.c_void_p(out.data_ptr() + 4 * F), _native._ld(out), _native._stream(x)),
+            'slots_gather')
+        return out
+
+
+class FusedSageSlotStack(Function):
+    """``L``-layer GraphSAGE (mean / sum aggregation, ReLU between layers, root weight + bias) on a
+    :class:`SlotBatch` whose ``x`` is the gathered ``[R, 2 F]`` buffer; returns the seed rows
+    ``[B, out_channels]``.  Layer ``l`` produces the rows of blocks ``0 .. L-l-1`` from the rows of
+    blocks ``0 .. L-l`` (trim_to_layer)."""
+
+    @staticmethod
+    def forward(ctx, cat0: Tensor, batch: SlotBatch, aggr: str, *params: Optional[Tensor]):
+        p = batch.plan
+        L = len(params) // 3
+        if L != p.L:
+            raise ValueError(f'{L} layers on a batch of {p.L} hops')
+        if cat0.shape[0] != p.R or cat0.dtype != torch.float32 or cat0.size(1) % 2:
+            raise ValueError(f"'x' must be the float32 [{p.R}, 2 F] buffer of SlotSampler.gather")
+        dev = cat0.device
+        Fi = cat0.size(1) // 2
+        cat = cat0
+        cats, wmats, bits = [], [], []
+        out = None
+        for l in range(L):
+            W_l, b, W_r = params[3 * l:3 * l + 3]
+            Fo = W_l.size(0)
+            m = p.bases[L - l]                       # rows produced = blocks 0 .. L-l-1
+            if not _native.sage_layer_forward_supported(Fi, Fo, aggr):
+                raise ValueError(f'layer {l} ({Fi} -> {Fo}, {aggr}) is outside the one-kernel '
+                                 f'layer (F % 4 == 0, F <= 256, Fo <= 256, sum / mean)')
+            wmat = torch.cat([W_l, W_r], dim=1)
+            last = l == L - 1
+            if last:
+                nxt, dst = None, torch.empty(m, Fo, dtype=torch.float32, device=dev)
+                out = dst
+                rb = None
+            else:
+                nxt = torch.empty(m, 2 * Fo, dtype=torch.float32, device=dev)
+                dst = nxt[:, Fo:]
+                rb = _native.relu_bits_like(m, Fo, dev)
+            _native.sage_layer_forward(batch.plan.row_begin, batch.src_id, cat[:, Fi:],
+                                       cat[:m, Fi:], wmat, b, aggr, not last, cat[:m, :Fi], dst,
+                                       save_agg=True, relu_bits=rb, rowend=batch.row_end)
+            cats.append(cat)
+            wmats.append(wmat)
+            bits.append(rb)
+            cat, Fi = nxt, Fo
+        ctx.batch, ctx.aggr, ctx.L = batch, aggr, L
+        ctx.has_bias = [params[3 * i + 1] is not None for i in range(L)]
+        ctx.n_bits = sum(b is not None for b in bits)
+        ctx.save_for_backward(*cats, *wmats, *[b for b in bits if b is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        L, batch, aggr = ctx.L, ctx.batch, ctx.aggr
+        p = batch.plan
+        saved = ctx.saved_tensors
+        cats, wmats = saved[:L], saved[L:2 * L]
+        bits = list(saved[2 * L:]) + [None]        # bits[l]: ReLU mask of layer l's output
+        grads: List[Optional[Tensor]] = [None] * (3 * L)
+        g = grad_out
+        if g.dim() != 2 or g.stride(1) != 1 or (g.size(0) > 1 and g.stride(0) < g.size(1)):
+            g = g.contiguous()
+        grad_x = None
+        for l in reversed(range(L)):
+            cat, wmat = cats[l], wmats[l]
+            Fi = cat.size(1) // 2
+            m = p.bases[L - l]
+            gw = _native.linear_wgrad(g, cat[:m], bias_grad=ctx.has_bias[l])
+            if ctx.has_bias[l]:
+                gw, grads[3 * l + 1] = gw
+            grads[3 * l], grads[3 * l + 2] = gw[:, :Fi], gw[:, Fi:]
+            if l == 0:
+                if ctx.needs_input_grad[0]:
+                    raise NotImplementedError('the slot stack does not differentiate its '
+                                              'gathered input features')
+                break
+            c = l - 1                                # this layer's transposed CSR
+            r_in = p.bases[L - l + 1]                # rows of the layer input = rows layer l-1 made
+            w_t = wmat.t()                           # [2 Fi, Fo]
+            scale = batch.inv_cnt[:m] if aggr == 'mean' else None
+            gagg = _native.linear_dgrad(g, w_t[:Fi].contiguous(), row_scale=scale,
+                                        n_scaled=Fi if scale is not None else 0)
+            g_in = torch.empty(r_in, Fi, dtype=torch.float32, device=g.device)
+            _native.linear_dgrad(g, w_t[Fi:].contiguous(), out=g_in[:m])
+            # g_in = relu'(h) * (A^T gagg + [groot ; 0]): rows past m have no root part
+            _native.spmm_csr(batch.t_ptr[c], batch.t_col[c], gagg, 'sum', n_rows=r_in, out=g_in,
+                             accumulate=True, accumulate_rows=m, relu_bits=bits[l - 1])
+            g = g_in
+        return (grad_x, None, None, *grads)
+
+
+def run_slot_stack(model, batch: SlotBatch) -> Tensor:
+    """``model``: a GraphSAGE of plain ``SAGEConv`` layers (``nn.models._fused_sage_hops.
+    eligible``-style: mean / sum aggregation, root weight, ReLU, no norm / dropout / jk)."""
+    params = []
+    for conv in model.convs:
+        params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
+    aggr = model.convs[0].aggr
+    return FusedSageSlotStack.apply(batch.x, batch, 'sum' if aggr == 'add' else aggr, *params)

@@ -43,6 +43,7 @@ def main():
     g64 = {k: p.grad.clone() for k, p in m64.named_parameters()}
     ref_vs_64 = {k: float((grads[k].double() - g64[k]).abs().max() / g64[k].abs().max())
                  for k in grads}
+    ref_vs_64_l2 = {k: float((grads[k].double() - g64[k]).norm() / g64[k].norm()) for k in grads}
     rows = torch.arange(0, x.size(0), max(x.size(0) // 1024, 1))[:1024]
     blob = {
         'scale': SCALE, 'classes': c, 'n': x.size(0), 'e': ei.size(1),
@@ -51,7 +52,7 @@ def main():
         'loss': loss.detach(), 'rows': rows, 'out_rows': out.detach()[rows].clone(),
         'out_absmax': float(out.detach().abs().max()),
         'grads64_as_f32': {k: v.float() for k, v in g64.items()},
-        'ref_vs_fp64': ref_vs_64,
+        'ref_vs_fp64': ref_vs_64, 'ref_vs_fp64_l2': ref_vs_64_l2,
         'made_with': f'torch {torch.__version__}, torch_geometric (reference) GraphSAGE, CPU',
     }
     path = os.path.join(ROOT, 'tests', 'golden', 'golden_bench_sample_v1.pt')

@@ -84,9 +84,13 @@ def test_config3_gat_arxiv_shape(dev):
     # (leaky_relu runs once per edge and head, 9.3 M evaluations: a pre-activation within fp32
     # rounding of 0 is expected about once — see assert_close_rows)
     assert_close_rows(xg.grad, xr.grad, max_bad_rows=32, what='gat layer grad_x')
-    assert_close_scaled(conv.att_src.grad, ps[1].grad, what='gat layer grad att_src')
-    assert_close_scaled(conv.att_dst.grad, ps[2].grad, what='gat layer grad att_dst')
-    assert_close_scaled(conv.lin.weight.grad, ps[0].grad, what='gat layer grad W')
+    # parameter gradients are sums over all 9.3 M (edge, head) terms: ONE term whose leaky_relu
+    # pre-activation lies within fp32 rounding of 0 (expected about once at this size, on either
+    # device) changes slope 1 <-> 0.2 and moves these sums by up to ~1e-4 of their scale; an error
+    # in the kernels would show at 1e-2 .. 1 (and in `out` / the per-row check above)
+    assert_close_scaled(conv.att_src.grad, ps[1].grad, tol=2e-4, what='gat layer grad att_src')
+    assert_close_scaled(conv.att_dst.grad, ps[2].grad, tol=2e-4, what='gat layer grad att_dst')
+    assert_close_scaled(conv.lin.weight.grad, ps[0].grad, tol=2e-4, what='gat layer grad W')
 
 
 def test_config5_rgcn_fb15k237_shape(dev):

@@ -261,7 +261,7 @@ def test_sage_layer_streamed_gather_is_bitwise_the_spmm(dev, F, Fo):
 
 @pytest.mark.parametrize('F,Fo', [(256, 256), (64, 128), (100, 96), (32, 32), (192, 64)])
 @pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
-def test_sage_layer_with_compressed_rows_in_and_out(dev, F, Fo, dtype):
+def test_sage_layer_with_compressed_rows_in_and_out(dev, request, F, Fo, dtype):
     """The one-kernel layer gathers COMPRESSED source rows (x_format) and writes its own output a
     second time in that layout (compressed_out): for F > 128 bitwise the dense launch — output,
     saved aggregated rows, ReLU bits (narrower rows: equal to fp32 rounding, the dense gather then
@@ -271,6 +271,9 @@ def test_sage_layer_with_compressed_rows_in_and_out(dev, F, Fo, dtype):
     import pytorch_geometric_amd as pga
     from pytorch_geometric_amd import _native
     from tests._util import assert_close_scaled, decompress_rows, random_graph
+    # (compressed rows in / out run the fp32-instruction schedule whatever the arithmetic mode: the
+    # bitwise comparisons below need the dense launches on the same schedule)
+    request.addfinalizer(lambda prev=_native.set_gemm_mode('fp32'): _native.set_gemm_mode(prev))
     n = 1037
     g = gen(5 * F + Fo)
     ei = random_graph(n, n, 30000, seed=F + 2 * Fo, skew=True).to(dtype)
