@@ -340,6 +340,11 @@ PYGAMD_API int pygamd_colsum(const float* x, int64_t ldx, int64_t n_rows, int64_
  * (aten::threshold_backward with threshold 0; `act` is the ReLU OUTPUT), and, when colsum_out is
  * not NULL, colsum_out[f] = sum_r grad_in[r,f] (zeroed internally, fp32 atomics).  grad_in may
  * alias grad.                                                                                   */
+/* out = act(x + bias) in one pass (bias NULL: none; relu != 0: ReLU, NaN propagating) — the tail
+ * of a conv layer: `out + self.bias` (gat_conv.py:378-385, gcn_conv.py:278-281) and the model's
+ * activation (basic_gnn.py:262-263).  Its backward is pygamd_relu_backward_colsum on the OUTPUT. */
+PYGAMD_API int pygamd_bias_act(const float* x, int64_t ldx, const float* bias, int64_t n_rows,
+                               int64_t F, int relu, float* out, int64_t ldo, void* stream);
 PYGAMD_API int pygamd_relu_backward_colsum(const float* grad, int64_t ldg, const float* act,
                                            int64_t lda, int64_t n_rows, int64_t F, float* grad_in,
                                            int64_t ldo, float* colsum_out, void* stream);

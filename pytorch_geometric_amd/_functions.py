@@ -443,3 +443,42 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
     if own_linear_eligible(x, weight):
         return LinearFunction.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+class BiasActFunction(Function):
+    """``relu(x + bias)`` (or ``x + bias``) in one pass, backward in one pass: the masked gradient
+    and — from the same read — its column sums, the bias gradient (``pygamd_bias_act`` /
+    ``pygamd_relu_backward_colsum``).  Replaces ``out + self.bias`` of a conv layer
+    (gat_conv.py:378-385, gcn_conv.py:278-281) followed by the model's ReLU
+    (basic_gnn.py:262-263): four ATen passes forward + backward become two."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, bias: Optional[Tensor], relu: bool):
+        x2 = x.reshape(-1, x.size(-1))
+        out = _native.bias_act(x2, bias, relu)
+        ctx.relu, ctx.has_bias, ctx.shape = relu, bias is not None, x.shape
+        res = _shaped(out, x.shape)
+        if relu:
+            ctx.save_for_backward(res)
+        return res
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out: Tensor):
+        g2 = grad_out.reshape(-1, grad_out.size(-1))
+        need_b = ctx.has_bias and ctx.needs_input_grad[1]
+        if ctx.relu:
+            (out, ) = ctx.saved_tensors
+            g, gb = _native.relu_backward_colsum(g2, out.reshape(-1, out.size(-1)), need_b)
+            return g.view(ctx.shape), (gb if need_b else None), None
+        return grad_out, (_native.colsum(g2) if need_b else None), None
+
+
+def bias_act(x: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:
+    """``relu(x + bias)`` / ``x + bias``; float32 device tensors take the one-pass kernels."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.numel() > 0 \
+            and (bias is None or (bias.dtype == torch.float32 and bias.dim() == 1)) \
+            and not torch.jit.is_scripting() and not torch.is_autocast_enabled():
+        return BiasActFunction.apply(x, bias, relu)
+    out = x if bias is None else x + bias
+    return out.relu() if relu else out

@@ -548,6 +548,21 @@ def spmm_minmax_backward_src(fwd, bwd, slot_map: Tensor, x: Tensor, out: Tensor,
     return grad_x
 
 
+def bias_act(x: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:
+    """``act(x + bias)`` as a new contiguous ``[n, F]`` tensor in one pass (``x`` may be a
+    row-strided view)."""
+    _require_device(x, bias)
+    x2 = _f32_rows(x, 'x')
+    out = torch.empty(x2.size(0), x2.size(1), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != x2.size(1):
+            raise ValueError(f"'bias' must be float32 with {x2.size(1)} entries")
+        bias = bias.contiguous()
+    check(_lib.load().pygamd_bias_act(_p(x2), _ld(x2), _p(bias), x2.size(0), x2.size(1),
+                                      int(relu), _p(out), _ld(out), _stream(x)), 'bias_act')
+    return out
+
+
 def relu_backward_colsum(grad: Tensor, act: Tensor, want_colsum: bool = True):
     """(grad * (act > 0) as a new contiguous tensor, its column sums | None) in one pass; ``act``
     is the ReLU output.  Inputs may be row-strided views."""

@@ -431,6 +431,22 @@ def neighbor_sampler(data, num_neighbors: List[int], seed: int = 0, replace: boo
                         subgraph_type)
 
 
+def _wrap_linear_forward(cls):
+    orig = cls.forward
+
+    def forward(self, x):
+        from ._functions import LinearFunction, own_linear_eligible
+        w = self.weight
+        if (_enabled() and isinstance(x, Tensor)
+                and not isinstance(w, torch.nn.parameter.UninitializedParameter)
+                and w.device == x.device and own_linear_eligible(x, w)):
+            return LinearFunction.apply(x, w, self.bias)
+        return orig(self, x)
+
+    forward.__wrapped__ = orig
+    return forward
+
+
 def install() -> None:
     """Idempotent.  Needs ``torch_geometric`` importable; raises ImportError otherwise."""
     if _state['installed']:
@@ -473,6 +489,19 @@ def install() -> None:
     prev = GraphSAGE.__dict__.get('forward')
     GraphSAGE.forward = _wrap_graphsage_forward(GraphSAGE)
     _state['forwards'].append((GraphSAGE, had_own, prev))
+
+    # the reference's own dense layer (nn/dense/linear.py:121-127: F.linear) on the fp32-MFMA
+    # kernels for float32 device inputs of >= OWN_GEMM_MIN_ROWS rows; everything else unchanged
+    from torch_geometric.nn.dense.linear import Linear as PygLinear
+    had_own = 'forward' in PygLinear.__dict__
+    prev = PygLinear.__dict__.get('forward')
+    PygLinear.forward = _wrap_linear_forward(PygLinear)
+    _state['forwards'].append((PygLinear, had_own, prev))
+
+    # seam S2: the operator names the reference calls when torch-sparse is importable
+    # (edge_index.py:1798-1810) — defined by this backend only when that extension is absent
+    from . import torch_sparse_ops
+    torch_sparse_ops.register()
 
     pyg_backend.mi355x = sys.modules[__name__]
     if not hasattr(pyg_backend, 'use_mi355x'):

@@ -415,7 +415,45 @@ static int launch_scatter(const float* src, int64_t lds, const IdxT* idx, int64_
 
 using namespace pygamd;
 
+// out = act(x + bias): the tail of a conv layer (gat_conv.py:378-385 / gcn_conv.py:278-281 `out + bias`
+// followed by the model's ReLU, basic_gnn.py:262-263) in ONE pass instead of two ATen passes
+template <int VW>
+__global__ void __launch_bounds__(kBlock)
+    bias_act_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ bias,
+                    int64_t n_rows, int64_t units, int relu, float* __restrict__ out, int64_t ldo) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t r = t / units;
+  if (r >= n_rows) return;
+  const int64_t c = (t - r * units) * VW;
+  Vec<VW> v = load_vec<VW>(x + r * ldx + c);
+#pragma unroll
+  for (int i = 0; i < VW; ++i) {
+    float y = v.v[i] + (bias ? bias[c + i] : 0.f);
+    if (relu) y = (y > 0.f || y != y) ? y : 0.f;  // NaN propagates like torch.relu
+    v.v[i] = y;
+  }
+  store_vec<VW>(out + r * ldo + c, v);
+}
+
 extern "C" {
+
+int pygamd_bias_act(const float* x, int64_t ldx, const float* bias, int64_t n_rows, int64_t F,
+                    int relu, float* out, int64_t ldo, void* stream) {
+  if (n_rows < 0 || F < 0 || ldx < F || ldo < F) return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows == 0 || F == 0) return PYGAMD_OK;
+  if (!x || !out) return PYGAMD_ERR_INVALID_ARG;
+  const bool v4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) &&
+                  aligned16(out);
+  if (v4) {
+    hipLaunchKernelGGL(bias_act_kernel<4>, dim3(flat_grid(n_rows * (F / 4))), dim3(kBlock), 0,
+                       as_stream(stream), x, ldx, bias, n_rows, F / 4, relu ? 1 : 0, out, ldo);
+  } else {
+    hipLaunchKernelGGL(bias_act_kernel<1>, dim3(flat_grid(n_rows * F)), dim3(kBlock), 0,
+                       as_stream(stream), x, ldx, bias, n_rows, F, relu ? 1 : 0, out, ldo);
+  }
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
 
 static int launch_colsum(const float* x, int64_t ldx, const float* act, int64_t lda, float* y,
                          int64_t ldy, int64_t n_rows, int64_t F, float* out, hipStream_t st) {

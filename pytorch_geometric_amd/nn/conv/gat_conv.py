@@ -6,7 +6,7 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.nn import Parameter
 
-from ..._functions import GatEdgeSoftmaxFunction, HeadDotFunction, SpmmFunction
+from ..._functions import GatEdgeSoftmaxFunction, HeadDotFunction, SpmmFunction, bias_act
 from ...edge_index import EdgeIndex, as_edge_index
 from ...utils import add_self_loops, remove_self_loops, softmax
 from ..dense.linear import Linear
@@ -165,7 +165,11 @@ class GATConv(MessagePassing):
         out = out.reshape(-1, H * C) if self.concat else out.mean(dim=1)
         if res is not None:
             out = out + res
-        if self.bias is not None:
+        # `fused_act` (set by BasicGNN for ReLU stacks): bias + the model's activation in one pass
+        fa = getattr(self, 'fused_act', None)
+        if fa is not None or (self.bias is not None and out.is_cuda):
+            out = bias_act(out, self.bias, fa == 'relu')
+        elif self.bias is not None:
             out = out + self.bias
         if return_attention_weights is None:
             return out

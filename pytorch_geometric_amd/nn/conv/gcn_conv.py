@@ -4,7 +4,7 @@ import torch
 from torch import Tensor
 from torch.nn import Parameter
 
-from ..._functions import SpmmFunction
+from ..._functions import SpmmFunction, bias_act
 from ...edge_index import EdgeIndex
 from ...utils import add_remaining_self_loops, scatter
 from ...utils.num_nodes import maybe_num_nodes
@@ -103,6 +103,10 @@ class GCNConv(MessagePassing):
             # IS a Tensor there): never aggregate an un-normalised handle silently
             edge_index, edge_weight = self._normalized_handle(x, edge_index, edge_weight)
         out = self.propagate(edge_index, x=self.lin(x), edge_weight=edge_weight)
+        # `fused_act` (set by BasicGNN for ReLU stacks): bias + the model's activation in one pass
+        fa = getattr(self, 'fused_act', None)
+        if fa is not None or (self.bias is not None and out.is_cuda):
+            return bias_act(out, self.bias, fa == 'relu')
         return out if self.bias is None else out + self.bias
 
     def message(self, x_j: Tensor, edge_weight: Optional[Tensor]) -> Tensor:

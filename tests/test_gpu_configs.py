@@ -84,13 +84,20 @@ def test_config3_gat_arxiv_shape(dev):
     # (leaky_relu runs once per edge and head, 9.3 M evaluations: a pre-activation within fp32
     # rounding of 0 is expected about once — see assert_close_rows)
     assert_close_rows(xg.grad, xr.grad, max_bad_rows=32, what='gat layer grad_x')
-    # parameter gradients are sums over all 9.3 M (edge, head) terms: ONE term whose leaky_relu
-    # pre-activation lies within fp32 rounding of 0 (expected about once at this size, on either
-    # device) changes slope 1 <-> 0.2 and moves these sums by up to ~1e-4 of their scale; an error
-    # in the kernels would show at 1e-2 .. 1 (and in `out` / the per-row check above)
-    assert_close_scaled(conv.att_src.grad, ps[1].grad, tol=2e-4, what='gat layer grad att_src')
-    assert_close_scaled(conv.att_dst.grad, ps[2].grad, tol=2e-4, what='gat layer grad att_dst')
-    assert_close_scaled(conv.lin.weight.grad, ps[0].grad, tol=2e-4, what='gat layer grad W')
+    # parameter gradients: sums over 169 k nodes / 9.3 M (edge, head) terms with heavy cancellation
+    # (|sum| ~ sqrt(N) x |term|): two correct fp32 evaluations differ by their summation order, and
+    # a leaky_relu pre-activation within rounding of 0 takes the other slope.  Judged against an
+    # fp64 evaluation, with the CPU fp32 reference's own distance to it as the yardstick.
+    p64 = [p.detach().double().requires_grad_(True) for p in ps]
+    x64 = x.double().requires_grad_(True)
+    O.gat_conv(x64, ei, p64[0], p64[1], p64[2], p64[3], 8, 32).backward(go.double())
+    for got, r32, r64, what in ((conv.att_src.grad, ps[1].grad, p64[1].grad, 'att_src'),
+                                (conv.att_dst.grad, ps[2].grad, p64[2].grad, 'att_dst'),
+                                (conv.lin.weight.grad, ps[0].grad, p64[0].grad, 'W')):
+        scale = max(float(r64.abs().max()), 1.0)
+        e_gpu = float((got.cpu().double() - r64).abs().max()) / scale
+        e_ref = float((r32.double() - r64).abs().max()) / scale
+        assert e_gpu <= max(2 * e_ref, 2e-5), f'gat layer grad {what}: {e_gpu:.2e} vs ref {e_ref:.2e}'
 
 
 def test_config5_rgcn_fb15k237_shape(dev):

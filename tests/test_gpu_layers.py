@@ -612,3 +612,39 @@ def test_key_range_is_validated_before_limited_bit_sorts(dev):
     ones = torch.sparse_coo_tensor(adj.indices(), torch.ones_like(adj.values()), (30, 30))
     out = pga.utils.spmm(ones.coalesce().to_sparse_csr(), x, 'max')
     assert out.shape == (30, 6)
+
+
+@pytest.mark.parametrize('kind', ['gcn', 'gat'])
+def test_basic_gnn_applies_bias_and_relu_in_the_layer(dev, kind):
+    """ReLU stacks of GCNConv / GATConv: the layer applies `out + bias` and the model's ReLU in ONE
+    pass (`fused_act`, _functions.BiasActFunction; backward = masked gradient + bias gradient from
+    one read) instead of an ATen add in the layer and an ATen clamp in the model.  Same values and
+    gradients as the unfused evaluation (LeakyReLU(0) is not a ReLU instance: no fusion), and a
+    layer called on its own afterwards still returns the reference's pre-activation output."""
+    from pytorch_geometric_amd.nn import GAT, GCN
+    from tests._util import assert_close_scaled, random_graph
+    g = gen(5)
+    n = 900
+    ei = random_graph(n, n, 12_000, seed=6).to(dev)
+    x = torch.randn(n, 24, generator=g).to(dev)
+    go = torch.randn(n, 6, generator=g).to(dev)
+    torch.manual_seed(3)
+    model = (GCN(24, 32, num_layers=3, out_channels=6) if kind == 'gcn'
+             else GAT(24, 32, num_layers=3, out_channels=6, heads=4)).to(dev)
+    for conv in model.convs:  # (zero-initialised biases would hide a dropped bias)
+        torch.nn.init.normal_(conv.bias, std=0.5)
+    res = []
+    for act in (torch.nn.ReLU(), torch.nn.LeakyReLU(0.0)):
+        model.act = act
+        model.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        out = model(xg, ei)
+        out.backward(go)
+        res.append((out.detach(), xg.grad, [p.grad.clone() for p in model.parameters()]))
+        assert all(getattr(c, 'fused_act', None) is None for c in model.convs)
+    assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-5, what='fused bias+ReLU output')
+    assert_close_scaled(res[0][1], res[1][1], what='fused bias+ReLU grad_x')
+    for a, b in zip(res[0][2], res[1][2]):
+        assert_close_scaled(a, b, what='fused bias+ReLU parameter gradient')
+    alone = model.convs[0](x, ei)
+    assert bool((alone < 0).any()), 'a layer called on its own must not apply the ReLU'

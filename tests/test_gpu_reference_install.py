@@ -370,3 +370,56 @@ def test_reference_node_loader_with_sampler_options(pyg, installed, dev):
             assert 'num_sampled_edges' not in b or b.num_sampled_edges is None
     with pytest.raises(NotImplementedError):
         installed.neighbor_sampler(data, [4, 2], subgraph_type='induced')
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'min', 'max'])
+@pytest.mark.parametrize('transpose', [False, True])
+def test_reference_torch_sparse_route_lands_on_this_backend(pyg, dev, monkeypatch, reduce,
+                                                            transpose):
+    """The reference's `_torch_sparse_spmm` (edge_index.py:1768-1810) — the route it takes on the
+    GPU when `torch_geometric.typing.WITH_TORCH_SPARSE` is on — calls
+    `torch.ops.torch_sparse.spmm_{sum,mean,min,max}`; with torch-sparse absent those names are
+    served by pytorch_geometric_amd/torch_sparse_ops.py.  NO backend.install() here: only the
+    operator names connect the two.  Values and gradients against the reference's CPU route."""
+    from pytorch_geometric_amd import torch_sparse_ops
+    if torch_sparse_ops.torch_sparse_present():
+        pytest.skip('the real torch-sparse owns the namespace in this environment')
+    assert torch_sparse_ops.register() is True
+    import torch_geometric.typing as pyg_typing
+    from torch_geometric import EdgeIndex
+    g = gen(12 + len(reduce))
+    n_src, n_dst, e = 300, 260, 4000
+    row = torch.randint(0, n_dst, (e, ), generator=g)
+    col = torch.randint(0, n_src, (e, ), generator=g)
+    if transpose:   # (n_src x n_dst)^T @ [n_src, F]: sorted by column
+        ei = torch.stack([col, row])
+        ei = ei[:, torch.argsort(ei[1] * n_src + ei[0])]
+        size, order = (n_src, n_dst), 'col'
+    else:
+        ei = torch.stack([row, col])
+        ei = ei[:, torch.argsort(ei[0] * n_src + ei[1])]
+        size, order = (n_dst, n_src), 'row'
+    x = torch.randn(n_src, 24, generator=g)
+    val = torch.rand(e, generator=g) if reduce in ('sum', 'mean') else None
+    go = torch.randn(n_dst, 24, generator=g)
+
+    def run(device, with_ts):
+        monkeypatch.setattr(pyg_typing, 'WITH_TORCH_SPARSE', with_ts)
+        adj = EdgeIndex(ei.to(device), sparse_size=size, sort_order=order)
+        xr = x.to(device).requires_grad_(True)
+        v = None if val is None else val.to(device).requires_grad_(True)
+        out = adj.matmul(xr, v, reduce=reduce, transpose=transpose)
+        out.backward(go.to(device))
+        return out.detach().cpu(), xr.grad.cpu(), None if v is None else v.grad.cpu()
+
+    sink = []
+    from pytorch_geometric_amd import _native
+    monkeypatch.setattr(_native, 'timing_sink', sink)
+    got = run(dev, True)
+    monkeypatch.setattr(_native, 'timing_sink', None)
+    assert any(info.get('reduce') == reduce for info, *_ in sink), 'no HIP SpMM launch was seen'
+    want = run('cpu', False)
+    assert_close(got[0], want[0], rtol=1e-5, atol=2e-5, what=f'{reduce} out')
+    assert_close(got[1], want[1], rtol=1e-5, atol=2e-5, what=f'{reduce} grad mat')
+    if val is not None:
+        assert_close(got[2], want[2], rtol=1e-5, atol=5e-5, what=f'{reduce} grad value')

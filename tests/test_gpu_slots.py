@@ -227,16 +227,18 @@ def test_slot_step_is_capturable_and_draws_fresh_batches(dev):
         for gb, p in zip(grads, model.parameters()):
             gb.copy_(p.grad)
 
-    cap = CapturedStep(step, warmup=2)       # epochs 1, 2 (warm-up) + 3 (capture)
+    cap = CapturedStep(step, warmup=2)       # (the capture itself records, it does not run)
     seen = []
     for _ in range(3):
-        cap()                                 # epochs 4, 5, 6
+        cap()
         torch.cuda.synchronize()
         seen.append((float(loss_buf), [gb.clone() for gb in grads]))
     assert len({round(s[0], 6) for s in seen}) == 3, 'replays did not draw new batches'
-    # eager twin of the last replay (same epoch, fresh loader state is not needed: epoch-stamped)
-    epoch.fill_(5)
-    step()                                    # -> epoch 6 again
+    # eager twin of the last replay: the same epoch again (claims are epoch-stamped, the sampler is
+    # a pure function of (seeds, epoch): nothing to reset)
+    last_epoch = int(epoch.item())
+    epoch.fill_(last_epoch - 1)
+    step()
     torch.cuda.synchronize()
     assert abs(float(loss_buf) - seen[-1][0]) <= 1e-5 * max(1.0, abs(seen[-1][0]))
     for a, c in zip(grads, seen[-1][1]):

