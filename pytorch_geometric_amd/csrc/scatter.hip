@@ -421,18 +421,21 @@ template <int VW>
 __global__ void __launch_bounds__(kBlock)
     bias_act_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ bias,
                     int64_t n_rows, int64_t units, int relu, float* __restrict__ out, int64_t ldo) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const int64_t r = t / units;
-  if (r >= n_rows) return;
-  const int64_t c = (t - r * units) * VW;
-  Vec<VW> v = load_vec<VW>(x + r * ldx + c);
+  const int64_t total = n_rows * units;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;  // (flat_grid caps the grid)
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t r = t / units;
+    const int64_t c = (t - r * units) * VW;
+    Vec<VW> v = load_vec<VW>(x + r * ldx + c);
 #pragma unroll
-  for (int i = 0; i < VW; ++i) {
-    float y = v.v[i] + (bias ? bias[c + i] : 0.f);
-    if (relu) y = (y > 0.f || y != y) ? y : 0.f;  // NaN propagates like torch.relu
-    v.v[i] = y;
+    for (int i = 0; i < VW; ++i) {
+      float y = v.v[i] + (bias ? bias[c + i] : 0.f);
+      if (relu) y = (y > 0.f || y != y) ? y : 0.f;  // NaN propagates like torch.relu
+      v.v[i] = y;
+    }
+    store_vec<VW>(out + r * ldo + c, v);
   }
-  store_vec<VW>(out + r * ldo + c, v);
 }
 
 extern "C" {

@@ -648,3 +648,9 @@ def test_basic_gnn_applies_bias_and_relu_in_the_layer(dev, kind):
         assert_close_scaled(a, b, what='fused bias+ReLU parameter gradient')
     alone = model.convs[0](x, ei)
     assert bool((alone < 0).any()), 'a layer called on its own must not apply the ReLU'
+    # the one-pass kernel on a block larger than its capped grid (grid-stride loop), strided input
+    from pytorch_geometric_amd import _native
+    big = torch.randn(300_000, 72, generator=g).to(dev)
+    b = torch.randn(64, generator=g).to(dev)
+    got = _native.bias_act(big[:, 4:68], b, True)
+    assert torch.equal(got, (big[:, 4:68] + b).relu())
