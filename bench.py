@@ -554,15 +554,19 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(loss_buf).item()
     # what the timed batches contained, recounted OUTSIDE the timed region (the captured step keeps
-    # no statistics): the sampler is a pure function of (seeds, epoch), so re-sampling a batch with
-    # its epoch reproduces it
+    # no statistics): the sampler is a pure function of (seeds, epoch) — the draws depend on them
+    # only — so a SECOND sampler with a fresh claim map, fed the same epochs in the same order,
+    # reproduces every batch (the first one's map already holds later epochs)
+    from pytorch_geometric_amd.slots import SlotSampler
     plan = loader._slots.plan
+    again = SlotSampler(loader._slots.colptr, loader._slots.row, loader.num_nodes, plan,
+                        seed=loader._slots.seed)
     hop_edges = torch.zeros(len(fan), dtype=torch.int64, device=dev)
     hop_nodes = torch.zeros(len(fan), dtype=torch.int64, device=dev)
     ep = torch.zeros(1, dtype=torch.int64, device=dev)
     for i, sd in enumerate(timed_seeds):
         ep.fill_(first_epoch + i)
-        sb = loader._slots.sample(sd, ep)
+        sb = again.sample(sd, ep)
         for h in range(len(fan)):
             hop_edges[h] += (sb.src_g[plan.ebase(h):plan.ebase(h + 1)] >= 0).sum()
             hop_nodes[h] += (sb.node_g[plan.bases[h + 1]:plan.bases[h + 2]] >= 0).sum()

@@ -668,7 +668,8 @@ PYGAMD_API int pygamd_slots_sample(const void* colptr, const void* row, int idx_
                                    int64_t* local_map, int64_t* src_g, int32_t* row_end,
                                    float* inv_cnt, void* stream);
 PYGAMD_API int pygamd_slots_resolve(const int64_t* src_g, int64_t slot_base, int64_t n_slots,
-                                    int64_t B, const int64_t* local_map, int32_t* src_id,
+                                    int64_t B, const int64_t* epoch_dev,
+                                    const int64_t* local_map, int32_t* src_id,
                                     int64_t* node_g, int32_t* const* counts /*[host]*/,
                                     int n_counts, void* stream);
 PYGAMD_API int pygamd_slots_gather(const float* x, int64_t ldx, int64_t F, const int64_t* node_g,

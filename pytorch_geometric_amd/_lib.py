@@ -134,7 +134,8 @@ SIGNATURES = {
     'pygamd_slots_seed': (c_int, [_P, c_int, c_int64, _P, _P, _P, _P]),
     'pygamd_slots_sample': (c_int, [_P, _P, c_int, _P, c_int64, c_int64, c_int, c_int64, c_int64,
                                     c_uint64, c_int, _P, _P, _P, _P, _P, _P]),
-    'pygamd_slots_resolve': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_int, _P]),
+    'pygamd_slots_resolve': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int,
+                                     _P]),
     'pygamd_slots_gather': (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
     'pygamd_slots_transpose': (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     'pygamd_edge_key': (c_int, [_P, _P, c_int, c_int64, c_int64, c_int, _P, _P]),

@@ -129,7 +129,8 @@ struct SlotCounters {
 // per-source edge counts of the transposed CSRs this hop belongs to
 __global__ void __launch_bounds__(kBlock)
     slots_resolve_kernel(const int64_t* __restrict__ src_g, int64_t slot_base, int64_t n_slots,
-                         int64_t B, const long long* __restrict__ local,
+                         int64_t B, const int64_t* __restrict__ epoch,
+                         const long long* __restrict__ local,
                          int32_t* __restrict__ src_id, int64_t* __restrict__ node_g,
                          SlotCounters counts, int n_counts) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -138,7 +139,10 @@ __global__ void __launch_bounds__(kBlock)
   const int64_t sg = src_g[slot];
   int64_t keep = -1;
   if (sg >= 0) {
-    const int64_t win = slot_key_id(local[sg]);
+    // (a claim of another epoch can only be there if the caller broke the contract — epochs must
+    // grow — and would name a row of some other batch: the slot then keeps its own node)
+    const long long key = local[sg];
+    const int64_t win = (static_cast<int64_t>(key) >> 32) == *epoch ? slot_key_id(key) : B + slot;
     src_id[slot] = static_cast<int32_t>(win);
     if (win == B + slot) keep = sg;  // this slot introduces the node: its row holds the features
     for (int c = 0; c < n_counts; ++c) atomicAdd(counts.p[c] + win, 1);
@@ -286,12 +290,12 @@ int pygamd_slots_sample(const void* colptr, const void* row, int idx_dtype, cons
 }
 
 int pygamd_slots_resolve(const int64_t* src_g, int64_t slot_base, int64_t n_slots, int64_t B,
-                         const int64_t* local_map, int32_t* src_id, int64_t* node_g,
-                         int32_t* const* counts, int n_counts, void* stream) {
+                         const int64_t* epoch_dev, const int64_t* local_map, int32_t* src_id,
+                         int64_t* node_g, int32_t* const* counts, int n_counts, void* stream) {
   if (n_slots < 0 || slot_base < 0 || n_counts < 0 || n_counts > kSlotMaxHops)
     return PYGAMD_ERR_INVALID_ARG;
   if (n_slots == 0) return PYGAMD_OK;
-  if (!src_g || !local_map || !src_id || !node_g || (n_counts > 0 && !counts))
+  if (!src_g || !epoch_dev || !local_map || !src_id || !node_g || (n_counts > 0 && !counts))
     return PYGAMD_ERR_INVALID_ARG;
   SlotCounters c = {};
   for (int i = 0; i < n_counts; ++i) {
@@ -299,7 +303,7 @@ int pygamd_slots_resolve(const int64_t* src_g, int64_t slot_base, int64_t n_slot
     c.p[i] = counts[i];
   }
   hipLaunchKernelGGL(slots_resolve_kernel, dim3(static_cast<unsigned>(ceil_div(n_slots, kBlock))),
-                     dim3(kBlock), 0, as_stream(stream), src_g, slot_base, n_slots, B,
+                     dim3(kBlock), 0, as_stream(stream), src_g, slot_base, n_slots, B, epoch_dev,
                      reinterpret_cast<const long long*>(local_map), src_id, node_g, c, n_counts);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;

@@ -152,7 +152,7 @@ class SlotSampler:
                 st), 'slots_sample')
             n_counts = max(p.L - 1 - h, 0)   # transposed CSRs c = 0 .. L - 2 - h contain hop h
             check(lib.pygamd_slots_resolve(
-                _i64p(self.src_g), p.ebase(h), p.cap[h + 1], p.B, _i64p(self.local),
+                _i64p(self.src_g), p.ebase(h), p.cap[h + 1], p.B, ep, _i64p(self.local),
                 _i64p(self.src_id), _i64p(self.node_g), self._counts_host, n_counts, st),
                 'slots_resolve')
         if p.n_csr > 0:
