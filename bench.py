@@ -1050,6 +1050,12 @@ def main():
                                          'ranks': [round(v, 3) for v in per_rank_ms]},
                 'process_group': dist.get_backend() if dist.is_initialized() else None,
                 'graph_gen_s': round(t_gen, 1),
+                # (short copies of the top-level `arithmetic` note and of the side figures: the
+                # driver's record keeps scalars and the first 120 characters of strings in here)
+                'arithmetic': ('3xbf16 split, 6 products, fp32 accumulate; err vs fp64 <= fp32 '
+                               'instruction (tests/test_gpu_split_accept.py)'
+                               if pga.get_gemm_mode() == 'split' else 'v_mfma_f32_32x32x2_f32'),
+                **side,
                 'gemm': gemm_desc(tuned),
                 'schedule': 'layers 1-2 forward AND layer 2 input gradient as ONE kernel each '
                             '(gather -> LDS -> MFMA); 256->47 layer transforms first, '

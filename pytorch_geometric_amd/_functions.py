@@ -134,6 +134,60 @@ class SpmmFunction(Function):
         return grad_x, grad_w, None, None, None
 
 
+# ---- large unsorted scatters: sort once, then a segment reduction ---------------------------------
+# The atomic scatter kernels move a cache line per 4-byte atomic: at the products shape
+# (E = 61.9 M rows of 256 floats) `scatter(msg, edge_index[1])` takes 206 ms = 0.04 of the HBM peak,
+# 311 ms for max (profiles/r04_unfused_propagate.md).  One stable radix sort of the index (a few ms,
+# cached per index tensor) turns the same call into a gather-SpMM over the sorted groups
+# (`col` = the sort permutation): 11.5 ms, deterministic.  Small inputs keep the atomics.
+SORTED_SCATTER_MIN_ROWS = 1 << 16
+SORTED_SCATTER_MIN_ELEMS = 1 << 23
+_scatter_plans = {}
+
+
+def _sorted_scatter_plan(index: Tensor, dim_size: int):
+    """(ptr [dim_size + 1], perm [n], hub) for `index`, cached by the identity + version of the
+    tensor it views (``edge_index[1]`` is a new view object on every call)."""
+    import weakref
+    base = index._base if index._base is not None else index
+    key = (id(base), index.storage_offset(), index.numel(), index.stride(0), index.dtype,
+           int(dim_size))
+    hit = _scatter_plans.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == index._version:
+        return hit[2]
+    lo, hi = _native.index_minmax(index)   # one host read per index tensor
+    if lo < 0 or hi >= dim_size:
+        _native._raise_out_of_range(index, dim_size, 'scatter', style='sync')
+    sorted_idx, perm = _native.index_sort(index, max_value=dim_size)
+    ptr = _native.index2ptr(sorted_idx, dim_size)
+    if perm.dtype != ptr.dtype:
+        perm = _native.cast_index(perm, ptr.dtype)
+    plan = (ptr, perm, _native.hub_plan(ptr))
+    if len(_scatter_plans) >= 8:
+        _scatter_plans.pop(next(iter(_scatter_plans)))
+    _scatter_plans[key] = (weakref.ref(base, lambda _, k=key: _scatter_plans.pop(k, None)),
+                           index._version, plan)
+    return plan
+
+
+def _use_sorted_scatter(rows: Tensor, index: Tensor, reduce: str) -> bool:
+    return (reduce in ('sum', 'mean', 'min', 'max') and index.numel() >= SORTED_SCATTER_MIN_ROWS
+            and rows.numel() >= SORTED_SCATTER_MIN_ELEMS and rows.dtype == torch.float32
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def _scatter_rows_auto(rows: Tensor, index: Tensor, dim_size: int, reduce: str,
+                       return_count: bool = False):
+    """`_native.scatter_rows` semantics; large inputs through the sorted route."""
+    if not _use_sorted_scatter(rows, index, reduce):
+        return _native.scatter_rows(rows, index, dim_size, reduce, return_count=return_count)
+    ptr, perm, hub = _sorted_scatter_plan(index, dim_size)
+    out = _native.spmm_csr(ptr, perm, rows, reduce, n_rows=dim_size, hub=hub)
+    if return_count:
+        return out, (ptr[1:] - ptr[:-1]).to(torch.float32)
+    return out
+
+
 class GatherFunction(Function):
     """``x.index_select(0, index)`` (message_passing.py:263-290); backward = scatter-add."""
 
@@ -147,8 +201,7 @@ class GatherFunction(Function):
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         (index,) = ctx.saved_tensors
-        g = _native.scatter_rows(_rows(grad_out), index, ctx.x_shape[0],
-                                 'sum')
+        g = _scatter_rows_auto(_rows(grad_out), index, ctx.x_shape[0], 'sum')
         return g.view(ctx.x_shape), None, None
 
 
@@ -160,17 +213,17 @@ class ScatterFunction(Function):
         s2 = _rows(src)
         ctx.reduce, ctx.src_shape = reduce, src.shape
         if reduce == 'mean':
-            out, count = _native.scatter_rows(s2, index, dim_size, reduce, return_count=True)
+            out, count = _scatter_rows_auto(s2, index, dim_size, reduce, return_count=True)
             ctx.save_for_backward(index, count)
         elif reduce in ('min', 'max', 'mul'):
             # the RETURNED tensor is what the backward compares against: saving it (not its 2-D
             # alias) lets autograd detect an in-place edit of the result
-            res = _shaped(_native.scatter_rows(s2, index, dim_size, reduce),
+            res = _shaped(_scatter_rows_auto(s2, index, dim_size, reduce),
                           (dim_size, *src.shape[1:]))
             ctx.save_for_backward(index, s2, res)
             return res
         else:
-            out = _native.scatter_rows(s2, index, dim_size, reduce)
+            out = _scatter_rows_auto(s2, index, dim_size, reduce)
             ctx.save_for_backward(index)
         return _shaped(out, (dim_size, *src.shape[1:]))
 

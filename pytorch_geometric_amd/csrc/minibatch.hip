@@ -178,6 +178,8 @@ struct SlotScans {
 };
 constexpr int kScanBlock = 1024;
 
+constexpr int kScanPer = 16;  // consecutive entries per thread and tile (four 16-byte loads)
+
 __global__ void __launch_bounds__(kScanBlock) slots_scan_kernel(SlotScans a) {
   __shared__ int wave_tot[kScanBlock / kWave];
   __shared__ int carry;
@@ -187,10 +189,27 @@ __global__ void __launch_bounds__(kScanBlock) slots_scan_kernel(SlotScans a) {
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  for (int64_t base = 0; base < n; base += kScanBlock) {  // coalesced tiles, carried total
-    const int64_t i = base + threadIdx.x;
-    const int v = i < n ? in[i] : 0;
-    int inc = v;
+  // tiles of 16 k entries: a thread sums its 16 consecutive entries, the sums are scanned across
+  // the workgroup (wave scan + 16 wave totals through LDS), the thread writes its 16 prefixes
+  for (int64_t base = 0; base < n; base += static_cast<int64_t>(kScanBlock) * kScanPer) {
+    const int64_t i0 = base + static_cast<int64_t>(threadIdx.x) * kScanPer;
+    int v[kScanPer];
+    if (i0 + kScanPer <= n && (reinterpret_cast<uintptr_t>(in + i0) & 15u) == 0) {
+      typedef int i4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int q = 0; q < kScanPer / 4; ++q) {
+        const i4 t = *reinterpret_cast<const i4*>(in + i0 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kScanPer; ++q) v[q] = i0 + q < n ? in[i0 + q] : 0;
+    }
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) sum += v[q];
+    int inc = sum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
       const int t = __shfl_up(inc, off, kWave);
@@ -200,7 +219,12 @@ __global__ void __launch_bounds__(kScanBlock) slots_scan_kernel(SlotScans a) {
     __syncthreads();
     int before = carry;
     for (int w = 0; w < wave; ++w) before += wave_tot[w];
-    if (i < n) out[i] = before + inc - v;
+    int run = before + inc - sum;  // exclusive prefix of this thread's first entry
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) {
+      if (i0 + q < n) out[i0 + q] = run;
+      run += v[q];
+    }
     __syncthreads();
     if (threadIdx.x == kScanBlock - 1) carry = before + inc;
     __syncthreads();

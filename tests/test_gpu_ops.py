@@ -1122,3 +1122,51 @@ def test_spmm_from_compressed_rows_is_bit_exact(dev, dtype, F, monkeypatch):
     with pytest.raises(ValueError):
         _native.spmm_csr(h.ptr, h.idx, z[:, :F], 'sum', n_rows=n_dst, hub=h.hub,
                          compressed_width=F)
+
+
+def test_large_unsorted_scatter_takes_the_sorted_route(dev, monkeypatch):
+    """`utils.scatter` on a large unsorted index: one cached radix sort + a segment reduction
+    instead of E x F float atomics (the literal north_star path at the products shape: 206 ms ->
+    sort + 11.5 ms, profiles/r04_unfused_propagate.md).  Same values as the atomic kernels
+    (max / min exactly, sums to fp32 rounding) and as the CPU, same gradients; the plan is cached per
+    index tensor — also through fresh views like `edge_index[1]` — and dropped when the index is
+    edited in place; out-of-range indices raise."""
+    from pytorch_geometric_amd import _functions, _native
+    from pytorch_geometric_amd.utils import scatter
+    g = gen(77)
+    n, e, F = 5000, 140_000, 64
+    ei = torch.stack([torch.randint(0, n, (e, ), generator=g),
+                      (torch.rand(e, generator=g).pow(3) * n).long()]).to(dev)
+    src = torch.randn(e, F, generator=g).to(dev)
+    assert _functions._use_sorted_scatter(src, ei[1], 'sum')
+    sorts = {'n': 0}
+    real = _native.index_sort
+
+    def counted(*a, **k):
+        sorts['n'] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(_native, 'index_sort', counted)
+    for reduce in ('sum', 'mean', 'max', 'min'):
+        s = src.clone().requires_grad_(True)
+        out = scatter(s, ei[1], 0, n, reduce)
+        go = torch.randn(n, F, generator=g).to(dev)
+        out.backward(go)
+        want_s = src.cpu().clone().requires_grad_(True)
+        want = torch.zeros(n, F).scatter_reduce(0, ei[1].cpu().view(-1, 1).expand(-1, F), want_s,
+                                                {'sum': 'sum', 'mean': 'mean', 'max': 'amax',
+                                                 'min': 'amin'}[reduce], include_self=False)
+        want.backward(go.cpu())
+        assert_close(out, want.detach(), rtol=1e-5, atol=2e-5, what=f'sorted scatter {reduce}')
+        assert_close(s.grad, want_s.grad, rtol=1e-5, atol=2e-5, what=f'sorted scatter {reduce} grad')
+        atom = _native.scatter_rows(src, ei[1], n, reduce)
+        if reduce in ('max', 'min'):
+            assert torch.equal(out.detach(), atom)
+        else:
+            assert_close(out, atom, rtol=1e-5, atol=2e-5, what='sorted vs atomic')
+    assert sorts['n'] == 1, 'the sort must be cached across calls and across views of the index'
+    ei[1, 0] = (ei[1, 0] + 1) % n          # in-place edit: the cached plan is stale
+    scatter(src, ei[1], 0, n, 'sum')
+    assert sorts['n'] == 2
+    with pytest.raises(IndexError):
+        scatter(src, ei[1], 0, n // 2, 'sum')
