@@ -44,7 +44,10 @@ __global__ void __launch_bounds__(kBlock)
   const bool replace = (flags & 1) != 0;
   // flags & 2: the draws depend on the frontier position too (disjoint trees)
   const uint64_t salt = (flags & 2) ? mix64(0xD1B54A32D192ED03ull * static_cast<uint64_t>(f + 1)) : 0;
-  if (seed_dev) seed += *seed_dev;  // (a captured graph bumps this word between replays)
+  // (a captured graph bumps this word between replays.  It is mixed in on its own, not added:
+  // the host seed is rng * 1000003 + hop, so `seed + word` would hand hop h + 1 of one replay the
+  // stream of hop h of the next — ADVICE r3)
+  if (seed_dev) seed = mix64(seed ^ mix64(*seed_dev * 0x9E3779B97F4A7C15ull));
   const uint64_t key = mix64(seed ^ mix64(static_cast<uint64_t>(v)) ^ salt);
   if (replace) {  // cnt = k independent draws from the deg in-neighbours (deg > 0 here)
     if (lane < cnt) {

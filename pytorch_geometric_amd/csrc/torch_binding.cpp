@@ -15,6 +15,7 @@
 // when the operands are plain HIP fp32 / int tensors and falls back to its own (validating,
 // error-typed) Python path otherwise.
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -62,6 +63,18 @@ inline int64_t ld(const Tensor& t) {
 }
 inline Tensor contig(const OptTensor& t) { return has(t) ? t->contiguous() : Tensor(); }
 
+// index tensors reach the kernels as raw pointers: same device and dtype as `like`, contiguous
+inline void check_index(const Tensor& t, const Tensor& like, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.device() == like.device(), "'", name, "' must live on ",
+              like.device());
+  TORCH_CHECK(t.is_contiguous(), "'", name, "' must be contiguous");
+  TORCH_CHECK(t.scalar_type() == like.scalar_type(), "'", name, "' must have the index dtype of '",
+              "rowptr' (", like.scalar_type(), "), got ", t.scalar_type());
+}
+inline void check_index(const OptTensor& t, const Tensor& like, const char* name) {
+  if (has(t)) check_index(*t, like, name);
+}
+
 // ---- CSR SpMM (pygamd_spmm_csr) ---------------------------------------------------------------
 // Every operator WRITES into tensors the caller allocated (the `out=` convention: mutable arguments
 // in the schema, nothing returned) — an operator that may or may not alias its result to an
@@ -72,6 +85,12 @@ void spmm_csr(const Tensor& rowptr, const OptTensor& col, const Tensor& x, int64
               int64_t n_hub, int64_t n_chunks, int64_t hub_threshold, int64_t hub_chunk,
               Tensor out, bool accumulate, int64_t hub_phase, const OptTensor& arg32,
               const OptTensor& relu_mask, const OptTensor& relu_bits) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(rowptr.device());
+  check_index(rowptr, rowptr, "rowptr");
+  check_index(col, rowptr, "col");
+  check_index(eid, rowptr, "eid");
+  check_index(hub_rows, rowptr, "hub_rows");
+  check_index(hub_cptr, rowptr, "hub_chunk_ptr");
   const Tensor x2 = rows_f32(x, "x");
   const int64_t F = x2.size(1);
   if (n_rows < 0) n_rows = rowptr.numel() - 1;
@@ -144,6 +163,7 @@ void spmm_csr(const Tensor& rowptr, const OptTensor& col, const Tensor& x, int64
 // ---- dense transform (csrc/gemm.hip) --------------------------------------------------------------
 void linear_forward(const Tensor& x, const Tensor& w, const OptTensor& bias, bool relu, Tensor out,
                     bool accumulate) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());
   const Tensor x2 = rows_f32(x, "x"), w2 = rows_f32(w, "weight");
   const int64_t M = x2.size(0), K = x2.size(1), N = w2.size(0);
   TORCH_CHECK(w2.size(1) == K, "'x' has ", K, " columns but 'weight' expects ", w2.size(1));
@@ -164,6 +184,7 @@ void linear_forward(const Tensor& x, const Tensor& w, const OptTensor& bias, boo
 void linear_dgrad(const Tensor& g, const Tensor& w_t, const OptTensor& row_scale, int64_t n_scaled,
                   Tensor out, bool accumulate, const OptTensor& relu_mask,
                   const OptTensor& relu_bits, const OptTensor& out_scaled) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(g.device());
   const Tensor g2 = rows_f32(g, "grad"), w2 = rows_f32(w_t, "weight_t");
   const int64_t M = g2.size(0), N = g2.size(1), K = w2.size(0);
   TORCH_CHECK(w2.size(1) == N, "'grad' has ", N, " columns but 'weight_t' expects ", w2.size(1));
@@ -200,6 +221,7 @@ void linear_dgrad(const Tensor& g, const Tensor& w_t, const OptTensor& row_scale
 // out [N, K1 + K2]; grad_b [N] (optional: the column sums of g from the same pass)
 void linear_wgrad(const Tensor& g, const Tensor& x, Tensor out, bool accumulate,
                   int64_t wgs_per_cu, const OptTensor& grad_b, const OptTensor& x2_) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(g.device());
   const Tensor g2 = rows_f32(g, "grad"), first = rows_f32(x, "x");
   Tensor second;
   if (has(x2_)) second = rows_f32(*x2_, "x2");
@@ -236,6 +258,11 @@ void sage_layer_fused(const Tensor& rowptr, const OptTensor& col, const Tensor& 
                         const OptTensor& relu_bits, const OptTensor& mask_bits,
                         const OptTensor& row_scale, const OptTensor& out_scaled, int64_t variant,
                         int64_t probe) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(rowptr.device());
+  check_index(rowptr, rowptr, "rowptr");
+  check_index(col, rowptr, "col");
+  check_index(hub_rows, rowptr, "hub_rows");
+  check_index(hub_cptr, rowptr, "hub_chunk_ptr");
   const Tensor xg = rows_f32(x_gather, "x"), xr = rows_f32(x_root, "x_root");
   const Tensor w2 = rows_f32(w, "weight");
   const int64_t n_rows = rowptr.numel() - 1, F = xg.size(1), Fo = w2.size(0);
@@ -313,6 +340,7 @@ void sage_layer_fused(const Tensor& rowptr, const OptTensor& col, const Tensor& 
 
 // ---- index / gather side -------------------------------------------------------------------------------
 Tensor index2ptr(const Tensor& index, int64_t size) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(index.device());
   const Tensor idx = index.contiguous();
   Tensor out = at::empty({size + 1}, idx.options());
   check(pygamd_index2ptr(ptr(idx), idx_dtype(idx), idx.numel(), size, ptr(out), cur_stream(idx)),
@@ -321,6 +349,7 @@ Tensor index2ptr(const Tensor& index, int64_t size) {
 }
 
 Tensor ptr2index(const Tensor& p, int64_t n) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(p.device());
   const Tensor pc = p.contiguous();
   Tensor out = at::empty({n}, pc.options());
   check(pygamd_ptr2index(ptr(pc), idx_dtype(pc), pc.numel() - 1, n, ptr(out), cur_stream(pc)),
@@ -329,6 +358,7 @@ Tensor ptr2index(const Tensor& p, int64_t n) {
 }
 
 Tensor gather_rows(const Tensor& x, const Tensor& index) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());
   const Tensor x2 = rows_f32(x, "x"), idx = index.contiguous();
   const int64_t n = idx.numel(), F = x2.size(1);
   Tensor out = at::empty({n, F}, x2.options());
@@ -341,6 +371,7 @@ Tensor gather_rows(const Tensor& x, const Tensor& index) {
 void gather_scatter_add(const Tensor& x, const Tensor& gather_idx, const Tensor& scatter_idx,
                         const OptTensor& scale, const OptTensor& w, Tensor out,
                         const OptTensor& n_valid) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());
   const Tensor x2 = rows_f32(x, "x");
   const int64_t F = x2.size(1);
   TORCH_CHECK(out.dim() == 2 && out.size(1) == F && out.scalar_type() == at::kFloat &&
@@ -356,6 +387,7 @@ void gather_scatter_add(const Tensor& x, const Tensor& gather_idx, const Tensor&
 
 Tensor sddmm_csr(const Tensor& rowptr, const OptTensor& col, const OptTensor& eid,
                  const Tensor& grad_out, const Tensor& x, int64_t n_edges, int64_t w_heads) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(rowptr.device());
   const Tensor g2 = rows_f32(grad_out, "grad_out"), x2 = rows_f32(x, "x");
   const int64_t F = x2.size(1);
   Tensor grad_w = at::zeros({n_edges, w_heads}, x2.options());
@@ -369,6 +401,7 @@ Tensor sddmm_csr(const Tensor& rowptr, const OptTensor& col, const OptTensor& ei
 
 // ---- segment softmax -----------------------------------------------------------------------------------
 Tensor segment_softmax_forward(const Tensor& src, const Tensor& p) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(src.device());
   const Tensor s2 = src.contiguous();
   Tensor out = at::empty_like(s2);
   check(pygamd_segment_softmax_forward(fptr(s2), ptr(p), idx_dtype(p), p.numel() - 1, s2.size(1),
@@ -378,6 +411,7 @@ Tensor segment_softmax_forward(const Tensor& src, const Tensor& p) {
 }
 
 Tensor segment_softmax_backward(const Tensor& out, const Tensor& grad_out, const Tensor& p) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(out.device());
   const Tensor o2 = out.contiguous(), g2 = grad_out.contiguous();
   Tensor grad_src = at::empty_like(o2);
   check(pygamd_segment_softmax_backward(fptr(o2), fptr(g2), ptr(p), idx_dtype(p), p.numel() - 1,

@@ -56,10 +56,20 @@ dst_sorted = _native.ptr2index(fwd.ptr, E)       # destination of every sorted s
 src_sorted = fwd.idx                             # its source
 src_u, dst_u = ei[0].contiguous(), ei[1].contiguous()
 b = 8
+from pytorch_geometric_amd import _functions  # noqa: E402
+from pytorch_geometric_amd.utils import scatter as u_scatter  # noqa: E402
+_t0, _t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+_t0.record()
+_functions._sorted_scatter_plan(dst_u, N)
+_t1.record()
+torch.cuda.synchronize()
+SORT_MS = _t0.elapsed_time(_t1)
 print(f'# The unfused propagate path at the products shape (N = {N}, E = {E}, int64 indices, fp32), '
       f'one MI355X\n')
 print('`python scripts/unfused_probe.py`: every launch timed alone (3 repetitions after one '
       'warm-up), algorithmic bytes as in the docstring, fraction of the 8 TB/s HBM peak.\n')
+print(f'One-time cost of the cached plan `utils.scatter` builds for the unsorted index (stable radix '
+      f'sort of E int64 keys + pointer + hub plan + one host read): {SORT_MS:.1f} ms.\n')
 print('| F | step | index | kernel(s) | ms | GB | GB/s | frac of 8 TB/s |')
 print('|---:|---|---|---|---:|---:|---:|---:|')
 g = torch.Generator(device=dev).manual_seed(0)
@@ -92,6 +102,12 @@ for F in [int(v) for v in args.widths.split(',')]:
                 fn = (lambda r=reduce: _native.scatter_rows(msg, dst, N, r))
                 kern = f'scatter_rows_kernel<{reduce}> (atomics)'
             row(f'scatter-{reduce} onto edge_index[1]', name, kern, timeit(fn), gb_scatter)
+            if not srt:
+                # what `utils.scatter` does since round 4 for a large unsorted index: one cached
+                # radix sort of the index, then a gather-SpMM over the sorted groups
+                row(f'scatter-{reduce} via utils.scatter (cached sort + segment reduction)', name,
+                    'spmm rows kernels, col = sort permutation',
+                    timeit(lambda r=reduce: u_scatter(msg, dst, 0, N, r)), gb_scatter + E * 8 / 1e9)
         # backward of scatter-sum: grad_msg = grad_out[edge_index[1]]; of the gather: scatter-add
         # of grad_msg onto edge_index[0] (never sorted when the list is destination-sorted)
         gmsg = _native.gather_rows(go, dst)
