@@ -85,19 +85,23 @@ if fetch and write:
             by_symbol[sym] = (2 * fv + wv) * 1024
             detail[sym] = {'FETCH_SIZE_KiB': fv, 'WRITE_SIZE_KiB': wv}
     F = 256
-    alg = E * (4 * F + 8) + (N + 1) * 8 + N * 4 * F + N * 4 * F + N * 4 * F
+    # DESIGN §3 / bench.py fused_algorithmic_bytes: the forward launch (aggregated rows stored) and
+    # the input-gradient launch (row-scaled second output instead); the counters average over both
+    fwd = E * (4 * F + 8) + (N + 1) * 8 + 3 * N * 4 * F + N * 4 * (F // 32)
+    bwd = E * (4 * F + 8) + (N + 1) * 8 + 3 * N * 4 * F + N * 4 * (F // 32)
+    alg = (fwd + bwd) / 2
     extra = {}
     key = 'sage_fused_split_kernel<long,64>'
     if key in by_symbol:
-        extra = {'dominant_kernel': key,
-                 'algorithmic_bytes_forward_launch': alg,
-                 'traffic_over_algorithmic_forward': round(by_symbol[key] / alg, 4),
-                 'note': 'the counter average runs over the forward launch (aggregated rows '
-                         'stored: 71.46 GB algorithmic) and the input-gradient launch (68.95 GB); '
-                         'their mean is 70.21 GB'}
+        extra = {'dominant_kernel': key, 'algorithmic_bytes_per_launch_mean': alg,
+                 'traffic_over_algorithmic': round(by_symbol[key] / alg, 4),
+                 'note': 'average over the forward launches (gather + root rows + stored '
+                         'aggregated rows + output + ReLU bits) and the input-gradient launches '
+                         '(gather + root rows + output + its row-scaled copy + mask bits); the '
+                         'weight term planes (768 KiB per launch) stay in L2'}
     with open(os.path.join(P, 'r04_pmc_bench.json'), 'w') as f:
         json.dump({'source': src, 'units': units,
                    'workload': {'scale': 1.0, 'index_dtype': 'int64', 'graph': 'power-law', 'N': N,
                                 'E': E},
                    'traffic_bytes_per_launch': by_symbol, 'counters': detail, **extra}, f, indent=1)
-    print('wrote profiles/r04_pmc_bench.json', extra.get('traffic_over_algorithmic_forward'))
+    print('wrote profiles/r04_pmc_bench.json', extra.get('traffic_over_algorithmic'))
