@@ -352,7 +352,9 @@ __device__ __forceinline__ void spec_half(const SageFusedArgs<IdxT>& a, const fl
                                           const bool (&col_ok)[NB], int lh,
                                           const int* wait_p, int wait_target, int* abort_flag,
                                           f32x16 (&acc)[NB]) {
-  constexpr int D = 4;
+  // (ring depth: 4 steps with one column block per wave; 2 with two — round 3's depth 4 spilled
+  // 16-17 registers there under the 128-register cap of a 1024-thread workgroup)
+  constexpr int D = NB >= 2 ? 2 : 4;
   const int F = static_cast<int>(a.g.F);
   const int n_steps = 4 * (F / kFK);  // steps of the full chunks
   const float* wp[NB];
