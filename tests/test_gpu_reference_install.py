@@ -368,8 +368,15 @@ def test_reference_node_loader_with_sampler_options(pyg, installed, dev):
             fwd_keys = set((loc[1] * m + loc[0]).tolist())
             assert fwd_keys == set((loc[0] * m + loc[1]).tolist())  # every edge has its reverse
             assert 'num_sampled_edges' not in b or b.num_sampled_edges is None
-    with pytest.raises(NotImplementedError):
-        installed.neighbor_sampler(data, [4, 2], subgraph_type='induced')
+    for b in batches(subgraph_type='induced'):   # every graph edge between the batch's nodes
+        nid = b.n_id.cpu()
+        inb = torch.zeros(N, dtype=torch.bool)
+        inb[nid] = True
+        want = int((inb[ei[0]] & inb[ei[1]]).sum())
+        assert b.edge_index.size(1) == want and b.e_id.numel() == want
+        loc = b.edge_index.cpu()
+        assert torch.equal(nid[loc[0]], ei[0, b.e_id.cpu()])
+        assert torch.equal(nid[loc[1]], ei[1, b.e_id.cpu()])
 
 
 @pytest.mark.parametrize('reduce', ['sum', 'mean', 'min', 'max'])

@@ -410,5 +410,40 @@ def test_bidirectional_subgraph_type(dev):
             assert (int(node[r]), int(node[c])) in ((s_, t_), (t_, s_))
             if c * m + r in fwd:                            # sampled in this direction: its own id
                 assert (int(node[r]), int(node[c])) == (s_, t_)
-    with pytest.raises(NotImplementedError):
-        NeighborSampler(ei.to(dev), n, [2], subgraph_type='induced')
+    with pytest.raises(ValueError):  # the reference's rule (sampler/neighbor_sampler.py:486-489)
+        NeighborSampler(ei.to(dev), n, [2], subgraph_type='induced', disjoint=True)
+
+
+def test_induced_subgraph_type(dev):
+    """`subgraph_type='induced'` (loader/neighbor_loader.py:146-147): the nodes of the directional
+    sample, and ALL edges of the graph between them — the reference's `utils.subgraph(node,
+    edge_index)` edge set (utils/_subgraph.py:103-107: both end points in `node`), relabelled to
+    batch positions, with their original edge ids."""
+    from pytorch_geometric_amd.sampler import NeighborSampler
+    g = gen(12)
+    n, e = 600, 6000
+    ei = torch.stack([torch.randint(0, n, (e, ), generator=g), torch.randint(0, n, (e, ),
+                                                                              generator=g)])
+    ei[1, :400] = 7                                     # a hub destination
+    seeds = torch.randperm(n, generator=g)[:40]
+    for fan in ([3, 2], [-1], [4]):
+        d = NeighborSampler(ei.to(dev), n, fan, seed=3).sample_from_nodes(seeds.to(dev), seed=9)
+        b = NeighborSampler(ei.to(dev), n, fan, seed=3,
+                            subgraph_type='induced').sample_from_nodes(seeds.to(dev), seed=9)
+        assert torch.equal(b.node, d.node) and b.num_sampled_nodes == d.num_sampled_nodes
+        assert b.num_sampled_edges is None
+        node = b.node.cpu()
+        inb = torch.zeros(n, dtype=torch.bool)
+        inb[node] = True
+        want = (inb[ei[0]] & inb[ei[1]]).nonzero().squeeze(1)       # edge ids of the induced set
+        got = b.edge.cpu()
+        assert torch.equal(torch.sort(got).values, want)
+        # local indices name the end points of exactly that edge
+        assert torch.equal(node[b.row.cpu()], ei[0, got]) and torch.equal(node[b.col.cpu()],
+                                                                          ei[1, got])
+        # grouped by destination in batch order
+        col = b.col.cpu()
+        assert bool((col[1:] >= col[:-1]).all())
+        # the map is clean afterwards: the next directional sample is unaffected
+        d2 = NeighborSampler(ei.to(dev), n, fan, seed=3).sample_from_nodes(seeds.to(dev), seed=9)
+        assert torch.equal(d2.node, d.node)
