@@ -186,13 +186,18 @@ def _fused_propagate(conv, edge_index, size, kwargs):
     """Returns the aggregated tensor, or NotImplemented when this call must take the reference
     path."""
     from ._functions import SpmmFunction
-    from .edge_index import as_edge_index
+    from .edge_index import EdgeIndex as Handle, as_edge_index
     # `fuse` is False for layers without `message_and_aggregate` (GATConv,
     # message_passing.py:154); for the others it stays the user's off switch
     fuse = True if type(conv).__name__ == 'GATConv' else getattr(conv, 'fuse', True)
     if not (_enabled() and fuse) or getattr(conv, 'explain', False):
         return NotImplemented
-    if not _ours_index(edge_index):
+    # this package's handle (a Tensor subclass) keeps its sorted forms; any other subclass (the
+    # reference's own EdgeIndex) stays on the reference path
+    handle = edge_index if isinstance(edge_index, Handle) else None
+    if handle is not None and not (handle.is_cuda and conv.flow == 'source_to_target'):
+        return NotImplemented
+    if handle is None and not _ours_index(edge_index):
         return NotImplemented
     if conv._propagate_forward_pre_hooks or conv._propagate_forward_hooks:
         return NotImplemented
@@ -237,7 +242,12 @@ def _fused_propagate(conv, edge_index, size, kwargs):
         n_dst = s_dst if s_dst is not None else n_dst
     if n_dst is None:
         n_dst = n_src
-    graph = as_edge_index(edge_index, n_src, n_dst, flip=not s2t)
+    if handle is not None:
+        if handle.sparse_size != (n_src, n_dst):
+            return NotImplemented
+        graph = handle
+    else:
+        graph = as_edge_index(edge_index, n_src, n_dst, flip=not s2t)
     reduce = 'sum' if aggr == 'add' else aggr
     if weight is not None and weight.dim() == 1 and x_src.dim() > 2:
         return NotImplemented

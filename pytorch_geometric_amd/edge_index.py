@@ -2,9 +2,15 @@
 source), the two stable permutations and the hub plans the SpMM kernels need.
 
 Mirrors the cache of the reference's ``EdgeIndex`` (torch_geometric/edge_index.py:589-696:
-``get_indptr`` / ``_sort_by_transpose`` / ``get_csr`` / ``get_csc`` / ``fill_cache_``) but is a plain
-object, not a Tensor subclass.  Message flow is ``source_to_target``: ``edge_index[0]`` = source j,
-``edge_index[1]`` = destination i (collect.jinja:31,67-68).
+``get_indptr`` / ``_sort_by_transpose`` / ``get_csr`` / ``get_csc`` / ``fill_cache_``).  Like the
+reference's (edge_index.py:173 ``class EdgeIndex(Tensor)``) the handle IS the ``[2, E]`` tensor: a
+``torch.Tensor`` subclass sharing the storage of the edge list it was built from, so it can be
+indexed, passed to ``torch`` functions and handed to code that expects a plain ``edge_index``.
+Unlike the reference it does not dispatch: ``__torch_function__`` is disabled, every ``torch``
+operation on a handle returns a plain tensor and the cache stays on the Python object (the
+sorted forms are used by this package's kernels, never rebuilt by an intercepted ``aten`` op).
+Message flow is ``source_to_target``: ``edge_index[0]`` = source j, ``edge_index[1]`` =
+destination i (collect.jinja:31,67-68).
 
 All integer outputs are bit-exact with ``torch.sort(stable=True)`` +
 ``torch._convert_indices_from_coo_to_csr`` (tests/test_gpu_graph.py).
@@ -62,7 +68,11 @@ def build_csr(key: Tensor, other: Tensor, n_rows: int, n_cols: int,
     return CSR(ptr, idx, perm, n_rows, n_cols)
 
 
-class EdgeIndex:
+def _plain(edge_index: Tensor) -> Tensor:
+    return edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
+
+
+class EdgeIndex(Tensor):
     r"""COO edge list of a (bipartite) graph with lazily built, cached sorted forms.
 
     Args:
@@ -74,8 +84,14 @@ class EdgeIndex:
         validate: range-check the indices against ``sparse_size`` once (two host syncs).
     """
 
-    def __init__(self, edge_index: Tensor, sparse_size: Optional[Tuple[int, int]] = None,
-                 sort_order: Optional[str] = None, validate: bool = True):
+    # every torch operation on a handle sees (and returns) a plain tensor
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def __new__(cls, edge_index: Tensor, sparse_size: Optional[Tuple[int, int]] = None,
+                sort_order: Optional[str] = None, validate: bool = True):
+        if not isinstance(edge_index, Tensor):
+            raise ValueError(f"'edge_index' must be a Tensor (got {type(edge_index)})")
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError(f"'edge_index' needs to be of shape [2, num_edges] "
                              f"(got {list(edge_index.shape)})")
@@ -84,6 +100,13 @@ class EdgeIndex:
                              f"(got '{edge_index.dtype}', expected int32 or int64)")
         if sort_order not in (None, 'row', 'col'):
             raise ValueError(f"invalid sort_order '{sort_order}'")
+        # shares storage, strides and version counter with `edge_index` (like nn.Parameter)
+        return Tensor._make_subclass(cls, _plain(edge_index), False)
+
+    def __init__(self, edge_index: Tensor, sparse_size: Optional[Tuple[int, int]] = None,
+                 sort_order: Optional[str] = None, validate: bool = True):
+        edge_index = _plain(edge_index)
+        # the plain tensor the handle was built from: what kernels, caches and `narrow` use
         self.edge_index = edge_index
         if sparse_size is None or sparse_size[0] is None or sparse_size[1] is None:
             n = 0
@@ -151,7 +174,8 @@ class EdgeIndex:
 
     def record_stream(self, stream) -> None:
         """Tell the caching allocator that `stream` uses the tensors of this handle (a handle
-        built on a side stream — the prefetching loader — and consumed on another)."""
+        built on a side stream — the prefetching loader — and consumed on another).  Covers
+        ``Tensor.record_stream`` of the handle itself: it shares ``edge_index``'s storage."""
         tensors = [self.edge_index]
         for csr in (self._csr, self._csc):
             if csr is not None:
@@ -195,10 +219,6 @@ class EdgeIndex:
     @property
     def num_dst_nodes(self) -> int:
         return self.sparse_size[1]
-
-    @property
-    def device(self):
-        return self.edge_index.device
 
     def by_dst(self) -> CSR:
         """ptr over destinations, idx = sources (``get_csc`` in the reference's row/col naming:
@@ -291,9 +311,49 @@ class EdgeIndex:
             self._slot_map = inv[bwd.perm.long()].contiguous()
         return self._slot_map
 
+    # -- tensor protocol -------------------------------------------------------------------------
+    def as_tensor(self) -> Tensor:
+        """The plain ``[2, E]`` tensor (``EdgeIndex.as_tensor``, edge_index.py:904-909)."""
+        return self.edge_index
+
+    def to(self, *args, **kwargs):
+        """Device / dtype moves keep the handle (sizes and sort order; the sorted forms are
+        rebuilt lazily on the new device); a move to a non-index dtype returns a plain tensor."""
+        out = self.edge_index.to(*args, **kwargs)
+        if out is self.edge_index:
+            return self
+        if out.dtype not in (torch.int32, torch.int64):
+            return out
+        moved = EdgeIndex(out, self.sparse_size, sort_order=self.sort_order, validate=False)
+        moved.atomic_backward = self.atomic_backward
+        return moved
+
+    def cuda(self, *args, **kwargs):
+        return self.to(torch.device('cuda', *args), **kwargs) if args else self.to('cuda', **kwargs)
+
+    def cpu(self):
+        return self.to('cpu')
+
+    def __deepcopy__(self, memo):
+        out = EdgeIndex(self.edge_index.clone(), self.sparse_size, sort_order=self.sort_order,
+                        validate=False)
+        out.atomic_backward = self.atomic_backward
+        memo[id(self)] = out
+        return out
+
+    def __reduce_ex__(self, protocol):
+        return (_rebuild, (self.edge_index, self.sparse_size, self.sort_order,
+                           self.atomic_backward))
+
     def __repr__(self) -> str:
         return (f'EdgeIndex(num_edges={self.num_edges}, sparse_size={self.sparse_size}, '
                 f'sort_order={self.sort_order})')
+
+
+def _rebuild(edge_index, sparse_size, sort_order, atomic_backward):
+    out = EdgeIndex(edge_index, sparse_size, sort_order=sort_order, validate=False)
+    out.atomic_backward = atomic_backward
+    return out
 
 
 # ---- cache for raw ``edge_index`` tensors ------------------------------------------------------

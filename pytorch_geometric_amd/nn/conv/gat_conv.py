@@ -116,13 +116,14 @@ class GATConv(MessagePassing):
             a_src = (x_src * self.att_src).sum(dim=-1)
             a_dst = None if x_dst is None else (x_dst * self.att_dst).sum(dim=-1)
 
-        if self.add_self_loops and isinstance(edge_index, Tensor):
+        if self.add_self_loops and isinstance(edge_index, Tensor) \
+                and not isinstance(edge_index, EdgeIndex):
             n = x_src.size(0) if x_dst is None else min(x_src.size(0), x_dst.size(0))
             n = min(size) if size is not None else n
             edge_index, edge_attr = self._with_self_loops(edge_index, edge_attr, n)
         elif self.add_self_loops and isinstance(edge_index, EdgeIndex):
-            # handles get the same remove + add self-loops treatment as tensors (the reference's
-            # EdgeIndex is a Tensor and takes that branch, gat_conv.py:334-347)
+            # handles get the same remove + add self-loops treatment as tensors (the reference
+            # takes one branch for both, gat_conv.py:334-347); the result is cached on the handle
             handle = edge_index
             n = min(handle.sparse_size) if size is None else min(size)
 

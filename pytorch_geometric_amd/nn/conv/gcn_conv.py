@@ -96,12 +96,12 @@ class GCNConv(MessagePassing):
                              f"input while this layer does not support bipartite message "
                              f"passing. Please try other layers such as 'SAGEConv' or "
                              f"'GraphConv' instead")
-        if self.normalize and isinstance(edge_index, Tensor):
-            edge_index, edge_weight = self._normalized(x, edge_index, edge_weight)
-        elif self.normalize and isinstance(edge_index, EdgeIndex):
-            # the reference normalises its EdgeIndex inputs too (gcn_conv.py:241-258, EdgeIndex
-            # IS a Tensor there): never aggregate an un-normalised handle silently
+        if self.normalize and isinstance(edge_index, EdgeIndex):
+            # the reference normalises its EdgeIndex inputs too (gcn_conv.py:241-258): never
+            # aggregate an un-normalised handle silently.  Checked first: a handle IS a Tensor
             edge_index, edge_weight = self._normalized_handle(x, edge_index, edge_weight)
+        elif self.normalize and isinstance(edge_index, Tensor):
+            edge_index, edge_weight = self._normalized(x, edge_index, edge_weight)
         out = self.propagate(edge_index, x=self.lin(x), edge_weight=edge_weight)
         # `fused_act` (set by BasicGNN for ReLU stacks): bias + the model's activation in one pass
         fa = getattr(self, 'fused_act', None)

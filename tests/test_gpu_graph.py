@@ -76,6 +76,41 @@ def test_edge_index_handles(dev, dtype, golden):
     assert torch.equal(fwd.perm[m.long()], bwd.perm)
 
 
+def test_edge_index_handle_is_a_tensor(dev):
+    """``class EdgeIndex(Tensor)`` in the reference (edge_index.py:173): the handle can be indexed,
+    passed to torch functions and to this package's own layers / utilities like the plain
+    ``[2, E]`` tensor it shares storage with; operations return plain tensors."""
+    import copy
+    import pickle
+
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd.nn import GATConv, GCNConv, SAGEConv
+    from pytorch_geometric_amd.utils import sort_edge_index
+    ei = random_graph(300, 300, 4000, seed=3).to(dev)
+    h = pga.EdgeIndex(ei, (300, 300))
+    assert isinstance(h, torch.Tensor) and h.is_cuda and h.shape == ei.shape
+    assert h.data_ptr() == ei.data_ptr() and h.as_tensor() is ei
+    assert type(h[0]) is torch.Tensor and torch.equal(h[1], ei[1])
+    assert type(h + 1) is torch.Tensor and torch.equal(torch.stack([h[0], h[1]]), ei)
+    assert torch.equal(sort_edge_index(h, num_nodes=300), sort_edge_index(ei, num_nodes=300))
+    h32 = h.to(torch.int32)
+    assert isinstance(h32, pga.EdgeIndex) and h32.sparse_size == (300, 300)
+    assert h32.dtype == torch.int32 and h.to(dev) is h
+    assert type(h.to(torch.float32)) is torch.Tensor
+    for twin in (copy.deepcopy(h), pickle.loads(pickle.dumps(h))):
+        assert isinstance(twin, pga.EdgeIndex) and twin.sparse_size == h.sparse_size
+        assert torch.equal(twin, ei)
+    x = torch.randn(300, 16, device=dev)
+    torch.manual_seed(0)
+    for conv in (SAGEConv(16, 8), GCNConv(16, 8), GATConv(16, 4, heads=2)):
+        conv = conv.to(dev)
+        assert_close(conv(x, h), conv(x, ei), rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError, match='shape'):
+        pga.EdgeIndex(torch.zeros(3, 4, dtype=torch.long, device=dev))
+    with pytest.raises(ValueError, match='data type'):
+        pga.EdgeIndex(torch.zeros(2, 4, device=dev))
+
+
 def test_presorted_edge_index(dev):
     import pytorch_geometric_amd as pga
     ei = random_graph(50, 60, 1000, seed=7)

@@ -430,3 +430,32 @@ def test_reference_torch_sparse_route_lands_on_this_backend(pyg, dev, monkeypatc
     assert_close(got[1], want[1], rtol=1e-5, atol=2e-5, what=f'{reduce} grad mat')
     if val is not None:
         assert_close(got[2], want[2], rtol=1e-5, atol=5e-5, what=f'{reduce} grad value')
+
+
+def test_reference_convs_accept_this_packages_edge_index_handle(pyg, installed, launches, dev):
+    """The handle is a Tensor subclass (as the reference's EdgeIndex is): the reference's layers
+    take it where they take ``edge_index``; SAGEConv / GraphConv aggregate on its cached sorted
+    forms (no sort per call), GCNConv / GATConv see a plain tensor after their own rewrite."""
+    import pytorch_geometric_amd as pga
+    from torch_geometric.nn import GATConv, GCNConv, GraphConv, SAGEConv
+    g = gen(11)
+    n, e = 257, 3000
+    x = torch.randn(n, 16, generator=g).to(dev)
+    ei = torch.randint(0, n, (2, e), generator=g).to(dev)
+    handle = pga.EdgeIndex(ei.clone(), (n, n))
+    assert isinstance(handle, torch.Tensor) and type(handle[0]) is torch.Tensor
+    torch.manual_seed(0)
+    for name, conv in [('sage', SAGEConv(16, 12)), ('graphconv', GraphConv(16, 12, aggr='max')),
+                       ('gcn', GCNConv(16, 12)), ('gat', GATConv(16, 4, heads=2))]:
+        conv = conv.to(dev)
+        go = torch.randn(n, conv(x, ei).size(1), generator=g)
+        want = _fwd_bwd(conv, (x, ei), go)
+        before, sorts = len(launches['sink']), launches['sorts']
+        got = _fwd_bwd(conv, (x, handle), go)
+        assert len(launches['sink']) > before, f'{name}: no SpMM launch with the handle'
+        if name in ('sage', 'graphconv'):
+            _fwd_bwd(conv, (x, handle), go)
+            assert launches['sorts'] - sorts <= 2, f'{name}: the handle was re-sorted per call'
+        assert_close(got[0], want[0], rtol=1e-5, atol=2e-5, what=f'{name} out')
+        for a, b in zip(got[1] + got[2], want[1] + want[2]):
+            assert_close_scaled(a, b, tol=2e-5, what=f'{name} grads')

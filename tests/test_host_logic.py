@@ -158,3 +158,26 @@ def test_propagate_hooks_run_without_a_gpu():
     post = conv.register_propagate_forward_hook(lambda m, i, o: o)
     assert len(conv._propagate_forward_hooks) == 1
     post.remove()
+
+
+def test_edge_index_handle_tensor_protocol_on_the_host():
+    """The handle is a Tensor subclass sharing its edge list's storage (edge_index.py:173 in the
+    reference); no kernel is needed for the protocol itself."""
+    import copy
+    import pickle
+
+    import pytorch_geometric_amd as pga
+    ei = torch.tensor([[0, 1, 2, 2], [1, 2, 0, 1]])
+    h = pga.EdgeIndex(ei, (3, 3), validate=False)
+    assert isinstance(h, torch.Tensor) and h.data_ptr() == ei.data_ptr()
+    assert h.as_tensor() is ei and h.num_edges == 4 and h.sparse_size == (3, 3)
+    assert type(h[0]) is torch.Tensor and type(h.flip(0)) is torch.Tensor
+    ei[0, 0] = 2  # in-place writes are seen by both, and by the version counter
+    assert int(h[0, 0]) == 2 and h._version == ei._version
+    assert h.to('cpu') is h and isinstance(h.to(torch.int32), pga.EdgeIndex)
+    assert type(h.to(torch.float32)) is torch.Tensor
+    for twin in (copy.deepcopy(h), pickle.loads(pickle.dumps(h))):
+        assert isinstance(twin, pga.EdgeIndex) and twin.sparse_size == (3, 3)
+        assert torch.equal(twin, ei) and twin.data_ptr() != ei.data_ptr()
+    assert pga.EdgeIndex(h, (3, 3), validate=False).as_tensor() is ei  # no handle-of-handle
+    assert pga.as_edge_index(h) is h
