@@ -27,6 +27,19 @@ PYGAMD_API int pygamd_lab_sage_layer_fused(const pygamd_spmm_args* graph,
                                            int probe, void* workspace, size_t workspace_bytes,
                                            void* stream);
 
+/* Schedule of pygamd_linear_wgrad / _wgrad2 in the split arithmetic (process-wide, like
+ * pygamd_set_gemm_mode):
+ *   variant 0  production: the staging threads split every operand element once on its way into
+ *              LDS (k-contiguous bf16 planes, one ds_read_b128 per fragment and term);
+ *   variant 1  round 3's schedule: fp32 rows in LDS, every wave splits its own fragments in
+ *              registers next to the matrix instructions.  Bitwise variant 0 for the weight
+ *              gradient (same terms, same order); the bias gradient differs in summation order;
+ *   2 / 4 / 8 (or-ed) timing probes of variant 0 on 16-byte-aligned operands, results
+ *              undefined: no matrix products / no conversion and LDS stores / no global loads;
+ *   32 (+ 8)   variant 0 with the residual subtractions as v_pk_add_f32 (what the compiler
+ *              emits unforced; same results).                                                  */
+PYGAMD_API int pygamd_lab_set_wgrad_variant(int variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,9 @@ SOURCES = ['capi.hip', 'graph.hip', 'spmm.hip', 'scatter.hip', 'softmax.hip', 's
 ARCH = 'gfx950'
 FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
+# Per-file additions (none at present; -fno-slp-vectorize on sage_fused.hip — no v_pk_add_f32 in
+# the gather loop — was measured neutral to slightly negative, profiles/r04_fused_noslp_probe.txt).
+EXTRA_FLAGS = {}
 
 
 def find_hipcc():
@@ -51,6 +54,7 @@ def source_hash():
             with open(p, 'rb') as f:
                 h.update(f.read())
     h.update(' '.join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -81,7 +85,7 @@ def build_library(force=False, verbose=True):
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src_path), headers_mtime)):
             return obj
-        cmd = [hipcc] + FLAGS + ['-c', src_path, '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', src_path, '-o', obj]
         if verbose:
             print('[pyg_amd build]', ' '.join(cmd), file=sys.stderr, flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)

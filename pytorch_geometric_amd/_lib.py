@@ -182,6 +182,7 @@ SIGNATURES = {
 LAB_SIGNATURES = {
     'pygamd_lab_sage_layer_fused': (c_int, [POINTER(SpmmArgs), POINTER(SageFusedArgs), c_int,
                                             c_int, _P, c_size_t, _P]),
+    'pygamd_lab_set_wgrad_variant': (c_int, [c_int]),
 }
 
 _lib = None

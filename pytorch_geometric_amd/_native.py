@@ -1177,6 +1177,12 @@ def set_gemm_mode(mode: str) -> str:
     return prev
 
 
+def lab_set_wgrad_variant(variant: int) -> None:
+    """LAB (include/pyg_amd_lab.h): 0 = production split weight gradient (operands split once on
+    their way into LDS), 1 = round 3's in-register schedule.  Tests and probes only."""
+    check(_lib.load().pygamd_lab_set_wgrad_variant(int(variant)), 'lab_set_wgrad_variant')
+
+
 def get_gemm_mode() -> str:
     code = _lib.load().pygamd_get_gemm_mode()
     return next(k for k, v in _lib.GEMM_MODES.items() if v == code)

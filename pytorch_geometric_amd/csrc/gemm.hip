@@ -29,6 +29,7 @@
 // (deterministic, no atomics).  Workgroups of one split are adjacent on one XCD: each row of g and
 // x leaves HBM once.
 #include "split_bf16.h"
+#include "../../include/pyg_amd_lab.h"
 
 namespace pygamd {
 
@@ -470,6 +471,7 @@ struct GemmTN {
   int N, K;
   int tiles_n, tiles_k, splits;
   int64_t rows_per_split;       // multiple of kWRows
+  int vec_g, vec_x, vec_x2;     // (split kernel) 16-byte loads are legal for this operand
 };
 
 // eight k values gathered one by one (the TN kernel's operands run DOWN the staged rows)
@@ -729,6 +731,333 @@ __global__ void __launch_bounds__(kBlock, 2) gemm_tn_kernel(GemmTN p) {
   }
 }
 
+// ---- TN, split arithmetic, operands converted ONCE ------------------------------------------------
+// The kernel above splits its operands in registers next to the matrix instructions: a lane
+// gathers eight values DOWN a staged column (eight ds_read_b32) and converts them, and the two
+// waves that share a column range convert the same values twice — the VALU, not the matrix pipe,
+// sets its pace (123 TFLOP/s of the 417 the six-term product allows, profiles/r04_bench_kernel_
+// stats.md).  Here the staging thread converts: it owns eight consecutive rows of four columns
+// (eight 16-byte global loads), splits them into the three bf16 terms as (row, row + 1) pairs and
+// writes, per column and term, ONE 16-byte vector of eight k-consecutive bf16 values — the layout
+// the operand read wants, so a fragment is ONE ds_read_b128 per term.  Per 32-row block and
+// thread: 16 split_pair (176 VALU instructions, half of before), 12 ds_write_b128, and per wave
+// 24 ds_read_b128 for 48 matrix instructions.
+//
+// LDS image of a wave group: [operand g | x][term 0..2][column 0..127][20 dwords]: 32 rows of a
+// column are 16 packed dwords, padded to 20 so that (i) the 16 lanes of a ds_read_b128 group,
+// which read 16 different columns at the same row group, start at 16 different 4-bank slots
+// (5 * column mod 16 is a bijection) and (ii) the eight lanes of a ds_write_b128 group — two
+// neighbouring column quads x four row groups, see `c4` / `rg` below — cover all 32 banks.
+//
+// Schedule: ONE 512-thread workgroup per CU = two groups of four waves (one wave of each group on
+// every SIMD), each with its own image (2 x 61,440 bytes), accumulators and half of the split's
+// blocks (group A the even ones, group B the odd ones; B's sums are added to A's through LDS at
+// the end).  The groups run in ANTI-PHASE, held there by the workgroup barrier: while A converts
+// block 2 i (VALU, LDS stores), B multiplies block 2 i - 1 (matrix pipe), then the roles swap.  Two
+// independent 256-thread workgroups per CU do not do this by themselves — they start together
+// and stay IN phase (both convert, then both multiply: measured, phases switched off one by one,
+// profiles/r04_wgrad_probe.txt: products alone 1.86 ms, conversion alone 1.46 ms, loads alone
+// 1.77 ms, all three 4.17 ms on the 2.45 M x (256 | 256) -> 256 gradient).
+constexpr int kCLD = 20;                 // dwords per staged column
+constexpr int kCPlane = kWTile * kCLD;   // dwords per (operand, term) plane
+constexpr int kTnGroup = 6 * kCPlane;    // dwords per wave group
+constexpr size_t kTnSplitLds = sizeof(uint32_t) * 2 * kTnGroup;
+constexpr int kTnThreads = 512;
+
+// PROBE (lab, timing only — results undefined for bits 1..3): bit 1 = no products, bit 2 = no
+// conversion / LDS stores, bit 3 = no global loads, bit 5 = packed residual subtractions
+// split_pair with the four residual subtractions pinned to single v_sub_f32: left to itself the
+// compiler packs them into two v_pk_add_f32, and a packed fp32 instruction in one wave stalls the
+// matrix instructions of the OTHER wave on the same SIMD (measured on the 2.45 M x 512 x 256
+// gradient with the loads switched off: conversion + products 3.26 ms packed = the sum of the two
+// alone, 2.57 ms with v_sub_f32; profiles/r04_wgrad_probe.txt)
+__device__ __forceinline__ float sub_f32_asm(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split_pair_scalar(float x0, float x1, uint32_t (&t)[3]) {
+  const uint32_t a = pack_bf16(x0, x1);
+  const float r0 = sub_f32_asm(x0, __uint_as_float(a << 16));
+  const float r1 = sub_f32_asm(x1, __uint_as_float(a & 0xffff0000u));
+  const uint32_t b = pack_bf16(r0, r1);
+  const float s0 = sub_f32_asm(r0, __uint_as_float(b << 16));
+  const float s1 = sub_f32_asm(r1, __uint_as_float(b & 0xffff0000u));
+  t[0] = a;
+  t[1] = b;
+  t[2] = pack_bf16(s0, s1);
+}
+
+template <bool VG, bool VX, int PROBE = 0>
+__global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) {
+  extern __shared__ __align__(16) uint32_t tn_lds[];
+  const int64_t b = blockIdx.x;
+  const int64_t per_xcd = gridDim.x >> 3;
+  const int64_t q = (b & 7) * per_xcd + (b >> 3);
+  const int tiles = p.tiles_n * p.tiles_k;
+  const int64_t split = q / tiles;
+  if (split >= p.splits) return;
+  const int t = static_cast<int>(q - split * tiles);
+  const int tn = t / p.tiles_k, tk = t - tn * p.tiles_k;
+  const int n0 = tn * kWTile;
+  const bool two = p.K1 < p.K;
+  const bool second = two && tk >= p.tiles_k1;
+  const float* __restrict__ xsrc = second ? p.x2 : p.x;
+  const int64_t xld = second ? p.ldx2 : p.ldx;
+  const int k0 = (second ? tk - p.tiles_k1 : tk) * kWTile;
+  const int Kop = second ? p.K - p.K1 : p.K1;
+  const int kout0 = (second ? p.K1 : 0) + k0;
+  const int64_t ra = split * p.rows_per_split;
+  int64_t rb = ra + p.rows_per_split;
+  rb = rb < p.M ? rb : p.M;
+  // (readfirstlane: the roles and everything derived from them live in scalar registers, so the
+  // role branches below are scalar branches)
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  uint32_t* const planes = tn_lds + grp * kTnGroup;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // staging (per group): waves 0, 1 stage g (columns 0..63, 64..127 of the tile), waves 2, 3
+  // stage x.  Lane bits: 0 = low bit of the column quad, 1..2 = row group (8 rows), 3..5 = high
+  // bits of the quad: a load instruction of a wave fetches 4 rows x 256 contiguous bytes.
+  const bool isx = wave >= 2;
+  const int c4 = (lane & 1) + 2 * (lane >> 3);
+  const int rg = (lane >> 1) & 3;
+  const int tc = 64 * (wave & 1) + 4 * c4;              // first of the thread's 4 tile columns
+  const float* __restrict__ src = isx ? xsrc : p.g;
+  const int64_t sld = isx ? xld : p.ldg;
+  const int col_lim = isx ? Kop - k0 : p.N - n0;        // valid columns of this tile (> 0)
+  const int col0 = isx ? k0 : n0;
+  // 16-byte loads per operand (VG: g; VX: x and x2): a 47-column g next to 256-column x's keeps
+  // the wide loads for the x's (scalar branch; folded when VG == VX)
+  const bool vec = isx ? VX : VG;
+  // Loads are UNCONDITIONAL (columns clamped to the tile's last valid one, the rows of a split's
+  // ragged last block to its last row) and the masks are applied to the values when they are
+  // converted: a predicated load makes the compiler wait for the whole batch right behind it
+  // (s_waitcnt vmcnt(0) after the last load of the block: no prefetch at all).
+  bool cok[4];
+  int64_t coff[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cok[e] = tc + e < col_lim;
+    coff[e] = col0 + (cok[e] ? tc + e : col_lim - 1);
+  }
+  const int64_t voff = col0 + (cok[0] ? tc : 0);  // (vector rows: the whole quad is valid or not)
+  const bool ragged_cols = !(cok[0] && cok[3]);  // some column of the thread is staged as zero
+  const float* const tp = src + (ra + 8 * rg) * sld;  // the thread's first row
+  // full blocks only (splits are multiples of 32 rows: only the LAST split has a ragged block,
+  // handled after the loops)
+  auto load_rows = [&](f32x4 (&st)[8], int64_t blk) {
+    if constexpr ((PROBE & 8) != 0) return;
+    const float* bp = tp + blk * kWRows * sld;
+    if (vec) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) st[r] = *reinterpret_cast<const f32x4*>(bp + r * sld + voff);
+    } else {
+      // four 4-byte loads off ONE row address (rows that are not 16-byte aligned: a 47-column
+      // g).  A quad that straddles the operand's last column reads up to three elements of the
+      // NEXT row (masked when converted) — which is why the block holding the operand's very
+      // last row always takes load_tail's exact addresses (`exact_tail` below).
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float* rp = bp + r * sld + voff;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st[r][e] = rp[e];
+      }
+    }
+  };
+  auto load_tail = [&](f32x4 (&st)[8], int64_t r0) {  // rows clamped to the last one
+    const int64_t last = rb - 1;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int64_t row = r0 + 8 * rg + r;
+      row = row < last ? row : last;
+      const float* sp = src + row * sld;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st[r][e] = sp[coff[e]];
+    }
+  };
+  const bool do_colsum = p.colsum != nullptr && tk == 0;  // workgroup-uniform
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  uint32_t* const wbase = planes + (isx ? 3 * kCPlane : 0) + tc * kCLD + 4 * rg;
+  auto store_rows = [&](f32x4 (&st)[8], int64_t r_end) {  // rows >= r_end are staged as zero
+    if constexpr ((PROBE & 4) != 0) return;
+    if (ragged_cols || r_end < INT64_MAX) {  // (thread-varying / uniform; edges only)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const bool rok = 8 * rg + r < r_end;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st[r][e] = (rok && cok[e]) ? st[r][e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      u32x4 w[3];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        uint32_t tt[3];
+        // (single v_sub_f32, see split_pair_scalar; PROBE bit 5 = the packed subtraction)
+        if constexpr ((PROBE & 32) != 0) split_pair(st[2 * qq][cc], st[2 * qq + 1][cc], tt);
+        else split_pair_scalar(st[2 * qq][cc], st[2 * qq + 1][cc], tt);
+        w[0][qq] = tt[0];
+        w[1][qq] = tt[1];
+        w[2][qq] = tt[2];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        *reinterpret_cast<u32x4*>(wbase + k * kCPlane + cc * kCLD) = w[k];
+    }
+    if (do_colsum && !isx) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) csum += st[r];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // wave-uniform: this wave's column ranges are not empty (columns past N / K inside a range are
+  // staged as zeros, so all four 32 x 32 blocks are computed)
+  const bool active = n0 + wn * 64 < p.N && k0 + wk * 64 < Kop;
+  // fragment of step s (rows 16 s + 8 lh .. + 7), term k, 32-column block i: one 16-byte read
+  const uint32_t* const ga = planes + (wn * 64 + li) * kCLD + 4 * lh;
+  const uint32_t* const xb = planes + 3 * kCPlane + (wk * 64 + li) * kCLD + 4 * lh;
+  auto frag = [&](const uint32_t* base, int i, int s) {
+    SplitFrag f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      f.p[k] = __builtin_bit_cast(
+          bf16x8, *reinterpret_cast<const u32x4*>(base + k * kCPlane + i * 32 * kCLD + 8 * s));
+    return f;
+  };
+  auto products = [&]() {
+    if constexpr ((PROBE & 2) != 0) return;
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const SplitFrag a0 = frag(ga, 0, s), a1 = frag(ga, 1, s);
+        const SplitFrag b0 = frag(xb, 0, s), b1 = frag(xb, 1, s);
+#pragma unroll
+        for (int k = 0; k < kSplitTerms; ++k) {
+          split_term(k, a0, b0, acc[0][0]);
+          split_term(k, a0, b1, acc[0][1]);
+          split_term(k, a1, b0, acc[1][0]);
+          split_term(k, a1, b1, acc[1][1]);
+        }
+      }
+    }
+  };
+
+  const int64_t n_rows = rb > ra ? rb - ra : 0;
+  // blocks of the pipelined loops: the full ones — minus the one that holds the operands' last
+  // row when some operand is read element-wise (see load_rows)
+  constexpr bool exact_tail = !(VG && VX);
+  const int64_t n_blocks = (exact_tail && rb == p.M && n_rows > 0) ? (n_rows - 1) / kWRows
+                                                                    : n_rows / kWRows;
+  const int64_t n_iter = (n_blocks + 1) / 2;  // group A: block 2 i, group B: block 2 i + 1
+  const int64_t last_blk = n_blocks - 1;
+  auto blk_of = [&](int64_t i) {  // this group's block of iteration i, clamped (re-loads)
+    const int64_t bi = 2 * i + grp;
+    return bi < last_blk ? bi : last_blk;
+  };
+  auto end_of = [&](int64_t i) {  // B has no block in the last iteration of an odd count: zeros
+    return 2 * i + grp < n_blocks ? INT64_MAX : static_cast<int64_t>(0);
+  };
+  // Two register sets per thread: the loads of iteration i + 1 are issued at the start of
+  // iteration i, by BOTH groups at the same point of the code — before the role branches — and
+  // unconditionally (prefetches past the end re-load the last block): s_waitcnt vmcnt counts
+  // loads in issue order, so every path into a wait must have issued the same loads in the same
+  // order, or the compiler has to wait for the NEWEST batch (measured: with a predicated load, or
+  // with the two roles as two separate loops, the prefetch collapses to none).
+  //   interval:   2 i                      2 i + 1
+  //   group A     convert block 2 i        multiply block 2 i
+  //   group B     multiply block 2 i - 1   convert block 2 i + 1
+  f32x4 sta[8], stb[8];
+  if constexpr ((PROBE & 8) != 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sta[r] = stb[r] = f32x4{1.f, 2.f, 3.f, 4.f};
+  }
+  const bool is_a = grp == 0;  // scalar
+  if (n_iter > 0) load_rows(sta, blk_of(0));
+  for (int64_t i = 0; i + 1 < n_iter; i += 2) {
+    load_rows(stb, blk_of(i + 1));
+    if (is_a) store_rows(sta, INT64_MAX); else if (i > 0) products();
+    __syncthreads();
+    if (is_a) products(); else store_rows(sta, end_of(i));
+    __syncthreads();
+    load_rows(sta, blk_of(i + 2));
+    if (is_a) store_rows(stb, INT64_MAX); else products();
+    __syncthreads();
+    if (is_a) products(); else store_rows(stb, end_of(i + 1));
+    __syncthreads();
+  }
+  if (n_iter & 1) {
+    if (is_a) store_rows(sta, INT64_MAX); else if (n_iter > 1) products();
+    __syncthreads();
+    if (is_a) products(); else store_rows(sta, end_of(n_iter - 1));
+    __syncthreads();
+  }
+  if (!is_a && n_iter > 0) products();  // B's last block
+  const int64_t tail_rows = n_rows - n_blocks * kWRows;  // 0..32, workgroup-uniform
+  if (tail_rows > 0) {  // the last split's ragged (or exactly addressed) block: group A
+    if (grp == 0) {
+      load_tail(sta, ra + n_blocks * kWRows);
+      store_rows(sta, tail_rows);
+    }
+    __syncthreads();
+    if (grp == 0) products();
+  }
+  // B's sums and both groups' bias-gradient partials go to A through LDS
+  __syncthreads();  // every product is done: the images are free
+  float* const cmb = reinterpret_cast<float*>(tn_lds);          // [4 waves][64][64 lanes]
+  float* const red = cmb + 4 * 64 * 64;                         // [2 groups][4 row groups][128]
+  if (grp == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          cmb[((wave * 4 + i * 2 + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+  }
+  if (do_colsum && !isx)
+    *reinterpret_cast<f32x4*>(&red[(grp * 4 + rg) * kWTile + tc]) = csum;
+  __syncthreads();
+  if (grp == 1) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        acc[i][j][e] += cmb[((wave * 4 + i * 2 + j) * 16 + e) * 64 + lane];
+  if (do_colsum && threadIdx.x < kWTile && n0 + static_cast<int>(threadIdx.x) < p.N) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r * kWTile + threadIdx.x];
+    p.colsum[split * p.N + n0 + threadIdx.x] = s;
+  }
+  float* __restrict__ slab = p.partial + split * static_cast<int64_t>(p.N) * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (k0 + wk * 64 + j * 32 + li >= Kop) continue;
+      const int col = kout0 + wk * 64 + j * 32 + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row < p.N) slab[static_cast<int64_t>(row) * p.K + col] = acc[i][j][e];
+      }
+    }
+  }
+}
+
 // out[n, k] (+)= sum over splits, in split order (deterministic)
 __global__ void __launch_bounds__(kBlock)
     gemm_tn_reduce_kernel(const float* __restrict__ partial, int splits, int64_t NK, int K,
@@ -786,6 +1115,7 @@ static int launch_nt(GemmNT p, bool vec, hipStream_t st) {
 }
 
 static int g_gemm_mode = 0;  // pygamd_set_gemm_mode
+static int g_wgrad_variant = 0;  // pygamd_lab_set_wgrad_variant
 
 // Shape of an NT launch: the tile and the number of K slices.  Outputs with >= kFillTiles tiles of
 // the large shape fill the chip by their rows alone (the full-batch layers); below that — sampled
@@ -859,6 +1189,13 @@ int pygamd_set_gemm_mode(int mode) {
 }
 
 int pygamd_get_gemm_mode(void) { return g_gemm_mode; }
+
+int pygamd_lab_set_wgrad_variant(int variant) {
+  if (variant < 0 || variant > 63 || ((variant & 1) && variant != 1))
+    return PYGAMD_ERR_INVALID_ARG;
+  g_wgrad_variant = variant;
+  return PYGAMD_OK;
+}
 
 int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
                           const float* bias, int64_t M, int64_t K, int64_t N, int relu,
@@ -978,16 +1315,44 @@ int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ld
   p.tiles_k1 = static_cast<int>(ceil_div(K1, kWTile));
   p.tiles_k = p.tiles_k1 + static_cast<int>(ceil_div(K2, kWTile));
   const int64_t tiles = static_cast<int64_t>(p.tiles_n) * p.tiles_k;
+  // the production split kernel: one 512-thread workgroup per CU (two wave groups share a
+  // split): half as many splits for the same number of waves
+  const bool split_once = g_gemm_mode == PYGAMD_GEMM_SPLIT_BF16 && !(g_wgrad_variant & 1);
   p.splits = static_cast<int>(wgrad_splits(M, tiles, wgs_per_cu));
+  if (split_once) p.splits = (p.splits + 1) / 2;
   p.colsum = bias_grad ? p.partial + static_cast<int64_t>(p.splits) * N * K : nullptr;
   p.rows_per_split = round_up(ceil_div(M > 0 ? M : 1, p.splits), kWRows);
   const bool vec = (N % 4 == 0) && (K1 % 4 == 0) && (K2 % 4 == 0) && (ldg % 4 == 0) &&
                    (ldx % 4 == 0) && (ldx2 % 4 == 0) && aligned16p(g) && aligned16p(x) &&
                    aligned16p(x2);
+  // (the split kernel decides per operand: a 47-column g next to 256-column x's keeps the wide
+  // loads for the x's)
+  p.vec_g = (N % 4 == 0) && (ldg % 4 == 0) && aligned16p(g);
+  p.vec_x = (K1 % 4 == 0) && (ldx % 4 == 0) && aligned16p(x);
+  p.vec_x2 = (K2 % 4 == 0) && (ldx2 % 4 == 0) && aligned16p(x2);
   const int64_t blocks = round_up(tiles * p.splits, 8);
-  const size_t lds = sizeof(float) * 4 * kWRows * kWLD;
+  size_t lds = sizeof(float) * 4 * kWRows * kWLD;
+  int threads = kBlock;
   void (*kern)(GemmTN) = nullptr;
-  if (g_gemm_mode == PYGAMD_GEMM_SPLIT_BF16) {
+  if (split_once) {
+    const bool vx = p.vec_x && p.vec_x2;
+    kern = p.vec_g ? (vx ? gemm_tn_split_kernel<true, true> : gemm_tn_split_kernel<true, false>)
+                   : (vx ? gemm_tn_split_kernel<false, true> : gemm_tn_split_kernel<false, false>);
+    switch (g_wgrad_variant) {  // lab: timing probes of the all-vector variant
+      case 2: kern = gemm_tn_split_kernel<true, true, 2>; break;
+      case 4: kern = gemm_tn_split_kernel<true, true, 4>; break;
+      case 6: kern = gemm_tn_split_kernel<true, true, 6>; break;
+      case 8: kern = gemm_tn_split_kernel<true, true, 8>; break;
+      case 10: kern = gemm_tn_split_kernel<true, true, 10>; break;
+      case 12: kern = gemm_tn_split_kernel<true, true, 12>; break;
+      case 14: kern = gemm_tn_split_kernel<true, true, 14>; break;
+      case 32: kern = gemm_tn_split_kernel<true, true, 32>; break;
+      case 40: kern = gemm_tn_split_kernel<true, true, 40>; break;
+      default: break;
+    }
+    lds = kTnSplitLds;
+    threads = kTnThreads;
+  } else if (g_gemm_mode == PYGAMD_GEMM_SPLIT_BF16) {  // lab: operands split in registers
     kern = vec ? gemm_tn_kernel<true, true> : gemm_tn_kernel<false, true>;
   } else {
     kern = vec ? gemm_tn_kernel<true, false> : gemm_tn_kernel<false, false>;
@@ -995,7 +1360,7 @@ int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ld
   PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), lds, st, p);
   PYGAMD_LAUNCH_CHECK();
   const int64_t NK = N * K;
   hipLaunchKernelGGL(gemm_tn_reduce_kernel,

@@ -475,6 +475,47 @@ def test_split_mode_forward_dgrad_wgrad(dev, split_mode, M, K, N):
                      what='split wgrad bias')
 
 
+@pytest.mark.parametrize('M,K,N,K2', [
+    (1, 1, 1, 0), (33, 7, 31, 0), (257, 512, 256, 0), (1000, 36, 130, 20), (4099, 100, 256, 100),
+    (70001, 256, 47, 256), (129, 129, 47, 3), (65, 300, 130, 0), (9000, 64, 64, 0),
+    (32, 8, 8, 0), (63, 8, 8, 0), (64, 8, 8, 0), (96, 8, 8, 8), (200000, 128, 128, 0),
+])
+def test_split_wgrad_production_schedule_against_the_in_register_one(dev, split_mode, M, K, N,
+                                                                     K2):
+    """The production split weight gradient converts every operand element once on its way into
+    LDS and runs two wave groups per workgroup in anti-phase (even / odd blocks of a split, summed
+    at the end); the lab switch (include/pyg_amd_lab.h) selects round 3's schedule, which converts
+    next to the matrix instructions.  Same six-term products, different summation trees: both must
+    meet the fp64 criterion of the other GEMM tests, agree with each other to rounding, and be
+    deterministic — ragged tiles, two operands, unaligned rows (element-wise loads), odd block
+    counts and many row splits included."""
+    from pytorch_geometric_amd import _native
+    g = gen(M + 3 * K + 7 * N)
+    go = torch.randn(M, N, generator=g).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    x2 = torch.randn(M, K2, generator=g).to(dev) if K2 else None
+    cases = [(go, x, x2)]
+    if K > 1 and N > 1:  # rows that are not 16-byte aligned: the element-wise loads
+        cases.append((torch.randn(M, N + 1, generator=g).to(dev)[:, 1:],
+                      torch.randn(M, K + 1, generator=g).to(dev)[:, 1:], x2))
+        cases.append((torch.randn(M, N + 1, generator=g).to(dev)[:, 1:], x, x2))
+    for go_, x_, x2_ in cases:
+        new, nb = _native.linear_wgrad(go_, x_, bias_grad=True, x2=x2_)
+        _native.lab_set_wgrad_variant(1)
+        try:
+            old, ob = _native.linear_wgrad(go_, x_, bias_grad=True, x2=x2_)
+        finally:
+            _native.lab_set_wgrad_variant(0)
+        cat = x_ if x2_ is None else torch.cat([x_, x2_], 1)
+        exact = go_.double().t() @ cat.double()
+        bound = go_.abs().double().t() @ cat.abs().double()
+        assert_sum_close(new, old, exact, abs_sum=bound, what='weight gradient')
+        assert_sum_close(nb, ob, go_.double().sum(0), abs_sum=go_.abs().double().sum(0),
+                         what='bias gradient')
+        again, ab = _native.linear_wgrad(go_, x_, bias_grad=True, x2=x2_)
+        assert torch.equal(again, new) and torch.equal(ab, nb)
+
+
 def test_split_mode_is_at_least_as_accurate_as_fp32(dev):
     """Error against fp64 of the two modes on one products-like shape (K = 512): the split mode's
     worst and mean errors must not exceed those of the exact fp32 instruction by more than 10 %."""
