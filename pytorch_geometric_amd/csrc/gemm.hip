@@ -776,6 +776,11 @@ __device__ __forceinline__ float sub_f32_asm(float a, float b) {
   asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ float add_f32_asm(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ void split_pair_scalar(float x0, float x1, uint32_t (&t)[3]) {
   const uint32_t a = pack_bf16(x0, x1);
   const float r0 = sub_f32_asm(x0, __uint_as_float(a << 16));
@@ -908,9 +913,12 @@ __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) 
       for (int k = 0; k < 3; ++k)
         *reinterpret_cast<u32x4*>(wbase + k * kCPlane + cc * kCLD) = w[k];
     }
-    if (do_colsum && !isx) {
+    if (do_colsum && !isx) {  // (single v_add_f32: no packed fp32 next to the partner's products)
 #pragma unroll
-      for (int r = 0; r < 8; ++r) csum += st[r];
+      for (int r = 0; r < 8; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] = add_f32_asm(csum[e], st[r][e]);
+      }
     }
   };
 
