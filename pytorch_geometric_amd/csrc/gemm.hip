@@ -764,35 +764,15 @@ constexpr int kTnGroup = 6 * kCPlane;    // dwords per wave group
 constexpr size_t kTnSplitLds = sizeof(uint32_t) * 2 * kTnGroup;
 constexpr int kTnThreads = 512;
 
-// PROBE (lab, timing only — results undefined for bits 1..3): bit 1 = no products, bit 2 = no
-// conversion / LDS stores, bit 3 = no global loads, bit 5 = packed residual subtractions
-// split_pair with the four residual subtractions pinned to single v_sub_f32: left to itself the
-// compiler packs them into two v_pk_add_f32, and a packed fp32 instruction in one wave stalls the
-// matrix instructions of the OTHER wave on the same SIMD (measured on the 2.45 M x 512 x 256
-// gradient with the loads switched off: conversion + products 3.26 ms packed = the sum of the two
-// alone, 2.57 ms with v_sub_f32; profiles/r04_wgrad_probe.txt)
-__device__ __forceinline__ float sub_f32_asm(float a, float b) {
-  float r;
-  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// (single v_add_f32 for the bias-gradient sums: no packed fp32 next to the partner's products)
 __device__ __forceinline__ float add_f32_asm(float a, float b) {
   float r;
   asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-__device__ __forceinline__ void split_pair_scalar(float x0, float x1, uint32_t (&t)[3]) {
-  const uint32_t a = pack_bf16(x0, x1);
-  const float r0 = sub_f32_asm(x0, __uint_as_float(a << 16));
-  const float r1 = sub_f32_asm(x1, __uint_as_float(a & 0xffff0000u));
-  const uint32_t b = pack_bf16(r0, r1);
-  const float s0 = sub_f32_asm(r0, __uint_as_float(b << 16));
-  const float s1 = sub_f32_asm(r1, __uint_as_float(b & 0xffff0000u));
-  t[0] = a;
-  t[1] = b;
-  t[2] = pack_bf16(s0, s1);
-}
 
+// PROBE (lab, timing only — results undefined for bits 1..3): bit 1 = no products, bit 2 = no
+// conversion / LDS stores, bit 3 = no global loads, bit 5 = packed residual subtractions
 template <bool VG, bool VX, int PROBE = 0>
 __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) {
   extern __shared__ __align__(16) uint32_t tn_lds[];
@@ -902,9 +882,9 @@ __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) 
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         uint32_t tt[3];
-        // (single v_sub_f32, see split_pair_scalar; PROBE bit 5 = the packed subtraction)
+        // (unpacked subtractions, split_bf16.h; PROBE bit 5 = the compiler's packed ones)
         if constexpr ((PROBE & 32) != 0) split_pair(st[2 * qq][cc], st[2 * qq + 1][cc], tt);
-        else split_pair_scalar(st[2 * qq][cc], st[2 * qq + 1][cc], tt);
+        else split_pair_single(st[2 * qq][cc], st[2 * qq + 1][cc], tt);
         w[0][qq] = tt[0];
         w[1][qq] = tt[1];
         w[2][qq] = tt[2];

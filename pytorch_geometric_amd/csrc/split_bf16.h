@@ -42,6 +42,29 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t (&t)[3])
   t[2] = pack_bf16(s0, s1);
 }
 
+// The same with the residual subtractions pinned to single v_sub_f32.  hipcc packs the two
+// subtractions of a pair into one v_pk_add_f32, and a packed fp32 instruction stalls the matrix
+// instructions of the OTHER waves on its SIMD: in the weight-gradient kernel, where one wave group
+// converts while its partner multiplies, that serialised the two.  The kernels
+// that convert and multiply in the same wave, or whose products hide under a gather (gemm_nt,
+// the one-kernel layer), measured the same with either form and keep the compiler's.
+__device__ __forceinline__ float sub_f32_single(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split_pair_single(float x0, float x1, uint32_t (&t)[3]) {
+  const uint32_t a = pack_bf16(x0, x1);
+  const float r0 = sub_f32_single(x0, __uint_as_float(a << 16));
+  const float r1 = sub_f32_single(x1, __uint_as_float(a & 0xffff0000u));
+  const uint32_t b = pack_bf16(r0, r1);
+  const float s0 = sub_f32_single(r0, __uint_as_float(b << 16));
+  const float s1 = sub_f32_single(r1, __uint_as_float(b & 0xffff0000u));
+  t[0] = a;
+  t[1] = b;
+  t[2] = pack_bf16(s0, s1);
+}
+
 // The six cross terms in the order they are accumulated (small ones first): term t multiplies
 // part kSplitTa[t] of a with part kSplitTb[t] of b.
 constexpr int kSplitTerms = 6;
