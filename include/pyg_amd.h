@@ -66,7 +66,8 @@ PYGAMD_API const char* pygamd_build_arch(void);      /* "gfx950" */
  * (torch_geometric/utils/_index_sort.py:10-32).  Stable LSD radix sort of non-negative integer
  * keys; `perm_out` (always int64, like torch.sort's indices) satisfies
  * keys_out[i] == keys_in[perm_out[i]] and is bit-identical to a stable sort.
- * `max_value` (>= every key, or <0 = unknown) bounds the radix passes.                        */
+ * `max_value` (>= every key, or <0 = unknown) bounds the radix passes (8 bits each; own kernels,
+ * csrc/graph.hip).  Out of place (keys_in != keys_out), n < 2^32.                              */
 PYGAMD_API int pygamd_index_sort_workspace_bytes(int idx_dtype, int64_t n, size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_index_sort(const void* keys_in, int idx_dtype, int64_t n, int64_t max_value,
                                  void* keys_out, int64_t* perm_out, void* workspace,

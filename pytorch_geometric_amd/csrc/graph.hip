@@ -1,13 +1,12 @@
 // graph.hip — integer side of the path: index_sort, index2ptr/ptr2index, range checks and the hub
 // plan of a CSR handle.  Everything here is bit-exact by construction (stable LSD radix sort,
-// boundary-detection for the pointer array).  See include/pyg_amd.h for the reference call sites.
+// boundary-detection for the pointer array) and hand-written: no library primitive.  See include/pyg_amd.h for the reference call sites.
 #include <cstring>
 #include <limits>
 #include <type_traits>
 
-#include <rocprim/rocprim.hpp>
-
 #include "common.h"
+#include "scan_device.h"
 
 namespace pygamd {
 
@@ -18,18 +17,150 @@ static int bits_for(int64_t max_value, int key_bits) {
   return b;
 }
 
+// ---- index_sort: stable LSD radix sort of (key, position) pairs, 8 bits per pass ---------------
+// Per pass three steps: (1) every workgroup counts the digits of its tile of 4096 keys into
+// counts[digit][workgroup]; (2) an exclusive scan over that table (digit-major, workgroup-minor)
+// IS the destination of the first key of each (digit, workgroup) run; (3) every workgroup re-reads
+// its tile in order and places each key at run start + its rank among the tile's earlier keys of
+// the same digit.  The rank is taken 256 keys at a time: inside a wave by eight ballots (the lanes
+// that agree with me on every digit bit, restricted to the lanes before me), across the four waves
+// through an LDS table.  Keys of one digit keep their order in every pass, so the sort is stable
+// and the permutation is the one torch.sort(stable=True) returns (tests/test_gpu_graph.py).
+// Passes only cover the bits max_value can set: 22 bits of node ids = 3 passes.
+constexpr int kSortItems = 16;                   // keys per thread
+constexpr int kSortTile = kBlock * kSortItems;   // 4096 keys per workgroup
+constexpr int kRadix = 256;
+static_assert(kBlock == kRadix, "one thread per digit in the table updates");
+
+template <typename KeyT>
+__global__ void __launch_bounds__(kBlock)
+    radix_count_kernel(const KeyT* __restrict__ keys, int64_t n, int shift,
+                       uint32_t* __restrict__ counts, int64_t n_tiles) {
+  __shared__ uint32_t hist[kRadix];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile;
+  const int lane = lane_id();
+#pragma unroll 4
+  for (int j = 0; j < kSortItems; ++j) {
+    const int64_t i = base + static_cast<int64_t>(j) * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    const unsigned d = valid ? static_cast<unsigned>((keys[i] >> shift) & (kRadix - 1)) : 0u;
+    // one LDS atomic per distinct digit of the wave (hub-heavy graphs repeat a digit often)
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const uint64_t m = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? m : ~m;
+    }
+    if (valid && (peers & ((1ull << lane) - 1)) == 0)
+      atomicAdd(&hist[d], static_cast<uint32_t>(__popcll(peers)));
+  }
+  __syncthreads();
+  counts[static_cast<int64_t>(threadIdx.x) * n_tiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// IOTA: the values are the positions themselves (first pass)
+template <typename KeyT, bool IOTA>
+__global__ void __launch_bounds__(kBlock)
+    radix_place_kernel(const KeyT* __restrict__ kin, const int64_t* __restrict__ vin, int64_t n,
+                       int shift, const uint32_t* __restrict__ starts, int64_t n_tiles,
+                       KeyT* __restrict__ kout, int64_t* __restrict__ vout) {
+  __shared__ uint32_t next[kRadix];                    // destination of a digit's next key
+  __shared__ uint32_t wave_cnt[kWavesPerBlock][kRadix];
+  next[threadIdx.x] = starts[static_cast<int64_t>(threadIdx.x) * n_tiles + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < kWavesPerBlock; ++w) wave_cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile;
+  const int lane = lane_id(), wave = wave_in_block();
+  for (int j = 0; j < kSortItems; ++j) {
+    const int64_t i = base + static_cast<int64_t>(j) * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    const KeyT k = valid ? kin[i] : static_cast<KeyT>(0);
+    const unsigned d = static_cast<unsigned>((k >> shift) & (kRadix - 1));
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const uint64_t m = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? m : ~m;
+    }
+    const uint32_t rank = static_cast<uint32_t>(__popcll(peers & ((1ull << lane) - 1)));
+    if (valid && rank == 0) wave_cnt[wave][d] = static_cast<uint32_t>(__popcll(peers));
+    __syncthreads();
+    if (valid) {
+      uint32_t pos = next[d] + rank;
+      for (int w = 0; w < wave; ++w) pos += wave_cnt[w][d];
+      kout[pos] = k;
+      vout[pos] = IOTA ? i : vin[i];
+    }
+    __syncthreads();
+    uint32_t add = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      add += wave_cnt[w][threadIdx.x];
+      wave_cnt[w][threadIdx.x] = 0;
+    }
+    next[threadIdx.x] += add;
+    __syncthreads();
+  }
+}
+
+static int64_t sort_tiles_of(int64_t n) { return ceil_div(n, kSortTile); }
+static size_t align256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+
+// workspace: [second key buffer][second value buffer][digit table][scan scratch]
+static size_t index_sort_ws_bytes(int64_t n, size_t key_size) {
+  const int64_t table = kRadix * sort_tiles_of(n);
+  return align256(static_cast<size_t>(n) * key_size) + align256(static_cast<size_t>(n) * 8) +
+         align256(static_cast<size_t>(table) * 4) + align256(scan_scratch_bytes(table));
+}
+
 template <typename IdxT>
 static int index_sort_impl(const void* keys_in, int64_t n, int64_t max_value, void* keys_out,
                            int64_t* perm_out, void* ws, size_t* ws_bytes, hipStream_t st) {
   // Keys are non-negative, so they sort identically as unsigned; radix passes only cover the
   // bits max_value can set.
   using KeyT = typename std::make_unsigned<IdxT>::type;
-  const KeyT* kin = static_cast<const KeyT*>(keys_in);
+  (void)ws_bytes;
+  if (n >= (static_cast<int64_t>(1) << 32)) return PYGAMD_ERR_INVALID_ARG;  // 32-bit positions
+  const int end_bit = bits_for(max_value, sizeof(IdxT) * 8);
+  const int passes = (end_bit + 7) / 8;
+  const int64_t tiles = sort_tiles_of(n), table = kRadix * tiles;
+  char* wp = static_cast<char*>(ws);
+  KeyT* k2 = reinterpret_cast<KeyT*>(wp);
+  wp += align256(static_cast<size_t>(n) * sizeof(KeyT));
+  int64_t* v2 = reinterpret_cast<int64_t*>(wp);
+  wp += align256(static_cast<size_t>(n) * 8);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(wp);
+  wp += align256(static_cast<size_t>(table) * 4);
+  uint32_t* sums = reinterpret_cast<uint32_t*>(wp);
   KeyT* kout = static_cast<KeyT*>(keys_out);
-  rocprim::counting_iterator<int64_t> iota(0);
-  const unsigned end_bit = static_cast<unsigned>(bits_for(max_value, sizeof(IdxT) * 8));
-  PYGAMD_HIP_CHECK(rocprim::radix_sort_pairs(ws, *ws_bytes, kin, kout, iota, perm_out,
-                                             static_cast<size_t>(n), 0u, end_bit, st));
+  const KeyT* ksrc = static_cast<const KeyT*>(keys_in);
+  const int64_t* vsrc = nullptr;
+  const dim3 grid(static_cast<unsigned>(tiles)), block(kBlock);
+  for (int p = 0; p < passes; ++p) {
+    // the last pass lands in the caller's buffers; the passes before it alternate
+    const bool to_out = ((passes - 1 - p) & 1) == 0;
+    KeyT* kdst = to_out ? kout : k2;
+    int64_t* vdst = to_out ? perm_out : v2;
+    const int shift = 8 * p;
+    hipLaunchKernelGGL((radix_count_kernel<KeyT>), grid, block, 0, st, ksrc, n, shift, counts,
+                       tiles);
+    PYGAMD_LAUNCH_CHECK();
+    const int rc = exclusive_scan_u32(counts, table, sums, st);
+    if (rc != PYGAMD_OK) return rc;
+    if (p == 0) {
+      hipLaunchKernelGGL((radix_place_kernel<KeyT, true>), grid, block, 0, st, ksrc, vsrc, n,
+                         shift, counts, tiles, kdst, vdst);
+    } else {
+      hipLaunchKernelGGL((radix_place_kernel<KeyT, false>), grid, block, 0, st, ksrc, vsrc, n,
+                         shift, counts, tiles, kdst, vdst);
+    }
+    PYGAMD_LAUNCH_CHECK();
+    ksrc = kdst;
+    vsrc = vdst;
+  }
   return PYGAMD_OK;
 }
 
@@ -214,6 +345,52 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// hub rows in ascending order: per-workgroup counts (256 rows each), an exclusive scan, and a
+// second pass that writes every hub row at its workgroup's start + its rank (ballots)
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    hub_count_kernel(IsHub<IdxT> pred, int64_t n_rows, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t wave_cnt[kWavesPerBlock];
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const uint64_t m = __ballot(r < n_rows && pred(r));
+  if (lane_id() == 0) wave_cnt[threadIdx.x >> 6] = static_cast<uint32_t>(__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) c += wave_cnt[w];
+    counts[blockIdx.x] = c;
+  }
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(kBlock)
+    hub_write_kernel(IsHub<IdxT> pred, int64_t n_rows, const uint32_t* __restrict__ starts,
+                     IdxT* __restrict__ hub_rows) {
+  __shared__ uint32_t wave_cnt[kWavesPerBlock];
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool hub = r < n_rows && pred(r);
+  const uint64_t m = __ballot(hub);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 0) wave_cnt[w] = static_cast<uint32_t>(__popcll(m));
+  __syncthreads();
+  if (hub) {
+    uint32_t pos = starts[blockIdx.x] +
+                   static_cast<uint32_t>(__popcll(m & ((1ull << lane_id()) - 1)));
+    for (int i = 0; i < w; ++i) pos += wave_cnt[i];
+    hub_rows[pos] = static_cast<IdxT>(r);
+  }
+}
+
+__global__ void hub_total_kernel(const uint32_t* __restrict__ total, int64_t* __restrict__ out) {
+  *out = static_cast<int64_t>(*total);
+}
+
+static size_t hub_plan_ws_bytes(int64_t n_rows) {
+  const int64_t blocks = ceil_div(n_rows, kBlock);
+  return 16 + align256(static_cast<size_t>(blocks) * 4) + align256(scan_scratch_bytes(blocks));
+}
+
 template <typename IdxT>
 static int hub_plan_impl(const void* rowptr_v, int64_t n_rows, int64_t threshold, int64_t chunk,
                          void* hub_rows_v, void* hub_chunk_ptr_v, int64_t cap,
@@ -222,22 +399,26 @@ static int hub_plan_impl(const void* rowptr_v, int64_t n_rows, int64_t threshold
   const IdxT* rowptr = static_cast<const IdxT*>(rowptr_v);
   IdxT* hub_rows = static_cast<IdxT*>(hub_rows_v);
   IdxT* hub_chunk_ptr = static_cast<IdxT*>(hub_chunk_ptr_v);
-  // workspace layout: [n_hub (int64)] [n_chunks (int64)] [rocprim temp ...]
+  if (n_rows >= (static_cast<int64_t>(1) << 32)) return PYGAMD_ERR_INVALID_ARG;
+  if (ws_bytes < hub_plan_ws_bytes(n_rows)) return PYGAMD_ERR_WORKSPACE;
+  // workspace layout: [n_hub (int64)] [n_chunks (int64)] [per-workgroup counts] [scan scratch]
   int64_t* counters = static_cast<int64_t*>(ws);
-  void* temp = static_cast<char*>(ws) + 16;
-  size_t temp_bytes = ws_bytes - 16;
-  rocprim::counting_iterator<int64_t> rows(0);
+  const int64_t blocks = ceil_div(n_rows, kBlock);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + 16);
+  uint32_t* sums = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + 16 +
+                                               align256(static_cast<size_t>(blocks) * 4));
   IsHub<IdxT> pred{rowptr, threshold};
-  // select() writes the selected row ids (ascending) and their count
-  size_t need = 0;
-  PYGAMD_HIP_CHECK(rocprim::select(nullptr, need, rows, hub_rows,
-                                   reinterpret_cast<size_t*>(counters),
-                                   static_cast<size_t>(n_rows), pred, st));
-  if (need > temp_bytes) return PYGAMD_ERR_WORKSPACE;
-  (void)cap;
-  PYGAMD_HIP_CHECK(rocprim::select(temp, need, rows, hub_rows,
-                                   reinterpret_cast<size_t*>(counters),
-                                   static_cast<size_t>(n_rows), pred, st));
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
+  hipLaunchKernelGGL((hub_count_kernel<IdxT>), grid, block, 0, st, pred, n_rows, counts);
+  PYGAMD_LAUNCH_CHECK();
+  const int rc = exclusive_scan_u32(counts, blocks, sums, st);
+  if (rc != PYGAMD_OK) return rc;
+  hipLaunchKernelGGL((hub_write_kernel<IdxT>), grid, block, 0, st, pred, n_rows, counts,
+                     hub_rows);
+  PYGAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(hub_total_kernel, dim3(1), dim3(1), 0, st, sums + scan_chunks_of(blocks),
+                     counters);
+  PYGAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL((hub_chunk_scan_kernel<IdxT>), dim3(1), dim3(kBlock), 0, st, rowptr,
                      hub_rows, counters, cap, chunk, hub_chunk_ptr, counters + 1);
   PYGAMD_LAUNCH_CHECK();
@@ -257,23 +438,8 @@ extern "C" {
 
 int pygamd_index_sort_workspace_bytes(int idx_dtype, int64_t n, size_t* bytes) {
   if (!bytes || n < 0) return PYGAMD_ERR_INVALID_ARG;
-  size_t need = 0;
-  rocprim::counting_iterator<int64_t> iota(0);
-  hipError_t e;
-  if (idx_dtype == PYGAMD_IDX_I64) {
-    e = rocprim::radix_sort_pairs(nullptr, need, static_cast<const uint64_t*>(nullptr),
-                                  static_cast<uint64_t*>(nullptr), iota,
-                                  static_cast<int64_t*>(nullptr), static_cast<size_t>(n), 0u, 64u,
-                                  static_cast<hipStream_t>(nullptr));
-  } else if (idx_dtype == PYGAMD_IDX_I32) {
-    e = rocprim::radix_sort_pairs(nullptr, need, static_cast<const uint32_t*>(nullptr),
-                                  static_cast<uint32_t*>(nullptr), iota,
-                                  static_cast<int64_t*>(nullptr), static_cast<size_t>(n), 0u, 32u,
-                                  static_cast<hipStream_t>(nullptr));
-  } else {
-    return PYGAMD_ERR_INVALID_ARG;
-  }
-  if (e != hipSuccess) return hip_fail(e);
+  if (idx_dtype != PYGAMD_IDX_I64 && idx_dtype != PYGAMD_IDX_I32) return PYGAMD_ERR_INVALID_ARG;
+  const size_t need = index_sort_ws_bytes(n, idx_dtype == PYGAMD_IDX_I64 ? 8 : 4);
   *bytes = need < 16 ? 16 : need;
   return PYGAMD_OK;
 }
@@ -283,7 +449,8 @@ int pygamd_index_sort(const void* keys_in, int idx_dtype, int64_t n, int64_t max
                       void* stream) {
   if (n < 0) return PYGAMD_ERR_INVALID_ARG;
   if (n == 0) return PYGAMD_OK;
-  if (!keys_in || !keys_out || !perm_out || !workspace) return PYGAMD_ERR_INVALID_ARG;
+  if (!keys_in || !keys_out || !perm_out || !workspace || keys_in == keys_out)
+    return PYGAMD_ERR_INVALID_ARG;  // (out of place: the first pass reads keys_in while writing)
   size_t need = 0;
   int rc = pygamd_index_sort_workspace_bytes(idx_dtype, n, &need);
   if (rc != PYGAMD_OK) return rc;
@@ -411,24 +578,8 @@ int pygamd_cast_index(const int64_t* src, int64_t n, int idx_dtype, void* out, v
 
 int pygamd_hub_plan_workspace_bytes(int idx_dtype, int64_t n_rows, size_t* bytes) {
   if (!bytes || n_rows < 0) return PYGAMD_ERR_INVALID_ARG;
-  size_t need = 0;
-  rocprim::counting_iterator<int64_t> rows(0);
-  hipError_t e;
-  if (idx_dtype == PYGAMD_IDX_I64) {
-    IsHub<int64_t> pred{nullptr, 0};
-    e = rocprim::select(nullptr, need, rows, static_cast<int64_t*>(nullptr),
-                        static_cast<size_t*>(nullptr), static_cast<size_t>(n_rows), pred,
-                        static_cast<hipStream_t>(nullptr));
-  } else if (idx_dtype == PYGAMD_IDX_I32) {
-    IsHub<int32_t> pred{nullptr, 0};
-    e = rocprim::select(nullptr, need, rows, static_cast<int32_t*>(nullptr),
-                        static_cast<size_t*>(nullptr), static_cast<size_t>(n_rows), pred,
-                        static_cast<hipStream_t>(nullptr));
-  } else {
-    return PYGAMD_ERR_INVALID_ARG;
-  }
-  if (e != hipSuccess) return hip_fail(e);
-  *bytes = need + 16;
+  if (idx_dtype != PYGAMD_IDX_I64 && idx_dtype != PYGAMD_IDX_I32) return PYGAMD_ERR_INVALID_ARG;
+  *bytes = hub_plan_ws_bytes(n_rows);
   return PYGAMD_OK;
 }
 
