@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 7
+#define PYGAMD_ABI_VERSION 8
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -95,6 +95,14 @@ PYGAMD_API int pygamd_permute_index(const void* src, int idx_dtype, const int64_
 /* out[i] = (idx_dtype) perm[i]; narrows an int64 permutation to the graph's index dtype.      */
 PYGAMD_API int pygamd_cast_index(const int64_t* src, int64_t n, int idx_dtype, void* out,
                                  void* stream);
+
+/* out[i] = in[0] + ... + in[i] over int32 / int64 counts: `torch.cumsum(x, 0)` where the
+ * reference builds offsets from counts (torch_geometric/utils/functions.py:5-26 `cumsum`,
+ * utils/_coalesce.py:186, the samplers' per-hop offsets).  `out` may be `in`.  One launch up to
+ * 32 k elements, three above.  The sum must fit the dtype.                                    */
+PYGAMD_API int pygamd_cumsum_workspace_bytes(int idx_dtype, int64_t n, size_t* bytes /*[host]*/);
+PYGAMD_API int pygamd_cumsum(const void* in, int idx_dtype, int64_t n, void* out, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- (f)-4: sort_edge_index / coalesce (torch_geometric/utils/_sort_edge_index.py:105-113,
  * utils/_coalesce.py:131-176).  Like the reference, both sort the compound key

@@ -157,6 +157,30 @@ def cast_index(src: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+def cumsum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """``torch.cumsum(x, 0)`` of a 1-D int32 / int64 device tensor on the own scan kernels
+    (``pygamd_cumsum``; ``out`` may be ``x`` or a contiguous slice such as ``offsets[1:]``)."""
+    _require_device(x, out)
+    if x.dim() != 1 or x.dtype not in (torch.int32, torch.int64):
+        raise ValueError(f"'x' must be a one-dimensional int32 / int64 tensor (got {x.dtype}, "
+                         f"{x.dim()} dimensions)")
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError("'out' must be contiguous with the shape and dtype of 'x'")
+    n = x.numel()
+    if n == 0:
+        return out
+    lib = _lib.load()
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_cumsum_workspace_bytes(_idx_dtype(x), n, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+    check(lib.pygamd_cumsum(_p(x), _idx_dtype(x), n, _p(out), _p(ws), nbytes.value, _stream(x)),
+          'cumsum')
+    return out
+
+
 def hub_plan(rowptr: Tensor, threshold: int = None, chunk: int = None):
     """Returns (hub_rows, hub_chunk_ptr, n_hub, n_chunks); tensors are None when n_hub == 0."""
     _require_device(rowptr)
@@ -1503,7 +1527,7 @@ def relabel_new_nodes(src_global: Tensor, local_map: Tensor, base: int):
     flag = torch.empty(m, dtype=torch.int64, device=src_global.device)
     check(lib.pygamd_relabel(1, _p(src_global), dt, m, None, _p(local_map), _p(flag), 0, None,
                              None, st))
-    scan = torch.cumsum(flag, 0)
+    scan = cumsum(flag)
     n_new = int(scan[-1])  # host sync: sizes the next hop (the frontier)
     new_nodes = torch.empty(n_new, dtype=src_global.dtype, device=src_global.device)
     check(lib.pygamd_relabel(2, _p(src_global), dt, m, None, _p(local_map), _p(scan), base, None,
@@ -1534,7 +1558,7 @@ def relabel_new_nodes_padded(src_global: Tensor, total: Tensor, local_map: Tenso
     flag = torch.empty(m, dtype=torch.int64, device=dev)
     check(lib.pygamd_relabel(1, _p(src_global), dt, m, _p(total), _p(local_map), _p(flag), 0,
                              None, None, st))
-    scan = torch.cumsum(flag, 0)
+    scan = cumsum(flag)
     check(lib.pygamd_relabel(2, _p(src_global), dt, m, _p(total), _p(local_map), _p(scan), 0,
                              _p(base), _p(new_nodes), st))
     check(lib.pygamd_relabel(3, _p(src_global), dt, m, _p(total), _p(local_map), None, 0, None,

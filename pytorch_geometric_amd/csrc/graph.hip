@@ -576,6 +576,29 @@ int pygamd_cast_index(const int64_t* src, int64_t n, int idx_dtype, void* out, v
   });
 }
 
+int pygamd_cumsum_workspace_bytes(int idx_dtype, int64_t n, size_t* bytes) {
+  if (!bytes || n < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (idx_dtype != PYGAMD_IDX_I64 && idx_dtype != PYGAMD_IDX_I32) return PYGAMD_ERR_INVALID_ARG;
+  const size_t need = scan_scratch_bytes(n, idx_dtype == PYGAMD_IDX_I64 ? 8 : 4);
+  *bytes = need < 16 ? 16 : need;
+  return PYGAMD_OK;
+}
+
+int pygamd_cumsum(const void* in, int idx_dtype, int64_t n, void* out, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  if (n < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0) return PYGAMD_OK;
+  if (!in || !out || !workspace) return PYGAMD_ERR_INVALID_ARG;
+  size_t need = 0;
+  const int rc = pygamd_cumsum_workspace_bytes(idx_dtype, n, &need);
+  if (rc != PYGAMD_OK) return rc;
+  if (workspace_bytes < need) return PYGAMD_ERR_WORKSPACE;
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    return cumsum_device<IdxT>(static_cast<const IdxT*>(in), n, static_cast<IdxT*>(out),
+                               static_cast<IdxT*>(workspace), as_stream(stream));
+  });
+}
+
 int pygamd_hub_plan_workspace_bytes(int idx_dtype, int64_t n_rows, size_t* bytes) {
   if (!bytes || n_rows < 0) return PYGAMD_ERR_INVALID_ARG;
   if (idx_dtype != PYGAMD_IDX_I64 && idx_dtype != PYGAMD_IDX_I32) return PYGAMD_ERR_INVALID_ARG;

@@ -85,7 +85,7 @@ def coalesce(edge_index, edge_attr: Attr = MISSING, num_nodes: Optional[int] = N
     perm = None
     if not is_sorted:
         key, perm = _native.index_sort(key, n * n)
-    scan = torch.cumsum(_native.run_flags(key), 0)
+    scan = _native.cumsum(_native.run_flags(key))
     n_unique = int(scan[-1])  # host sync, where the reference has `mask.all()` / mask indexing
     if n_unique == E:  # nothing to merge: only the order changes
         if perm is None:

@@ -244,3 +244,23 @@ def test_preprocessing_edge_cases(dev):
         U.coalesce(one, num_nodes=2**32)                      # key overflow, like the reference
     with pytest.raises(ValueError):
         U.sort_edge_index(torch.zeros(3, 4, dtype=torch.long, device=dev))
+
+
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+@pytest.mark.parametrize('n', [0, 1, 63, 4096, 4097, 32768, 32769, 1_000_003])
+def test_cumsum_bit_exact(dev, dtype, n):
+    """``pygamd_cumsum`` = ``torch.cumsum(x, 0)`` on integer counts (one launch up to 32 k
+    elements, three above), also in place and into the ``offsets[1:]`` slice the samplers use."""
+    from pytorch_geometric_amd import _native
+    x = torch.randint(0, 50, (n, ), generator=gen(n + 1)).to(dtype)
+    want = torch.cumsum(x, 0)
+    assert_close(_native.cumsum(x.to(dev)), want)
+    offsets = torch.zeros(n + 1, dtype=dtype, device=dev)
+    _native.cumsum(x.to(dev), out=offsets[1:])
+    assert_close(offsets[1:], want)
+    assert int(offsets[0]) == 0
+    y = x.to(dev)
+    assert _native.cumsum(y, out=y) is y
+    assert_close(y, want)
+    with pytest.raises(ValueError, match='one-dimensional'):
+        _native.cumsum(torch.zeros(2, 2, dtype=dtype, device=dev))
