@@ -913,8 +913,9 @@ def main():
     # largest summed time ----
     def symbol(info):
         if info.get('kind') == 'gemm':
-            return {'wgrad': 'gemm_tn_kernel', 'dgrad': 'gemm_nt_kernel',
-                    'forward': 'gemm_nt_kernel'}[info['op']]
+            # (csrc/gemm.hip: the weight gradient has its own kernel in the split arithmetic)
+            tn = 'gemm_tn_split_kernel' if pga.get_gemm_mode() == 'split' else 'gemm_tn_kernel'
+            return {'wgrad': tn, 'dgrad': 'gemm_nt_kernel', 'forward': 'gemm_nt_kernel'}[info['op']]
         lpr = 4
         while lpr < 64 and lpr * 4 < info['F']:
             lpr <<= 1

@@ -78,7 +78,8 @@ if fetch and write:
                      ('sage_fused_fwd_kernel<long,32>', 'sage_fused_fwd_kernel<long, 32'),
                      ('spmm_sum_rows<long,F=48>', 'spmm_sum_rows<long, 4, 16, 1, 0'),
                      ('spmm_sum_rows_sparse<long,F=48>', 'spmm_sum_rows_sparse<long, 4, 16, 1'),
-                     ('gemm_tn_kernel', 'gemm_tn_kernel'), ('gemm_nt_kernel', 'gemm_nt_kernel'),
+                     ('gemm_tn_split_kernel', 'gemm_tn_split_kernel'),
+                     ('gemm_tn_kernel', 'gemm_tn_kernel<'), ('gemm_nt_kernel', 'gemm_nt_kernel'),
                      ('rows_pack_kernel', 'rows_pack_kernel')):
         fv, wv = pick(fetch, sub), pick(write, sub)
         if fv is not None and wv is not None:

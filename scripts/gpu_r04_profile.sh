@@ -51,6 +51,12 @@ pmc fetch FETCH_SIZE 'spmm_sum_rows|sage_fused|gemm_|rows_pack' python $R/bench.
 echo "== PMC WRITE_SIZE"
 pmc write WRITE_SIZE 'spmm_sum_rows|sage_fused|gemm_|rows_pack' python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-figures
 fi
+if want configs; then
+echo "== kernel stats: configs 3 / 5"
+prof config3 python $R/scripts/time_gat.py
+prof config5 python $R/scripts/time_rgcn.py
+python $R/scripts/time_configs.py 2>&1 | grep -v amdgpu.ids | tee $R/gpurun_out/${TAG}_configs_timings.txt
+fi
 [[ -n "${ONLY:-}" ]] && exit 0
 echo "== kernel stats: bench with the exact fp32 instruction (side figure)"
 prof bench_fp32 python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-figures --arith fp32
