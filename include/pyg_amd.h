@@ -461,10 +461,12 @@ PYGAMD_API int pygamd_segment_softmax_backward(const float* out, const float* gr
  * utils/_softmax.py:82-88 (scatter-max, gather, exp, scatter-sum, gather, div) as four launches:
  * group maxima (atomic float max), exp + group sums (fp32 atomics), normalisation.  `workspace`:
  * 2 x N x H floats (forward), N x H floats (backward).  Rows whose index is out of range are
- * skipped (their output is left untouched by the forward, their gradient is 0).               */
+ * skipped (their output is left untouched by the forward, their gradient is 0) and, like in the
+ * scatter kernels, reported: `*err` ([dev] int32, may be NULL, zeroed by the caller) becomes
+ * non-zero — the reference's scatter / index_select path raises there (ABI 8).               */
 PYGAMD_API int pygamd_softmax_index_forward(const float* src, const void* index, int idx_dtype,
                                             int64_t n, int64_t H, int64_t N, float* workspace,
-                                            float* out, void* stream);
+                                            float* out, int32_t* err, void* stream);
 PYGAMD_API int pygamd_softmax_index_backward(const float* out, const float* grad_out,
                                              const void* index, int idx_dtype, int64_t n,
                                              int64_t H, int64_t N, float* workspace,

@@ -230,6 +230,9 @@ class ScatterFunction(Function):
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         reduce = ctx.reduce
+        # the forward's index flag has normally arrived by now: raise before gathering with an
+        # index the forward found out of range (no wait: INDEX_CHECK='async')
+        _native.poll_index_errors()
         g2 = _rows(grad_out)
         if reduce in ('sum', 'add'):
             (index,) = ctx.saved_tensors

@@ -162,7 +162,7 @@ SIGNATURES = {
                                             c_int64, c_int64, _P, c_int64, _P, c_size_t, _P]),
     'pygamd_scatter_argmax': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     'pygamd_softmax_index_forward': (c_int, [_P, _P, c_int, c_int64, c_int64, c_int64, _P, _P,
-                                             _P]),
+                                             _P, _P]),
     'pygamd_softmax_index_backward': (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_int64, _P,
                                               _P, _P]),
     'pygamd_segment_softmax_forward': (c_int, [_P, _P, c_int, c_int64, c_int64, _P, _P]),

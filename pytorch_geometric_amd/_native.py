@@ -7,6 +7,7 @@ and raises otherwise — there is no CPU fallback.
 import collections
 import ctypes
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -683,7 +684,7 @@ class _FlagRing:
         self.host[slot:slot + 1].copy_(self.dev[slot:slot + 1], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev.device))
-        self.pending.append((slot, ev, what, size, index, error_style))
+        self.pending.append((slot, ev, what, size, index, _error_style.value))
 
     def poll(self, wait: bool = False):
         while self.pending:
@@ -717,8 +718,47 @@ def check_index_errors():
 
 
 # 'dim_size' while an `Aggregation.__call__` is running: a flagged launch is then reported the way
-# the reference's wrapper reports it (nn/aggr/base.py:131-141), whenever the flag arrives
-error_style = None
+# the reference's wrapper reports it (nn/aggr/base.py:131-141), whenever the flag arrives.  Per
+# thread (a DataLoader worker thread's aggregation must not restyle another thread's error) and
+# recorded per launch by `_FlagRing.publish`.
+class _ErrorStyle(threading.local):
+    value = None
+
+
+_error_style = _ErrorStyle()
+
+
+def set_error_style(style):
+    """Sets this thread's report style for flagged launches; returns the previous one."""
+    prev, _error_style.value = _error_style.value, style
+    return prev
+
+
+def _index_flag(device, active: bool):
+    """(ring, slot, flag tensor or None) for one index-checking launch, per ``INDEX_CHECK``."""
+    if not active or INDEX_CHECK == 'off':
+        return None, None, None
+    if INDEX_CHECK == 'async' and not torch.cuda.is_current_stream_capturing():
+        ring = _flag_ring(device)
+        ring.poll()  # raises for an EARLIER launch whose flag has arrived meanwhile
+        slot = ring.acquire()
+        return ring, slot, ring.dev[slot:slot + 1]
+    return None, None, torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def _index_flag_done(ring, slot, err, what: str, size: int, index: Tensor):
+    if ring is not None:
+        ring.publish(slot, what, size, index)
+    elif err is not None and INDEX_CHECK == 'sync':
+        _raise_if_flagged(err, index, size, what)
+
+
+def poll_index_errors(wait: bool = False):
+    """Looks at the flags that have arrived (``wait=True``: at all of them, blocking) and raises
+    for the first flagged launch.  Called at the entry of the scatter backward and at the end of an
+    ``Aggregation`` call with a caller-supplied ``dim_size``."""
+    for ring in list(_flag_rings.values()):
+        ring.poll(wait=wait)
 
 
 def _raise_out_of_range(index: Tensor, size: int, what: str, style=None):
@@ -885,8 +925,13 @@ def softmax_index_forward(src: Tensor, index: Tensor, num_groups: int) -> Tensor
     n, H = s2.shape
     out = torch.zeros_like(s2)
     ws = torch.empty(2 * max(num_groups, 1) * max(H, 1), dtype=torch.float32, device=src.device)
+    # an index outside [0, num_groups) is skipped by the kernels and reported like a scatter's
+    # (the reference's scatter / index_select path raises there, utils/_softmax.py:82-88)
+    ring, slot, err = _index_flag(src.device, n > 0 and H > 0)
     check(lib.pygamd_softmax_index_forward(_p(s2), _p(idx), _idx_dtype(idx), n, H, num_groups,
-                                           _p(ws), _p(out), _stream(src)), 'softmax_index_forward')
+                                           _p(ws), _p(out), _p(err), _stream(src)),
+          'softmax_index_forward')
+    _index_flag_done(ring, slot, err, 'softmax', num_groups, idx)
     return out
 
 

@@ -300,13 +300,17 @@ template <typename IdxT, int PHASE>
 __global__ void __launch_bounds__(kBlock)
     softmax_index_kernel(const float* __restrict__ src, const IdxT* __restrict__ index, int64_t n,
                          int64_t H, int64_t N, float* __restrict__ gmax, float* __restrict__ gsum,
-                         float* __restrict__ out, const float* __restrict__ grad_out) {
+                         float* __restrict__ out, const float* __restrict__ grad_out,
+                         int32_t* __restrict__ err) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= n * H) return;
   const int64_t k = t / H;
   const int64_t h = t - k * H;
   const int64_t g = static_cast<int64_t>(index[k]);
-  if (g < 0 || g >= N) return;  // (out of range: skipped, like the scatter kernels)
+  if (g < 0 || g >= N) {  // out of range: skipped and flagged, like the scatter kernels
+    if (PHASE == 0 && err != nullptr && h == 0) *err = 1;
+    return;
+  }
   const int64_t s = g * H + h;
   if constexpr (PHASE == 0) {         // group maxima
     atomic_max_f32(gmax + s, src[t]);
@@ -365,12 +369,15 @@ int pygamd_segment_softmax_backward(const float* out, const float* grad_out, con
 
 int pygamd_softmax_index_forward(const float* src, const void* index, int idx_dtype, int64_t n,
                                  int64_t H, int64_t N, float* workspace, float* out,
-                                 void* stream) {
+                                 int32_t* err, void* stream) {
   if (n < 0 || H < 0 || N < 0) return PYGAMD_ERR_INVALID_ARG;
   if (n == 0 || H == 0) return PYGAMD_OK;
   if (!src || !index || !out || (N > 0 && !workspace)) return PYGAMD_ERR_INVALID_ARG;
-  if (N == 0) return PYGAMD_OK;
   hipStream_t st = as_stream(stream);
+  if (N == 0) {  // every index is out of range
+    if (err) PYGAMD_HIP_CHECK(hipMemsetAsync(err, 1, 1, st));
+    return PYGAMD_OK;
+  }
   float* gmax = workspace;
   float* gsum = workspace + N * H;
   const dim3 ginit(static_cast<unsigned>(ceil_div(N * H, kBlock)));
@@ -379,12 +386,13 @@ int pygamd_softmax_index_forward(const float* src, const void* index, int idx_dt
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     const IdxT* idx = static_cast<const IdxT*>(index);
+    int32_t* const no_flag = nullptr;
     hipLaunchKernelGGL((softmax_index_kernel<IdxT, 0>), grid, dim3(kBlock), 0, st, src, idx, n, H,
-                       N, gmax, gsum, out, static_cast<const float*>(nullptr));
+                       N, gmax, gsum, out, static_cast<const float*>(nullptr), err);
     hipLaunchKernelGGL((softmax_index_kernel<IdxT, 1>), grid, dim3(kBlock), 0, st, src, idx, n, H,
-                       N, gmax, gsum, out, static_cast<const float*>(nullptr));
+                       N, gmax, gsum, out, static_cast<const float*>(nullptr), no_flag);
     hipLaunchKernelGGL((softmax_index_kernel<IdxT, 2>), grid, dim3(kBlock), 0, st, src, idx, n, H,
-                       N, gmax, gsum, out, static_cast<const float*>(nullptr));
+                       N, gmax, gsum, out, static_cast<const float*>(nullptr), no_flag);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });
@@ -410,10 +418,11 @@ int pygamd_softmax_index_backward(const float* out, const float* grad_out, const
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     const IdxT* idx = static_cast<const IdxT*>(index);
+    int32_t* const no_flag = nullptr;
     hipLaunchKernelGGL((softmax_index_kernel<IdxT, 3>), grid, dim3(kBlock), 0, st, out, idx, n, H,
-                       N, static_cast<float*>(nullptr), workspace, grad_src, grad_out);
+                       N, static_cast<float*>(nullptr), workspace, grad_src, grad_out, no_flag);
     hipLaunchKernelGGL((softmax_index_kernel<IdxT, 4>), grid, dim3(kBlock), 0, st, out, idx, n, H,
-                       N, static_cast<float*>(nullptr), workspace, grad_src, grad_out);
+                       N, static_cast<float*>(nullptr), workspace, grad_src, grad_out, no_flag);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });

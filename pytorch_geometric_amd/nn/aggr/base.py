@@ -33,11 +33,18 @@ class Aggregation(torch.nn.Module):
                 raise ValueError(f"Encountered invalid 'dim_size' (got "
                                  f"'{dim_size}' but expected "
                                  f"'{ptr.numel() - 1}')")
+        given = index is not None and dim_size is not None
         if index is not None and dim_size is None:
             dim_size = _native.index_minmax(index)[1] + 1 if index.numel() > 0 else 0
-        prev, _native.error_style = _native.error_style, 'dim_size'
+        prev = _native.set_error_style('dim_size')
         try:
-            return super().__call__(x, index=index, ptr=ptr, dim_size=dim_size, dim=dim, **kwargs)
+            out = super().__call__(x, index=index, ptr=ptr, dim_size=dim_size, dim=dim, **kwargs)
+            # a caller-supplied `dim_size` is the one way an index can be out of range here: look
+            # at this call's flags before returning (one host wait — what inferring `dim_size`
+            # costs on the other branch), so that the error is raised by THIS call
+            if given and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+                _native.poll_index_errors(wait=True)
+            return out
         except (IndexError, RuntimeError) as e:  # same recovery as nn/aggr/base.py:131-141
             if index is not None and index.numel() > 0:
                 hi = _native.index_minmax(index)[1]
@@ -47,7 +54,7 @@ class Aggregation(torch.nn.Module):
                                      f">= '{hi + 1}')")
             raise e
         finally:
-            _native.error_style = prev
+            _native.set_error_style(prev)
 
     def __repr__(self) -> str:
         return f'{self.__class__.__name__}()'

@@ -138,6 +138,29 @@ def test_scatter_out_of_range_raises(dev):
         _native.INDEX_CHECK = 'async'
 
 
+def test_unsorted_softmax_out_of_range_is_reported(dev):
+    """The index branch of ``softmax`` (utils/_softmax.py:82-88) with a ``num_nodes`` that is too
+    small: the reference's scatter raises; the one-operator kernels skip such rows AND flag them
+    (asynchronously by default, at the call site with PYGAMD_CHECK_INDEX=sync)."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    src = torch.randn(6, 2, device=dev)
+    idx = torch.tensor([3, 0, 7, 1, 0, 2], device=dev)  # unsorted, one value >= num_nodes
+    with pytest.raises((IndexError, RuntimeError), match='out of bounds'):
+        pga.utils.softmax(src, idx, num_nodes=4)
+        pga.check_index_errors()
+    pga.check_index_errors()
+    ok = pga.utils.softmax(src, idx, num_nodes=8)
+    pga.check_index_errors()
+    assert_close(ok.sum(0)[0:1], torch.tensor([5.0]), rtol=1e-5, atol=1e-5)  # five groups
+    _native.INDEX_CHECK = 'sync'
+    try:
+        with pytest.raises((IndexError, RuntimeError), match='out of bounds'):
+            pga.utils.softmax(src, idx, num_nodes=4)
+    finally:
+        _native.INDEX_CHECK = 'async'
+
+
 def test_scatter_errors(dev):
     import pytorch_geometric_amd as pga
     src = torch.randn(2, 5, 2, device=dev)
@@ -151,9 +174,11 @@ def test_scatter_errors(dev):
     with pytest.raises(pga.PygAmdError, match='no CPU fallback'):
         pga.utils.scatter(torch.randn(4, 2), torch.tensor([0, 0, 1, 1]))
     agg = pga.nn.MeanAggregation()
+    # a caller-supplied dim_size that is too small is reported by the call ITSELF (the wrapper
+    # looks at its own flags before returning; nn/aggr/base.py:131-141 in the reference)
     with pytest.raises(ValueError, match="invalid 'dim_size'"):
         agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
-        pga.check_index_errors()  # (the flag travels asynchronously by default)
+    pga.check_index_errors()  # nothing left pending
     with pytest.raises(ValueError, match='invalid dimension'):
         agg(torch.randn(5, 3, device=dev), idx, dim=2)
 
