@@ -866,16 +866,8 @@ __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) 
   const bool do_colsum = p.colsum != nullptr && tk == 0;  // workgroup-uniform
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   uint32_t* const wbase = planes + (isx ? 3 * kCPlane : 0) + tc * kCLD + 4 * rg;
-  auto store_rows = [&](f32x4 (&st)[8], int64_t r_end) {  // rows >= r_end are staged as zero
-    if constexpr ((PROBE & 4) != 0) return;
-    if (ragged_cols || r_end < INT64_MAX) {  // (thread-varying / uniform; edges only)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const bool rok = 8 * rg + r < r_end;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) st[r][e] = (rok && cok[e]) ? st[r][e] : 0.f;
-      }
-    }
+  // registers -> the three term planes (no masks) + the bias-gradient sums
+  auto convert_store = [&](f32x4 (&st)[8]) {
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       u32x4 w[3];
@@ -901,6 +893,38 @@ __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) 
       }
     }
   };
+  // A full block inside the loop.  16-byte operands: a column quad is valid or not as a whole and
+  // the invalid ones were zeroed in the planes ONCE (below), so there is no mask and no merge of a
+  // masked with an unmasked copy of the registers (45 moves per block before).  Element-wise
+  // operands: the boundary quad is masked per element.
+  auto store_rows = [&](f32x4 (&st)[8]) {
+    if constexpr ((PROBE & 4) != 0) return;
+    if (!vec && ragged_cols) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st[r][e] = cok[e] ? st[r][e] : 0.f;
+      }
+    }
+    if (!vec || cok[0]) convert_store(st);  // (ONE inlined copy: the loop body is large already)
+  };
+  // A block after the loop: rows >= r_end and invalid columns are staged as zero
+  auto store_tail = [&](f32x4 (&st)[8], int64_t r_end) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const bool rok = 8 * rg + r < r_end;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st[r][e] = (rok && cok[e]) ? st[r][e] : 0.f;
+    }
+    convert_store(st);
+  };
+  if (vec && !cok[0]) {  // this thread's slots stay zero for the whole loop
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(wbase + k * kCPlane + cc * kCLD) = zero;
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -947,14 +971,14 @@ __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) 
   constexpr bool exact_tail = !(VG && VX);
   const int64_t n_blocks = (exact_tail && rb == p.M && n_rows > 0) ? (n_rows - 1) / kWRows
                                                                     : n_rows / kWRows;
-  const int64_t n_iter = (n_blocks + 1) / 2;  // group A: block 2 i, group B: block 2 i + 1
-  const int64_t last_blk = n_blocks - 1;
+  // the pipelined loop takes an EVEN number of blocks (group A: block 2 i, group B: block 2 i + 1:
+  // both always have one); what is left — at most three blocks' worth of rows — follows it
+  const int64_t n_pipe = n_blocks & ~static_cast<int64_t>(1);
+  const int64_t n_iter = n_pipe / 2;
+  const int64_t last_blk = n_pipe - 1;
   auto blk_of = [&](int64_t i) {  // this group's block of iteration i, clamped (re-loads)
     const int64_t bi = 2 * i + grp;
     return bi < last_blk ? bi : last_blk;
-  };
-  auto end_of = [&](int64_t i) {  // B has no block in the last iteration of an odd count: zeros
-    return 2 * i + grp < n_blocks ? INT64_MAX : static_cast<int64_t>(0);
   };
   // Two register sets per thread: the loads of iteration i + 1 are issued at the start of
   // iteration i, by BOTH groups at the same point of the code — before the role branches — and
@@ -974,31 +998,34 @@ __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) 
   if (n_iter > 0) load_rows(sta, blk_of(0));
   for (int64_t i = 0; i + 1 < n_iter; i += 2) {
     load_rows(stb, blk_of(i + 1));
-    if (is_a) store_rows(sta, INT64_MAX); else if (i > 0) products();
+    if (is_a) store_rows(sta); else if (i > 0) products();
     __syncthreads();
-    if (is_a) products(); else store_rows(sta, end_of(i));
+    if (is_a) products(); else store_rows(sta);
     __syncthreads();
     load_rows(sta, blk_of(i + 2));
-    if (is_a) store_rows(stb, INT64_MAX); else products();
+    if (is_a) store_rows(stb); else products();
     __syncthreads();
-    if (is_a) products(); else store_rows(stb, end_of(i + 1));
+    if (is_a) products(); else store_rows(stb);
     __syncthreads();
   }
   if (n_iter & 1) {
-    if (is_a) store_rows(sta, INT64_MAX); else if (n_iter > 1) products();
+    if (is_a) store_rows(sta); else if (n_iter > 1) products();
     __syncthreads();
-    if (is_a) products(); else store_rows(sta, end_of(n_iter - 1));
+    if (is_a) products(); else store_rows(sta);
     __syncthreads();
   }
   if (!is_a && n_iter > 0) products();  // B's last block
-  const int64_t tail_rows = n_rows - n_blocks * kWRows;  // 0..32, workgroup-uniform
-  if (tail_rows > 0) {  // the last split's ragged (or exactly addressed) block: group A
-    if (grp == 0) {
-      load_tail(sta, ra + n_blocks * kWRows);
-      store_rows(sta, tail_rows);
+  // the rows behind the pipelined blocks (an odd full block, the last split's ragged block, the
+  // exactly addressed last block of an element-wise operand): group A, 32 rows at a time
+  for (int64_t r0 = n_pipe * kWRows; r0 < n_rows; r0 += kWRows) {  // (workgroup-uniform)
+    if (is_a) {
+      load_tail(sta, ra + r0);
+      const int64_t left = n_rows - r0;
+      store_tail(sta, left < kWRows ? left : kWRows);
     }
     __syncthreads();
-    if (grp == 0) products();
+    if (is_a) products();
+    __syncthreads();
   }
   // B's sums and both groups' bias-gradient partials go to A through LDS
   __syncthreads();  // every product is done: the images are free
