@@ -693,9 +693,18 @@ def init_ranks(args):
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('RANK', str(rank))
         os.environ.setdefault('WORLD_SIZE', str(world))
+        # PYGAMD_BENCH_SHARE_GPU=1 (tests only, never a measurement): every rank on GPU 0, the
+        # collectives over gloo on device tensors — RCCL refuses two ranks on one device, and a
+        # one-GPU box is all the builder has: this is how the N > 1 compute path (per-rank graphs,
+        # parameter broadcast, bucket all-reduce, max-over-ranks timing, the parity leg) runs on
+        # hardware before the driver's 8-GPU node does
+        share = has_gpu and os.environ.get('PYGAMD_BENCH_SHARE_GPU') == '1'
+        if share:
+            local_rank = 0
         if has_gpu:
             torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl' if has_gpu else 'gloo', rank=rank, world_size=world)
+        dist.init_process_group('nccl' if has_gpu and not share else 'gloo', rank=rank,
+                                world_size=world)
         assert dist.get_world_size() == world
     if world != args.gpus:
         raise RuntimeError(f'--gpus {args.gpus} but the process group has {world} rank(s): '

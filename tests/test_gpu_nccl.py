@@ -93,3 +93,31 @@ def test_bench_step_under_torchrun_with_rccl(mode):
     assert out['config']['allreduce_ms_per_step'] > 0      # the collective really ran
     if mode == 'fullbatch':
         assert out['config']['process_group'] == 'nccl'
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_the_one_gpu():
+    """The N > 1 COMPUTE path on hardware: two ranks of `bench.py --gpus 2`, both on GPU 0
+    (PYGAMD_BENCH_SHARE_GPU=1: collectives over gloo on device tensors — RCCL refuses two ranks on
+    one device).  Not a measurement; what is covered is everything the 8-GPU run does around the
+    kernels: per-rank graph replicas, parameter broadcast, the flat-bucket all-reduce every step,
+    barrier + max-over-ranks timing, one JSON line from rank 0 with both ranks' timings, and the
+    parity leg against the committed reference sample."""
+    e = _env()
+    e['PYGAMD_BENCH_SHARE_GPU'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', e['MASTER_PORT'],
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--scale', '0.02', '--no-cpu-baseline']
+    res = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=860, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0
+    pr = out['config']['per_rank_ms_per_step']
+    assert len(pr['ranks']) == 2 and 0 < pr['min'] <= pr['max']
+    assert abs(out['ms_per_step'] - pr['max']) < 1e-6 * max(pr['max'], 1.0) + 1e-3
+    assert out['config']['allreduce_ms_per_step'] > 0
+    assert out['config']['process_group'] == 'gloo'
+    assert out['scaling'] == 'weak'
