@@ -539,22 +539,40 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
         timed_seeds.append(sd)
         return sd
 
+    trace = [] if os.environ.get('PYGAMD_STEP_TRACE') == '1' else None  # (diagnosis only)
+
     def step():  # (the timed twin of the warm-up step: it also remembers its seeds)
+        ts = [time.perf_counter()] if trace is not None else None
+
+        def mark():
+            if ts is not None:
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter())
+
         seeds_buf.copy_(next_logged())
+        mark()
         captured()
+        mark()
         if use_dist:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             bucket.all_reduce_mean(force=True)
             e1.record()
             ar_events.append((e0, e1))
+            mark()
             opt.step()
+            mark()
+        if ts is not None:
+            trace.append([round((b - a) * 1e3, 3) for a, b in zip(ts, ts[1:])])
 
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if trace is not None and rank == 0:
+        print('[step trace, ms: seeds copy | step | all-reduce | optimizer]', trace[:8],
+              file=sys.stderr, flush=True)
     assert torch.isfinite(loss_buf).item()
     # what the timed batches contained, recounted OUTSIDE the timed region (the captured step keeps
     # no statistics): the sampler is a pure function of (seeds, epoch) — the draws depend on them
