@@ -486,7 +486,9 @@ PYGAMD_API int pygamd_segment_logsumexp_backward(const float* src, const float* 
 /* ---- a15: GAT node terms ----------------------------------------------------------------------
  * out_a[n,h] = sum_c x[n, h*C + c] * att_a[h*C + c]  (and out_b with att_b when given) — the
  * `(x * att).sum(-1)` pair of nn/conv/gat_conv.py:330-332 in one pass over x.  Backward:
- * grad_x[n,f] = grad_a[n,h(f)] att_a[f] + grad_b[n,h(f)] att_b[f]  (grad_x may be NULL),
+ * grad_x[n,f] (+)= grad_a[n,h(f)] att_a[f] + grad_b[n,h(f)] att_b[f]  (grad_x may be NULL;
+ * `accumulate` != 0 adds to what grad_x holds — the gradient of the same x through the
+ * aggregation, so that the two do not meet in a separate add pass; ABI 8),
  * grad_att_a[f] = sum_n grad_a[n,h(f)] x[n,f]  (zeroed internally, atomics).                     */
 PYGAMD_API int pygamd_head_dot_forward(const float* x, int64_t ldx, const float* att_a,
                                        const float* att_b, int64_t n_rows, int64_t H, int64_t C,
@@ -494,7 +496,7 @@ PYGAMD_API int pygamd_head_dot_forward(const float* x, int64_t ldx, const float*
 PYGAMD_API int pygamd_head_dot_backward(const float* x, int64_t ldx, const float* att_a,
                                         const float* att_b, const float* grad_a,
                                         const float* grad_b, int64_t n_rows, int64_t H,
-                                        int64_t C, float* grad_x, int64_t ldg,
+                                        int64_t C, float* grad_x, int64_t ldg, int accumulate,
                                         float* grad_att_a, float* grad_att_b, void* stream);
 
 /* ---- a15: fused GAT edge logits ------------------------------------------------------------

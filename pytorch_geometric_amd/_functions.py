@@ -418,6 +418,57 @@ class GatEdgeSoftmaxFunction(Function):
         return g_src, g_dst, None, None
 
 
+class GatAttendFunction(Function):
+    """One GAT attention + aggregation step on projected features ``x [N, H, C]`` (source and
+    destination features are the same tensor): node terms ``(x * att).sum(-1)``, edge logits +
+    leaky ReLU + softmax per destination, weighted aggregation (gat_conv.py:330-332, 387-408) —
+    the three kernels of HeadDotFunction / GatEdgeSoftmaxFunction / SpmmFunction under ONE
+    autograd node, so that the two gradients of ``x`` (through the aggregation and through the
+    node terms) meet inside ``head_dot_bwd_kernel`` instead of in a separate add pass."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, att_src: Tensor, att_dst: Tensor, graph: EdgeIndex,
+                slope: float, n_dst: int):
+        N, H, C = x.shape
+        x2 = x.reshape(N, H * C)
+        a_src, a_dst = _native.head_dot_forward(x2, att_src.reshape(-1), att_dst.reshape(-1),
+                                                H, C)
+        fwd = graph.by_dst()
+        a_dst = a_dst[:n_dst].contiguous()
+        alpha = _native.gat_edge_softmax_forward(fwd.ptr, fwd.idx, a_src, a_dst, slope)
+        out = _native.spmm_csr(fwd.ptr, fwd.idx, x2, 'sum', n_rows=fwd.n_rows, w=alpha,
+                               hub=fwd.hub)
+        ctx.save_for_backward(x2, att_src, att_dst, a_src, a_dst, alpha)
+        ctx.graph, ctx.slope, ctx.dims = graph, slope, (N, H, C)
+        return out.view(fwd.n_rows, H, C)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out: Tensor):
+        x2, att_src, att_dst, a_src, a_dst, alpha = ctx.saved_tensors
+        N, H, C = ctx.dims
+        graph = ctx.graph
+        fwd, bwd = graph.by_dst(), graph.by_src()
+        g2 = _rows(grad_out)
+        # d x through the aggregation: the same coefficients on the transposed handle
+        grad_x = _native.spmm_csr(bwd.ptr, bwd.idx, g2, 'sum', n_rows=bwd.n_rows,
+                                  eid=graph.src_slot_to_dst_slot(), w=alpha, hub=bwd.hub)
+        # d alpha[k, h] = <grad_out[i, h, :], x[j, h, :]>, then back through the edge softmax
+        grad_alpha = _native.sddmm_csr(fwd.ptr, fwd.idx, None, g2, x2, fwd.nnz, H)
+        g_src, g_dst = _native.gat_edge_softmax_backward(fwd.ptr, fwd.idx, a_src, a_dst, alpha,
+                                                         grad_alpha.view(alpha.shape), ctx.slope)
+        if g_dst.size(0) < N:  # destinations are a prefix of the nodes
+            pad = g_dst.new_zeros(N, H)
+            pad[:g_dst.size(0)] = g_dst
+            g_dst = pad
+        # d x through the node terms is ADDED to grad_x by the kernel that also reduces d att
+        _, g_att_src, g_att_dst = _native.head_dot_backward(
+            x2, att_src.reshape(-1), att_dst.reshape(-1), g_src, g_dst, H, C, True,
+            accumulate_into=grad_x)
+        return (grad_x.view(N, H, C), g_att_src.view(att_src.shape),
+                g_att_dst.view(att_dst.shape), None, None, None)
+
+
 class HeadDotFunction(Function):
     """(a_src, a_dst) = ((x * att_src).sum(-1), (x * att_dst).sum(-1)) for x [N, H, C] and
     att_* [1, H, C] (nn/conv/gat_conv.py:330-332) — one pass over x, one fused backward."""

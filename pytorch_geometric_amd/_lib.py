@@ -173,7 +173,7 @@ SIGNATURES = {
     'pygamd_head_dot_forward': (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int64, _P, _P,
                                         _P]),
     'pygamd_head_dot_backward': (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int64,
-                                         _P, c_int64, _P, _P, _P]),
+                                         _P, c_int64, c_int, _P, _P, _P]),
     'pygamd_gat_edge_softmax_forward': (c_int, [_P, _P, c_int, _P, _P, c_int64, c_int64,
                                                 c_float, _P, _P]),
     'pygamd_gat_edge_softmax_backward': (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int64,

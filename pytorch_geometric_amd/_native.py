@@ -1524,8 +1524,11 @@ def head_dot_forward(x: Tensor, att_a: Tensor, att_b: Optional[Tensor], H: int, 
 
 
 def head_dot_backward(x: Tensor, att_a: Tensor, att_b: Optional[Tensor], grad_a: Tensor,
-                      grad_b: Optional[Tensor], H: int, C: int, need_grad_x: bool):
-    _require_device(x, att_a, att_b, grad_a, grad_b)
+                      grad_b: Optional[Tensor], H: int, C: int, need_grad_x: bool,
+                      accumulate_into: Optional[Tensor] = None):
+    """``accumulate_into`` ([n, H*C], unit inner stride): the input gradient is ADDED to it (the
+    gradient of the same x through the aggregation) instead of going to a fresh tensor."""
+    _require_device(x, att_a, att_b, grad_a, grad_b, accumulate_into)
     lib = _lib.load()
     x2 = _f32_rows(x, 'x')
     n = x2.size(0)
@@ -1535,10 +1538,17 @@ def head_dot_backward(x: Tensor, att_a: Tensor, att_b: Optional[Tensor], grad_a:
     if att_b is not None:
         att_b, grad_b = att_b.contiguous(), grad_b.contiguous()
         g_att_b = torch.empty(H * C, dtype=torch.float32, device=x.device)
-    grad_x = torch.empty(n, H * C, dtype=torch.float32, device=x.device) if need_grad_x else None
+    if accumulate_into is not None:
+        grad_x = _f32_rows(accumulate_into, 'accumulate_into')
+        if grad_x is not accumulate_into or grad_x.shape != (n, H * C):
+            raise ValueError("'accumulate_into' must be [n, H * C] float32 with unit inner stride")
+    else:
+        grad_x = torch.empty(n, H * C, dtype=torch.float32, device=x.device) \
+            if need_grad_x else None
     check(lib.pygamd_head_dot_backward(_p(x2), _ld(x2), _p(att_a), _p(att_b), _p(grad_a),
                                        _p(grad_b), n, H, C, _p(grad_x),
-                                       H * C if grad_x is not None else 0, _p(g_att_a),
+                                       _ld(grad_x) if grad_x is not None else 0,
+                                       1 if accumulate_into is not None else 0, _p(g_att_a),
                                        _p(g_att_b), _stream(x)), 'head_dot_backward')
     return grad_x, g_att_a, g_att_b
 

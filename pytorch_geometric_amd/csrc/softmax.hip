@@ -238,7 +238,8 @@ __global__ void __launch_bounds__(kBlock)
                         const float* __restrict__ att_b, const float* __restrict__ ga,
                         const float* __restrict__ gb, int64_t n_rows, int H, int C,
                         int64_t rows_per_block, float* __restrict__ grad_x, int64_t ldg,
-                        float* __restrict__ grad_att_a, float* __restrict__ grad_att_b) {
+                        int accumulate, float* __restrict__ grad_att_a,
+                        float* __restrict__ grad_att_b) {
   const int64_t F = static_cast<int64_t>(H) * C;
   const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
@@ -261,7 +262,11 @@ __global__ void __launch_bounds__(kBlock)
       for (int u = 0; u < 4; ++u) {
         sa = fmaf(va[u], xv[u], sa);
         sb = fmaf(vb[u], xv[u], sb);
-        if (grad_x) grad_x[(n + u) * ldg + f] = va[u] * wa + vb[u] * wb;
+        if (grad_x) {
+          float* gp = grad_x + (n + u) * ldg + f;
+          const float v = va[u] * wa + vb[u] * wb;
+          *gp = accumulate ? *gp + v : v;
+        }
       }
     }
     for (; n < r1; ++n) {
@@ -270,7 +275,11 @@ __global__ void __launch_bounds__(kBlock)
       const float vb = gb ? gb[n * H + h] : 0.f;
       sa = fmaf(va, xv, sa);
       sb = fmaf(vb, xv, sb);
-      if (grad_x) grad_x[n * ldg + f] = va * wa + vb * wb;
+      if (grad_x) {
+        float* gp = grad_x + n * ldg + f;
+        const float v = va * wa + vb * wb;
+        *gp = accumulate ? *gp + v : v;
+      }
     }
     atomicAdd(grad_att_a + f, sa);
     if (grad_att_b) atomicAdd(grad_att_b + f, sb);
@@ -484,8 +493,8 @@ int pygamd_head_dot_forward(const float* x, int64_t ldx, const float* att_a, con
 
 int pygamd_head_dot_backward(const float* x, int64_t ldx, const float* att_a, const float* att_b,
                              const float* grad_a, const float* grad_b, int64_t n_rows, int64_t H,
-                             int64_t C, float* grad_x, int64_t ldg, float* grad_att_a,
-                             float* grad_att_b, void* stream) {
+                             int64_t C, float* grad_x, int64_t ldg, int accumulate,
+                             float* grad_att_a, float* grad_att_b, void* stream) {
   if (n_rows < 0 || H < 1 || C < 1 || ldx < H * C) return PYGAMD_ERR_INVALID_ARG;
   if (!att_a || !grad_att_a || (att_b && (!grad_b || !grad_att_b)))
     return PYGAMD_ERR_INVALID_ARG;
@@ -500,7 +509,8 @@ int pygamd_head_dot_backward(const float* x, int64_t ldx, const float* att_a, co
   blocks = ceil_div(n_rows, rows_per_block);
   hipLaunchKernelGGL(head_dot_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
                      st, x, ldx, att_a, att_b, grad_a, grad_b, n_rows, static_cast<int>(H),
-                     static_cast<int>(C), rows_per_block, grad_x, ldg, grad_att_a, grad_att_b);
+                     static_cast<int>(C), rows_per_block, grad_x, ldg, accumulate ? 1 : 0,
+                     grad_att_a, grad_att_b);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }

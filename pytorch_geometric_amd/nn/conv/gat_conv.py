@@ -6,7 +6,8 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.nn import Parameter
 
-from ..._functions import GatEdgeSoftmaxFunction, HeadDotFunction, SpmmFunction, bias_act
+from ..._functions import (GatAttendFunction, GatEdgeSoftmaxFunction, HeadDotFunction,
+                           SpmmFunction, bias_act)
 from ...edge_index import EdgeIndex, as_edge_index
 from ...utils import add_self_loops, remove_self_loops, softmax
 from ..dense.linear import Linear
@@ -110,7 +111,15 @@ class GATConv(MessagePassing):
                 return_attention_weights: Optional[bool] = None):
         H, C = self.heads, self.out_channels
         x_src, x_dst, res = self._project(x)
-        if x_dst is x_src and x_src.is_cuda and self.fuse:
+        # one autograd node for node terms + edge softmax + aggregation (GatAttendFunction) when
+        # nothing between them is observable: no edge features, no dropout on the coefficients,
+        # nobody asking for them
+        attend = (x_dst is x_src and x_src.is_cuda and self.fuse and edge_attr is None
+                  and self.flow == 'source_to_target' and return_attention_weights is None
+                  and not (self.training and self.dropout > 0))
+        if attend:
+            a_src = a_dst = None  # computed inside the fused node
+        elif x_dst is x_src and x_src.is_cuda and self.fuse:
             a_src, a_dst = HeadDotFunction.apply(x_src, self.att_src, self.att_dst)
         else:
             a_src = (x_src * self.att_src).sum(dim=-1)
@@ -139,7 +148,16 @@ class GATConv(MessagePassing):
 
         use_fused = (self.fuse and edge_attr is None and a_dst is not None
                      and self.flow == 'source_to_target')
-        if use_fused:
+        if attend and edge_attr is None:
+            n_src = x_src.size(0)
+            n_dst = n_src if size is None else size[1]
+            graph = as_edge_index(edge_index, n_src, n_dst)
+            out = GatAttendFunction.apply(x_src, self.att_src, self.att_dst, graph,
+                                          self.negative_slope, n_dst)
+            alpha = None
+        elif attend:  # (the self-loop rewrite produced edge attributes: cannot happen without
+            raise AssertionError('edge attributes appeared on the fused GAT path')  # input ones)
+        elif use_fused:
             n_src = x_src.size(0)
             n_dst = x_dst.size(0) if size is None else size[1]
             graph = as_edge_index(edge_index, n_src, n_dst)

@@ -4,7 +4,7 @@ checks (fused vs unfused, edge permutation invariance, flow reversal)."""
 import pytest
 import torch
 
-from tests._util import assert_close, gen
+from tests._util import assert_close, assert_close_scaled, gen
 
 pytestmark = pytest.mark.gpu
 
@@ -654,3 +654,40 @@ def test_basic_gnn_applies_bias_and_relu_in_the_layer(dev, kind):
     b = torch.randn(64, generator=g).to(dev)
     got = _native.bias_act(big[:, 4:68], b, True)
     assert torch.equal(got, (big[:, 4:68] + b).relu())
+
+
+def test_gat_single_autograd_node_matches_the_three_function_path(dev):
+    """`GATConv` runs node terms + edge softmax + aggregation as ONE autograd node
+    (`GatAttendFunction`: the two gradients of the projected features meet inside the node-term
+    backward kernel) when nothing between them is observable; asking for the attention weights
+    takes the three-function path.  Same kernels, same order: outputs bitwise equal, gradients
+    equal up to the one reordered addition."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd.nn import GATConv
+    g = gen(21)
+    n, e = 500, 6000
+    x = torch.randn(n, 24, generator=g).to(dev)
+    ei = torch.randint(0, n, (2, e), generator=g).to(dev)
+    go = torch.randn(n, 4 * 8, generator=g).to(dev)
+    torch.manual_seed(0)
+    conv = GATConv(24, 8, heads=4).to(dev)
+
+    def run(**kw):
+        for p in conv.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        out = conv(xx, ei, **kw)
+        out = out[0] if isinstance(out, tuple) else out
+        out.backward(go)
+        return out.detach(), xx.grad, [p.grad.clone() for p in conv.parameters()]
+
+    one = run()
+    three = run(return_attention_weights=True)
+    assert torch.equal(one[0], three[0])
+    assert_close(one[1], three[1], rtol=1e-5, atol=1e-6, what='grad x')
+    for a, b in zip(one[2], three[2]):
+        assert_close_scaled(a, b, tol=2e-6, what='grad param')
+    # a handle as input and eval mode take the same node
+    h = pga.EdgeIndex(ei, (n, n))
+    conv.eval()
+    assert torch.equal(conv(x, h), conv(x, ei))
