@@ -251,22 +251,21 @@ __global__ void __launch_bounds__(kBlock)
     float sa = 0.f, sb = 0.f;
     int64_t n = r0;
     for (; n + 4 <= r1; n += 4) {
-      float xv[4], va[4], vb[4];
+      float xv[4], va[4], vb[4], old[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         xv[u] = x[(n + u) * ldx + f];
         va[u] = ga[(n + u) * H + h];
         vb[u] = gb ? gb[(n + u) * H + h] : 0.f;
+        // (the values to add to, loaded with the operands: four rows in flight, not a
+        // read-modify-write per row)
+        old[u] = (grad_x && accumulate) ? grad_x[(n + u) * ldg + f] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         sa = fmaf(va[u], xv[u], sa);
         sb = fmaf(vb[u], xv[u], sb);
-        if (grad_x) {
-          float* gp = grad_x + (n + u) * ldg + f;
-          const float v = va[u] * wa + vb[u] * wb;
-          *gp = accumulate ? *gp + v : v;
-        }
+        if (grad_x) grad_x[(n + u) * ldg + f] = old[u] + (va[u] * wa + vb[u] * wb);
       }
     }
     for (; n < r1; ++n) {
