@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 8
+#define PYGAMD_ABI_VERSION 9
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -95,6 +95,16 @@ PYGAMD_API int pygamd_permute_index(const void* src, int idx_dtype, const int64_
 /* out[i] = (idx_dtype) perm[i]; narrows an int64 permutation to the graph's index dtype.      */
 PYGAMD_API int pygamd_cast_index(const int64_t* src, int64_t n, int idx_dtype, void* out,
                                  void* stream);
+
+/* out[i] = index[i] if 0 <= index[i] < size, else `size` (a sentinel group behind the last real
+ * one); *err (device int32, may be NULL) is set to 1 when any entry was replaced.  The sorted route
+ * of a large unsorted `scatter` (torch_geometric/utils/_scatter.py:68-100) sorts these keys, so an
+ * out-of-range index can neither corrupt the plan nor cost a blocking min / max read: such rows
+ * fall behind the last group and are skipped — as the atomic kernels skip them — and the flag
+ * travels to the host as theirs does (ABI 9).  `out` has `out_dtype` (int32 needs
+ * size < 2^31: narrower keys sort in fewer bytes), out != index.                               */
+PYGAMD_API int pygamd_index_guard(const void* index, int idx_dtype, int64_t n, int64_t size,
+                                  void* out, int out_dtype, int32_t* err, void* stream);
 
 /* out[i] = in[0] + ... + in[i] over int32 / int64 counts: `torch.cumsum(x, 0)` where the
  * reference builds offsets from counts (torch_geometric/utils/functions.py:5-26 `cumsum`,

@@ -1,5 +1,7 @@
 """Autograd glue: each ``torch.autograd.Function`` pairs one forward HIP kernel with the HIP kernels
 of its backward.  Formulas follow the reference's CPU path (see the docstrings for file:line)."""
+import collections
+import os
 from typing import Optional
 
 import torch
@@ -108,13 +110,13 @@ class SpmmFunction(Function):
             g2 = g2 * fwd.inv_degree().view(-1, 1)
         if ctx.needs_input_grad[0]:
             scale = fwd.inv_degree() if (reduce == 'mean' and w is None) else None
-            if graph.atomic_backward and (w is None or w.dim() == 1):
+            if graph.atomic_backward and (w is None or w.dim() == 1 or w.size(1) == 1):
                 # graph used once (sampled batch): edge-parallel atomics on the COO list
-                # instead of sorting by source
-                w_coo = w
+                # instead of sorting by source (one weight per edge: also a single-head GAT)
+                w_coo = w if w is None else w.reshape(-1)
                 if w is not None and ctx.w_order == 'slot':
-                    w_coo = torch.empty_like(w)
-                    w_coo[fwd.perm.long()] = w
+                    w_coo = torch.empty_like(w_coo)
+                    w_coo[fwd.perm.long()] = w.reshape(-1)
                 ei = graph.edge_index
                 grad_x = _native.gather_scatter_add(g2, ei[1], ei[0], graph.num_src_nodes,
                                                     scale=scale, w=w_coo)
@@ -140,33 +142,89 @@ class SpmmFunction(Function):
 # 311 ms for max (profiles/r04_unfused_propagate.md).  One stable radix sort of the index (a few ms,
 # cached per index tensor) turns the same call into a gather-SpMM over the sorted groups
 # (`col` = the sort permutation): 11.5 ms, deterministic.  Small inputs keep the atomics.
+#
+# Who takes the sorted route:
+#   * an index of >= SORTED_SCATTER_ALWAYS_ROWS entries always: the sort costs a small fraction of
+#     what the atomics cost there, even for an index tensor that is never seen again;
+#   * a smaller one (>= SORTED_SCATTER_MIN_ROWS) only when the same tensor (identity + version) has
+#     been seen before, or when it is a row of an `EdgeIndex` handle — a sampled batch's fresh
+#     index keeps the atomics instead of paying a sort it never amortises.
+# Building a plan reads nothing back to the host: `pygamd_index_guard` folds every out-of-range
+# entry into a sentinel group behind the last real one (skipped, as the atomic kernels skip such
+# rows) and raises the launch's error flag, which travels as PYGAMD_CHECK_INDEX says (async: flag
+# ring; sync: one blocking read; off: nothing).  The hub split plan (one host read) is added the
+# first time a cached plan is REUSED.  Plans are int32 whenever the sizes fit and the cache is
+# bounded in BYTES (PYGAMD_SCATTER_PLAN_BYTES, default 1 GiB; a plan at the products shape is
+# 0.26 GB), oldest out first; an entry also dies with its index tensor.
 SORTED_SCATTER_MIN_ROWS = 1 << 16
 SORTED_SCATTER_MIN_ELEMS = 1 << 23
-_scatter_plans = {}
+SORTED_SCATTER_ALWAYS_ROWS = 1 << 20
+SCATTER_PLAN_CACHE_BYTES = int(os.environ.get('PYGAMD_SCATTER_PLAN_BYTES', str(1 << 30)))
+SCATTER_SEEN_ENTRIES = 64
+_scatter_plans = collections.OrderedDict()  # key -> [weakref(base), version, plan, nbytes, hub?]
+_scatter_seen = collections.OrderedDict()   # key -> (weakref(base), version): met once, no plan
+_INT32_MAX = (1 << 31) - 1
 
 
-def _sorted_scatter_plan(index: Tensor, dim_size: int):
-    """(ptr [dim_size + 1], perm [n], hub) for `index`, cached by the identity + version of the
-    tensor it views (``edge_index[1]`` is a new view object on every call)."""
-    import weakref
+def _index_key(index: Tensor, dim_size: int):
+    """Identity of an index tensor: the tensor it views (``edge_index[1]`` is a new view object on
+    every call) + where in it + its version counter."""
     base = index._base if index._base is not None else index
-    key = (id(base), index.storage_offset(), index.numel(), index.stride(0), index.dtype,
-           int(dim_size))
-    hit = _scatter_plans.get(key)
-    if hit is not None and hit[0]() is base and hit[1] == index._version:
-        return hit[2]
-    lo, hi = _native.index_minmax(index)   # one host read per index tensor
-    if lo < 0 or hi >= dim_size:
-        _native._raise_out_of_range(index, dim_size, 'scatter', style='sync')
-    sorted_idx, perm = _native.index_sort(index, max_value=dim_size)
-    ptr = _native.index2ptr(sorted_idx, dim_size)
+    return base, (id(base), index.storage_offset(), index.numel(), index.stride(0), index.dtype,
+                  int(dim_size))
+
+
+def _build_scatter_plan(index: Tensor, dim_size: int):
+    n = index.numel()
+    small = n < _INT32_MAX and dim_size + 1 < _INT32_MAX
+    ring, slot, err = _native._index_flag(index.device, True)
+    keys = _native.index_guard(index, dim_size, err,
+                               dtype=torch.int32 if small else torch.int64)
+    _native._index_flag_done(ring, slot, err, 'scatter', dim_size, index)
+    sorted_keys, perm = _native.index_sort(keys, max_value=dim_size)
+    # group `dim_size` = the out-of-range entries: it has a pointer entry and no output row
+    ptr = _native.index2ptr(sorted_keys, dim_size + 1)[:dim_size + 1]
     if perm.dtype != ptr.dtype:
         perm = _native.cast_index(perm, ptr.dtype)
-    plan = (ptr, perm, _native.hub_plan(ptr))
-    if len(_scatter_plans) >= 8:
-        _scatter_plans.pop(next(iter(_scatter_plans)))
-    _scatter_plans[key] = (weakref.ref(base, lambda _, k=key: _scatter_plans.pop(k, None)),
-                           index._version, plan)
+    return ptr, perm
+
+
+def _plan_bytes(ptr: Tensor, perm: Tensor) -> int:
+    return ptr.numel() * ptr.element_size() + perm.numel() * perm.element_size()
+
+
+def _sorted_scatter_plan(index: Tensor, dim_size: int, force: bool = True):
+    """(ptr [dim_size + 1], perm [n], hub) for ``index``, or None when the rule above leaves this
+    call to the atomic kernels (``force=False`` and a first sighting)."""
+    import weakref
+    base, key = _index_key(index, dim_size)
+    hit = _scatter_plans.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == index._version:
+        _scatter_plans.move_to_end(key)
+        if not hit[4]:  # reused: now the hub split pays (one host read, once)
+            ptr, perm, _ = hit[2]
+            hit[2], hit[4] = (ptr, perm, _native.hub_plan(ptr)), True
+        return hit[2]
+    if hit is not None:
+        _scatter_plans.pop(key, None)
+    if not force and not isinstance(base, EdgeIndex):
+        seen = _scatter_seen.get(key)
+        if seen is None or seen[0]() is not base or seen[1] != index._version:
+            _scatter_seen[key] = (weakref.ref(base, lambda _, k=key: _scatter_seen.pop(k, None)),
+                                  index._version)
+            while len(_scatter_seen) > SCATTER_SEEN_ENTRIES:
+                _scatter_seen.popitem(last=False)
+            return None
+    _scatter_seen.pop(key, None)
+    ptr, perm = _build_scatter_plan(index, dim_size)
+    plan = (ptr, perm, None)
+    nbytes = _plan_bytes(ptr, perm)
+    if nbytes <= SCATTER_PLAN_CACHE_BYTES:
+        held = sum(e[3] for e in _scatter_plans.values())
+        while _scatter_plans and held + nbytes > SCATTER_PLAN_CACHE_BYTES:
+            held -= _scatter_plans.popitem(last=False)[1][3]
+        _scatter_plans[key] = [weakref.ref(base, lambda _, k=key: _scatter_plans.pop(k, None)),
+                               index._version, plan, nbytes, False]
     return plan
 
 
@@ -179,9 +237,13 @@ def _use_sorted_scatter(rows: Tensor, index: Tensor, reduce: str) -> bool:
 def _scatter_rows_auto(rows: Tensor, index: Tensor, dim_size: int, reduce: str,
                        return_count: bool = False):
     """`_native.scatter_rows` semantics; large inputs through the sorted route."""
-    if not _use_sorted_scatter(rows, index, reduce):
+    plan = None
+    if _use_sorted_scatter(rows, index, reduce):
+        plan = _sorted_scatter_plan(index, dim_size,
+                                    force=index.numel() >= SORTED_SCATTER_ALWAYS_ROWS)
+    if plan is None:
         return _native.scatter_rows(rows, index, dim_size, reduce, return_count=return_count)
-    ptr, perm, hub = _sorted_scatter_plan(index, dim_size)
+    ptr, perm, hub = plan
     out = _native.spmm_csr(ptr, perm, rows, reduce, n_rows=dim_size, hub=hub)
     if return_count:
         return out, (ptr[1:] - ptr[:-1]).to(torch.float32)

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 from . import _build
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 X_DENSE, X_COMPRESSED = 0, 1  # pygamd_x_format  # PYGAMD_ABI_VERSION of include/pyg_amd.h
 IDX_I32, IDX_I64 = 0, 1
 SUM, MEAN, MIN, MAX, MUL, ANY = 0, 1, 2, 3, 4, 5
@@ -65,6 +65,7 @@ SIGNATURES = {
     'pygamd_index_minmax': (c_int, [_P, c_int, c_int64, _P, _P]),
     'pygamd_permute_index': (c_int, [_P, c_int, _P, c_int64, _P, _P]),
     'pygamd_cast_index': (c_int, [_P, c_int64, c_int, _P, _P]),
+    'pygamd_index_guard': (c_int, [_P, c_int, c_int64, c_int64, _P, c_int, _P, _P]),
     'pygamd_cumsum_workspace_bytes': (c_int, [c_int, c_int64, POINTER(c_size_t)]),
     'pygamd_cumsum': (c_int, [_P, c_int, c_int64, _P, _P, c_size_t, _P]),
     'pygamd_hub_plan_workspace_bytes': (c_int, [c_int, c_int64, POINTER(c_size_t)]),

@@ -158,6 +158,20 @@ def cast_index(src: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+def index_guard(index: Tensor, size: int, err: Optional[Tensor] = None,
+                dtype: Optional[torch.dtype] = None) -> Tensor:
+    """A copy of ``index`` (as ``dtype``, default its own) with every entry outside ``[0, size)``
+    replaced by the sentinel ``size``; ``err`` (device int32[1]) is set when there was one.  No
+    host read."""
+    _require_device(index, err)
+    index = index.contiguous()
+    out = torch.empty(index.numel(), dtype=dtype or index.dtype, device=index.device)
+    lib = _lib.load()
+    check(lib.pygamd_index_guard(_p(index), _idx_dtype(index), index.numel(), int(size), _p(out),
+                                 _idx_dtype(out), _p(err), _stream(index)), 'index_guard')
+    return out
+
+
 def cumsum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """``torch.cumsum(x, 0)`` of a 1-D int32 / int64 device tensor on the own scan kernels
     (``pygamd_cumsum``; ``out`` may be ``x`` or a contiguous slice such as ``offsets[1:]``)."""
@@ -753,10 +767,17 @@ def _index_flag_done(ring, slot, err, what: str, size: int, index: Tensor):
         _raise_if_flagged(err, index, size, what)
 
 
-def poll_index_errors(wait: bool = False):
+def poll_index_errors(wait: bool = False, device=None):
     """Looks at the flags that have arrived (``wait=True``: at all of them, blocking) and raises
-    for the first flagged launch.  Called at the entry of the scatter backward and at the end of an
-    ``Aggregation`` call with a caller-supplied ``dim_size``."""
+    for the first flagged launch.  ``device``: only that device's ring (a caller that knows where
+    its launch ran does not touch — or wait on — the other GPUs' rings).  Called at the entry of
+    the scatter backward and at the end of an ``Aggregation`` call with a caller-supplied
+    ``dim_size``."""
+    if device is not None:
+        ring = _flag_rings.get(torch.device(device))
+        if ring is not None:
+            ring.poll(wait=wait)
+        return
     for ring in list(_flag_rings.values()):
         ring.poll(wait=wait)
 

@@ -291,6 +291,23 @@ __global__ void __launch_bounds__(kBlock)
   if (i < n) out[i] = static_cast<IdxT>(src[i]);
 }
 
+// out[i] = index[i] when it lies in [0, size), else the sentinel `size` (one group past the last:
+// a sort by these keys puts such entries behind every real group); *err = 1 if any entry was
+// replaced.  One plain store per wave that saw one — nobody reads the flag before the stream does.
+template <typename IdxT, typename OutT>
+__global__ void __launch_bounds__(kBlock)
+    index_guard_kernel(const IdxT* __restrict__ index, int64_t n, int64_t size,
+                       OutT* __restrict__ out, int32_t* __restrict__ err) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+    const int64_t v = static_cast<int64_t>(index[i]);
+    bad = v < 0 || v >= size;
+    out[i] = static_cast<OutT>(bad ? size : v);
+  }
+  if (err != nullptr && __any(bad) && (threadIdx.x & 63) == 0) *err = 1;
+}
+
 // ---- hub plan -------------------------------------------------------------------------------
 template <typename IdxT>
 struct IsHub {
@@ -571,6 +588,29 @@ int pygamd_cast_index(const int64_t* src, int64_t n, int idx_dtype, void* out, v
     const unsigned grid = static_cast<unsigned>(ceil_div(n, kBlock));
     hipLaunchKernelGGL((cast_index_kernel<IdxT>), dim3(grid), dim3(kBlock), 0, as_stream(stream),
                        src, n, static_cast<IdxT*>(out));
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  });
+}
+
+int pygamd_index_guard(const void* index, int idx_dtype, int64_t n, int64_t size, void* out,
+                       int out_dtype, int32_t* err, void* stream) {
+  if (n < 0 || size < 0) return PYGAMD_ERR_INVALID_ARG;
+  if (out_dtype != PYGAMD_IDX_I64 && out_dtype != PYGAMD_IDX_I32) return PYGAMD_ERR_INVALID_ARG;
+  if (out_dtype == PYGAMD_IDX_I32 && size > 0x7fffffffLL) return PYGAMD_ERR_INVALID_ARG;
+  if (idx_dtype != PYGAMD_IDX_I64 && idx_dtype != PYGAMD_IDX_I32) return PYGAMD_ERR_INVALID_ARG;
+  if (n == 0) return PYGAMD_OK;
+  if (!index || !out || index == out) return PYGAMD_ERR_INVALID_ARG;
+  const unsigned grid = static_cast<unsigned>(ceil_div(n, kBlock));
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    if (out_dtype == PYGAMD_IDX_I64)
+      hipLaunchKernelGGL((index_guard_kernel<IdxT, int64_t>), dim3(grid), dim3(kBlock), 0,
+                         as_stream(stream), static_cast<const IdxT*>(index), n, size,
+                         static_cast<int64_t*>(out), err);
+    else
+      hipLaunchKernelGGL((index_guard_kernel<IdxT, int32_t>), dim3(grid), dim3(kBlock), 0,
+                         as_stream(stream), static_cast<const IdxT*>(index), n, size,
+                         static_cast<int32_t*>(out), err);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });

@@ -39,11 +39,16 @@ class Aggregation(torch.nn.Module):
         prev = _native.set_error_style('dim_size')
         try:
             out = super().__call__(x, index=index, ptr=ptr, dim_size=dim_size, dim=dim, **kwargs)
-            # a caller-supplied `dim_size` is the one way an index can be out of range here: look
-            # at this call's flags before returning (one host wait — what inferring `dim_size`
-            # costs on the other branch), so that the error is raised by THIS call
+            # a caller-supplied `dim_size` is the one way an index can be out of range here.  The
+            # launch was flagged in the 'dim_size' style, so whoever meets the flag raises the
+            # reference's ValueError (nn/aggr/base.py:131-141): this call when the flag has already
+            # arrived (no wait), else the next scatter / aggregation call, the backward, or
+            # `check_index_errors()`.  Only PYGAMD_CHECK_INDEX=sync blocks the host here — with
+            # the default 'async' a per-aggregation wait would serialise host and device in every
+            # unfused conv layer (MessagePassing.aggregate always supplies `dim_size`).
             if given and x.is_cuda and not torch.cuda.is_current_stream_capturing():
-                _native.poll_index_errors(wait=True)
+                _native.poll_index_errors(wait=_native.INDEX_CHECK == 'sync',
+                                          device=x.device)
             return out
         except (IndexError, RuntimeError) as e:  # same recovery as nn/aggr/base.py:131-141
             if index is not None and index.numel() > 0:

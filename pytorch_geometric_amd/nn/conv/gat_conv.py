@@ -12,6 +12,7 @@ from ...edge_index import EdgeIndex, as_edge_index
 from ...utils import add_self_loops, remove_self_loops, softmax
 from ..dense.linear import Linear
 from ..inits import glorot, zeros
+from ._act_request import requested_activation
 from .message_passing import MessagePassing
 
 
@@ -114,12 +115,21 @@ class GATConv(MessagePassing):
         # one autograd node for node terms + edge softmax + aggregation (GatAttendFunction) when
         # nothing between them is observable: no edge features, no dropout on the coefficients,
         # nobody asking for them
-        attend = (x_dst is x_src and x_src.is_cuda and self.fuse and edge_attr is None
+        # The kernels take float32: half / bf16 inputs or an autocast region step aside to the
+        # composed path.  A handle marked `atomic_backward` (a sampled batch, used once) keeps the
+        # HeadDot + SpmmFunction route, whose backward runs edge-parallel atomics instead of
+        # building the by-source sort the fused node's backward needs.
+        native = (x_src.is_cuda and x_src.dtype == torch.float32 and self.fuse
+                  and not torch.is_autocast_enabled())
+        # (the edge-parallel atomic backward exists for one weight per edge: heads == 1)
+        one_shot = (isinstance(edge_index, EdgeIndex) and edge_index.atomic_backward
+                    and self.heads == 1)
+        attend = (x_dst is x_src and native and edge_attr is None and not one_shot
                   and self.flow == 'source_to_target' and return_attention_weights is None
                   and not (self.training and self.dropout > 0))
         if attend:
             a_src = a_dst = None  # computed inside the fused node
-        elif x_dst is x_src and x_src.is_cuda and self.fuse:
+        elif x_dst is x_src and native:
             a_src, a_dst = HeadDotFunction.apply(x_src, self.att_src, self.att_dst)
         else:
             a_src = (x_src * self.att_src).sum(dim=-1)
@@ -139,14 +149,16 @@ class GATConv(MessagePassing):
             def build():
                 ei, ea = remove_self_loops(handle.edge_index, edge_attr)
                 ei, ea = add_self_loops(ei, ea, fill_value=self.fill_value, num_nodes=n)
-                return EdgeIndex(ei, handle.sparse_size, validate=False), ea
+                out = EdgeIndex(ei, handle.sparse_size, validate=False)
+                out.atomic_backward = handle.atomic_backward
+                return out, ea
 
             if edge_attr is None:
                 edge_index, edge_attr = handle.derived(('self_loops', n), build)
             else:
                 edge_index, edge_attr = build()
 
-        use_fused = (self.fuse and edge_attr is None and a_dst is not None
+        use_fused = (native and edge_attr is None and a_dst is not None
                      and self.flow == 'source_to_target')
         if attend and edge_attr is None:
             n_src = x_src.size(0)
@@ -184,8 +196,8 @@ class GATConv(MessagePassing):
         out = out.reshape(-1, H * C) if self.concat else out.mean(dim=1)
         if res is not None:
             out = out + res
-        # `fused_act` (set by BasicGNN for ReLU stacks): bias + the model's activation in one pass
-        fa = getattr(self, 'fused_act', None)
+        # a ReLU stack's request (BasicGNN, _act_request): bias + the model's activation in one pass
+        fa = requested_activation(self)
         if fa is not None or (self.bias is not None and out.is_cuda):
             out = bias_act(out, self.bias, fa == 'relu')
         elif self.bias is not None:

@@ -10,6 +10,7 @@ from ...utils import add_remaining_self_loops, scatter
 from ...utils.num_nodes import maybe_num_nodes
 from ..dense.linear import Linear
 from ..inits import zeros
+from ._act_request import requested_activation
 from .message_passing import MessagePassing
 
 
@@ -103,8 +104,8 @@ class GCNConv(MessagePassing):
         elif self.normalize and isinstance(edge_index, Tensor):
             edge_index, edge_weight = self._normalized(x, edge_index, edge_weight)
         out = self.propagate(edge_index, x=self.lin(x), edge_weight=edge_weight)
-        # `fused_act` (set by BasicGNN for ReLU stacks): bias + the model's activation in one pass
-        fa = getattr(self, 'fused_act', None)
+        # a ReLU stack's request (BasicGNN, _act_request): bias + the model's activation in one pass
+        fa = requested_activation(self)
         if fa is not None or (self.bias is not None and out.is_cuda):
             return bias_act(out, self.bias, fa == 'relu')
         return out if self.bias is None else out + self.bias

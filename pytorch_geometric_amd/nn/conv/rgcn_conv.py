@@ -10,6 +10,7 @@ from ..._functions import GatherFunction, SpmmFunction, bias_act, linear
 from ...edge_index import EdgeIndex
 from ...utils._segment_matmul import block_segment_matmul, segment_matmul
 from ..inits import glorot, zeros
+from ._act_request import requested_activation
 from .message_passing import MessagePassing
 
 
@@ -197,7 +198,7 @@ class RGCNConv(MessagePassing):
                 out = out + root[x_r]
             else:
                 out = out + linear(x_r, root.t())
-        fa = getattr(self, 'fused_act', None)  # (BasicGNN-style ReLU stacks: bias + ReLU in one pass)
+        fa = requested_activation(self)  # (BasicGNN-style ReLU stacks: bias + ReLU in one pass)
         if fa is not None or (self.bias is not None and out.is_cuda):
             return bias_act(out, self.bias, fa == 'relu')
         if self.bias is not None:
@@ -260,7 +261,7 @@ class FastRGCNConv(RGCNConv):
         if self.root is not None:
             out = out + (self.root[x_r] if not torch.is_floating_point(x_r)
                          else linear(x_r, self.root.t()))
-        fa = getattr(self, 'fused_act', None)  # (BasicGNN-style ReLU stacks: bias + ReLU in one pass)
+        fa = requested_activation(self)  # (BasicGNN-style ReLU stacks: bias + ReLU in one pass)
         if fa is not None or (self.bias is not None and out.is_cuda):
             return bias_act(out, self.bias, fa == 'relu')
         if self.bias is not None:

@@ -6,6 +6,7 @@ from torch.nn import ModuleList
 
 from ...utils import trim_to_layer
 from ..conv import GATConv, GCNConv, MessagePassing, SAGEConv
+from ..conv._act_request import has_forward_hooks, request_activation
 
 _ACTS = {'relu': torch.nn.ReLU, 'elu': torch.nn.ELU, 'leaky_relu': torch.nn.LeakyReLU,
          'gelu': torch.nn.GELU, 'tanh': torch.nn.Tanh, 'sigmoid': torch.nn.Sigmoid}
@@ -71,27 +72,27 @@ class BasicGNN(torch.nn.Module):
             raise NotImplementedError("'trim_to_layer' functionality does not yet support "
                                       "trimming of both 'edge_weight' and 'edge_attr'")
         # ReLU stacks of layers that end in `out + bias` (GCNConv, GATConv, RGCNConv): the layer
-        # applies bias + ReLU itself in one pass (`fused_act`, _functions.BiasActFunction) instead of
-        # an ATen add here and an ATen clamp there (and two more passes in the backward)
-        fused = [False] * self.num_layers
+        # applies bias + ReLU itself in one pass (_functions.BiasActFunction) instead of an ATen
+        # add here and an ATen clamp there (and two more passes in the backward).  The request is
+        # per CALL (a thread-local slot naming the conv object, consumed by that layer call:
+        # nn/conv/_act_request.py), never module state; a layer with forward hooks is not asked
+        # (its hooks must see the reference's pre-activation output).
         fuse_ok = isinstance(self.act, torch.nn.ReLU) and isinstance(x, Tensor) and x.is_cuda \
-            and x.dtype == torch.float32
+            and x.dtype == torch.float32 and not has_forward_hooks(self.act)
         for i, conv in enumerate(self.convs):
-            want = fuse_ok and i < self.num_layers - 1 and hasattr(conv, 'bias') \
+            if num_sampled_nodes_per_hop is not None:
+                x, edge_index, value = trim_to_layer(
+                    i, num_sampled_nodes_per_hop, num_sampled_edges_per_hop, x, edge_index,
+                    edge_weight if edge_weight is not None else edge_attr)
+                if edge_weight is not None:
+                    edge_weight = value
+                else:
+                    edge_attr = value
+            fused = fuse_ok and i < self.num_layers - 1 and hasattr(conv, 'bias') \
                 and type(conv).__name__ in ('GCNConv', 'GATConv', 'RGCNConv', 'FastRGCNConv') \
-                and type(conv).__module__.startswith('pytorch_geometric_amd')
-            conv.fused_act = 'relu' if want else None
-            fused[i] = want
-        try:
-            for i, conv in enumerate(self.convs):
-                if num_sampled_nodes_per_hop is not None:
-                    x, edge_index, value = trim_to_layer(
-                        i, num_sampled_nodes_per_hop, num_sampled_edges_per_hop, x, edge_index,
-                        edge_weight if edge_weight is not None else edge_attr)
-                    if edge_weight is not None:
-                        edge_weight = value
-                    else:
-                        edge_attr = value
+                and type(conv).__module__.startswith('pytorch_geometric_amd') \
+                and not has_forward_hooks(conv)
+            with request_activation(conv, 'relu' if fused else None):
                 if self.supports_edge_weight and self.supports_edge_attr:
                     x = conv(x, edge_index, edge_weight=edge_weight, edge_attr=edge_attr)
                 elif self.supports_edge_weight:
@@ -100,13 +101,10 @@ class BasicGNN(torch.nn.Module):
                     x = conv(x, edge_index, edge_attr=edge_attr)
                 else:
                     x = conv(x, edge_index)
-                if i < self.num_layers - 1:
-                    if self.act is not None and not fused[i]:
-                        x = self.act(x)
-                    x = self.dropout(x)
-        finally:  # a layer called on its own keeps the reference's semantics
-            for conv in self.convs:
-                conv.fused_act = None
+            if i < self.num_layers - 1:
+                if self.act is not None and not fused:
+                    x = self.act(x)
+                x = self.dropout(x)
         return x
 
     def __repr__(self) -> str:

@@ -23,6 +23,7 @@ hipGraph — with as few, as fat kernels as the path allows (round 3: 181 kernel
 Padding rows (holes) hold finite values forward (zero features, or an aggregation of nothing) and
 receive exactly zero gradient backward: no entry of a transposed CSR points at them."""
 import ctypes
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -86,6 +87,21 @@ class SlotBatch:
     t_col: List[Tensor]  # per transposed CSR: [slots] int32 (filled prefix = ptr[-1])
     x: Optional[Tensor] = None   # [R, 2 F] = [ (aggregation target) | x[node_g] ]
     y: Optional[Tensor] = None
+    # The index tensors above are the SAMPLER's buffers, overwritten by its next `sample()`:
+    # `stamp` is the sampler's call counter when this batch was drawn, `owner` the sampler.  The
+    # stack's backward reads `t_ptr / t_col / inv_cnt` again and refuses a batch whose sampler has
+    # moved on (prefetching the next batch before `backward()` needs a second SlotSampler).
+    stamp: int = 0
+    owner: Optional[object] = None
+
+    def check_current(self, where: str) -> None:
+        owner = self.owner() if self.owner is not None else None
+        if owner is not None and owner.calls != self.stamp:
+            raise RuntimeError(
+                f'{where}: this SlotBatch was drawn by sample() call {self.stamp} of its '
+                f'SlotSampler, which has sampled again since (call {owner.calls}) into the same '
+                f'buffers; run backward() before sampling the next batch, or prefetch with a '
+                f'second SlotSampler')
 
 
 class SlotSampler:
@@ -99,6 +115,7 @@ class SlotSampler:
         if colptr.dtype != row.dtype or colptr.dtype not in (torch.int32, torch.int64):
             raise ValueError("'colptr' / 'row' must share an int32 / int64 dtype")
         self.colptr, self.row, self.plan, self.seed = colptr, row, plan, int(seed)
+        self.calls = 0   # sample() calls so far (host side): the stamp of the batch it returns
         dev = colptr.device
         p = plan
         # the claim map: zero = "never claimed"; epochs >= 1 always beat it — never reset
@@ -160,8 +177,9 @@ class SlotSampler:
                 _i64p(self.src_g), _i64p(self.src_id), p.L, self._fan_host, self._bases_host,
                 p.n_csr, self._slots_host, self._rows_host, self._counts_host, self._cursor_host,
                 self._ptr_host, self._col_host, st), 'slots_transpose')
+        self.calls += 1
         return SlotBatch(p, self.node_g, self.src_g, self.src_id, self.row_end, self.inv_cnt,
-                         self.t_ptr, self.t_col)
+                         self.t_ptr, self.t_col, stamp=self.calls, owner=weakref.ref(self))
 
     @torch.no_grad()
     def gather(self, x: Tensor, batch: SlotBatch, out: Optional[Tensor] = None) -> Tensor:
@@ -187,6 +205,7 @@ class FusedSageSlotStack(Function):
     @staticmethod
     def forward(ctx, cat0: Tensor, batch: SlotBatch, aggr: str, *params: Optional[Tensor]):
         p = batch.plan
+        batch.check_current('FusedSageSlotStack.forward')
         L = len(params) // 3
         if L != p.L:
             raise ValueError(f'{L} layers on a batch of {p.L} hops')
@@ -230,6 +249,7 @@ class FusedSageSlotStack(Function):
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         L, batch, aggr = ctx.L, ctx.batch, ctx.aggr
+        batch.check_current('FusedSageSlotStack.backward')
         p = batch.plan
         saved = ctx.saved_tensors
         cats, wmats = saved[:L], saved[L:2 * L]
@@ -267,9 +287,54 @@ class FusedSageSlotStack(Function):
         return (grad_x, None, None, *grads)
 
 
+def check_slot_model(model, batch: Optional[SlotBatch] = None) -> None:
+    """Raises ``ValueError`` naming the first thing about ``model`` the slot stack would silently
+    ignore or trip over (cf. ``nn.models._fused_sage_hops.eligible``, which steps aside instead):
+    the stack computes ``relu(lin_l(aggr_j x_j) + lin_r(x_i))`` per layer and nothing else."""
+    from .nn.conv import SAGEConv
+    convs = list(getattr(model, 'convs', []))
+    if not convs:
+        raise ValueError('run_slot_stack needs a model with a `convs` list of SAGEConv layers')
+    if batch is not None and len(convs) != batch.plan.L:
+        raise ValueError(f'{len(convs)} layers on a batch of {batch.plan.L} hops')
+    act = getattr(model, 'act', None)
+    if act is not None and not isinstance(act, torch.nn.ReLU):
+        raise ValueError(f'the slot stack applies ReLU between layers (model.act is '
+                         f'{type(act).__name__})')
+    drop = getattr(model, 'dropout', None)
+    p_drop = drop.p if isinstance(drop, torch.nn.Dropout) else (drop or 0.0)
+    if p_drop > 0 and model.training:
+        raise ValueError(f'the slot stack has no dropout (model.dropout = {p_drop} in training '
+                         f'mode)')
+    if getattr(model, 'norms', None) is not None and any(
+            not isinstance(n, torch.nn.Identity) for n in model.norms):
+        raise ValueError('the slot stack has no normalisation layers (model.norms)')
+    if getattr(model, 'jk_mode', None) not in (None, 'last'):
+        raise ValueError(f"the slot stack has no jumping knowledge (jk='{model.jk_mode}')")
+    aggr = convs[0].aggr
+    for l, conv in enumerate(convs):
+        if not isinstance(conv, SAGEConv):
+            raise ValueError(f'convs[{l}] is a {type(conv).__name__}, not a SAGEConv')
+        if conv.aggr not in ('mean', 'sum', 'add'):
+            raise ValueError(f"convs[{l}].aggr = '{conv.aggr}': the slot stack aggregates with "
+                             f"mean or sum")
+        if conv.aggr != aggr:
+            raise ValueError(f"convs[{l}].aggr = '{conv.aggr}' but convs[0].aggr = '{aggr}': one "
+                             f"aggregation for the whole stack")
+        if not conv.root_weight:
+            raise ValueError(f'convs[{l}] has root_weight=False (no lin_r): unsupported')
+        if getattr(conv, 'normalize', False):
+            raise ValueError(f'convs[{l}] has normalize=True: unsupported')
+        if getattr(conv, 'project', False):
+            raise ValueError(f'convs[{l}] has project=True: unsupported')
+        if getattr(conv, 'flow', 'source_to_target') != 'source_to_target':
+            raise ValueError(f"convs[{l}].flow = '{conv.flow}': unsupported")
+
+
 def run_slot_stack(model, batch: SlotBatch) -> Tensor:
-    """``model``: a GraphSAGE of plain ``SAGEConv`` layers (``nn.models._fused_sage_hops.
-    eligible``-style: mean / sum aggregation, root weight, ReLU, no norm / dropout / jk)."""
+    """``model``: a GraphSAGE of plain ``SAGEConv`` layers (mean / sum aggregation, root weight,
+    ReLU, no norm / dropout / jk — anything else raises, :func:`check_slot_model`)."""
+    check_slot_model(model, batch)
     params = []
     for conv in model.convs:
         params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]

@@ -617,10 +617,13 @@ def test_key_range_is_validated_before_limited_bit_sorts(dev):
 @pytest.mark.parametrize('kind', ['gcn', 'gat'])
 def test_basic_gnn_applies_bias_and_relu_in_the_layer(dev, kind):
     """ReLU stacks of GCNConv / GATConv: the layer applies `out + bias` and the model's ReLU in ONE
-    pass (`fused_act`, _functions.BiasActFunction; backward = masked gradient + bias gradient from
-    one read) instead of an ATen add in the layer and an ATen clamp in the model.  Same values and
-    gradients as the unfused evaluation (LeakyReLU(0) is not a ReLU instance: no fusion), and a
-    layer called on its own afterwards still returns the reference's pre-activation output."""
+    pass (_functions.BiasActFunction; backward = masked gradient + bias gradient from one read)
+    instead of an ATen add in the layer and an ATen clamp in the model.  Same values and gradients
+    as the unfused evaluation (LeakyReLU(0) is not a ReLU instance: no fusion), and a layer called
+    on its own afterwards still returns the reference's pre-activation output.  The request is
+    call-time state (a thread-local slot consumed by the layer call, nn/conv/_act_request.py):
+    nothing is written on the modules, and a layer with a forward hook is not asked to fuse — its
+    hook sees the pre-activation output."""
     from pytorch_geometric_amd.nn import GAT, GCN
     from tests._util import assert_close_scaled, random_graph
     g = gen(5)
@@ -641,13 +644,55 @@ def test_basic_gnn_applies_bias_and_relu_in_the_layer(dev, kind):
         out = model(xg, ei)
         out.backward(go)
         res.append((out.detach(), xg.grad, [p.grad.clone() for p in model.parameters()]))
-        assert all(getattr(c, 'fused_act', None) is None for c in model.convs)
+        assert all(not hasattr(c, 'fused_act') for c in model.convs)
     assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-5, what='fused bias+ReLU output')
     assert_close_scaled(res[0][1], res[1][1], what='fused bias+ReLU grad_x')
     for a, b in zip(res[0][2], res[1][2]):
         assert_close_scaled(a, b, what='fused bias+ReLU parameter gradient')
     alone = model.convs[0](x, ei)
     assert bool((alone < 0).any()), 'a layer called on its own must not apply the ReLU'
+    # which path ran: the one-pass kernel is asked for ReLU by the two inner layers of a ReLU stack
+    from pytorch_geometric_amd import _functions
+    from pytorch_geometric_amd.nn.conv import _act_request
+    asked = []
+    real = _functions.BiasActFunction.apply
+
+    class Spy:
+        @staticmethod
+        def apply(out, bias, relu):
+            asked.append(bool(relu))
+            return real(out, bias, relu)
+
+    _functions.BiasActFunction, keep = Spy, _functions.BiasActFunction
+    try:
+        model.act = torch.nn.ReLU()
+        model(x, ei)
+        assert asked == [True, True, False], asked
+        # a forward hook on a layer observes its output: that layer is not asked to fuse, and the
+        # hook sees negative (pre-activation) values; the model's result is unchanged
+        seen = []
+        hook = model.convs[0].register_forward_hook(lambda m, i, o: seen.append(o.detach()))
+        del asked[:]
+        hooked = model(x, ei)
+        hook.remove()
+        assert asked == [False, True, False], asked
+        assert bool((seen[0] < 0).any())
+        assert_close(hooked.detach(), res[0][0], rtol=1e-5, atol=1e-5, what='hooked stack output')
+        # a request never outlives the layer call it was made for, and is this thread's alone
+        import threading
+        with _act_request.request_activation(model.convs[0], 'relu'):
+            other = []
+            t = threading.Thread(
+                target=lambda: other.append(_act_request.requested_activation(model.convs[0])))
+            t.start()
+            t.join()
+            assert other == [None]
+            assert _act_request.requested_activation(model.convs[1]) is None
+            assert _act_request.requested_activation(model.convs[0]) == 'relu'
+            assert _act_request.requested_activation(model.convs[0]) is None  # consumed
+        assert _act_request.requested_activation(model.convs[0]) is None
+    finally:
+        _functions.BiasActFunction = keep
     # the one-pass kernel on a block larger than its capped grid (grid-stride loop), strided input
     from pytorch_geometric_amd import _native
     big = torch.randn(300_000, 72, generator=g).to(dev)
@@ -691,3 +736,59 @@ def test_gat_single_autograd_node_matches_the_three_function_path(dev):
     h = pga.EdgeIndex(ei, (n, n))
     conv.eval()
     assert torch.equal(conv(x, h), conv(x, ei))
+
+
+def test_gat_steps_aside_for_half_precision_and_autocast(dev):
+    """the one-node GAT attention (`GatAttendFunction`) and the HeadDot / edge-softmax
+    kernels take float32.  bf16 inputs and autocast regions run the composed path (values close to
+    the float32 result at bf16 resolution) instead of raising; a single-head layer on a handle
+    marked `atomic_backward` keeps the route whose backward does not sort by source."""
+    from pytorch_geometric_amd import _functions
+    from pytorch_geometric_amd.edge_index import EdgeIndex
+    from pytorch_geometric_amd.nn import GATConv
+    g = gen(12)
+    n, e = 400, 5000
+    x = torch.randn(n, 16, generator=g).to(dev)
+    ei = torch.randint(0, n, (2, e), generator=g).to(dev)
+    torch.manual_seed(0)
+    conv = GATConv(16, 8, heads=2).to(dev)
+    want = conv(x, ei).detach()
+    used = []
+    real = _functions.GatAttendFunction.apply
+
+    class Spy:
+        @staticmethod
+        def apply(*a):
+            used.append(1)
+            return real(*a)
+
+    import pytorch_geometric_amd.nn.conv.gat_conv as gat_mod
+    keep, gat_mod.GatAttendFunction = gat_mod.GatAttendFunction, Spy
+    try:
+        conv(x, ei)
+        assert used == [1]
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = conv(x, ei)
+        assert used == [1], 'an autocast region must not reach the float32-only fused node'
+        assert_close(out.float(), want, rtol=5e-2, atol=5e-2, what='GAT under autocast')
+        half = GATConv(16, 8, heads=2).to(dev).to(torch.bfloat16)
+        half.load_state_dict({k: v.to(torch.bfloat16) for k, v in conv.state_dict().items()})
+        out = half(x.to(torch.bfloat16), ei)
+        assert out.dtype == torch.bfloat16 and used == [1]
+        assert_close(out.float(), want, rtol=1e-1, atol=1e-1, what='bf16 GAT')
+        # one-shot handle, one head: HeadDot + SpmmFunction (atomic backward), no by-source sort
+        torch.manual_seed(1)
+        one = GATConv(16, 8, heads=1, add_self_loops=False).to(dev)
+        h = EdgeIndex(ei, (n, n), validate=False)
+        ref_out = one(x, h)
+        assert used == [1, 1]
+        h2 = EdgeIndex(ei, (n, n), validate=False)
+        h2.atomic_backward = True
+        xg = x.clone().requires_grad_(True)
+        out = one(xg, h2)
+        assert used == [1, 1]
+        assert_close(out, ref_out.detach(), rtol=1e-5, atol=1e-5, what='one-shot GAT output')
+        out.sum().backward()
+        assert h2._csc is None, 'the one-shot route must not build the by-source form'
+    finally:
+        gat_mod.GatAttendFunction = keep

@@ -174,11 +174,29 @@ def test_scatter_errors(dev):
     with pytest.raises(pga.PygAmdError, match='no CPU fallback'):
         pga.utils.scatter(torch.randn(4, 2), torch.tensor([0, 0, 1, 1]))
     agg = pga.nn.MeanAggregation()
-    # a caller-supplied dim_size that is too small is reported by the call ITSELF (the wrapper
-    # looks at its own flags before returning; nn/aggr/base.py:131-141 in the reference)
+    # a caller-supplied dim_size that is too small is reported in the reference's words
+    # (nn/aggr/base.py:131-141) by whoever meets the launch's flag: with the default 'async' the
+    # call does NOT wait for it (no host/device serialisation per aggregation) ...
+    from pytorch_geometric_amd import _native
+    assert _native.INDEX_CHECK == 'async'
     with pytest.raises(ValueError, match="invalid 'dim_size'"):
         agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
+        pga.check_index_errors()
     pga.check_index_errors()  # nothing left pending
+    # ... a later aggregation call meets the flag once it has arrived ...
+    agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="invalid 'dim_size'"):
+        agg(torch.randn(5, 3, device=dev), idx, dim_size=2)
+    pga.check_index_errors()
+    # ... and PYGAMD_CHECK_INDEX=sync raises at the call site itself
+    _native.INDEX_CHECK = 'sync'
+    try:
+        with pytest.raises(ValueError, match="invalid 'dim_size'"):
+            agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
+    finally:
+        _native.INDEX_CHECK = 'async'
+    pga.check_index_errors()
     with pytest.raises(ValueError, match='invalid dimension'):
         agg(torch.randn(5, 3, device=dev), idx, dim=2)
 
@@ -840,6 +858,7 @@ def test_one_pass_multi_reduce(dev, F, sorted_index):
     assert_sum_close(xg.grad, xr.grad, x64.grad, rtol=2e-5, atol=2e-5, what='grad')
     with pytest.raises(ValueError, match="invalid 'dim_size'"):
         fused(xg, index.to(dev), dim_size=3)
+        pga.check_index_errors()
 
 
 def test_round2_entry_points_on_empty_and_degenerate_inputs(dev):
@@ -1155,7 +1174,12 @@ def test_large_unsorted_scatter_takes_the_sorted_route(dev, monkeypatch):
     sort + 11.5 ms, profiles/r04_unfused_propagate.md).  Same values as the atomic kernels
     (max / min exactly, sums to fp32 rounding) and as the CPU, same gradients; the plan is cached per
     index tensor — also through fresh views like `edge_index[1]` — and dropped when the index is
-    edited in place; out-of-range indices raise."""
+    edited in place.  Route rule: an index below SORTED_SCATTER_ALWAYS_ROWS entries
+    is sorted from its SECOND sighting on (a sampled batch's one-shot index keeps the atomics), a
+    row of an `EdgeIndex` handle or a larger index at once; building a plan reads nothing back to
+    the host (`pygamd_index_guard`): out-of-range entries land in a sentinel group that is skipped,
+    and the flag travels as PYGAMD_CHECK_INDEX says; plans are int32 and the cache is bounded in
+    bytes."""
     from pytorch_geometric_amd import _functions, _native
     from pytorch_geometric_amd.utils import scatter
     g = gen(77)
@@ -1172,6 +1196,19 @@ def test_large_unsorted_scatter_takes_the_sorted_route(dev, monkeypatch):
         return real(*a, **k)
 
     monkeypatch.setattr(_native, 'index_sort', counted)
+    minmax = {'n': 0}
+    real_mm = _native.index_minmax
+
+    def counted_mm(*a, **k):
+        minmax['n'] += 1
+        return real_mm(*a, **k)
+
+    monkeypatch.setattr(_native, 'index_minmax', counted_mm)
+    _functions._scatter_plans.clear()
+    _functions._scatter_seen.clear()
+    assert e < _functions.SORTED_SCATTER_ALWAYS_ROWS
+    scatter(src, ei[1], 0, n, 'sum')     # first sighting: atomics, nothing sorted, nothing cached
+    assert sorts['n'] == 0 and not _functions._scatter_plans and len(_functions._scatter_seen) == 1
     for reduce in ('sum', 'mean', 'max', 'min'):
         s = src.clone().requires_grad_(True)
         out = scatter(s, ei[1], 0, n, reduce)
@@ -1195,8 +1232,52 @@ def test_large_unsorted_scatter_takes_the_sorted_route(dev, monkeypatch):
         else:
             assert_sum_close(atom, want.detach(), ex, what='atomic route, same inputs')
     assert sorts['n'] == 1, 'the sort must be cached across calls and across views of the index'
+    assert minmax['n'] == 0, 'building or using a plan must not read the index range back'
+    (entry, ) = _functions._scatter_plans.values()
+    ptr, perm, hub = entry[2]
+    assert ptr.dtype == perm.dtype == torch.int32 and ptr.numel() == n + 1 and perm.numel() == e
+    assert entry[4] and hub is not None, 'the hub plan is added when a plan is reused'
+    assert entry[3] == 4 * (n + 1 + e)
     ei[1, 0] = (ei[1, 0] + 1) % n          # in-place edit: the cached plan is stale
+    scatter(src, ei[1], 0, n, 'sum')       # ... and this version of the index is new: atomics
+    assert sorts['n'] == 1
     scatter(src, ei[1], 0, n, 'sum')
     assert sorts['n'] == 2
-    with pytest.raises(IndexError):
-        scatter(src, ei[1], 0, n // 2, 'sum')
+    # a row of an EdgeIndex handle, or an index past the always-threshold: sorted at first sight
+    from pytorch_geometric_amd.edge_index import EdgeIndex
+    h = EdgeIndex(ei.clone(), sparse_size=(n, n), validate=False)
+    scatter(src, h[1], 0, n, 'sum')
+    assert sorts['n'] == 3
+    monkeypatch.setattr(_functions, 'SORTED_SCATTER_ALWAYS_ROWS', 1 << 16)
+    fresh = ei[1].clone()
+    scatter(src, fresh, 0, n, 'sum')
+    assert sorts['n'] == 4
+    # out-of-range entries: skipped like the atomic kernels skip them, flagged without a wait
+    import pytorch_geometric_amd as pga
+    pga.check_index_errors()
+    bad = fresh.clone()
+    bad[5], bad[77] = n + 3, -1
+    got = scatter(src, bad, 0, n, 'sum')
+    assert sorts['n'] == 5 and minmax['n'] == 0
+    keep = torch.ones(e, dtype=torch.bool, device=dev)
+    keep[5] = keep[77] = False
+    want = _native.scatter_rows(src[keep], fresh[keep], n, 'sum')
+    assert_close(got, want, rtol=1e-5, atol=1e-4, what='out-of-range rows are skipped')
+    with pytest.raises(IndexError, match='out of bounds'):
+        pga.check_index_errors()
+    pga.check_index_errors()
+    _native.INDEX_CHECK = 'sync'
+    try:
+        with pytest.raises(IndexError, match='out of bounds'):
+            scatter(src, bad.clone(), 0, n, 'sum')
+    finally:
+        _native.INDEX_CHECK = 'async'
+    pga.check_index_errors()
+    # the cache is bounded in bytes: with room for one plan the older one goes
+    _functions._scatter_plans.clear()
+    monkeypatch.setattr(_functions, 'SCATTER_PLAN_CACHE_BYTES', 4 * (n + 1 + e) + 64)
+    a, b = fresh.clone(), fresh.clone()
+    scatter(src, a, 0, n, 'sum')
+    scatter(src, b, 0, n, 'sum')
+    assert len(_functions._scatter_plans) == 1
+    assert next(iter(_functions._scatter_plans))[0] == id(b)

@@ -243,3 +243,67 @@ def test_slot_step_is_capturable_and_draws_fresh_batches(dev):
     assert abs(float(loss_buf) - seen[-1][0]) <= 1e-5 * max(1.0, abs(seen[-1][0]))
     for a, c in zip(grads, seen[-1][1]):
         assert_close_scaled(a, c, tol=2e-5, what='replay vs eager gradient')
+
+
+def test_slot_stack_refuses_unsupported_models_and_stale_batches(dev):
+    """`run_slot_stack` computes relu(lin_l(aggr x_j) + lin_r(x_i)) and nothing else — a
+    model with dropout / normalize / project / root_weight=False / mixed aggregations raises
+    instead of being silently mis-evaluated; and a batch whose sampler has sampled again (its
+    index buffers are the sampler's own) is refused by forward and backward."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd.nn import GraphSAGE
+    from pytorch_geometric_amd.slots import SlotPlan, SlotSampler, run_slot_stack
+    n, B, fan = 2000, 40, [4, 3]
+    g = gen(3)
+    ei = _graph(n, 30_000, seed=2)
+    csc = pga.EdgeIndex(ei.to(dev), (n, n)).by_dst()
+    x = torch.randn(n, 16, generator=g).to(dev)
+    plan = SlotPlan(B, fan, dev)
+    smp = SlotSampler(csc.ptr, csc.idx, n, plan, seed=1)
+    epoch = torch.ones(1, dtype=torch.int64, device=dev)
+    seeds = torch.randperm(n, generator=g)[:B].to(dev)
+
+    def batch():
+        epoch.add_(1)
+        b = smp.sample(seeds, epoch)
+        b.x = smp.gather(x, b)
+        return b
+
+    def model(**kw):
+        torch.manual_seed(0)
+        return GraphSAGE(16, 24, num_layers=2, out_channels=5, **kw).to(dev)
+
+    b = batch()
+    for kw, msg in ((dict(dropout=0.5), 'dropout'), (dict(normalize=True), 'normalize'),
+                    (dict(project=True), 'project'), (dict(root_weight=False), 'root_weight'),
+                    (dict(aggr='max'), 'aggr'), (dict(act='elu'), 'ReLU')):
+        with pytest.raises(ValueError, match=msg):
+            run_slot_stack(model(**kw), b)
+    m = model(dropout=0.5).eval()          # dropout is the identity in eval mode: fine
+    run_slot_stack(m, b)
+    m = model()
+    m.convs[1].aggr = 'sum'
+    with pytest.raises(ValueError, match='one aggregation'):
+        run_slot_stack(m, b)
+    with pytest.raises(ValueError, match='3 layers on a batch of 2 hops'):
+        torch.manual_seed(0)
+        run_slot_stack(GraphSAGE(16, 24, num_layers=3, out_channels=5).to(dev), b)
+    # stale batches
+    m = model()
+    out = run_slot_stack(m, b)
+    nxt = batch()                          # the sampler's buffers now hold the NEXT batch
+    with pytest.raises(RuntimeError, match='sampled again'):
+        out.sum().backward()
+    with pytest.raises(RuntimeError, match='sampled again'):
+        run_slot_stack(m, b)
+    out = run_slot_stack(m, nxt)           # the current batch is fine, forward and backward
+    out.sum().backward()
+    # a second sampler is how the next batch is prefetched before backward()
+    smp2 = SlotSampler(csc.ptr, csc.idx, n, plan, seed=1)
+    cur = batch()
+    out = run_slot_stack(m, cur)
+    epoch.add_(1)
+    ahead = smp2.sample(seeds, epoch)
+    ahead.x = smp2.gather(x, ahead)
+    out.sum().backward()
+    run_slot_stack(m, ahead).sum().backward()
