@@ -382,11 +382,20 @@ PYGAMD_API int pygamd_relu_backward_colsum(const float* grad, int64_t ldg, const
  * into the column block [b*N, (b+1)*N) of out (ldx >= blocks*K, ldo >= blocks*N); no transposed
  * copies of the activations or the weights are needed.  blocks = 1: plain segment_matmul.      */
 PYGAMD_API int pygamd_segment_matmul_tile_rows(void);
+/* `n_groups` = number of weight matrices (segments * blocks).  `workspace` (device, 16-byte
+ * aligned, pygamd_segment_matmul_workspace_bytes(n_groups, K, N); may be NULL): with it, in
+ * PYGAMD_GEMM_SPLIT_BF16 mode, for dense weights (w_stride_n == 1, w_stride_k == N,
+ * w_seg_stride == K * N) with K <= 128, K % 4 == 0 and 16-byte-aligned rows of x, the product
+ * runs on the convert-once split kernel (csrc/segmm.hip: the weights' bf16 term planes are
+ * written there by a pre-pass, every call); otherwise on the exact fp32 kernel (ABI 9).        */
+PYGAMD_API int pygamd_segment_matmul_workspace_bytes(int64_t n_groups, int64_t K, int64_t N,
+                                                     size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w,
                                      int64_t w_seg_stride, int64_t w_stride_k,
-                                     int64_t w_stride_n, const int32_t* tiles, int64_t n_tiles,
-                                     int64_t K, int64_t N, int64_t blocks, float* out,
-                                     int64_t ldo, void* stream);
+                                     int64_t w_stride_n, int64_t n_groups, const int32_t* tiles,
+                                     int64_t n_tiles, int64_t K, int64_t N, int64_t blocks,
+                                     float* out, int64_t ldo, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 PYGAMD_API int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g,
                                            int64_t ldg, const int32_t* chunks, int64_t n_chunks,
                                            int64_t n_seg, int64_t K, int64_t N, int64_t blocks,

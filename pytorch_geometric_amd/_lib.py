@@ -125,8 +125,11 @@ SIGNATURES = {
                                      c_int64, c_int64, c_int, c_int, _P, c_int64, _P, _P,
                                      c_size_t, _P]),
     'pygamd_segment_matmul_tile_rows': (c_int, []),
-    'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64,
-                                      c_int64, c_int64, c_int64, _P, c_int64, _P]),
+    'pygamd_segment_matmul_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
+                                                      POINTER(c_size_t)]),
+    'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P,
+                                      c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P,
+                                      c_size_t, _P]),
     'pygamd_segment_matmul_wgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64,
                                             c_int64, c_int64, c_int64, _P, _P]),
     'pygamd_sample_max_fanout': (c_int, []),

@@ -1448,8 +1448,14 @@ def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False,
         raise ValueError(f"'inputs' has {x2.size(1)} columns but the weights expect "
                          f"{blocks * K}")
     out = torch.empty(x2.size(0), blocks * N, dtype=torch.float32, device=x.device)
-    check(lib.pygamd_segment_matmul(_p(x2), _ld(x2), _p(w), Kw * Nw, sk, sn, _p(tiles), n_tiles,
-                                    K, N, blocks, _p(out), _ld(out), _stream(x)),
+    # the bf16 term planes of the weights (split arithmetic, K <= 128: csrc/segmm.hip)
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_segment_matmul_workspace_bytes(G, K, N, ctypes.byref(nbytes)))
+    ws = (torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+          if nbytes.value > 0 and get_gemm_mode() == 'split' else None)
+    check(lib.pygamd_segment_matmul(_p(x2), _ld(x2), _p(w), Kw * Nw, sk, sn, G, _p(tiles),
+                                    n_tiles, K, N, blocks, _p(out), _ld(out), _p(ws),
+                                    0 if ws is None else nbytes.value, _stream(x)),
           'segment_matmul')
     return out
 

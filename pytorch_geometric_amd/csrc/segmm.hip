@@ -14,7 +14,7 @@
 // bandwidth bound: ~10 TB/s at the MFMA rate) — and the next chunk is prefetched into registers
 // while the matrix cores work on the current one (PMC of the unpipelined kernel: 64 % of the
 // wave cycles parked in s_waitcnt / barrier, MFMA pipe 31 % busy).
-#include "common.h"
+#include "split_bf16.h"
 
 namespace pygamd {
 
@@ -232,6 +232,288 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- split arithmetic, K <= 128 (the per-relation weights of an RGCN layer, a HeteroLinear) ------
+// The kernel above loses its time, not its bytes or flops: a tile is 128 x 100 x 100 — four k
+// chunks, each with a global -> LDS -> barrier -> MFMA round trip, so the matrix pipe is 31 %
+// busy (0.80 ms per launch at the FB15k-237 shape against 0.27 ms of HBM bytes and 0.35 ms of
+// fp32 matrix time).  This one runs the 3 x bf16 split (split_bf16.h: same error bound as the
+// fp32 instruction, 2.7 x fewer matrix cycles) and keeps the VALU — which the split makes the
+// scarce pipe — for the one conversion nobody else can do:
+//   * W is converted ONCE per call by a pre-pass (segmm_split_weights_kernel) into bf16 term
+//     planes in a caller-provided workspace, [group][term][k-group of 8][column][16 bytes]; a
+//     workgroup copies its 64-column slice into LDS ([term][column][68 dwords]: a fragment is one
+//     ds_read_b128 per term; 17 * column + k-group is conflict-free for reads and writes) with
+//     16-byte loads and no arithmetic — ONE barrier per workgroup, none in the k loop.  (Converted
+//     inside the workgroup, as the first version did, every weight element was split 9 times per
+//     launch: a third of the kernel's 1,192 VALU instructions per wave and tile.)
+//   * A: every wave owns 32 rows, loads ALL of their K columns up front (one batch of loads per
+//     workgroup: with a chunk-at-a-time prefetch every chunk waited ~1 us for HBM behind 0.3 us of
+//     products), stages them 32 k-columns at a time in a WAVE-PRIVATE fp32 buffer ([32][36]:
+//     coalesced 16-byte loads in, 8 consecutive floats per lane out), splits its fragment in
+//     registers (each element once per column half: the rows are the wave's alone) and multiplies
+//     — no barrier; the split of step s + 1 is issued between the matrix instructions of step s.
+// A workgroup owns (tile of 128 rows) x (64 output columns): 70.6 KB of LDS, two workgroups per
+// CU, so one copies its weights while the other multiplies; the two column halves of a tile are
+// neighbours in ONE XCD's queue (the second read of the tile's rows is an L2 hit).
+// k index of bf16 step (chunk c, half-chunk f) in lane half h: 32 c + 16 h + 8 f + (0..7) = k-group
+// 4 c + 2 h + f — A and B are filed under the same rule, which is all the reduction needs.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSK = 128;             // largest K
+constexpr int kSN = 64;              // output columns per workgroup
+constexpr int kSLDB = kSK / 2 + 4;   // dwords per staged B column (128 bf16 + 4 pad)
+constexpr int kSLDA = 36;            // floats per staged A row (32 + 4 pad)
+constexpr int kSBPlane = kSN * kSLDB;                 // dwords per term plane
+constexpr int kSAWave = 32 * kSLDA;                   // floats per wave buffer
+constexpr size_t kSegSplitLds = sizeof(uint32_t) * 3 * kSBPlane + sizeof(float) * 4 * kSAWave;
+
+struct SegFrag {
+  bf16x8 p[3];
+};
+
+__device__ __forceinline__ SegFrag seg_split8(const f32x4& v0, const f32x4& v1) {
+  u32x4 w[3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = q < 2 ? v0[2 * q] : v1[2 * q - 4];
+    const float x1 = q < 2 ? v0[2 * q + 1] : v1[2 * q - 3];
+    uint32_t t[3];
+    split_pair(x0, x1, t);
+    w[0][q] = t[0];
+    w[1][q] = t[1];
+    w[2][q] = t[2];
+  }
+  SegFrag f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) f.p[t] = __builtin_bit_cast(bf16x8, w[t]);
+  return f;
+}
+
+// planes[((g * 3 + term) * KG + kg) * N + n] (16 bytes) = bf16 term `term` of W[g][8 kg .. + 7][n]
+__global__ void __launch_bounds__(kBlock)
+    segmm_split_weights_kernel(const float* __restrict__ w, int K, int N, int KG, int64_t total,
+                               u32x4* __restrict__ planes) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;   // (g, kg, n)
+  if (i >= total) return;
+  const int n = static_cast<int>(i % N);
+  const int64_t gk = i / N;
+  const int kg = static_cast<int>(gk % KG);
+  const int64_t g = gk / KG;
+  const float* __restrict__ wc = w + (g * K + 8 * kg) * N + n;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 8 * kg + e < K ? wc[static_cast<int64_t>(e) * N] : 0.f;
+  u32x4 pw[3];
+#pragma unroll
+  for (int p4 = 0; p4 < 4; ++p4) {
+    uint32_t tt[3];
+    split_pair(v[2 * p4], v[2 * p4 + 1], tt);
+    pw[0][p4] = tt[0];
+    pw[1][p4] = tt[1];
+    pw[2][p4] = tt[2];
+  }
+#pragma unroll
+  for (int tm = 0; tm < 3; ++tm) planes[((g * 3 + tm) * KG + kg) * N + n] = pw[tm];
+}
+
+// NC = number of 32-wide k chunks (K <= 32 NC): compile-time, so that every global load of a
+// workgroup is issued up front in one batch and the k loop unrolls without branches.
+template <int NC>
+__global__ void __launch_bounds__(kBlock, 2)
+    segmm_split_kernel(const float* __restrict__ x, int64_t ldx, const u32x4* __restrict__ planes,
+                       const int32_t* __restrict__ tiles, int64_t n_items, int n_halves, int K,
+                       int N, int blocks, float* __restrict__ out, int64_t ldo) {
+  extern __shared__ __align__(16) uint32_t seg_lds[];
+  uint32_t* const Bp = seg_lds;                                        // [3][kSN][kSLDB]
+  const int64_t q = xcd_logical_block();
+  if (q >= n_items) return;
+  const int64_t t = q / n_halves;
+  const int n0 = static_cast<int>(q - t * n_halves) * kSN;
+  const int seg = tiles[3 * t];
+  const int64_t row0 = tiles[3 * t + 1];
+  const int rows = tiles[3 * t + 2];
+  const int wave = wave_in_block(), lane = lane_id();
+  float* const As = reinterpret_cast<float*>(seg_lds + 3 * kSBPlane) + wave * kSAWave;
+  const int blk = blocks > 1 ? seg % blocks : 0;
+  x += static_cast<int64_t>(blk) * K;
+  out += static_cast<int64_t>(blk) * N;
+  const int KG = (K + 7) >> 3;
+
+  // ---- weight slice: lane -> column, wave + 4 i -> (term, k-group) slot of the LDS image.  Loads
+  // are unconditional (clamped to a stored element); dead slots (k-groups past K, columns past N)
+  // become zeros on their way into LDS.
+  constexpr int kSlots = 3 * 4 * NC;               // (term, k-group) pairs of the image
+  const int bn = lane;
+  const bool bn_ok = n0 + bn < N;
+  const u32x4* __restrict__ pseg =
+      planes + static_cast<int64_t>(seg) * 3 * KG * N + (bn_ok ? n0 + bn : N - 1);
+  u32x4 wv[kSlots / 4];
+#pragma unroll
+  for (int i = 0; i < kSlots / 4; ++i) {
+    const int sl = wave + 4 * i;                   // (uniform)
+    const int tm = sl / (4 * NC), kg = sl - tm * (4 * NC);
+    wv[i] = pseg[static_cast<int64_t>(tm * KG + (kg < KG ? kg : KG - 1)) * N];
+  }
+  // ---- this wave's rows, every chunk (clamped: rows >= 1, K % 4 == 0)
+  const int my_rows = rows - 32 * wave;            // <= 0: nothing to do but the staging below
+  const int kq = lane & 7, rr = lane >> 3;
+  f32x4 ra[NC][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int r = 32 * wave + rr + 8 * j;
+    r = r < rows ? r : rows - 1;
+    const float* pa = x + (row0 + r) * ldx;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      int k = 32 * c + 4 * kq;
+      k = k < K ? k : K - 4;
+      ra[c][j] = *reinterpret_cast<const f32x4*>(pa + k);
+    }
+  }
+  // ---- B planes into LDS
+#pragma unroll
+  for (int i = 0; i < kSlots / 4; ++i) {
+    const int sl = wave + 4 * i;
+    const int tm = sl / (4 * NC), kg = sl - tm * (4 * NC);
+    const bool ok = bn_ok && kg < KG;
+    u32x4 v = wv[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0u;
+    *reinterpret_cast<u32x4*>(Bp + tm * kSBPlane + bn * kSLDB + 4 * kg) = v;
+  }
+  __syncthreads();
+  if (my_rows <= 0) return;
+
+  const int li = lane & 31, lh = lane >> 5;
+  f32x16 acc[2];
+  zero_acc(acc[0]);
+  zero_acc(acc[1]);
+  float* const a_st = As + rr * kSLDA + 4 * kq;    // store slot of load j: + 8 j rows
+  const float* const a_rd = As + li * kSLDA + 16 * lh;
+  const uint32_t* const b_rd = Bp + li * kSLDB + 8 * lh;
+  const bool full_rows = my_rows >= 32;            // (uniform)
+  // registers -> the wave's buffer; columns past K and rows past the tile are staged as zeros (a
+  // clamped value could be Inf / NaN: Inf * 0 = NaN).  Interior chunks of full tiles: plain stores.
+  auto stage = [&](const f32x4 (&rc)[4], int c) {
+    if (full_rows && 32 * c + 32 <= K) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(a_st + 8 * j * kSLDA) = rc[j];
+    } else {
+      const int k = 32 * c + 4 * kq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool r_ok = rr + 8 * j < my_rows;
+        f32x4 v = rc[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (r_ok && k + e < K) ? v[e] : 0.f;
+        *reinterpret_cast<f32x4*>(a_st + 8 * j * kSLDA) = v;
+      }
+    }
+  };
+  auto read_a = [&](int f, f32x4& v0, f32x4& v1) {
+    v0 = *reinterpret_cast<const f32x4*>(a_rd + 8 * f);
+    v1 = *reinterpret_cast<const f32x4*>(a_rd + 8 * f + 4);
+  };
+  auto read_b = [&](int c, int f, SegFrag& b0, SegFrag& b1) {
+#pragma unroll
+    for (int tm = 0; tm < 3; ++tm) {
+      const uint32_t* bp = b_rd + tm * kSBPlane + 16 * c + 4 * f;
+      b0.p[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp));
+      b1.p[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + 32 * kSLDB));
+    }
+  };
+  // One bf16 step = 12 matrix instructions (terms outside, the two column blocks inside:
+  // neighbours write different accumulators — the compiler, left alone, sorts them into two
+  // dependent chains of six and the in-order wave then stalls at every second instruction) with
+  // the split of the NEXT step's fragment issued between them: four groups of three matrix
+  // instructions + one split_pair, fenced by scheduling barriers.  Columns past N are zeros in the
+  // planes, so both blocks are always computed.
+  auto step = [&](const SegFrag& a, const SegFrag& b0, const SegFrag& b1, const f32x4& v0,
+                  const f32x4& v1, SegFrag& nxt) {
+    u32x4 w3[3];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+      for (int m = 3 * g4; m < 3 * g4 + 3; ++m) {
+        const int tm = m >> 1;
+        if (m & 1)
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[kSplitTa[tm]], b1.p[kSplitTb[tm]],
+                                                           acc[1], 0, 0, 0);
+        else
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[kSplitTa[tm]], b0.p[kSplitTb[tm]],
+                                                           acc[0], 0, 0, 0);
+      }
+      const float x0 = g4 < 2 ? v0[2 * g4] : v1[2 * g4 - 4];
+      const float x1 = g4 < 2 ? v0[2 * g4 + 1] : v1[2 * g4 - 3];
+      uint32_t tt[3];
+      split_pair(x0, x1, tt);
+      // (pinned HERE: in the unrolled loop LLVM otherwise sinks the split to its use — behind the
+      // step's last matrix instruction, where nothing covers it)
+      asm volatile("" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]));
+      w3[0][g4] = tt[0];
+      w3[1][g4] = tt[1];
+      w3[2][g4] = tt[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 3; ++tm) nxt.p[tm] = __builtin_bit_cast(bf16x8, w3[tm]);
+  };
+  f32x4 v0, v1;
+  SegFrag a_cur, a_nxt, b0c, b1c, b0n, b1n;
+  stage(ra[0], 0);
+  read_a(0, v0, v1);
+  read_b(0, 0, b0c, b1c);
+  a_cur = seg_split8(v0, v1);
+  // the K tail is staged as zeros; its second step is skipped when it holds nothing at all
+  const bool tail_step = K > 32 * (NC - 1) + 8;    // (uniform)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    read_a(1, v0, v1);                             // (first: the split waits for these two only)
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(c, 1, b0n, b1n);
+    __builtin_amdgcn_sched_barrier(0);
+    step(a_cur, b0c, b1c, v0, v1, a_nxt);
+    // (the wave's own LDS operations execute in order: its reads of chunk c above are behind it)
+    if (c + 1 < NC) {                              // (compile-time: the loop is unrolled)
+      stage(ra[c + 1 < NC ? c + 1 : c], c + 1);
+      read_a(0, v0, v1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(c + 1, 0, b0c, b1c);
+      __builtin_amdgcn_sched_barrier(0);
+      step(a_nxt, b0n, b1n, v0, v1, a_cur);
+    } else if (tail_step) {
+      __builtin_amdgcn_sched_barrier(0);
+      step(a_nxt, b0n, b1n, v0, v1, a_cur);        // (converts a stale fragment: never used)
+    }
+  }
+  // ---- epilogue: reg e of lane l is D[(e & 3) + 8 (e >> 2) + 4 (l >> 5)][l & 31]
+  const int col0 = n0 + li, col1 = col0 + 32;
+  float* __restrict__ ob = out + (row0 + 32 * wave + 4 * lh) * ldo + col0;
+  if (full_rows && n0 + kSN <= N) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float* op = ob + ((e & 3) + 8 * (e >> 2)) * ldo;
+      op[0] = acc[0][e];
+      op[32] = acc[1][e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (r < my_rows) {
+        float* op = ob + ((e & 3) + 8 * (e >> 2)) * ldo;
+        if (col0 < N) op[0] = acc[0][e];
+        if (col1 < N) op[32] = acc[1][e];
+      }
+    }
+  }
+}
+
 }  // namespace pygamd
 
 using namespace pygamd;
@@ -240,17 +522,79 @@ extern "C" {
 
 int pygamd_segment_matmul_tile_rows(void) { return kTM; }
 
+static bool segmm_split_ok(const float* x, int64_t ldx, int64_t w_seg_stride, int64_t w_stride_k,
+                           int64_t w_stride_n, int64_t K, int64_t N) {
+  // 16-byte rows (K % 4, ldx % 4, aligned base) and dense weights [G, K, N] with K <= 128
+  return pygamd_get_gemm_mode() == PYGAMD_GEMM_SPLIT_BF16 && K >= 4 && K <= kSK && K % 4 == 0 &&
+         N >= 1 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 &&
+         w_stride_n == 1 && w_stride_k == N && w_seg_stride == K * N;
+}
+
+int pygamd_segment_matmul_workspace_bytes(int64_t n_groups, int64_t K, int64_t N, size_t* bytes) {
+  if (!bytes || n_groups < 0 || K < 0 || N < 0) return PYGAMD_ERR_INVALID_ARG;
+  // the bf16 term planes of the convert-once kernel (K <= 128, K % 4 == 0); nothing otherwise
+  *bytes = (K >= 4 && K <= kSK && K % 4 == 0)
+               ? static_cast<size_t>(n_groups) * 3 * ceil_div(K, 8) * N * sizeof(u32x4)
+               : 0;
+  return PYGAMD_OK;
+}
+
 int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w, int64_t w_seg_stride,
-                          int64_t w_stride_k, int64_t w_stride_n, const int32_t* tiles,
-                          int64_t n_tiles, int64_t K, int64_t N, int64_t blocks, float* out,
-                          int64_t ldo, void* stream) {
-  if (n_tiles < 0 || K < 0 || N < 0 || blocks < 1 || blocks > INT32_MAX || K > INT32_MAX ||
-      N > INT32_MAX || ldx < blocks * K || ldo < blocks * N)
+                          int64_t w_stride_k, int64_t w_stride_n, int64_t n_groups,
+                          const int32_t* tiles, int64_t n_tiles, int64_t K, int64_t N,
+                          int64_t blocks, float* out, int64_t ldo, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (n_tiles < 0 || n_groups < 0 || K < 0 || N < 0 || blocks < 1 || blocks > INT32_MAX ||
+      K > INT32_MAX || N > INT32_MAX || ldx < blocks * K || ldo < blocks * N)
     return PYGAMD_ERR_INVALID_ARG;
   if (n_tiles == 0 || N == 0) return PYGAMD_OK;
   if (!x || !w || !tiles || !out) return PYGAMD_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  size_t need = 0;
+  pygamd_segment_matmul_workspace_bytes(n_groups, K, N, &need);
+  // split arithmetic (the library's default, pygamd_set_gemm_mode), a weight that fits the LDS
+  // planes and a workspace for them: the convert-once kernel.  Anything else keeps the general
+  // fp32 kernel (exact products: never less accurate).
+  if (workspace && need > 0 && workspace_bytes >= need &&
+      (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0 &&
+      segmm_split_ok(x, ldx, w_seg_stride, w_stride_k, w_stride_n, K, N)) {
+    u32x4* planes = static_cast<u32x4*>(workspace);
+    const int KG = static_cast<int>(ceil_div(K, 8));
+    const int64_t total = n_groups * KG * N;
+    hipLaunchKernelGGL(segmm_split_weights_kernel,
+                       dim3(static_cast<unsigned>(ceil_div(total, kBlock))), dim3(kBlock), 0, st, w,
+                       static_cast<int>(K), static_cast<int>(N), KG, total, planes);
+    PYGAMD_LAUNCH_CHECK();
+    const int n_halves = static_cast<int>(ceil_div(N, kSN));
+    const int64_t n_items = n_tiles * n_halves;
+    const unsigned sgrid = static_cast<unsigned>(round_up(n_items, 8));
+    static bool attr_set[5] = {false, false, false, false, false};
+    const int nc = static_cast<int>(ceil_div(K, 32));
+    auto launch = [&](auto kernel) -> int {
+      if (!attr_set[nc]) {  // (once per instantiation: the planes need more than 64 KB)
+        PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(kSegSplitLds)));
+        attr_set[nc] = true;
+      }
+      hipLaunchKernelGGL(kernel, dim3(sgrid), dim3(kBlock), kSegSplitLds, st, x, ldx, planes, tiles,
+                         n_items, n_halves, static_cast<int>(K), static_cast<int>(N),
+                         static_cast<int>(blocks), out, ldo);
+      return PYGAMD_OK;
+    };
+    int rc;
+    switch (nc) {
+      case 1: rc = launch(segmm_split_kernel<1>); break;
+      case 2: rc = launch(segmm_split_kernel<2>); break;
+      case 3: rc = launch(segmm_split_kernel<3>); break;
+      default: rc = launch(segmm_split_kernel<4>); break;
+    }
+    if (rc != PYGAMD_OK) return rc;
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  }
   const dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>(ceil_div(N, kTN)));
-  hipLaunchKernelGGL(segmm_kernel, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, w,
+  hipLaunchKernelGGL(segmm_kernel, grid, dim3(kBlock), 0, st, x, ldx, w,
                      w_seg_stride, w_stride_k, w_stride_n, tiles, static_cast<int>(K),
                      static_cast<int>(N), static_cast<int>(blocks), out, ldo);
   PYGAMD_LAUNCH_CHECK();

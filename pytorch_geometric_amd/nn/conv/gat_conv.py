@@ -112,28 +112,40 @@ class GATConv(MessagePassing):
                 return_attention_weights: Optional[bool] = None):
         H, C = self.heads, self.out_channels
         x_src, x_dst, res = self._project(x)
+        # The kernels compute in float32.  Half / bf16 projected features — a half
+        # model, or an autocast region whose `Linear` ran in bf16 — are widened HERE and take the
+        # same native path; outside autocast the result is handed back in their dtype.  (They used
+        # to reach float32-only kernels as they were and raise: ADVICE r4.)
+        low = None
+        if x_src.is_cuda and x_src.dtype in (torch.float16, torch.bfloat16):
+            low = x_src.dtype
+            same = x_dst is x_src
+            x_src = x_src.float()
+            x_dst = x_src if same else (None if x_dst is None else x_dst.float())
+            res = None if res is None else res.float()
+        att_src, att_dst = self.att_src, self.att_dst
+        if att_src.dtype != x_src.dtype:
+            att_src, att_dst = att_src.to(x_src.dtype), att_dst.to(x_src.dtype)
+        native = x_src.is_cuda and x_src.dtype == torch.float32 and self.fuse
+        # A single-head layer on a handle marked `atomic_backward` (a sampled batch, used once)
+        # keeps the HeadDot + SpmmFunction route, whose backward runs edge-parallel atomics instead
+        # of building the by-source sort the fused node's backward needs (the atomic backward
+        # exists for one weight per edge: heads == 1).
+        one_shot = (isinstance(edge_index, EdgeIndex) and edge_index.atomic_backward
+                    and self.heads == 1)
         # one autograd node for node terms + edge softmax + aggregation (GatAttendFunction) when
         # nothing between them is observable: no edge features, no dropout on the coefficients,
         # nobody asking for them
-        # The kernels take float32: half / bf16 inputs or an autocast region step aside to the
-        # composed path.  A handle marked `atomic_backward` (a sampled batch, used once) keeps the
-        # HeadDot + SpmmFunction route, whose backward runs edge-parallel atomics instead of
-        # building the by-source sort the fused node's backward needs.
-        native = (x_src.is_cuda and x_src.dtype == torch.float32 and self.fuse
-                  and not torch.is_autocast_enabled())
-        # (the edge-parallel atomic backward exists for one weight per edge: heads == 1)
-        one_shot = (isinstance(edge_index, EdgeIndex) and edge_index.atomic_backward
-                    and self.heads == 1)
         attend = (x_dst is x_src and native and edge_attr is None and not one_shot
                   and self.flow == 'source_to_target' and return_attention_weights is None
                   and not (self.training and self.dropout > 0))
         if attend:
             a_src = a_dst = None  # computed inside the fused node
         elif x_dst is x_src and native:
-            a_src, a_dst = HeadDotFunction.apply(x_src, self.att_src, self.att_dst)
+            a_src, a_dst = HeadDotFunction.apply(x_src, att_src, att_dst)
         else:
-            a_src = (x_src * self.att_src).sum(dim=-1)
-            a_dst = None if x_dst is None else (x_dst * self.att_dst).sum(dim=-1)
+            a_src = (x_src * att_src).sum(dim=-1)
+            a_dst = None if x_dst is None else (x_dst * att_dst).sum(dim=-1)
 
         if self.add_self_loops and isinstance(edge_index, Tensor) \
                 and not isinstance(edge_index, EdgeIndex):
@@ -164,7 +176,7 @@ class GATConv(MessagePassing):
             n_src = x_src.size(0)
             n_dst = n_src if size is None else size[1]
             graph = as_edge_index(edge_index, n_src, n_dst)
-            out = GatAttendFunction.apply(x_src, self.att_src, self.att_dst, graph,
+            out = GatAttendFunction.apply(x_src, att_src, att_dst, graph,
                                           self.negative_slope, n_dst)
             alpha = None
         elif attend:  # (the self-loop rewrite produced edge attributes: cannot happen without
@@ -202,6 +214,8 @@ class GATConv(MessagePassing):
             out = bias_act(out, self.bias, fa == 'relu')
         elif self.bias is not None:
             out = out + self.bias
+        if low is not None and not torch.is_autocast_enabled():
+            out = out.to(low)
         if return_attention_weights is None:
             return out
         coo = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index

@@ -617,3 +617,74 @@ def test_small_m_gemm_is_deterministic_and_unsliced_without_workspace(dev):
                                      out.data_ptr(), N, None, 0, st) == 0
     torch.cuda.synchronize()
     assert_close(out, a, rtol=1e-5, atol=1e-4, what='unsliced vs sliced')
+
+
+SEGMM_SHAPES = [  # (K, N, blocks): K <= 128 and K % 4 == 0 take the convert-once split kernel
+    (4, 1, 1), (8, 5, 1), (28, 31, 1), (32, 32, 1), (36, 33, 2), (64, 64, 1), (96, 65, 1),
+    (100, 100, 5), (128, 128, 1), (128, 200, 1), (20, 130, 3), (100, 7, 1),
+]
+
+
+@pytest.mark.parametrize('K,N,blocks', SEGMM_SHAPES)
+def test_segment_matmul_split_kernel(dev, K, N, blocks):
+    """`segmm_split_kernel` (csrc/segmm.hip: weights converted once per workgroup into bf16 term
+    planes, rows staged per wave): ragged segments incl. empty, 1-row, 31/32/33 and > 128-row ones,
+    every K tail (chunks of 32, steps of 16, k-groups of 8) and column tail (halves of 64, blocks
+    of 32), block-diagonal groups.  Values against fp64 within the |x|.|w| bound and no further
+    from fp64 than the exact-instruction kernel on the same inputs (the split's acceptance rule);
+    the transposed use (the input gradient) and garbage behind the operands' ends (padding must be
+    staged as zeros, never multiplied as Inf * 0)."""
+    from pytorch_geometric_amd import _native
+    g = gen(K * 131 + N * 7 + blocks)
+    lens = [0, 1, 31, 32, 33, 0, 127, 128, 129, 300, 5]
+    ptr = [0]
+    for n in lens:
+        ptr.append(ptr[-1] + n)
+    S, R = ptr[-1], len(lens)
+    # the operands sit inside larger buffers filled with NaN: a read past an end shows up
+    xbuf = torch.full((S + 2, blocks * K + 8), float('nan'))
+    x = torch.randn(S, blocks * K, generator=g)
+    xbuf[1:S + 1, 4:4 + blocks * K] = x
+    w = torch.randn(R * blocks, K, N, generator=g) / K ** 0.5
+    ex = torch.empty(S, blocks * N, dtype=torch.float64)
+    bound = torch.empty_like(ex)
+    for r in range(R):
+        for b in range(blocks):
+            xs = x[ptr[r]:ptr[r + 1], b * K:(b + 1) * K].double()
+            ws = w[r * blocks + b].double()
+            ex[ptr[r]:ptr[r + 1], b * N:(b + 1) * N] = xs @ ws
+            bound[ptr[r]:ptr[r + 1], b * N:(b + 1) * N] = xs.abs() @ ws.abs()
+    plan = _native.segmm_plan(tuple(ptr), dev, blocks)
+    xg = xbuf.to(dev)[1:S + 1, 4:4 + blocks * K]
+    assert xg.data_ptr() % 16 == 0 and xg.stride(0) % 4 == 0
+    wg = w.to(dev)
+    outs = {}
+    for mode in ('fp32', 'split'):
+        prev = _native.set_gemm_mode(mode)
+        try:
+            outs[mode] = _native.segment_matmul(xg, wg, plan, blocks=blocks).cpu().double()
+        finally:
+            _native.set_gemm_mode(prev)
+    assert bool(torch.isfinite(outs['split']).all())
+    tol = 1e-5 * bound + 1e-30
+    err = {m: (o - ex).abs() for m, o in outs.items()}
+    assert bool((err['split'] <= torch.maximum(tol, 2 * err['fp32'])).all()), \
+        (float((err['split'] / (bound + 1e-30)).max()), float((err['fp32'] / (bound + 1e-30)).max()))
+    rel = {m: float((e / (bound + 1e-30)).mean()) for m, e in err.items()}
+    assert rel['split'] <= 1.25 * rel['fp32'] + 1e-9, rel
+    # the transposed use: grad_x = grad_out @ W^T (N takes the role of K; only when it fits)
+    go = torch.randn(S, blocks * N, generator=g)
+    prev = _native.set_gemm_mode('split')
+    try:
+        gx = _native.segment_matmul(go.to(dev), wg, plan, transpose_w=True, blocks=blocks)
+    finally:
+        _native.set_gemm_mode(prev)
+    exg = torch.empty(S, blocks * K, dtype=torch.float64)
+    bg = torch.empty_like(exg)
+    for r in range(R):
+        for b in range(blocks):
+            gs = go[ptr[r]:ptr[r + 1], b * N:(b + 1) * N].double()
+            wt = w[r * blocks + b].double().t()
+            exg[ptr[r]:ptr[r + 1], b * K:(b + 1) * K] = gs @ wt
+            bg[ptr[r]:ptr[r + 1], b * K:(b + 1) * K] = gs.abs() @ wt.abs()
+    assert bool(((gx.cpu().double() - exg).abs() <= 1e-5 * bg + 1e-30).all())

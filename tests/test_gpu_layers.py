@@ -738,11 +738,13 @@ def test_gat_single_autograd_node_matches_the_three_function_path(dev):
     assert torch.equal(conv(x, h), conv(x, ei))
 
 
-def test_gat_steps_aside_for_half_precision_and_autocast(dev):
-    """the one-node GAT attention (`GatAttendFunction`) and the HeadDot / edge-softmax
-    kernels take float32.  bf16 inputs and autocast regions run the composed path (values close to
-    the float32 result at bf16 resolution) instead of raising; a single-head layer on a handle
-    marked `atomic_backward` keeps the route whose backward does not sort by source."""
+def test_gat_takes_half_precision_and_autocast_inputs(dev):
+    """the GAT kernels (the one-node attention `GatAttendFunction`, HeadDot, the edge
+    softmax) compute in float32.  bf16 features — a bf16 model, or an autocast region whose Linear
+    ran in bf16 — are widened at the layer's entry and take the SAME native path (they used to
+    reach float32-only kernels and raise); outside autocast the result comes back in the input
+    dtype.  A single-head layer on a handle marked `atomic_backward` keeps the route whose
+    backward does not sort by source."""
     from pytorch_geometric_amd import _functions
     from pytorch_geometric_amd.edge_index import EdgeIndex
     from pytorch_geometric_amd.nn import GATConv
@@ -759,34 +761,37 @@ def test_gat_steps_aside_for_half_precision_and_autocast(dev):
     class Spy:
         @staticmethod
         def apply(*a):
-            used.append(1)
+            used.append(a[0].dtype)
             return real(*a)
 
     import pytorch_geometric_amd.nn.conv.gat_conv as gat_mod
     keep, gat_mod.GatAttendFunction = gat_mod.GatAttendFunction, Spy
     try:
         conv(x, ei)
-        assert used == [1]
+        assert used == [torch.float32]
+        xg = x.clone().requires_grad_(True)
         with torch.autocast('cuda', dtype=torch.bfloat16):
-            out = conv(x, ei)
-        assert used == [1], 'an autocast region must not reach the float32-only fused node'
+            out = conv(xg, ei)
+        assert used == [torch.float32] * 2, 'the fused node sees widened (float32) features'
         assert_close(out.float(), want, rtol=5e-2, atol=5e-2, what='GAT under autocast')
+        out.float().sum().backward()
+        assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
         half = GATConv(16, 8, heads=2).to(dev).to(torch.bfloat16)
         half.load_state_dict({k: v.to(torch.bfloat16) for k, v in conv.state_dict().items()})
         out = half(x.to(torch.bfloat16), ei)
-        assert out.dtype == torch.bfloat16 and used == [1]
+        assert out.dtype == torch.bfloat16 and used == [torch.float32] * 3
         assert_close(out.float(), want, rtol=1e-1, atol=1e-1, what='bf16 GAT')
         # one-shot handle, one head: HeadDot + SpmmFunction (atomic backward), no by-source sort
         torch.manual_seed(1)
         one = GATConv(16, 8, heads=1, add_self_loops=False).to(dev)
         h = EdgeIndex(ei, (n, n), validate=False)
         ref_out = one(x, h)
-        assert used == [1, 1]
+        assert len(used) == 4
         h2 = EdgeIndex(ei, (n, n), validate=False)
         h2.atomic_backward = True
         xg = x.clone().requires_grad_(True)
         out = one(xg, h2)
-        assert used == [1, 1]
+        assert len(used) == 4
         assert_close(out, ref_out.detach(), rtol=1e-5, atol=1e-5, what='one-shot GAT output')
         out.sum().backward()
         assert h2._csc is None, 'the one-shot route must not build the by-source form'

@@ -183,10 +183,11 @@ def test_scatter_errors(dev):
         agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
         pga.check_index_errors()
     pga.check_index_errors()  # nothing left pending
-    # ... a later aggregation call meets the flag once it has arrived ...
-    agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
-    torch.cuda.synchronize()
+    # ... the call itself (its end looks at the flags that have ARRIVED) or a later aggregation
+    # call meets the flag once it has arrived ...
     with pytest.raises(ValueError, match="invalid 'dim_size'"):
+        agg(torch.randn(5, 3, device=dev), idx, dim_size=1)
+        torch.cuda.synchronize()
         agg(torch.randn(5, 3, device=dev), idx, dim_size=2)
     pga.check_index_errors()
     # ... and PYGAMD_CHECK_INDEX=sync raises at the call site itself
@@ -1257,11 +1258,11 @@ def test_large_unsorted_scatter_takes_the_sorted_route(dev, monkeypatch):
     pga.check_index_errors()
     bad = fresh.clone()
     bad[5], bad[77] = n + 3, -1
-    got = scatter(src, bad, 0, n, 'sum')
-    assert sorts['n'] == 5 and minmax['n'] == 0
     keep = torch.ones(e, dtype=torch.bool, device=dev)
     keep[5] = keep[77] = False
     want = _native.scatter_rows(src[keep], fresh[keep], n, 'sum')
+    got = scatter(src, bad, 0, n, 'sum')
+    assert sorts['n'] == 5 and minmax['n'] == 0
     assert_close(got, want, rtol=1e-5, atol=1e-4, what='out-of-range rows are skipped')
     with pytest.raises(IndexError, match='out of bounds'):
         pga.check_index_errors()
