@@ -348,6 +348,20 @@ PYGAMD_API int pygamd_sddmm_csr(const void* rowptr, const void* col, const void*
                                 int idx_dtype, const float* grad_out, int64_t ldg,
                                 const float* x, int64_t ldx, int64_t n_rows, int64_t F,
                                 int32_t w_heads, int32_t head_dim, float* grad_w, void* stream);
+/* The two halves of a weighted aggregation's backward from ONE gather (ABI 9): over a CSR whose
+ * row r holds `rows[r, :]` in registers and gathers x[col[k], :] for its slots k (e(k) = eid[k],
+ * or k when eid is NULL),
+ *   grad_w[e(k), h] = <rows[r, head h], x[col[k], head h]>          (the SDDMM above) and
+ *   agg[r, f]       = sum_k w[e(k), head(f)] * x[col[k], f]          (pygamd_spmm_csr, per-head w).
+ * GATConv's backward over the by-source form (nn/conv/gat_conv.py:387-409: rows = the projected
+ * source features, x = the destinations' gradient rows, w = the attention coefficients) gets the
+ * coefficient gradients and the aggregation's input gradient at the cost of one of them.  grad_w
+ * must be zeroed by the caller when F > 256 (a head may span two lane groups: atomic adds).     */
+PYGAMD_API int pygamd_sddmm_spmm_csr(const void* rowptr, const void* col, const void* eid,
+                                     int idx_dtype, const float* rows, int64_t ldr,
+                                     const float* x, int64_t ldx, int64_t n_rows, int64_t F,
+                                     int32_t w_heads, int32_t head_dim, const float* w,
+                                     float* grad_w, float* agg, int64_t lda, void* stream);
 
 /* ---- a17: bias gradient of Linear --------------------------------------------------------------
  * out[f] = sum_r x[r, f]  (grad_bias = grad_out.sum(0), nn/dense/linear.py:121-127 backward).

@@ -22,6 +22,9 @@ SOURCES = ['capi.hip', 'graph.hip', 'spmm.hip', 'scatter.hip', 'softmax.hip', 's
 ARCH = 'gfx950'
 FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
+# lab builds (e.g. PYGAMD_EXTRA_HIPCC_FLAGS=-DPYGAMD_GATHER_NT=1): part of the source hash, so the
+# library is rebuilt when the variable changes — and rebuilt back when it is unset again
+FLAGS += os.environ.get('PYGAMD_EXTRA_HIPCC_FLAGS', '').split()
 # Per-file additions (none at present; -fno-slp-vectorize on sage_fused.hip — no v_pk_add_f32 in
 # the gather loop — was measured neutral to slightly negative, profiles/r04_fused_noslp_probe.txt).
 EXTRA_FLAGS = {}
@@ -81,7 +84,10 @@ def build_library(force=False, verbose=True):
 
     def compile_one(src):
         src_path = os.path.join(CSRC_DIR, src)
-        obj = os.path.join(BUILD_DIR, src.replace('.hip', '.o'))
+        # (objects are kept per flag set: a lab build must not pick up the default build's)
+        import hashlib
+        tag = hashlib.sha1(' '.join(FLAGS + EXTRA_FLAGS.get(src, [])).encode()).hexdigest()[:8]
+        obj = os.path.join(BUILD_DIR, src.replace('.hip', f'.{tag}.o'))
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src_path), headers_mtime)):
             return obj

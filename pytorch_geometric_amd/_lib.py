@@ -95,6 +95,8 @@ SIGNATURES = {
                                                     c_int64, _P]),
     'pygamd_sddmm_csr': (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                  c_int32, c_int32, _P, _P]),
+    'pygamd_sddmm_spmm_csr': (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int64, c_int64,
+                                      c_int64, c_int32, c_int32, _P, _P, _P, c_int64, _P]),
     'pygamd_colsum': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'pygamd_bias_act': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, _P, c_int64, _P]),
     'pygamd_relu_backward_colsum': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P,

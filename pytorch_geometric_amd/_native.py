@@ -659,6 +659,36 @@ def sddmm_csr(rowptr, col, eid, grad_out, x, n_edges: int, w_heads: int) -> Tens
     return grad_w
 
 
+def sddmm_spmm_csr(rowptr, col, eid, rows, x, w, n_edges: int, w_heads: int):
+    """(grad_w [n_edges, w_heads], agg [n_rows, F]) from ONE gather of ``x[col[k]]``:
+    ``grad_w[e(k), h] = <rows[r, head h], x[col[k], head h]>`` and
+    ``agg[r] = sum_k w[e(k), head] * x[col[k]]`` (``pygamd_sddmm_spmm_csr``)."""
+    _require_device(rowptr, col, eid, rows, x, w)
+    lib = _lib.load()
+    r2, x2 = _f32_rows(rows, 'rows'), _f32_rows(x, 'x')
+    F = x2.size(1)
+    if r2.size(1) != F:
+        raise ValueError("'rows' and 'x' must have the same width")
+    w2 = w.reshape(-1, w_heads).contiguous()
+    if w2.dtype != torch.float32 or w2.size(0) < n_edges:
+        raise ValueError("'w' must hold one float32 weight per edge and head")
+    n_rows = rowptr.numel() - 1
+    agg = torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
+    # One 64-lane pass of 16-byte lanes covers 256 columns: every head's dot product is then
+    # finished inside the wave and stored.  Wider rows, or rows that only take 4-byte lanes
+    # (unaligned views), are covered by several lane groups whose partial sums meet in atomic adds
+    # on a zeroed buffer.
+    one_pass = (F % 4 == 0 and F <= 256 and (F // max(w_heads, 1)) % 4 == 0
+                and all(t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0 for t in (r2, x2, agg)))
+    alloc = torch.empty if one_pass else torch.zeros
+    grad_w = alloc(n_edges, w_heads, dtype=torch.float32, device=x.device)
+    check(lib.pygamd_sddmm_spmm_csr(_p(rowptr), _p(col), _p(eid), _idx_dtype(rowptr), _p(r2),
+                                    _ld(r2), _p(x2), _ld(x2), n_rows, F, w_heads,
+                                    F // max(w_heads, 1), _p(w2), _p(grad_w), _p(agg), _ld(agg),
+                                    _stream(x)), 'sddmm_spmm_csr')
+    return grad_w, agg
+
+
 # ---- unsorted gather / scatter ----------------------------------------------------------------
 class IndexOutOfRange(PygAmdError, IndexError):
     """An index outside [0, size) reached a scatter/gather kernel (the reference's ATen CPU

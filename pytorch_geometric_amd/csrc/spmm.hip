@@ -993,14 +993,21 @@ __global__ void __launch_bounds__(kBlock)
 // is finished with a SEGMENTED xor-free shuffle reduction over the lanes that share a head
 // (p += shfl_down(p, 2^s) while lane + 2^s is still inside the head): exact for any head width
 // that is a multiple of VW, e.g. 8 lanes for C = 32, 10 lanes for C = 40.
-template <typename IdxT, int VW, int LPR, int CH>
+//
+// AGG (pygamd_sddmm_spmm_csr): the same pass also aggregates the gathered rows with per-(slot, head)
+// weights, agg[i, f] = sum_k w[e(k), head(f)] * x[col[k], f] — the two halves of a GAT layer's
+// backward over the by-source CSR (row held in registers = the source's own features, gathered
+// rows = the destinations' gradients): d alpha of every edge AND the aggregation's d x from ONE
+// gather of the gradient rows, which is what both cost.
+template <typename IdxT, int VW, int LPR, int CH, bool AGG>
 __global__ void __launch_bounds__(kBlock)
     sddmm_rows(const IdxT* __restrict__ rowptr, const IdxT* __restrict__ col,
                const IdxT* __restrict__ eid, const float* __restrict__ grad_out, int64_t ldg,
                const float* __restrict__ x, int64_t ldx, int64_t n_rows, int64_t F, int w_heads,
-               int head_dim, int use_atomic, float* __restrict__ grad_w) {
+               int head_dim, int use_atomic, float* __restrict__ grad_w,
+               const float* __restrict__ w, float* __restrict__ agg, int64_t lda) {
   constexpr int EPI = kWave / LPR;
-  constexpr int U = (CH == 1) ? (LPR < 4 ? LPR : 4) : 2;
+  constexpr int U = (CH == 1) ? (LPR < 4 ? LPR : 4) : (AGG ? 4 : 2);
   constexpr int STEP = EPI * U;
   const int lane = lane_id();
   const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
@@ -1036,6 +1043,11 @@ __global__ void __launch_bounds__(kBlock)
       for (int i = 0; i < VW; ++i) gv[c].v[i] = 0.f;
     }
   }
+  float sum[CH][VW];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int i = 0; i < VW; ++i) sum[c][i] = 0.f;
   for (IdxT base = start; base < end; base += kWave) {
     const IdxT rem = end - base;
     const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
@@ -1070,6 +1082,11 @@ __global__ void __launch_bounds__(kBlock)
             const Vec<VW> v = load_vec<VW>(xr + fo[c2]);
 #pragma unroll
             for (int i = 0; i < VW; ++i) acc = fmaf(v.v[i], gv[c2].v[i], acc);
+            if constexpr (AGG) {
+              const float wv = w[static_cast<int64_t>(e[u]) * w_heads + head[c2]];
+#pragma unroll
+              for (int i = 0; i < VW; ++i) sum[c2][i] = fmaf(v.v[i], wv, sum[c2][i]);
+            }
           }
           p[u][c2] = acc;
         }
@@ -1092,6 +1109,20 @@ __global__ void __launch_bounds__(kBlock)
               *dst = v;
             }
           }
+        }
+      }
+    }
+  }
+  if constexpr (AGG) {
+    combine_subgroups<VW, LPR, CH>(sum);
+    if (sub == 0) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (fv[c]) {
+          Vec<VW> o;
+#pragma unroll
+          for (int i = 0; i < VW; ++i) o.v[i] = sum[c][i];
+          store_vec<VW>(agg + row * lda + fo[c], o);
         }
       }
     }
@@ -1259,12 +1290,20 @@ template <typename IdxT, int VW, int LPR, int CH>
 static int launch_sddmm_shape(const Shape& s, const void* rowptr, const void* col,
                               const void* eid, const float* grad_out, int64_t ldg, const float* x,
                               int64_t ldx, int64_t n_rows, int64_t F, int w_heads, int head_dim,
-                              int use_atomic, float* grad_w, hipStream_t st) {
+                              int use_atomic, float* grad_w, const float* w, float* agg,
+                              int64_t lda, hipStream_t st) {
   dim3 grid(wave_grid(n_rows), s.tiles);
-  hipLaunchKernelGGL((sddmm_rows<IdxT, VW, LPR, CH>), grid, dim3(kBlock), 0, st,
-                     static_cast<const IdxT*>(rowptr), static_cast<const IdxT*>(col),
-                     static_cast<const IdxT*>(eid), grad_out, ldg, x, ldx, n_rows, F, w_heads,
-                     head_dim, use_atomic, grad_w);
+  if (agg != nullptr) {
+    hipLaunchKernelGGL((sddmm_rows<IdxT, VW, LPR, CH, true>), grid, dim3(kBlock), 0, st,
+                       static_cast<const IdxT*>(rowptr), static_cast<const IdxT*>(col),
+                       static_cast<const IdxT*>(eid), grad_out, ldg, x, ldx, n_rows, F, w_heads,
+                       head_dim, use_atomic, grad_w, w, agg, lda);
+  } else {
+    hipLaunchKernelGGL((sddmm_rows<IdxT, VW, LPR, CH, false>), grid, dim3(kBlock), 0, st,
+                       static_cast<const IdxT*>(rowptr), static_cast<const IdxT*>(col),
+                       static_cast<const IdxT*>(eid), grad_out, ldg, x, ldx, n_rows, F, w_heads,
+                       head_dim, use_atomic, grad_w, w, agg, lda);
+  }
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }
@@ -1273,11 +1312,11 @@ template <typename IdxT>
 static int launch_sddmm(const Shape& s, const void* rowptr, const void* col, const void* eid,
                         const float* grad_out, int64_t ldg, const float* x, int64_t ldx,
                         int64_t n_rows, int64_t F, int w_heads, int head_dim, int use_atomic,
-                        float* grad_w, hipStream_t st) {
+                        float* grad_w, const float* w, float* agg, int64_t lda, hipStream_t st) {
 #define PYGAMD_SDDMM(VW, LPR, CH)                                                               \
   return launch_sddmm_shape<IdxT, VW, LPR, CH>(s, rowptr, col, eid, grad_out, ldg, x, ldx,     \
                                                n_rows, F, w_heads, head_dim, use_atomic, grad_w, \
-                                               st)
+                                               w, agg, lda, st)
   if (s.vw == 4) {
     switch (s.lpr) {
       case 4: PYGAMD_SDDMM(4, 4, 1);
@@ -1865,7 +1904,38 @@ int pygamd_sddmm_csr(const void* rowptr, const void* col, const void* eid, int i
   hipStream_t st = as_stream(stream);
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     return launch_sddmm<IdxT>(s, rowptr, col, eid, grad_out, ldg, x, ldx, n_rows, F, w_heads, hd,
-                              use_atomic, grad_w, st);
+                              use_atomic, grad_w, nullptr, nullptr, 0, st);
+  });
+}
+
+int pygamd_sddmm_spmm_csr(const void* rowptr, const void* col, const void* eid, int idx_dtype,
+                          const float* rows, int64_t ldr, const float* x, int64_t ldx,
+                          int64_t n_rows, int64_t F, int32_t w_heads, int32_t head_dim,
+                          const float* w, float* grad_w, float* agg, int64_t lda, void* stream) {
+  if (n_rows < 0 || F < 0 || w_heads < 1 || ldr < F || ldx < F || lda < F)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (n_rows == 0 || F == 0) return PYGAMD_OK;
+  if (!rowptr || !rows || !x || !grad_w || !w || !agg) return PYGAMD_ERR_INVALID_ARG;
+  const int hd = (w_heads > 1) ? head_dim : static_cast<int>(F);
+  if (static_cast<int64_t>(hd) * w_heads != F) return PYGAMD_ERR_INVALID_ARG;
+  pygamd_spmm_args probe = {};
+  probe.F = F;
+  probe.ldx = ldx;
+  // 16-byte lanes only if the held rows AND the output take them (the probe has one `out`)
+  const bool both16 = ldr % 4 == 0 && lda % 4 == 0 &&
+                      ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(agg)) &
+                       15u) == 0;
+  probe.ldo = both16 ? 4 : 1;
+  probe.x = x;
+  probe.out = agg;
+  probe.w_heads = w_heads;
+  probe.head_dim = hd;
+  const Shape s = pick_shape(&probe);
+  const int use_atomic = (s.ch > 1 || s.tiles > 1) ? 1 : 0;
+  hipStream_t st = as_stream(stream);
+  return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
+    return launch_sddmm<IdxT>(s, rowptr, col, eid, rows, ldr, x, ldx, n_rows, F, w_heads, hd,
+                              use_atomic, grad_w, w, agg, lda, st);
   });
 }
 

@@ -106,7 +106,11 @@ __device__ __forceinline__ void spmm_batch(const SpmmDev<IdxT>& a, int j, int cn
 #pragma unroll
     for (int c2 = 0; c2 < CH; ++c2) {
       if (fv[c2] && valid) {
+#ifdef PYGAMD_GATHER_NT  // lab: gathered rows with the non-temporal hint (scripts/README.md)
+        v[u][c2] = load_vec_streamed<VW>(xr + fo[c2]);
+#else
         v[u][c2] = load_vec<VW>(xr + fo[c2]);
+#endif
       } else {
 #pragma unroll
         for (int i = 0; i < VW; ++i) v[u][c2].v[i] = 0.f;

@@ -1263,7 +1263,8 @@ def test_large_unsorted_scatter_takes_the_sorted_route(dev, monkeypatch):
     want = _native.scatter_rows(src[keep], fresh[keep], n, 'sum')
     got = scatter(src, bad, 0, n, 'sum')
     assert sorts['n'] == 5 and minmax['n'] == 0
-    assert_close(got, want, rtol=1e-5, atol=1e-4, what='out-of-range rows are skipped')
+    # (groups of thousands of rows, summed in another order: judged at the size of the sums)
+    assert_close(got, want, rtol=1e-4, atol=2e-3, what='out-of-range rows are skipped')
     with pytest.raises(IndexError, match='out of bounds'):
         pga.check_index_errors()
     pga.check_index_errors()
@@ -1282,3 +1283,66 @@ def test_large_unsorted_scatter_takes_the_sorted_route(dev, monkeypatch):
     scatter(src, b, 0, n, 'sum')
     assert len(_functions._scatter_plans) == 1
     assert next(iter(_functions._scatter_plans))[0] == id(b)
+
+
+@pytest.mark.parametrize('H,C', [(8, 32), (8, 40), (1, 16), (4, 4), (2, 6), (1, 5)])
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_sddmm_spmm_one_gather(dev, H, C, dtype):
+    """`pygamd_sddmm_spmm_csr`: the SDDMM (per-edge, per-head dot products) and the per-head
+    weighted aggregation over the same CSR from ONE gather — the GAT backward over the by-source
+    form.  Against the two stand-alone entry points (same kernels' arithmetic: dot products
+    bitwise, sums to rounding) and against fp64; widths that take the 16-byte lanes, two chunks
+    per lane (F = 320: heads spanning lane groups, atomic adds), several rows per wave (F = 16) and
+    the scalar lanes (C = 5, 6); an edge-id map (results filed under another slot order)."""
+    from pytorch_geometric_amd import _native
+    g = gen(H * 100 + C)
+    n_src, n_dst, e = 700, 500, 9000
+    F = H * C
+    src = torch.randint(0, n_src, (e, ), generator=g)
+    src[:400] = 3                                    # one long row
+    dst = torch.randint(0, n_dst, (e, ), generator=g)
+    order = torch.argsort(src, stable=True)
+    src, dst = src[order], dst[order]
+    ptr = torch.zeros(n_src + 1, dtype=torch.long)
+    ptr[1:] = torch.bincount(src, minlength=n_src).cumsum(0)
+    eid = torch.randperm(e, generator=g)             # where edge k's weight / result lives
+    rows = torch.randn(n_src, F, generator=g)
+    x = torch.randn(n_dst, F, generator=g)
+    w = torch.rand(e, H, generator=g)
+    gw, agg = _native.sddmm_spmm_csr(ptr.to(dtype).to(dev), dst.to(dtype).to(dev),
+                                     eid.to(dtype).to(dev), rows.to(dev), x.to(dev), w.to(dev),
+                                     e, H)
+    # fp64 references
+    xr = x[dst].double().view(e, H, C)
+    ex_gw = torch.zeros(e, H, dtype=torch.float64)
+    ex_gw[eid] = (rows[src].double().view(e, H, C) * xr).sum(-1)
+    ex_agg = torch.zeros(n_src, H, C, dtype=torch.float64).index_add_(
+        0, src, w[eid].double().unsqueeze(-1) * xr).view(n_src, F)
+    bound_gw = torch.zeros(e, H, dtype=torch.float64)
+    bound_gw[eid] = (rows[src].double().view(e, H, C).abs() * xr.abs()).sum(-1)
+    bound_agg = torch.zeros(n_src, H, C, dtype=torch.float64).index_add_(
+        0, src, w[eid].double().unsqueeze(-1) * xr.abs()).view(n_src, F)
+    assert bool(((gw.cpu().double() - ex_gw).abs() <= 1e-5 * bound_gw + 1e-12).all())
+    assert bool(((agg.cpu().double() - ex_agg).abs() <= 1e-5 * bound_agg + 1e-12).all())
+    # the stand-alone entry points on the same inputs
+    gw2 = _native.sddmm_csr(ptr.to(dtype).to(dev), dst.to(dtype).to(dev), eid.to(dtype).to(dev),
+                            rows.to(dev), x.to(dev), e, H)
+    assert_close(gw, gw2, rtol=1e-6, atol=1e-6, what='fused vs stand-alone SDDMM')
+    agg2 = _native.spmm_csr(ptr.to(dtype).to(dev), dst.to(dtype).to(dev), x.to(dev), 'sum',
+                            n_rows=n_src, eid=eid.to(dtype).to(dev), w=w.to(dev))
+    assert_close(agg, agg2, rtol=1e-5, atol=1e-5, what='fused vs stand-alone weighted SpMM')
+    # strided operands (columns of wider buffers, 16-byte aligned or not)
+    for off in (4, 3):
+        big_r = torch.randn(n_src, F + 8, generator=g).to(dev)
+        big_x = torch.randn(n_dst, F + 8, generator=g).to(dev)
+        gw3, agg3 = _native.sddmm_spmm_csr(
+            ptr.to(dtype).to(dev), dst.to(dtype).to(dev), None, big_r[:, off:off + F],
+            big_x[:, off:off + F], w.to(dev), e, H)
+        gw4 = _native.sddmm_csr(ptr.to(dtype).to(dev), dst.to(dtype).to(dev), None,
+                                big_r[:, off:off + F].contiguous(),
+                                big_x[:, off:off + F].contiguous(), e, H)
+        assert_close(gw3, gw4, rtol=1e-5, atol=1e-5, what=f'strided SDDMM off={off}')
+        agg4 = _native.spmm_csr(ptr.to(dtype).to(dev), dst.to(dtype).to(dev),
+                                big_x[:, off:off + F].contiguous(), 'sum', n_rows=n_src,
+                                w=w.to(dev))
+        assert_close(agg3, agg4, rtol=1e-5, atol=1e-5, what=f'strided SpMM off={off}')
