@@ -461,6 +461,108 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// The extremum ALONE (no argument, no tie flag requested: `scatter(..., 'max')` of the unfused
+// path, whose backward compares the saved output instead; inference): the kernel above spends
+// ~14 VALU instructions per gathered element on its argument / tie / first-source bookkeeping —
+// 5.4 ms on top of the 11.9 ms the same gather takes as a sum at the products shape, F = 256
+// (profiles/r04_unfused_propagate.md: 0.35-0.48 of the HBM peak) — against 4 here:
+// take = (v > best) | isnan(v): a NaN replaces anything and is then only replaced by a NaN.
+template <typename IdxT, int VW, int LPR, int CH, bool IS_MAX, bool IDENT>
+__global__ void __launch_bounds__(kBlock)
+    spmm_minmax_rows_plain(SpmmDev<IdxT> a, const IdxT* __restrict__ hub_rows, int64_t n_hub) {
+  constexpr int EPI = kWave / LPR;
+  constexpr int U = spmm_unroll<LPR, CH>();
+  constexpr int STEP = EPI * U;
+  const int lane = lane_id();
+  const int64_t wid = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  int64_t row;
+  if (wid < n_hub) {
+    row = hub_rows[wid];
+  } else {
+    row = wid - n_hub;
+    if (row >= a.n_rows) return;
+  }
+  const IdxT start = a.rowptr[row];
+  const IdxT end = a.rowptr[row + 1];
+  if (wid >= n_hub && n_hub > 0 && end - start > a.hub_threshold) return;  // done by a hub wave
+  int fo[CH], head[CH];
+  bool fv[CH];
+  feature_slots<VW, LPR, CH>(lane, a.F, 1, fo, fv, head);
+  const int sub = lane / LPR;
+  const float init = IS_MAX ? -INFINITY : INFINITY;
+  float best[CH][VW];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int i = 0; i < VW; ++i) best[c][i] = init;
+  auto merge = [](float val, float cur) {
+    const bool take = (IS_MAX ? (val > cur) : (val < cur)) | (val != val);
+    return take ? val : cur;
+  };
+  for (IdxT base = start; base < end; base += kWave) {
+    const IdxT rem = end - base;
+    const int cnt = rem < kWave ? static_cast<int>(rem) : kWave;
+    IdxT myc = 0;
+    if (lane < cnt) {
+      if constexpr (IDENT) {
+        myc = base + lane;
+      } else {
+        myc = __builtin_nontemporal_load(&a.col[base + lane]);  // streamed once
+      }
+    }
+    for (int j = 0; j < cnt; j += STEP) {
+      Vec<VW> v[U][CH];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = j + u * EPI + sub;
+        const bool ok = k < cnt;
+        const int kk = ok ? k : cnt - 1;
+        IdxT c;
+        if constexpr (EPI == 1) {
+          c = bcast_uniform(myc, kk);
+        } else {
+          c = bcast_lane(myc, kk);
+        }
+        const float* __restrict__ xr = a.x + static_cast<int64_t>(c) * a.ldx;
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+          if (fv[c2] && ok) {
+            v[u][c2] = load_vec<VW>(xr + fo[c2]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < VW; ++i) v[u][c2].v[i] = init;  // (neutral: never taken)
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2)
+#pragma unroll
+          for (int i = 0; i < VW; ++i) best[c2][i] = merge(v[u][c2].v[i], best[c2][i]);
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int i = 0; i < VW; ++i) best[c][i] = merge(bcast_lane(best[c][i], lane ^ off), best[c][i]);
+  }
+  if (lane < LPR) {
+    const bool empty = end == start;  // (scatter_reduce_ with include_self=False: empty groups -> 0)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (fv[c]) {
+        Vec<VW> o;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] = empty ? 0.f : best[c][i];
+        store_vec<VW>(a.out + row * a.ldo + fo[c], o);
+      }
+    }
+  }
+}
+
 // Fast half of the min/max backward: outputs with a unique extremum.  Thread = (row, VW features):
 // one read of arg32 and grad_out, a col lookup inside the row's own slot range, one fp32 atomic
 // into the single attaining source row.  No edge pass.
@@ -1245,6 +1347,17 @@ static int launch_minmax(const pygamd_spmm_args* p, const Shape& s, hipStream_t 
   const int64_t n_hub = p->n_hub > 0 ? p->n_hub : 0;
   const IdxT* hub_rows = static_cast<const IdxT*>(p->hub_rows);
   dim3 grid(wave_grid(p->n_rows + n_hub), s.tiles);
+  if (!a.arg_out && !a.arg32_out) {  // nobody asked which slot attained the extremum
+    if (p->reduce == PYGAMD_MAX) {
+      hipLaunchKernelGGL((spmm_minmax_rows_plain<IdxT, VW, LPR, CH, true, IDENT>), grid,
+                         dim3(kBlock), 0, st, a, hub_rows, n_hub);
+    } else {
+      hipLaunchKernelGGL((spmm_minmax_rows_plain<IdxT, VW, LPR, CH, false, IDENT>), grid,
+                         dim3(kBlock), 0, st, a, hub_rows, n_hub);
+    }
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  }
   if (p->reduce == PYGAMD_MAX) {
     hipLaunchKernelGGL((spmm_minmax_rows<IdxT, VW, LPR, CH, true, IDENT>), grid, dim3(kBlock), 0,
                        st, a, hub_rows, n_hub);

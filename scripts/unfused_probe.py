@@ -6,7 +6,7 @@ with the [E, F] message tensor materialised in HBM.  Sorted index = the destinat
 list (scatter = one segment reduction per destination, no atomics); unsorted = the edge list as
 generated (fp32 atomics / compare-and-swap loops).
 Algorithmic bytes: gather E*(4F + b) read + E*4F written; scatter E*(4F + b) read + N*4F written.
-Usage: python scripts/unfused_probe.py [--scale s] > profiles/r04_unfused_propagate.md"""
+Usage: python scripts/unfused_probe.py [--scale s] > profiles/r05_unfused_propagate.md"""
 import argparse
 import os
 import sys
@@ -97,7 +97,7 @@ for F in [int(v) for v in args.widths.split(',')]:
         for reduce in ('sum', 'mean', 'max'):
             if srt:
                 fn = (lambda r=reduce: _native.spmm_csr(fwd.ptr, None, msg, r, n_rows=N))
-                kern = 'spmm_sum_rows<IDENT>' if reduce != 'max' else 'spmm_minmax_rows<IDENT>'
+                kern = 'spmm_sum_rows<IDENT>' if reduce != 'max' else 'spmm_minmax_rows_plain<IDENT>'
             else:
                 fn = (lambda r=reduce: _native.scatter_rows(msg, dst, N, r))
                 kern = f'scatter_rows_kernel<{reduce}> (atomics)'

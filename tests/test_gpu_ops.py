@@ -1346,3 +1346,45 @@ def test_sddmm_spmm_one_gather(dev, H, C, dtype):
                                 big_x[:, off:off + F].contiguous(), 'sum', n_rows=n_src,
                                 w=w.to(dev))
         assert_close(agg3, agg4, rtol=1e-5, atol=1e-5, what=f'strided SpMM off={off}')
+
+
+@pytest.mark.parametrize('F', [1, 5, 48, 100, 256, 320])
+@pytest.mark.parametrize('dtype', [torch.int64, torch.int32])
+def test_spmm_minmax_without_argument(dev, F, dtype):
+    """`spmm_minmax_rows_plain`: the extremum alone (no argument / tie output requested — what the
+    unfused `scatter(..., 'max')` path and inference take): bit-equal to the argument-tracking
+    kernel and to ATen's amax / amin, including NaN (propagates), +-inf data, an all -inf row, empty
+    rows (-> 0), hub rows and the identity-column form (`col = None`: a segment reduction)."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _native
+    n_src, n_dst = 400, 330
+    ei = random_graph(n_src, n_dst, 8000, seed=F + 5, skew=True)
+    ei[1][ei[1] == 7] = 8                       # destination 7 is empty
+    extra = torch.stack([torch.full((700, ), 3), torch.full((700, ), 11)])   # a 700-slot row
+    ei = torch.cat([ei, extra], dim=1)
+    g = gen(F + 31)
+    x = torch.randn(n_src, F, generator=g)
+    x[5] = float('nan')
+    x[6, ::2] = float('inf')
+    x[9] = float('-inf')
+    only = (ei[0] == 9).nonzero().view(-1)
+    if only.numel() > 0:                        # a destination whose every neighbour is row 9
+        ei[1, only] = 12
+        ei = ei[:, ~((ei[1] == 12) & (ei[0] != 9))]
+    h = pga.EdgeIndex(ei.to(dtype).to(dev), (n_src, n_dst))
+    fwd = h.by_dst()
+    xg = x.to(dev)
+    idx = ei[1].view(-1, 1).expand(-1, F)
+    for red, aten in (('max', 'amax'), ('min', 'amin')):
+        want = torch.zeros(n_dst, F).scatter_reduce(0, idx, x[ei[0]], aten, include_self=False)
+        got = _native.spmm_csr(fwd.ptr, fwd.idx, xg, red, n_rows=n_dst, hub=fwd.hub)
+        assert torch.equal(torch.nan_to_num(got.cpu(), nan=123.0),
+                           torch.nan_to_num(want, nan=123.0)), red
+        assert bool(torch.isnan(got.cpu()).eq(torch.isnan(want)).all())
+        tracked, _ = _native.spmm_csr(fwd.ptr, fwd.idx, xg, red, n_rows=n_dst, hub=fwd.hub,
+                                      save_arg32=True)
+        assert torch.equal(torch.nan_to_num(got, nan=123.0), torch.nan_to_num(tracked, nan=123.0))
+        # identity columns: rows grouped by pointer (utils.segment's reduction)
+        msgs = xg[fwd.idx.long()]
+        seg = _native.spmm_csr(fwd.ptr, None, msgs, red, n_rows=n_dst, hub=fwd.hub)
+        assert torch.equal(torch.nan_to_num(seg, nan=123.0), torch.nan_to_num(got, nan=123.0))
