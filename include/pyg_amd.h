@@ -404,14 +404,21 @@ PYGAMD_API int pygamd_segment_matmul_tile_rows(void);
  * written there by a pre-pass, every call); otherwise on the exact fp32 kernel (ABI 9).        */
 PYGAMD_API int pygamd_segment_matmul_workspace_bytes(int64_t n_groups, int64_t K, int64_t N,
                                                      size_t* bytes /*[host]*/);
-PYGAMD_API int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w,
-                                     int64_t w_seg_stride, int64_t w_stride_k,
+/* `x_rows` / `g_rows` (device int64, or NULL): operand row r is x[x_rows[r]] (g[g_rows[r]]) — the
+ * rows of a smaller tensor gathered on the fly.  RGCNConv sums its transformed (relation,
+ * destination) rows per destination (rgcn_conv.py:284-290 + aggregate); the backward of that sum
+ * hands every pair row the gradient row of its destination, and with the index the input- and
+ * weight-gradient launches read those rows where they are instead of from a gathered [pairs, F]
+ * copy (ABI 9).                                                                                */
+PYGAMD_API int pygamd_segment_matmul(const float* x, int64_t ldx, const int64_t* x_rows,
+                                     const float* w, int64_t w_seg_stride, int64_t w_stride_k,
                                      int64_t w_stride_n, int64_t n_groups, const int32_t* tiles,
                                      int64_t n_tiles, int64_t K, int64_t N, int64_t blocks,
                                      float* out, int64_t ldo, void* workspace,
                                      size_t workspace_bytes, void* stream);
 PYGAMD_API int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g,
-                                           int64_t ldg, const int32_t* chunks, int64_t n_chunks,
+                                           int64_t ldg, const int64_t* g_rows,
+                                           const int32_t* chunks, int64_t n_chunks,
                                            int64_t n_seg, int64_t K, int64_t N, int64_t blocks,
                                            float* grad_w, void* stream);
 

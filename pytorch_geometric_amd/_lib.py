@@ -129,10 +129,10 @@ SIGNATURES = {
     'pygamd_segment_matmul_tile_rows': (c_int, []),
     'pygamd_segment_matmul_workspace_bytes': (c_int, [c_int64, c_int64, c_int64,
                                                       POINTER(c_size_t)]),
-    'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P,
-                                      c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P,
+    'pygamd_segment_matmul': (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int64,
+                                      _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P,
                                       c_size_t, _P]),
-    'pygamd_segment_matmul_wgrad': (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64,
+    'pygamd_segment_matmul_wgrad': (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64,
                                             c_int64, c_int64, c_int64, _P, _P]),
     'pygamd_sample_max_fanout': (c_int, []),
     'pygamd_sample_neighbors': (c_int, [_P, _P, c_int, _P, c_int64, _P, c_int64, c_uint64, c_int,

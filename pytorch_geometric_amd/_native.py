@@ -1459,11 +1459,21 @@ def segmm_plan(ptr_host: tuple, device, blocks: int = 1):
     return _segmm_plans[key]
 
 
+def _row_index(rows: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if rows is None:
+        return None
+    if rows.dim() != 1 or rows.dtype not in (torch.int32, torch.int64):
+        raise ValueError(f"'{name}' must be a one-dimensional int32 / int64 tensor")
+    return rows.to(torch.int64).contiguous()
+
+
 def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False,
-                   blocks: int = 1) -> Tensor:
+                   blocks: int = 1, x_rows: Optional[Tensor] = None) -> Tensor:
     """out[seg] = x[seg] @ W[g]  (or @ W[g]^T when transpose_w) — W is [G, K, N] contiguous.
-    ``blocks`` > 1: x is [S, blocks*K], W is [segments*blocks, K, N], out is [S, blocks*N]."""
-    _require_device(x, w)
+    ``blocks`` > 1: x is [S, blocks*K], W is [segments*blocks, K, N], out is [S, blocks*N].
+    ``x_rows`` [S]: operand row s is ``x[x_rows[s]]`` (gathered inside the kernel)."""
+    _require_device(x, w, x_rows)
+    x_rows = _row_index(x_rows, 'x_rows')
     lib = _lib.load()
     tiles, n_tiles = plan[0], plan[1]
     x2 = _f32_rows(x, 'x')
@@ -1477,27 +1487,33 @@ def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False,
     if x2.size(1) != blocks * K:
         raise ValueError(f"'inputs' has {x2.size(1)} columns but the weights expect "
                          f"{blocks * K}")
-    out = torch.empty(x2.size(0), blocks * N, dtype=torch.float32, device=x.device)
+    n_out = x2.size(0) if x_rows is None else x_rows.numel()
+    out = torch.empty(n_out, blocks * N, dtype=torch.float32, device=x.device)
     # the bf16 term planes of the weights (split arithmetic, K <= 128: csrc/segmm.hip)
     nbytes = ctypes.c_size_t(0)
     check(lib.pygamd_segment_matmul_workspace_bytes(G, K, N, ctypes.byref(nbytes)))
     ws = (torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
           if nbytes.value > 0 and get_gemm_mode() == 'split' else None)
-    check(lib.pygamd_segment_matmul(_p(x2), _ld(x2), _p(w), Kw * Nw, sk, sn, G, _p(tiles),
+    check(lib.pygamd_segment_matmul(_p(x2), _ld(x2), _p(x_rows), _p(w), Kw * Nw, sk, sn, G,
+                                    _p(tiles),
                                     n_tiles, K, N, blocks, _p(out), _ld(out), _p(ws),
                                     0 if ws is None else nbytes.value, _stream(x)),
           'segment_matmul')
     return out
 
 
-def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int, blocks: int = 1) -> Tensor:
-    """grad_W[g] = x[seg]^T @ grad[seg] -> [G, K, N]  (G = n_seg groups incl. blocks)."""
-    _require_device(x, g)
+def segment_matmul_wgrad(x: Tensor, g: Tensor, plan, n_seg: int, blocks: int = 1,
+                         g_rows: Optional[Tensor] = None) -> Tensor:
+    """grad_W[g] = x[seg]^T @ grad[seg] -> [G, K, N]  (G = n_seg groups incl. blocks).
+    ``g_rows`` [S]: gradient row s is ``g[g_rows[s]]`` (gathered inside the kernel)."""
+    _require_device(x, g, g_rows)
+    g_rows = _row_index(g_rows, 'g_rows')
     lib = _lib.load()
     x2, g2 = _f32_rows(x, 'x'), _f32_rows(g, 'grad')
     K, N = x2.size(1) // blocks, g2.size(1) // blocks
     gw = torch.empty(n_seg, K, N, dtype=torch.float32, device=x.device)
-    check(lib.pygamd_segment_matmul_wgrad(_p(x2), _ld(x2), _p(g2), _ld(g2), _p(plan[2]), plan[3],
+    check(lib.pygamd_segment_matmul_wgrad(_p(x2), _ld(x2), _p(g2), _ld(g2), _p(g_rows),
+                                          _p(plan[2]), plan[3],
                                           n_seg, K, N, blocks, _p(gw), _stream(x)),
           'segment_matmul_wgrad')
     return gw

@@ -30,8 +30,8 @@ __device__ __forceinline__ void zero_acc(f32x16& a) {
 }
 
 __global__ void __launch_bounds__(kBlock)
-    segmm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
-                 int64_t w_seg_stride, int64_t w_sk, int64_t w_sn,
+    segmm_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ x_rows,
+                 const float* __restrict__ w, int64_t w_seg_stride, int64_t w_sk, int64_t w_sn,
                  const int32_t* __restrict__ tiles, int K, int N, int blocks,
                  float* __restrict__ out, int64_t ldo) {
   __shared__ float As[kTM][kTK + 1];   // stride 33: the MFMA's column reads are conflict-free
@@ -58,20 +58,28 @@ __global__ void __launch_bounds__(kBlock)
   // two full 128-byte runs (a per-thread run of consecutive k would touch 64 lines per load)
   const int ak = threadIdx.x & 31;
   const int ar = threadIdx.x >> 5;
-  const float* __restrict__ xa = x + row0 * ldx + ak;
+  // (x_rows: row r of the operand is x[x_rows[r]] — the rows of another tensor gathered on the fly)
+  const float* __restrict__ xa = x + ak;
   // B tile: thread -> (k = tid / 128 + 2 j, col = tid % 128): 512-byte coalesced weight rows
   const int bc = threadIdx.x & (kTN - 1);
   const int bk = threadIdx.x >> 7;
   const bool bcol_ok = n0 + bc < N;
   const float* __restrict__ wb = wseg + static_cast<int64_t>(bcol_ok ? n0 + bc : 0) * w_sn;
   float a_nx[16], b_nx[16];
+  int64_t arow[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int r = ar + 8 * q;
+    const int64_t rr = row0 + (r < rows ? r : 0);
+    arow[q] = x_rows ? x_rows[rr] : rr;
+  }
   auto prefetch = [&](int k0) {
     const bool ak_ok = k0 + ak < K;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int r = ar + 8 * q;
       const bool ok = ak_ok && r < rows;
-      a_nx[q] = ok ? xa[static_cast<int64_t>(ok ? r : 0) * ldx + k0] : 0.f;
+      a_nx[q] = ok ? xa[arow[q] * ldx + k0] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -142,7 +150,8 @@ constexpr int kWT = 128;   // k / n columns per workgroup
 
 __global__ void __launch_bounds__(kBlock)
     segmm_wgrad_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g,
-                       int64_t ldg, const int32_t* __restrict__ chunks, int K, int N, int blocks,
+                       int64_t ldg, const int64_t* __restrict__ g_rows,
+                       const int32_t* __restrict__ chunks, int K, int N, int blocks,
                        float* __restrict__ gw) {
   __shared__ float Xs[kWR][kWT + 4];
   __shared__ float Gs[kWR][kWT + 4];
@@ -165,11 +174,24 @@ __global__ void __launch_bounds__(kBlock)
   zero_acc(acc11);
   // staging: thread -> (col = tid % 128, rows tid / 128 + 2 j)
   const int sc = threadIdx.x & (kWT - 1);
-  const int sr = threadIdx.x >> 7;
+  const int sr = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 7));  // (scalar)
   const bool xk_ok = k0 + sc < K, gn_ok = n0 + sc < N;
   const float* __restrict__ xs = x + (xk_ok ? k0 + sc : 0);
   const float* __restrict__ gs = g + (gn_ok ? n0 + sc : 0);
   float x_nx[kWR / 2], g_nx[kWR / 2];
+  // g_rows: the gradient rows are read through an index.  A wave stages whole rows (`sr` is
+  // wave-uniform), so the index is a scalar load — issued ONE BLOCK AHEAD of the row loads that
+  // depend on it (loaded next to them, every block waited for two memory round trips: the launch
+  // went from 0.81 to 1.18 ms at the FB15k-237 shape).
+  int64_t gi[kWR / 2];
+  auto load_index = [&](int64_t r) {
+#pragma unroll
+    for (int j = 0; j < kWR / 2; ++j) {
+      const int64_t rr = r + sr + 2 * j;
+      const int64_t rs = rr < rb ? rr : ra;
+      gi[j] = g_rows ? g_rows[rs] : rs;
+    }
+  };
   auto prefetch = [&](int64_t r) {
 #pragma unroll
     for (int j = 0; j < kWR / 2; ++j) {
@@ -177,13 +199,15 @@ __global__ void __launch_bounds__(kBlock)
       const bool ok = rr < rb;
       const int64_t rs = ok ? rr : ra;
       x_nx[j] = (ok && xk_ok) ? xs[rs * ldx] : 0.f;
-      g_nx[j] = (ok && gn_ok) ? gs[rs * ldg] : 0.f;
+      g_nx[j] = (ok && gn_ok) ? gs[gi[j] * ldg] : 0.f;
     }
+    load_index(r + kWR);   // (clamped inside: past the end it re-reads the chunk's first row)
   };
   // wave-uniform: which 32-wide halves of this wave's k / n range exist at all
   const bool kq0 = k0 + wk * 64 < K, kq1 = k0 + wk * 64 + 32 < K;
   const bool nq0 = n0 + wn * 64 < N, nq1 = n0 + wn * 64 + 32 < N;
   const int kh = lane >> 5;
+  load_index(ra);
   prefetch(ra);
   for (int64_t r = ra; r < rb; r += kWR) {
 #pragma unroll
@@ -320,7 +344,8 @@ __global__ void __launch_bounds__(kBlock)
 // workgroup is issued up front in one batch and the k loop unrolls without branches.
 template <int NC>
 __global__ void __launch_bounds__(kBlock, 2)
-    segmm_split_kernel(const float* __restrict__ x, int64_t ldx, const u32x4* __restrict__ planes,
+    segmm_split_kernel(const float* __restrict__ x, int64_t ldx,
+                       const int64_t* __restrict__ x_rows, const u32x4* __restrict__ planes,
                        const int32_t* __restrict__ tiles, int64_t n_items, int n_halves, int K,
                        int N, int blocks, float* __restrict__ out, int64_t ldo) {
   extern __shared__ __align__(16) uint32_t seg_lds[];
@@ -362,7 +387,7 @@ __global__ void __launch_bounds__(kBlock, 2)
   for (int j = 0; j < 4; ++j) {
     int r = 32 * wave + rr + 8 * j;
     r = r < rows ? r : rows - 1;
-    const float* pa = x + (row0 + r) * ldx;
+    const float* pa = x + (x_rows ? x_rows[row0 + r] : row0 + r) * ldx;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       int k = 32 * c + 4 * kq;
@@ -539,10 +564,10 @@ int pygamd_segment_matmul_workspace_bytes(int64_t n_groups, int64_t K, int64_t N
   return PYGAMD_OK;
 }
 
-int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w, int64_t w_seg_stride,
-                          int64_t w_stride_k, int64_t w_stride_n, int64_t n_groups,
-                          const int32_t* tiles, int64_t n_tiles, int64_t K, int64_t N,
-                          int64_t blocks, float* out, int64_t ldo, void* workspace,
+int pygamd_segment_matmul(const float* x, int64_t ldx, const int64_t* x_rows, const float* w,
+                          int64_t w_seg_stride, int64_t w_stride_k, int64_t w_stride_n,
+                          int64_t n_groups, const int32_t* tiles, int64_t n_tiles, int64_t K,
+                          int64_t N, int64_t blocks, float* out, int64_t ldo, void* workspace,
                           size_t workspace_bytes, void* stream) {
   if (n_tiles < 0 || n_groups < 0 || K < 0 || N < 0 || blocks < 1 || blocks > INT32_MAX ||
       K > INT32_MAX || N > INT32_MAX || ldx < blocks * K || ldo < blocks * N)
@@ -577,8 +602,8 @@ int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w, int64_t w
                                              static_cast<int>(kSegSplitLds)));
         attr_set[nc] = true;
       }
-      hipLaunchKernelGGL(kernel, dim3(sgrid), dim3(kBlock), kSegSplitLds, st, x, ldx, planes, tiles,
-                         n_items, n_halves, static_cast<int>(K), static_cast<int>(N),
+      hipLaunchKernelGGL(kernel, dim3(sgrid), dim3(kBlock), kSegSplitLds, st, x, ldx, x_rows,
+                         planes, tiles, n_items, n_halves, static_cast<int>(K), static_cast<int>(N),
                          static_cast<int>(blocks), out, ldo);
       return PYGAMD_OK;
     };
@@ -594,7 +619,7 @@ int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w, int64_t w
     return PYGAMD_OK;
   }
   const dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>(ceil_div(N, kTN)));
-  hipLaunchKernelGGL(segmm_kernel, grid, dim3(kBlock), 0, st, x, ldx, w,
+  hipLaunchKernelGGL(segmm_kernel, grid, dim3(kBlock), 0, st, x, ldx, x_rows, w,
                      w_seg_stride, w_stride_k, w_stride_n, tiles, static_cast<int>(K),
                      static_cast<int>(N), static_cast<int>(blocks), out, ldo);
   PYGAMD_LAUNCH_CHECK();
@@ -602,7 +627,7 @@ int pygamd_segment_matmul(const float* x, int64_t ldx, const float* w, int64_t w
 }
 
 int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g, int64_t ldg,
-                                const int32_t* chunks, int64_t n_chunks, int64_t n_seg,
+                                const int64_t* g_rows, const int32_t* chunks, int64_t n_chunks, int64_t n_seg,
                                 int64_t K, int64_t N, int64_t blocks, float* grad_w,
                                 void* stream) {
   if (n_seg < 0 || n_chunks < 0 || K < 0 || N < 0 || blocks < 1 || blocks > INT32_MAX ||
@@ -617,7 +642,7 @@ int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g, int
   if (ceil_div(K, kWT) > 65535 || ceil_div(N, kWT) > 65535) return PYGAMD_ERR_UNSUPPORTED;
   const dim3 grid(static_cast<unsigned>(n_chunks), static_cast<unsigned>(ceil_div(K, kWT)),
                   static_cast<unsigned>(ceil_div(N, kWT)));
-  hipLaunchKernelGGL(segmm_wgrad_kernel, grid, dim3(kBlock), 0, st, x, ldx, g, ldg, chunks,
+  hipLaunchKernelGGL(segmm_wgrad_kernel, grid, dim3(kBlock), 0, st, x, ldx, g, ldg, g_rows, chunks,
                      static_cast<int>(K), static_cast<int>(N), static_cast<int>(blocks), grad_w);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;

@@ -8,7 +8,7 @@ from torch.nn import Parameter
 from ... import _native
 from ..._functions import GatherFunction, SpmmFunction, bias_act, linear
 from ...edge_index import EdgeIndex
-from ...utils._segment_matmul import block_segment_matmul, segment_matmul
+from ...utils._segment_matmul import segment_matmul_sum
 from ..inits import glorot, zeros
 from ._act_request import requested_activation
 from .message_passing import MessagePassing
@@ -183,14 +183,11 @@ class RGCNConv(MessagePassing):
             reduce = 'sum' if self.aggr == 'add' else self.aggr
             # (1) per-(relation, destination) neighbourhood reduce at the input width
             agg = SpmmFunction.apply(x_l, None, h.pair_graph, reduce, 'coo')  # [S, F_in]
-            # (2) relation-segmented transform
-            if self.num_blocks is not None:
-                # block b of a pair row times weight[r, b]: column blocks in place, one launch
-                t = block_segment_matmul(agg, h.rel_ptr, weight)  # [S, F_out]
-            else:
-                t = segment_matmul(agg, h.rel_ptr, weight)  # [S, F_out]
-            # (3) sum the pair rows of every destination
-            out = SpmmFunction.apply(t, None, h.out_graph, 'sum', 'coo')
+            # (2) relation-segmented transform (block b of a pair row times weight[r, b]: column
+            # blocks in place, one launch) and (3) the sum of the pair rows of every destination,
+            # as one autograd node: the backward of (3) is a row gather that the gradient launches
+            # of (2) do themselves
+            out = segment_matmul_sum(agg, h.rel_ptr, weight, h.out_graph)
 
         root = self.root
         if root is not None:

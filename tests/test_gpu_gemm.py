@@ -688,3 +688,59 @@ def test_segment_matmul_split_kernel(dev, K, N, blocks):
             exg[ptr[r]:ptr[r + 1], b * K:(b + 1) * K] = gs @ wt
             bg[ptr[r]:ptr[r + 1], b * K:(b + 1) * K] = gs.abs() @ wt.abs()
     assert bool(((gx.cpu().double() - exg).abs() <= 1e-5 * bg + 1e-30).all())
+
+
+@pytest.mark.parametrize('mode', ['split', 'fp32'])
+@pytest.mark.parametrize('K,N,blocks', [(100, 100, 5), (36, 20, 2), (130, 33, 1)])
+def test_segment_matmul_row_index_operands(dev, mode, K, N, blocks):
+    """`x_rows` / `g_rows` of pygamd_segment_matmul(_wgrad): operand row s is `x[x_rows[s]]` —
+    bit-equal to gathering the rows first and running the plain call (same kernels, same order),
+    for the convert-once split kernel, the fp32 kernel (K = 130) and the weight gradient; and the
+    autograd node RGCNConv uses (`segment_matmul_sum`: grouped GEMM + per-destination sum, whose
+    backward reads the destinations' gradient rows through the index) against plain PyTorch."""
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd.edge_index import EdgeIndex
+    from pytorch_geometric_amd.utils._segment_matmul import segment_matmul_sum
+    g = gen(K + 3 * N + blocks)
+    lens = [0, 3, 129, 64, 1, 200]
+    ptr = [0]
+    for n in lens:
+        ptr.append(ptr[-1] + n)
+    S, R, n_small = ptr[-1], len(lens), 57
+    small = torch.randn(n_small, blocks * K, generator=g).to(dev)
+    rows = torch.randint(0, n_small, (S, ), generator=g).to(dev)
+    w = (torch.randn(R * blocks, K, N, generator=g) / K ** 0.5).to(dev)
+    plan = _native.segmm_plan(tuple(ptr), dev, blocks)
+    prev = _native.set_gemm_mode(mode)
+    try:
+        got = _native.segment_matmul(small, w, plan, blocks=blocks, x_rows=rows)
+        want = _native.segment_matmul(small[rows], w, plan, blocks=blocks)
+        assert torch.equal(got, want)
+        gsmall = torch.randn(n_small, blocks * N, generator=g).to(dev)
+        xs = torch.randn(S, blocks * K, generator=g).to(dev)
+        gw = _native.segment_matmul_wgrad(xs, gsmall, plan, R * blocks, blocks, g_rows=rows)
+        gw_want = _native.segment_matmul_wgrad(xs, gsmall[rows], plan, R * blocks, blocks)
+        assert_close(gw, gw_want, rtol=1e-5, atol=1e-5, what='wgrad through the row index')
+        # the autograd node: rows of the product summed per destination
+        n_dst = 40
+        dst = torch.randint(0, n_dst, (S, ), generator=g).to(dev)
+        out_graph = EdgeIndex(torch.stack([torch.arange(S, device=dev), dst]), (S, n_dst),
+                              sort_order='row', validate=False)
+        w4 = w.view(R, blocks, K, N) if blocks > 1 else w
+        xin = xs.clone().requires_grad_(True)
+        wp = w4.clone().requires_grad_(True)
+        out = segment_matmul_sum(xin, tuple(ptr), wp, out_graph)
+        go = torch.randn(n_dst, blocks * N, generator=g).to(dev)
+        out.backward(go)
+        xr = xs.double().cpu().requires_grad_(True)
+        wr = w.double().cpu().requires_grad_(True)
+        t = torch.cat([torch.cat([xr[ptr[r]:ptr[r + 1], b * K:(b + 1) * K] @ wr[r * blocks + b]
+                                  for b in range(blocks)], dim=1) for r in range(R)])
+        ref = torch.zeros(n_dst, blocks * N, dtype=torch.float64).index_add_(0, dst.cpu(), t)
+        ref.backward(go.double().cpu())
+        assert_close(out, ref.detach().float(), rtol=1e-5, atol=5e-5, what='segment_matmul_sum')
+        assert_close(xin.grad, xr.grad.float(), rtol=1e-5, atol=5e-5, what='grad inputs')
+        assert_close(wp.grad.reshape(wr.shape), wr.grad.float(), rtol=1e-4, atol=1e-4,
+                     what='grad weights')
+    finally:
+        _native.set_gemm_mode(prev)
