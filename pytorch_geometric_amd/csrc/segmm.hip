@@ -539,6 +539,162 @@ __global__ void __launch_bounds__(kBlock, 2)
   }
 }
 
+// ---- weight gradient, split arithmetic, operands converted once ---------------------------------
+// grad_W[g] = x[seg]^T @ grad[seg] reduces over ROWS: both operands reach the matrix instruction
+// transposed (eight k-consecutive bf16 values per lane = eight consecutive rows of one column).
+// As in gemm_tn_split_kernel (csrc/gemm.hip) the STAGING thread converts: it owns eight consecutive
+// rows of one column (eight 4-byte loads, each a 256-byte run across the wave), splits them into
+// the three bf16 terms as (row, row + 1) pairs and writes, per term, ONE 16-byte vector — so a
+// fragment is one ds_read_b128 per term, every element is converted exactly once per workgroup
+// (176 VALU instructions per thread and 32-row block; the fp32 kernel above needs 64 matrix
+// instructions of 64 cycles per wave and block, this one 48 of 32).  LDS image:
+// [operand x | g][term][column 0..127][20 dwords] (4 row groups x 4 dwords + 4 pad: 5 * column
+// mod 16 is a bijection for the 16-lane read groups) = 61,440 bytes, single-buffered with two
+// barriers per block, two workgroups per CU (one converts while the other multiplies).  The loads
+// of block b + 1 are issued before the products of block b; the row index of the gradient
+// operand (g_rows) is a scalar load one block further ahead.
+constexpr int kWLD = 20;                    // dwords per staged column
+constexpr int kWPlane = kWT * kWLD;         // dwords per (operand, term) plane
+constexpr size_t kWgSplitLds = sizeof(uint32_t) * 6 * kWPlane;
+
+__global__ void __launch_bounds__(kBlock, 2)
+    segmm_wgrad_split_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g,
+                             int64_t ldg, const int64_t* __restrict__ g_rows,
+                             const int32_t* __restrict__ chunks, int K, int N, int blocks,
+                             float* __restrict__ gw) {
+  extern __shared__ __align__(16) uint32_t wg_lds[];
+  const int t = blockIdx.x;
+  const int seg = chunks[3 * t];
+  const int64_t ra = chunks[3 * t + 1];
+  const int64_t rb = ra + chunks[3 * t + 2];
+  const int k0 = blockIdx.y * kWT;
+  const int n0 = blockIdx.z * kWT;
+  const int wave = wave_in_block(), lane = lane_id();
+  const int wk = wave >> 1, wn = wave & 1;
+  const int blk = blocks > 1 ? seg % blocks : 0;
+  x += static_cast<int64_t>(blk) * K;
+  g += static_cast<int64_t>(blk) * N;
+  // staging: thread -> column tid % 128, row groups (tid / 128) and (tid / 128) + 2 of the block
+  const int sc = threadIdx.x & (kWT - 1);
+  const int gsel = wave >> 1;                         // (scalar: tid / 128)
+  const bool xk_ok = k0 + sc < K, gn_ok = n0 + sc < N;
+  const float* __restrict__ xs = x + (xk_ok ? k0 + sc : 0);
+  const float* __restrict__ gs = g + (gn_ok ? n0 + sc : 0);
+  float xv[2][8], gv[2][8];
+  int64_t gi[2][8];
+  auto load_index = [&](int64_t r) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t rr = r + 8 * (gsel + 2 * u) + e;
+        const int64_t rs = rr < rb ? rr : ra;
+        gi[u][e] = g_rows ? g_rows[rs] : rs;
+      }
+  };
+  auto load_rows = [&](int64_t r) {                   // unconditional (clamped), masked at the split
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t rr = r + 8 * (gsel + 2 * u) + e;
+        const int64_t rs = rr < rb ? rr : ra;
+        xv[u][e] = xs[rs * ldx];
+        gv[u][e] = gs[gi[u][e] * ldg];
+      }
+    load_index(r + kWR);                              // (clamped inside)
+  };
+  uint32_t* const wx = wg_lds + sc * kWLD;
+  uint32_t* const wgp = wg_lds + 3 * kWPlane + sc * kWLD;
+  auto convert_store = [&](int64_t r) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int gq = gsel + 2 * u;
+      u32x4 px[3], pg[3];
+#pragma unroll
+      for (int p4 = 0; p4 < 4; ++p4) {
+        const bool ok0 = r + 8 * gq + 2 * p4 < rb, ok1 = r + 8 * gq + 2 * p4 + 1 < rb;
+        uint32_t tt[3];
+        split_pair((ok0 && xk_ok) ? xv[u][2 * p4] : 0.f, (ok1 && xk_ok) ? xv[u][2 * p4 + 1] : 0.f,
+                   tt);
+        px[0][p4] = tt[0];
+        px[1][p4] = tt[1];
+        px[2][p4] = tt[2];
+        split_pair((ok0 && gn_ok) ? gv[u][2 * p4] : 0.f, (ok1 && gn_ok) ? gv[u][2 * p4 + 1] : 0.f,
+                   tt);
+        pg[0][p4] = tt[0];
+        pg[1][p4] = tt[1];
+        pg[2][p4] = tt[2];
+      }
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm) {
+        *reinterpret_cast<u32x4*>(wx + tm * kWPlane + 4 * gq) = px[tm];
+        *reinterpret_cast<u32x4*>(wgp + tm * kWPlane + 4 * gq) = pg[tm];
+      }
+    }
+  };
+  f32x16 acc[2][2];                                   // [k half][n half] of this wave's 64 x 64
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) zero_acc(acc[i][j]);
+  // wave-uniform: this wave's 64-column ranges are not both empty (columns past K / N inside a
+  // range are staged as zeros, so all four 32 x 32 blocks are computed)
+  const bool active = k0 + wk * 64 < K && n0 + wn * 64 < N;
+  const int li = lane & 31, lh = lane >> 5;
+  const uint32_t* const fa = wg_lds + (wk * 64 + li) * kWLD + 4 * lh;
+  const uint32_t* const fb = wg_lds + 3 * kWPlane + (wn * 64 + li) * kWLD + 4 * lh;
+  auto frag = [&](const uint32_t* base, int half, int sstep) {
+    SegFrag f;
+#pragma unroll
+    for (int tm = 0; tm < 3; ++tm)
+      f.p[tm] = __builtin_bit_cast(
+          bf16x8, *reinterpret_cast<const u32x4*>(base + tm * kWPlane + half * 32 * kWLD +
+                                                  8 * sstep));
+    return f;
+  };
+  load_index(ra);
+  load_rows(ra);
+  for (int64_t r = ra; r < rb; r += kWR) {
+    convert_store(r);
+    __syncthreads();
+    load_rows(r + kWR);                               // in flight during the products below
+    if (active) {
+#pragma unroll
+      for (int sstep = 0; sstep < 2; ++sstep) {
+        const SegFrag a0 = frag(fa, 0, sstep), a1 = frag(fa, 1, sstep);
+        const SegFrag b0 = frag(fb, 0, sstep), b1 = frag(fb, 1, sstep);
+#pragma unroll
+        for (int tm = 0; tm < kSplitTerms; ++tm) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.p[kSplitTa[tm]],
+                                                              b0.p[kSplitTb[tm]], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.p[kSplitTa[tm]],
+                                                              b1.p[kSplitTb[tm]], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.p[kSplitTa[tm]],
+                                                              b0.p[kSplitTb[tm]], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.p[kSplitTa[tm]],
+                                                              b1.p[kSplitTb[tm]], acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  float* __restrict__ gseg = gw + static_cast<int64_t>(seg) * K * N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + 32 * j + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kr = k0 + wk * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (kr < K && col < N) atomicAdd(gseg + static_cast<int64_t>(kr) * N + col, acc[i][j][e]);
+      }
+    }
+  }
+}
+
 }  // namespace pygamd
 
 using namespace pygamd;
@@ -642,6 +798,20 @@ int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g, int
   if (ceil_div(K, kWT) > 65535 || ceil_div(N, kWT) > 65535) return PYGAMD_ERR_UNSUPPORTED;
   const dim3 grid(static_cast<unsigned>(n_chunks), static_cast<unsigned>(ceil_div(K, kWT)),
                   static_cast<unsigned>(ceil_div(N, kWT)));
+  if (pygamd_get_gemm_mode() == PYGAMD_GEMM_SPLIT_BF16) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(segmm_wgrad_split_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(kWgSplitLds)));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(segmm_wgrad_split_kernel, grid, dim3(kBlock), kWgSplitLds, st, x, ldx, g,
+                       ldg, g_rows, chunks, static_cast<int>(K), static_cast<int>(N),
+                       static_cast<int>(blocks), grad_w);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  }
   hipLaunchKernelGGL(segmm_wgrad_kernel, grid, dim3(kBlock), 0, st, x, ldx, g, ldg, g_rows, chunks,
                      static_cast<int>(K), static_cast<int>(N), static_cast<int>(blocks), grad_w);
   PYGAMD_LAUNCH_CHECK();
