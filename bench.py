@@ -63,12 +63,12 @@ def spmm_algorithmic_bytes(info) -> float:
 
 def pmc_traffic(args, N, E, kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this very command
-    (profiles/r04_pmc_bench.json, r03_pmc_bench.json: FETCH_SIZE and WRITE_SIZE in separate passes, converted as
-    /opt/skills/guides/MI355X_MICROARCH.md prescribes; collected by scripts/gpu_r03_profile.sh).
+    (profiles/r05_pmc_bench.json, r04_..., r03_...: FETCH_SIZE and WRITE_SIZE in separate passes, converted as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes; collected by scripts/gpu_r05_profile.sh).
     Counters cannot be read from inside this process, so a number is only reported when this run is
     the workload the counters were collected on; otherwise null."""
     d = None
-    for name in ('r04_pmc_bench.json', 'r03_pmc_bench.json'):  # newest file that knows the kernel
+    for name in ('r05_pmc_bench.json', 'r04_pmc_bench.json', 'r03_pmc_bench.json'):  # newest file that knows the kernel
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 cand = json.load(f)
@@ -83,6 +83,24 @@ def pmc_traffic(args, N, E, kernel: str):
     same = (w.get('N') == N and w.get('E') == E and not args.uniform
             and w.get('index_dtype') == args.index_dtype)
     return d.get('traffic_bytes_per_launch', {}).get(kernel) if same else None
+
+
+def measured_copy_bandwidth(dev, n_bytes: int = 1 << 30, reps: int = 5) -> float:
+    """GB/s (read + written bytes) of a device-to-device copy of `n_bytes` on this box, timed with
+    HIP events: SURVEY.md 8(d)'s secondary denominator for the HBM-bound kernels (the guide's
+    figure for this chip: 6.29 TB/s for a float4 copy against the 8 TB/s spec).  A measurement
+    probe, not part of the timed step."""
+    src = torch.empty(n_bytes // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * n_bytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def fused_algorithmic_bytes(info) -> float:
@@ -998,6 +1016,12 @@ def main():
         return e
 
     roofline = hbm_entry(dom) if dom else {}
+    if dom:  # the same launch against what a plain device copy reaches on THIS box
+        copy_gbs = measured_copy_bandwidth(dev)
+        roofline['copy_bandwidth'] = {
+            'measured': round(copy_gbs, 1), 'unit': 'GB/s',
+            'what': 'device-to-device copy of 1 GiB (read + written bytes), HIP events, this run',
+            'frac_of_copy': round(roofline['achieved'] / copy_gbs, 4)}
     roofline['share_of_step'] = round(tot_ms.get(dom, 0.0) / (elapsed * 1e3), 4) if dom else None
     roofline['others'] = {k: round(tot_ms[k] / args.steps, 3) for k in sorted(tot_ms) if k != dom}
     if dom_any != dom:  # (a GEMM symbol leads: say so; the HBM entry above stays the aggregation)
