@@ -67,6 +67,8 @@ def pmc_traffic(args, N, E, kernel: str):
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; collected by scripts/gpu_r05_profile.sh).
     Counters cannot be read from inside this process, so a number is only reported when this run is
     the workload the counters were collected on; otherwise null."""
+    if _live_traffic is not None:   # this run's own counter passes (live_pmc_traffic)
+        return _live_traffic.get(kernel)
     d = None
     for name in ('r05_pmc_bench.json', 'r04_pmc_bench.json', 'r03_pmc_bench.json'):  # newest file that knows the kernel
         try:
@@ -83,6 +85,70 @@ def pmc_traffic(args, N, E, kernel: str):
     same = (w.get('N') == N and w.get('E') == E and not args.uniform
             and w.get('index_dtype') == args.index_dtype)
     return d.get('traffic_bytes_per_launch', {}).get(kernel) if same else None
+
+
+# bench symbol -> substring of the device symbol rocprofv3 prints
+_PMC_SYMBOLS = (('sage_fused_split_kernel<long,64>', 'sage_fused_split_kernel<long, 64'),
+                ('sage_fused_split_kernel<long,32>', 'sage_fused_split_kernel<long, 32'),
+                ('sage_fused_fwd_kernel<long,64>', 'sage_fused_fwd_kernel<long, 64'),
+                ('sage_fused_fwd_kernel<long,32>', 'sage_fused_fwd_kernel<long, 32'),
+                ('spmm_sum_rows<long,F=48>', 'spmm_sum_rows<long, 4, 16, 1, 0'),
+                ('spmm_sum_rows_sparse<long,F=48>', 'spmm_sum_rows_sparse<long, 4, 16, 1'))
+_live_traffic = None   # {bench symbol: HBM bytes per launch} from THIS run's PMC passes, or None
+
+
+def live_pmc_traffic(args):
+    """HBM bytes per launch of the aggregation kernels from two rocprofv3 PMC passes run NOW, on
+    this box, over this very command (2 timed steps): `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    in separate passes with `--kernel-trace` only, as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes; FETCH_SIZE doubled (gfx950 reports 64 B per 128-byte request), both in KiB.
+    Returns {symbol: bytes} or None (no rocprofv3, already under a profiler, a pass failed or
+    timed out: the committed profile then serves, and the line says which it was)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get('PYGAMD_BENCH_CHILD') or shutil.which('rocprofv3') is None:
+        return None
+    if any('rocprof' in os.environ.get(k, '') for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES',
+                                                        'HSA_TOOLS_LIB')):
+        return None   # this process is being profiled itself
+    sums = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out = tempfile.mkdtemp(prefix='pygamd_pmc_', dir='/tmp')
+        cmd = ['rocprofv3', '--pmc', ctr, '--kernel-trace', '-d', out, '-o', 'pmc',
+               '--output-format', 'csv', '--', sys.executable, os.path.abspath(__file__),
+               '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-side-figures',
+               '--no-live-pmc', '--scale', str(args.scale), '--index-dtype', args.index_dtype]
+        if args.uniform:
+            cmd.append('--uniform')
+        if args.arith is not None:
+            cmd += ['--arith', args.arith]
+        env = dict(os.environ, TMPDIR='/tmp', PYGAMD_BENCH_CHILD='1')
+        try:
+            res = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, timeout=300)
+            if res.returncode != 0:
+                return None
+            vals = {}
+            for f in glob.glob(os.path.join(out, '**', '*counter_collection*.csv'),
+                               recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get('Counter_Name') != ctr:
+                            continue
+                        for sym, sub in _PMC_SYMBOLS:
+                            if sub in r['Kernel_Name']:
+                                vals.setdefault(sym, []).append(float(r['Counter_Value']))
+            if not vals:
+                return None
+            sums[ctr] = {k: sum(v) / len(v) for k, v in vals.items()}
+        except (OSError, ValueError, KeyError, subprocess.SubprocessError):
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return {k: (2.0 * sums['FETCH_SIZE'][k] + sums['WRITE_SIZE'][k]) * 1024.0
+            for k in sums['FETCH_SIZE'] if k in sums['WRITE_SIZE']}
 
 
 def measured_copy_bandwidth(dev, n_bytes: int = 1 << 30, reps: int = 5) -> float:
@@ -832,6 +898,9 @@ def main():
     ap.add_argument('--no-side-figures', action='store_true',
                     help='full-batch mode: skip the short re-timings printed beside the headline '
                          '(exact fp32 instruction, dense loss)')
+    ap.add_argument('--no-live-pmc', action='store_true',
+                    help='full-batch mode: do not run the two rocprofv3 --pmc passes that give '
+                         'roofline.traffic for THIS run (the committed profile serves instead)')
     ap.add_argument('--no-tuned-gemm', action='store_true',
                     help='use the default rocBLAS/hipBLASLt heuristics instead of the shipped '
                          'TunableOp table')
@@ -1015,7 +1084,20 @@ def main():
             e['mfma_frac_of_157.3'] = round(flops / (ms * 1e-3) / 1e12 / 157.3, 4)
         return e
 
+    # HBM traffic of this run: two PMC passes over this command in child processes (rank 0 of a
+    # one-GPU run, not for the short profiling invocations)
+    global _live_traffic
+    if (rank == 0 and world == 1 and not args.no_live_pmc and not args.no_side_figures
+            and not args.no_cpu_baseline):
+        _live_traffic = live_pmc_traffic(args)
     roofline = hbm_entry(dom) if dom else {}
+    if dom:
+        roofline['traffic_source'] = (
+            'live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, '
+            '--kernel-trace only) over this command with 2 steps, run by this process; '
+            '(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch'
+            if _live_traffic is not None else
+            'committed profile (profiles/r05_pmc_bench.json, same command and workload)')
     if dom:  # the same launch against what a plain device copy reaches on THIS box
         copy_gbs = measured_copy_bandwidth(dev)
         roofline['copy_bandwidth'] = {
