@@ -329,18 +329,26 @@ __global__ void __launch_bounds__(kBlock)
   // together but send the whole gradient to one row, which is what the one-winner backward does
   // (round 3: on a multigraph like the products-shaped one they were the bulk of the marked
   // outputs and kept the tie kernel at 10 ms)
+  // (r5) the bookkeeping costs VALU issue slots on every gathered element, and this kernel is
+  // bound by them (5.4 ms on top of the 11.9 ms the same gather takes as a sum, F = 256): the
+  // first source is kept in 32 bits (node ids of a graph differ in their low 32 bits), "empty" and
+  // "the extremum is a NaN" are lane masks carried along instead of compares per element, and the
+  // two orderings share their compares — 7 VALU instructions per element (3 compares of the value,
+  // 1 of the source, 3 selects) + scalar mask logic, instead of ~14.
   float best[CH][VW];
   int32_t barg[CH][VW];
-  IdxT bsrc[CH][VW];
-  bool tie[CH][VW];
+  uint32_t bsrc[CH][VW];
+  bool tie[CH][VW], has[CH][VW], bnan[CH][VW];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
       best[c][i] = init;
       barg[c][i] = -1;
-      bsrc[c][i] = 0;
+      bsrc[c][i] = 0u;
       tie[c][i] = false;
+      has[c][i] = false;
+      bnan[c][i] = false;
     }
   }
   for (IdxT base = start; base < end; base += kWave) {
@@ -358,7 +366,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < cnt; j += STEP) {
       Vec<VW> v[U][CH];
       bool ok[U];
-      IdxT cs[U];
+      uint32_t cs[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = j + u * EPI + sub;
@@ -370,7 +378,7 @@ __global__ void __launch_bounds__(kBlock)
         } else {
           c = bcast_lane(myc, kk);
         }
-        cs[u] = c;
+        cs[u] = static_cast<uint32_t>(c);
         const float* __restrict__ xr = a.x + static_cast<int64_t>(c) * a.ldx;
 #pragma unroll
         for (int c2 = 0; c2 < CH; ++c2) {
@@ -390,16 +398,21 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
           for (int i = 0; i < VW; ++i) {
             const float val = v[u][c2].v[i];
-            const bool empty = barg[c2][i] < 0;
-            const bool gt = better_val<IS_MAX>(val, best[c2][i]);
-            const bool lt = better_val<IS_MAX>(best[c2][i], val);
-            // the first valid slot always wins over the (arg == -1) initial state
-            const bool take = ok[u] & (empty | gt);
+            const bool vn = val != val;
+            const bool c_gt = IS_MAX ? (val > best[c2][i]) : (val < best[c2][i]);
+            const bool c_lt = IS_MAX ? (val < best[c2][i]) : (val > best[c2][i]);
+            // better_val(val, best) and better_val(best, val): a NaN beats any non-NaN
+            const bool gt = !bnan[c2][i] & (vn | c_gt);
+            const bool lt = !vn & (bnan[c2][i] | c_lt);
+            // the first valid slot always wins over the initial state
+            const bool take = ok[u] & (!has[c2][i] | gt);
             const bool other_src = cs[u] != bsrc[c2][i];
-            tie[c2][i] = take ? false : (tie[c2][i] | (ok[u] & !empty & !lt & other_src));
+            tie[c2][i] = take ? false : (tie[c2][i] | (ok[u] & has[c2][i] & !lt & other_src));
             best[c2][i] = take ? val : best[c2][i];
             barg[c2][i] = take ? slot : barg[c2][i];
             bsrc[c2][i] = take ? cs[u] : bsrc[c2][i];
+            bnan[c2][i] = take ? vn : bnan[c2][i];
+            has[c2][i] = has[c2][i] | take;
           }
         }
       }
@@ -415,7 +428,8 @@ __global__ void __launch_bounds__(kBlock)
         const float ov = bcast_lane(best[c][i], lane ^ off);
         const int32_t oa = bcast_lane(barg[c][i], lane ^ off);
         const bool ot = bcast_lane(static_cast<int32_t>(tie[c][i]), lane ^ off) != 0;
-        const IdxT os = bcast_lane(bsrc[c][i], lane ^ off);
+        const uint32_t os = static_cast<uint32_t>(
+            bcast_lane(static_cast<int32_t>(bsrc[c][i]), lane ^ off));
         // Branch-free on purpose: hipcc 7.2 drops the guarded assignment of the nested-if form
         // of this update for VW = 4 (found by tests/test_gpu_ops.py::test_spmm_minmax_vs_oracle).
         const bool other_valid = oa >= 0;
