@@ -57,6 +57,12 @@ prof config3 python $R/scripts/time_gat.py
 prof config5 python $R/scripts/time_rgcn.py
 python $R/scripts/time_configs.py 2>&1 | grep -v amdgpu.ids | tee $R/gpurun_out/${TAG}_configs_timings.txt
 fi
+if want minibatch; then
+echo "== kernel stats: minibatch, captured slot batches (full papers100M shape)"
+prof minibatch python $R/bench.py --mode minibatch --capture --steps 100 --warmup 20
+echo "== kernel stats: minibatch, the same static-shape step eagerly (per-kernel times)"
+PYGAMD_CAPTURE=0 prof minibatch_eager python $R/bench.py --mode minibatch --capture --steps 50 --warmup 10
+fi
 [[ -n "${ONLY:-}" ]] && exit 0
 echo "== kernel stats: bench with the exact fp32 instruction (side figure)"
 prof bench_fp32 python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-figures --arith fp32
