@@ -34,6 +34,12 @@ def _register_fakes():
     register_fake('pyg_amd_c::segment_softmax_forward')(lambda src, ptr: torch.empty_like(src))
     register_fake('pyg_amd_c::segment_softmax_backward')(
         lambda out, grad_out, ptr: torch.empty_like(out))
+    # the C++ autograd nodes (shape functions only: under torch.compile the Python route is taken)
+    register_fake('pyg_amd_c::linear_ag')(
+        lambda x, weight, bias: x.new_empty(*x.shape[:-1], weight.size(0)))
+    register_fake('pyg_amd_c::bias_act_ag')(lambda x, bias, relu: torch.empty_like(x))
+    register_fake('pyg_amd_c::spmm_ag')(
+        lambda x, w, rowptr, *rest: x.new_empty(rowptr.numel() - 1, *x.shape[1:]))
 
 
 def ops():

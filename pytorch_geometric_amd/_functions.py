@@ -621,11 +621,58 @@ def own_linear_eligible(x: Tensor, weight: Tensor) -> bool:
             and not torch.jit.is_scripting() and not torch.is_autocast_enabled())
 
 
+# The autograd nodes of csrc/torch_binding.cpp (LinearAG / SpmmAG / BiasActAG): the same kernels in
+# the same order as LinearFunction / SpmmFunction / BiasActFunction below, with forward AND backward
+# running in C++ — an eager, launch-bound step (2-layer GCN at the Cora shape) spends most of its
+# host time in the Python Functions and their marshalling (scripts/eager_probe.py).  Taken for
+# plain float32 operands when nothing beyond those nodes is asked for; PYGAMD_CPP_AUTOGRAD=0, a
+# missing binding, torch.compile tracing or bench.py's per-launch timing sink keep the Python nodes.
+CPP_AUTOGRAD = os.environ.get('PYGAMD_CPP_AUTOGRAD', '1') != '0'
+
+
+def _cpp_nodes():
+    if not CPP_AUTOGRAD or _native.timing_sink is not None or torch.compiler.is_compiling():
+        return None
+    from . import _compiled
+    return _compiled.ops()
+
+
+def _plain_f32(*ts) -> bool:
+    return all(t is None or (type(t) in (Tensor, torch.nn.Parameter) and t.is_cuda
+                             and t.dtype == torch.float32) for t in ts)
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
     """``F.linear`` semantics (``weight [out, in]``); large float32 HIP inputs run on csrc/gemm.hip."""
     if own_linear_eligible(x, weight):
+        C = _cpp_nodes()
+        if C is not None and _plain_f32(x, weight, bias) and x.size(-1) == weight.size(1) \
+                and (bias is None or bias.numel() == weight.size(0)):
+            return C.linear_ag(x, weight, bias)
         return LinearFunction.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+def spmm_node(x: Tensor, w: Optional[Tensor], graph: EdgeIndex, reduce: str,
+              w_order: str) -> Tensor:
+    """``SpmmFunction.apply`` semantics; sum / mean with no gradient asked for the weights run as
+    the C++ autograd node."""
+    C = _cpp_nodes()
+    if (C is not None and reduce in ('sum', 'mean') and _plain_f32(x, w) and x.dim() >= 2
+            and x.numel() > 0 and x.size(0) == graph.num_src_nodes and not graph.atomic_backward
+            and (w is None or (w.dim() == 1 and not w.requires_grad
+                               and w.numel() == graph.num_edges))):
+        fwd, bwd = graph.by_dst(), graph.by_src()
+        eid = eid_t = None
+        if w is not None:
+            eid = fwd.perm if w_order == 'coo' else None
+            eid_t = bwd.perm if w_order == 'coo' else graph.src_slot_to_dst_slot()
+        (h_rows, h_cptr, n_hub, n_chunks), (t_rows, t_cptr, t_hub, t_chunks) = fwd.hub, bwd.hub
+        inv = fwd.inv_degree() if reduce == 'mean' else None
+        return C.spmm_ag(x, w, fwd.ptr, fwd.idx, eid, h_rows, h_cptr, n_hub, n_chunks, bwd.ptr,
+                         bwd.idx, eid_t, t_rows, t_cptr, t_hub, t_chunks, inv,
+                         _native.REDUCE_IDS[reduce], _native.HUB_THRESHOLD, _native.HUB_CHUNK)
+    return SpmmFunction.apply(x, w, graph, reduce, w_order)
 
 
 class BiasActFunction(Function):
@@ -662,6 +709,9 @@ def bias_act(x: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:
     if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.numel() > 0 \
             and (bias is None or (bias.dtype == torch.float32 and bias.dim() == 1)) \
             and not torch.jit.is_scripting() and not torch.is_autocast_enabled():
+        C = _cpp_nodes()
+        if C is not None and _plain_f32(x, bias) and (bias is None or bias.numel() == x.size(-1)):
+            return C.bias_act_ag(x, bias, bool(relu))
         return BiasActFunction.apply(x, bias, relu)
     out = x if bias is None else x + bias
     return out.relu() if relu else out

@@ -17,6 +17,7 @@
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
 #include "../../include/pyg_amd.h"
@@ -423,6 +424,186 @@ Tensor segment_softmax_backward(const Tensor& out, const Tensor& grad_out, const
 
 int64_t abi_version() { return pygamd_abi_version(); }
 
+// ---- autograd nodes in C++ ----------------------------------------------------
+// The three operators a launch-bound layer stack spends its host time in — F.linear
+// (nn/dense/linear.py:121-127), the weighted sum / mean aggregation of message_and_aggregate
+// (utils/_spmm.py:12-136, edge_index.py:1849-1900 for the transposed backward) and the layer tail
+// `act(out + bias)` (gcn_conv.py:278-281 + basic_gnn.py:262-263) — as torch::autograd::Function s:
+// forward AND backward run without re-entering Python (an eager 2-layer GCN step at the Cora shape
+// spent ~0.4 of its 0.5 ms in the Python autograd Functions and their ctypes / marshalling glue
+// around 0.12 ms of GPU work, scripts/eager_probe.py).  Same entry points of the C ABI, same order,
+// as pytorch_geometric_amd/_functions.py {LinearFunction, SpmmFunction, BiasActFunction}; that
+// module routes here when the operands are plain float32 HIP tensors and nothing exotic is asked
+// for (no gradient w.r.t. the edge weights, sum / mean only), and stays the reference
+// implementation for everything else.
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+inline Tensor rows2d(const Tensor& t) { return t.reshape({-1, t.size(-1)}); }
+
+struct LinearAG : public torch::autograd::Function<LinearAG> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& weight,
+                        const OptTensor& bias) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const Tensor x2 = rows2d(x);
+    Tensor out = at::empty({x2.size(0), weight.size(0)}, x2.options());
+    linear_forward(x2, weight, bias, false, out, false);
+    ctx->save_for_backward({x2, weight});
+    ctx->saved_data["has_bias"] = has(bias);
+    ctx->saved_data["x_shape"] = x.sizes().vec();
+    std::vector<int64_t> shape = x.sizes().vec();
+    shape.back() = weight.size(0);
+    return out.view(shape);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &x2 = saved[0], &weight = saved[1];
+    const Tensor g2 = rows2d(grads[0]);
+    Tensor gx, gw, gb;
+    if (ctx->needs_input_grad(0)) {
+      const Tensor wt = weight.t().contiguous();
+      gx = at::empty({g2.size(0), weight.size(1)}, g2.options());
+      linear_dgrad(g2, wt, c10::nullopt, 0, gx, false, c10::nullopt, c10::nullopt, c10::nullopt);
+      gx = gx.view(ctx->saved_data["x_shape"].toIntVector());
+    }
+    const bool need_b = ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2);
+    if (ctx->needs_input_grad(1)) {
+      gw = at::empty({weight.size(0), weight.size(1)}, g2.options());
+      if (need_b) gb = at::empty({weight.size(0)}, g2.options());
+      linear_wgrad(g2, x2, gw, false, 2, need_b ? OptTensor(gb) : c10::nullopt, c10::nullopt);
+    } else if (need_b) {
+      gb = at::empty({weight.size(0)}, g2.options());
+      const Tensor g = rows_f32(g2, "grad");
+      check(pygamd_colsum(fptr(g), ld(g), g.size(0), g.size(1), static_cast<float*>(ptr(gb)),
+                          cur_stream(g)), "colsum");
+    }
+    return {gx, gw, gb};
+  }
+};
+
+Tensor linear_ag(const Tensor& x, const Tensor& weight, const OptTensor& bias) {
+  return LinearAG::apply(x, weight, bias);
+}
+
+struct BiasActAG : public torch::autograd::Function<BiasActAG> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const OptTensor& bias, bool relu) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());
+    const Tensor x2 = rows_f32(rows2d(x), "x");
+    const Tensor b = contig(bias);
+    TORCH_CHECK(!b.defined() || (b.scalar_type() == at::kFloat && b.numel() == x2.size(1)),
+                "'bias' must be float32 with ", x2.size(1), " entries");
+    Tensor out = at::empty({x2.size(0), x2.size(1)}, x2.options());
+    check(pygamd_bias_act(fptr(x2), ld(x2), fptr(b), x2.size(0), x2.size(1), relu ? 1 : 0,
+                          static_cast<float*>(ptr(out)), ld(out), cur_stream(x2)), "bias_act");
+    out = out.view(x.sizes());
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["has_bias"] = b.defined();
+    if (relu) ctx->save_for_backward({out});
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const Tensor g2 = rows_f32(rows2d(grads[0]), "grad");
+    const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(g2.device());
+    const bool need_b = ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(1);
+    Tensor gb;
+    if (need_b) gb = at::empty({g2.size(1)}, g2.options());
+    if (ctx->saved_data["relu"].toBool()) {
+      const Tensor act = rows_f32(rows2d(ctx->get_saved_variables()[0]), "act");
+      Tensor gin = at::empty({g2.size(0), g2.size(1)}, g2.options());
+      check(pygamd_relu_backward_colsum(fptr(g2), ld(g2), fptr(act), ld(act), g2.size(0),
+                                        g2.size(1), static_cast<float*>(ptr(gin)), ld(gin),
+                                        static_cast<float*>(ptr(gb)), cur_stream(g2)),
+            "relu_backward_colsum");
+      return {gin.view(grads[0].sizes()), gb, Tensor()};
+    }
+    if (need_b)
+      check(pygamd_colsum(fptr(g2), ld(g2), g2.size(0), g2.size(1), static_cast<float*>(ptr(gb)),
+                          cur_stream(g2)), "colsum");
+    return {grads[0], gb, Tensor()};
+  }
+};
+
+Tensor bias_act_ag(const Tensor& x, const OptTensor& bias, bool relu) {
+  return BiasActAG::apply(x, bias, relu);
+}
+
+// out[i] = reduce_{slots k of row i} w[eid[k]] * x[col[k]] (sum / mean; w, eid optional); the
+// backward w.r.t. x runs the same kernel on the transposed CSR (rowptr_t, col_t, eid_t), with the
+// mean's 1/deg folded into the gathered gradient rows (src_scale) or, with weights, applied to
+// the gradient first — exactly SpmmFunction's schedule.  No gradient w.r.t. w here.
+struct SpmmAG : public torch::autograd::Function<SpmmAG> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const OptTensor& w,
+                        const Tensor& rowptr, const Tensor& col, const OptTensor& eid,
+                        const OptTensor& hub_rows, const OptTensor& hub_cptr, int64_t n_hub,
+                        int64_t n_chunks, const Tensor& rowptr_t, const Tensor& col_t,
+                        const OptTensor& eid_t, const OptTensor& hub_rows_t,
+                        const OptTensor& hub_cptr_t, int64_t n_hub_t, int64_t n_chunks_t,
+                        const OptTensor& inv_deg, int64_t reduce, int64_t hub_threshold,
+                        int64_t hub_chunk) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    TORCH_CHECK(reduce == PYGAMD_SUM || reduce == PYGAMD_MEAN, "spmm_ag: sum / mean only");
+    const Tensor x2 = x.reshape({x.size(0), -1});
+    const int64_t n_rows = rowptr.numel() - 1;
+    Tensor out = at::empty({n_rows, x2.size(1)}, x2.options());
+    spmm_csr(rowptr, col, x2, reduce, n_rows, eid, w, c10::nullopt, hub_rows, hub_cptr, n_hub,
+             n_chunks, hub_threshold, hub_chunk, out, false, 0, c10::nullopt, c10::nullopt,
+             c10::nullopt);
+    ctx->save_for_backward({rowptr_t, col_t, has(eid_t) ? *eid_t : Tensor(),
+                            has(hub_rows_t) ? *hub_rows_t : Tensor(),
+                            has(hub_cptr_t) ? *hub_cptr_t : Tensor(),
+                            has(w) ? *w : Tensor(), has(inv_deg) ? *inv_deg : Tensor()});
+    ctx->saved_data["n_hub_t"] = n_hub_t;
+    ctx->saved_data["n_chunks_t"] = n_chunks_t;
+    ctx->saved_data["reduce"] = reduce;
+    ctx->saved_data["hub_threshold"] = hub_threshold;
+    ctx->saved_data["hub_chunk"] = hub_chunk;
+    ctx->saved_data["x_shape"] = x.sizes().vec();
+    std::vector<int64_t> shape = x.sizes().vec();
+    shape[0] = n_rows;
+    return out.view(shape);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    variable_list res(20);
+    if (!ctx->needs_input_grad(0)) return res;
+    const auto sv = ctx->get_saved_variables();
+    const Tensor &rowptr_t = sv[0], &col_t = sv[1];
+    auto opt = [](const Tensor& t) { return t.defined() ? OptTensor(t) : c10::nullopt; };
+    const int64_t reduce = ctx->saved_data["reduce"].toInt();
+    Tensor g2 = grads[0].reshape({grads[0].size(0), -1});
+    OptTensor scale = c10::nullopt;
+    if (reduce == PYGAMD_MEAN && sv[6].defined()) {
+      if (sv[5].defined()) {
+        g2 = g2 * sv[6].view({-1, 1});   // (weights AND mean: the rare form, one ATen pass)
+      } else {
+        scale = sv[6];
+      }
+    }
+    const int64_t n_src = rowptr_t.numel() - 1;
+    Tensor gx = at::empty({n_src, g2.size(1)}, g2.options());
+    spmm_csr(rowptr_t, col_t, g2, PYGAMD_SUM, n_src, opt(sv[2]), opt(sv[5]), scale, opt(sv[3]),
+             opt(sv[4]), ctx->saved_data["n_hub_t"].toInt(), ctx->saved_data["n_chunks_t"].toInt(),
+             ctx->saved_data["hub_threshold"].toInt(), ctx->saved_data["hub_chunk"].toInt(), gx,
+             false, 0, c10::nullopt, c10::nullopt, c10::nullopt);
+    res[0] = gx.view(ctx->saved_data["x_shape"].toIntVector());
+    return res;
+  }
+};
+
+Tensor spmm_ag(const Tensor& x, const OptTensor& w, const Tensor& rowptr, const Tensor& col,
+               const OptTensor& eid, const OptTensor& hub_rows, const OptTensor& hub_cptr,
+               int64_t n_hub, int64_t n_chunks, const Tensor& rowptr_t, const Tensor& col_t,
+               const OptTensor& eid_t, const OptTensor& hub_rows_t, const OptTensor& hub_cptr_t,
+               int64_t n_hub_t, int64_t n_chunks_t, const OptTensor& inv_deg, int64_t reduce,
+               int64_t hub_threshold, int64_t hub_chunk) {
+  return SpmmAG::apply(x, w, rowptr, col, eid, hub_rows, hub_cptr, n_hub, n_chunks, rowptr_t,
+                       col_t, eid_t, hub_rows_t, hub_cptr_t, n_hub_t, n_chunks_t, inv_deg, reduce,
+                       hub_threshold, hub_chunk);
+}
+
 }  // namespace
 
 TORCH_LIBRARY(pyg_amd_c, m) {
@@ -458,6 +639,14 @@ TORCH_LIBRARY(pyg_amd_c, m) {
       "int n_edges, int w_heads) -> Tensor");
   m.def("segment_softmax_forward(Tensor src, Tensor ptr) -> Tensor");
   m.def("segment_softmax_backward(Tensor out, Tensor grad_out, Tensor ptr) -> Tensor");
+  // autograd nodes in C++ (forward and backward without re-entering Python)
+  m.def("linear_ag(Tensor x, Tensor weight, Tensor? bias) -> Tensor");
+  m.def("bias_act_ag(Tensor x, Tensor? bias, bool relu) -> Tensor");
+  m.def(
+      "spmm_ag(Tensor x, Tensor? w, Tensor rowptr, Tensor col, Tensor? eid, Tensor? hub_rows, "
+      "Tensor? hub_cptr, int n_hub, int n_chunks, Tensor rowptr_t, Tensor col_t, Tensor? eid_t, "
+      "Tensor? hub_rows_t, Tensor? hub_cptr_t, int n_hub_t, int n_chunks_t, Tensor? inv_deg, "
+      "int reduce, int hub_threshold, int hub_chunk) -> Tensor");
 }
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch
@@ -474,4 +663,57 @@ TORCH_LIBRARY_IMPL(pyg_amd_c, CUDA, m) {
   m.impl("sddmm_csr", &sddmm_csr);
   m.impl("segment_softmax_forward", &segment_softmax_forward);
   m.impl("segment_softmax_backward", &segment_softmax_backward);
+}
+
+// the same three operators below the autograd key (inference_mode, calls from inside another
+// node's backward): forward only
+namespace {
+Tensor linear_plain(const Tensor& x, const Tensor& weight, const OptTensor& bias) {
+  const Tensor x2 = rows2d(x);
+  Tensor out = at::empty({x2.size(0), weight.size(0)}, x2.options());
+  linear_forward(x2, weight, bias, false, out, false);
+  std::vector<int64_t> shape = x.sizes().vec();
+  shape.back() = weight.size(0);
+  return out.view(shape);
+}
+Tensor bias_act_plain(const Tensor& x, const OptTensor& bias, bool relu) {
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());
+  const Tensor x2 = rows_f32(rows2d(x), "x");
+  const Tensor b = contig(bias);
+  TORCH_CHECK(!b.defined() || (b.scalar_type() == at::kFloat && b.numel() == x2.size(1)),
+              "'bias' must be float32 with ", x2.size(1), " entries");
+  Tensor out = at::empty({x2.size(0), x2.size(1)}, x2.options());
+  check(pygamd_bias_act(fptr(x2), ld(x2), fptr(b), x2.size(0), x2.size(1), relu ? 1 : 0,
+                        static_cast<float*>(ptr(out)), ld(out), cur_stream(x2)), "bias_act");
+  return out.view(x.sizes());
+}
+Tensor spmm_plain(const Tensor& x, const OptTensor& w, const Tensor& rowptr, const Tensor& col,
+                  const OptTensor& eid, const OptTensor& hub_rows, const OptTensor& hub_cptr,
+                  int64_t n_hub, int64_t n_chunks, const Tensor&, const Tensor&, const OptTensor&,
+                  const OptTensor&, const OptTensor&, int64_t, int64_t, const OptTensor&,
+                  int64_t reduce, int64_t hub_threshold, int64_t hub_chunk) {
+  TORCH_CHECK(reduce == PYGAMD_SUM || reduce == PYGAMD_MEAN, "spmm_ag: sum / mean only");
+  const Tensor x2 = x.reshape({x.size(0), -1});
+  const int64_t n_rows = rowptr.numel() - 1;
+  Tensor out = at::empty({n_rows, x2.size(1)}, x2.options());
+  spmm_csr(rowptr, col, x2, reduce, n_rows, eid, w, c10::nullopt, hub_rows, hub_cptr, n_hub,
+           n_chunks, hub_threshold, hub_chunk, out, false, 0, c10::nullopt, c10::nullopt,
+           c10::nullopt);
+  std::vector<int64_t> shape = x.sizes().vec();
+  shape[0] = n_rows;
+  return out.view(shape);
+}
+}  // namespace
+
+TORCH_LIBRARY_IMPL(pyg_amd_c, CUDA, m) {
+  m.impl("linear_ag", &linear_plain);
+  m.impl("bias_act_ag", &bias_act_plain);
+  m.impl("spmm_ag", &spmm_plain);
+}
+
+// the autograd key: these operators build their own graph nodes (torch::autograd::Function)
+TORCH_LIBRARY_IMPL(pyg_amd_c, AutogradCUDA, m) {
+  m.impl("linear_ag", &linear_ag);
+  m.impl("bias_act_ag", &bias_act_ag);
+  m.impl("spmm_ag", &spmm_ag);
 }

@@ -4,7 +4,7 @@ import torch
 from torch import Tensor
 from torch.nn import Parameter
 
-from ..._functions import SpmmFunction, bias_act
+from ..._functions import SpmmFunction, spmm_node, bias_act
 from ...edge_index import EdgeIndex
 from ...utils import add_remaining_self_loops, scatter
 from ...utils.num_nodes import maybe_num_nodes
@@ -115,4 +115,4 @@ class GCNConv(MessagePassing):
 
     def message_and_aggregate(self, graph: EdgeIndex, x: Tensor,
                               edge_weight: Optional[Tensor]) -> Tensor:
-        return SpmmFunction.apply(x, edge_weight, graph, 'sum', 'coo')
+        return spmm_node(x, edge_weight, graph, 'sum', 'coo')

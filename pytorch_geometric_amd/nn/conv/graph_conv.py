@@ -2,7 +2,7 @@ from typing import Optional, Tuple, Union
 
 from torch import Tensor
 
-from ..._functions import SpmmFunction
+from ..._functions import SpmmFunction, spmm_node
 from ...edge_index import EdgeIndex
 from ..dense.linear import Linear
 from .message_passing import MessagePassing
@@ -47,4 +47,4 @@ class GraphConv(MessagePassing):
 
     def message_and_aggregate(self, graph: EdgeIndex, x, edge_weight) -> Tensor:
         reduce = {'add': 'sum'}.get(self.aggr, self.aggr)
-        return SpmmFunction.apply(x[0], edge_weight, graph, reduce, 'coo')
+        return spmm_node(x[0], edge_weight, graph, reduce, 'coo')

@@ -3,7 +3,7 @@ from typing import Optional, Tuple, Union
 import torch.nn.functional as F
 from torch import Tensor
 
-from ..._functions import SpmmFunction
+from ..._functions import SpmmFunction, spmm_node
 from ...edge_index import EdgeIndex
 from ..dense.linear import Linear
 from .message_passing import MessagePassing
@@ -62,7 +62,7 @@ class SAGEConv(MessagePassing):
 
     def message_and_aggregate(self, graph: EdgeIndex, x) -> Tensor:
         reduce = {'add': 'sum'}.get(self.aggr, self.aggr)
-        return SpmmFunction.apply(x[0], None, graph, reduce, 'coo')
+        return spmm_node(x[0], None, graph, reduce, 'coo')
 
     def __repr__(self) -> str:
         return (f'{type(self).__name__}({self.in_channels}, {self.out_channels}, '

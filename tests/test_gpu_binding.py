@@ -135,3 +135,89 @@ def test_typed_errors_survive_the_compiled_route(dev):
         _native.spmm_csr(fwd.ptr, fwd.idx, torch.randn(50, 8), 'sum')
     with pytest.raises(ValueError, match="columns but 'weight' expects"):
         _native.linear_forward(torch.randn(50, 8, device=dev), torch.randn(4, 9, device=dev))
+
+
+def test_cpp_autograd_nodes_match_the_python_ones(dev, monkeypatch):
+    """`torch.ops.pyg_amd_c.{linear_ag, spmm_ag, bias_act_ag}` (torch::autograd::Function s in
+    csrc/torch_binding.cpp: forward and backward without re-entering Python) against the Python
+    Functions they mirror: same kernels in the same order, so values and gradients are BITWISE
+    equal; through a whole 2-layer GCN (the launch-bound config 1) and a SAGEConv layer; routed
+    only for plain float32 operands without a gradient w.r.t. the edge weights; usable under
+    inference_mode."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd import _compiled, _functions
+    from pytorch_geometric_amd.nn import GCN, SAGEConv
+    if _compiled.ops() is None:
+        pytest.skip('compiled binding not available')
+    g = gen(3)
+    n, e = 1500, 9000
+    ei = torch.randint(0, n, (2, e), generator=g).to(dev)
+    x = torch.randn(n, 40, generator=g).to(dev)
+    go = torch.randn(n, 6, generator=g).to(dev)
+    torch.manual_seed(0)
+    model = GCN(40, 24, num_layers=2, out_channels=6, cached=True).to(dev)
+    for conv in model.convs:
+        torch.nn.init.normal_(conv.bias, std=0.3)
+    _functions.OWN_GEMM_MIN_ROWS, keep_rows = 1, _functions.OWN_GEMM_MIN_ROWS
+
+    def run(flag):
+        monkeypatch.setattr(_functions, 'CPP_AUTOGRAD', flag)
+        model.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        out = model(xg, ei)
+        out.backward(go)
+        return out.detach(), xg.grad, [p.grad.clone() for p in model.parameters()]
+
+    try:
+        used = []
+        C = _compiled.ops()
+        real = C.spmm_ag
+        py = run(False)
+        cpp = run(True)
+        assert torch.equal(py[0], cpp[0]) and torch.equal(py[1], cpp[1])
+        for a, b in zip(py[2], cpp[2]):
+            # (weights bitwise; the bias gradients are column sums that meet in fp32 atomics:
+            # equal up to the order of those adds)
+            assert torch.equal(a, b) if a.dim() > 1 else bool(
+                ((a - b).abs() <= 1e-5 * a.abs().max().clamp(min=1)).all())
+        # the C++ nodes are in the graph: the output's grad_fn is not a Python Function
+        monkeypatch.setattr(_functions, 'CPP_AUTOGRAD', True)
+        out = model(x.clone().requires_grad_(True), ei)
+        names = set()
+        stack = [out.grad_fn]
+        while stack:
+            f = stack.pop()
+            if f is None:
+                continue
+            names.add(f.name())
+            stack += [nf for nf, _ in f.next_functions]
+        for node in ('LinearAG', 'SpmmAG', 'BiasActAG'):
+            assert any(f'::{node}>' in nm for nm in names), (node, names)
+        assert not any(nm.endswith('FunctionBackward') for nm in names), names
+        # SAGEConv (mean aggregation: 1/deg folded into the transposed launch)
+        torch.manual_seed(1)
+        conv = SAGEConv(40, 16).to(dev)
+        res = []
+        for flag in (False, True):
+            monkeypatch.setattr(_functions, 'CPP_AUTOGRAD', flag)
+            conv.zero_grad()
+            xg = x.clone().requires_grad_(True)
+            o = conv(xg, ei)
+            o.backward(torch.ones_like(o))
+            res.append((o.detach(), xg.grad, [p.grad.clone() for p in conv.parameters()]))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        for a, b in zip(res[0][2], res[1][2]):
+            assert torch.equal(a, b) if a.dim() > 1 else bool(
+                ((a - b).abs() <= 1e-5 * a.abs().max().clamp(min=1)).all())
+        # weights that need a gradient stay on the Python node (it owns the SDDMM)
+        h = pga.EdgeIndex(ei, (n, n))
+        w = torch.rand(e, generator=g).to(dev).requires_grad_(True)
+        o = _functions.spmm_node(x, w, h, 'sum', 'coo')
+        assert o.grad_fn.name() == 'SpmmFunctionBackward'
+        o.sum().backward()
+        assert w.grad is not None
+        with torch.inference_mode():
+            o = model(x, ei)
+        assert_close(o, py[0], rtol=0, atol=0, what='inference_mode')
+    finally:
+        _functions.OWN_GEMM_MIN_ROWS = keep_rows
