@@ -151,22 +151,58 @@ def live_pmc_traffic(args):
             for k in sums['FETCH_SIZE'] if k in sums['WRITE_SIZE']}
 
 
-def measured_copy_bandwidth(dev, n_bytes: int = 1 << 30, reps: int = 5) -> float:
-    """GB/s (read + written bytes) of a device-to-device copy of `n_bytes` on this box, timed with
+def measured_copy_bandwidth(dev, n_bytes: int = 1 << 30, reps: int = 5) -> dict:
+    """GB/s (read + written bytes) of device-to-device copies of `n_bytes` on this box, timed with
     HIP events: SURVEY.md 8(d)'s secondary denominator for the HBM-bound kernels (the guide's
-    figure for this chip: 6.29 TB/s for a float4 copy against the 8 TB/s spec).  A measurement
-    probe, not part of the timed step."""
+    figure for this chip: 6.29 TB/s for a float4 copy against the 8 TB/s spec).  Two copies:
+    torch's `copy_` and the best schedule of the library's own streaming probe
+    (pygamd_lab_copy: 4 / 8 loads in flight, plain / non-temporal, 4 / 8 / 16 workgroups per CU).
+    Measurement probes, not part of the timed step."""
+    from pytorch_geometric_amd import _lib
     src = torch.empty(n_bytes // 4, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
-    dst.copy_(src)
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return 2.0 * n_bytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def rate(fn):
+        fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return 2.0 * n_bytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    def probe(variant, per_cu):
+        rc = _lib.load().pygamd_lab_copy(src.data_ptr(), dst.data_ptr(), n_bytes, variant, per_cu,
+                                        stream)
+        if rc:
+            raise RuntimeError(f'pygamd_lab_copy: {rc}')
+
+    out = {'torch_copy': rate(lambda: dst.copy_(src))}
+    best = None
+    for variant in range(4):
+        for per_cu in (4, 8, 16):
+            r = rate(lambda: probe(variant, per_cu))
+            if best is None or r > best[0]:
+                best = (r, variant, per_cu)
+    if not torch.equal(src, dst):
+        raise RuntimeError('pygamd_lab_copy: copy differs from its source')
+    read = None  # the read half alone (the dominant kernel reads 14 bytes for every byte it writes)
+    for variant in range(4, 8):
+        for per_cu in (4, 8, 16):
+            r = rate(lambda: probe(variant, per_cu)) / 2.0
+            if read is None or r > read[0]:
+                read = (r, variant, per_cu)
+    out['read'] = read[0]
+    out['read_schedule'] = {'non_temporal': bool(read[1] & 1),
+                            'loads_in_flight': 8 if read[1] & 2 else 4,
+                            'workgroups_per_cu': read[2]}
+    out['probe'] = best[0]
+    out['probe_schedule'] = {'non_temporal': bool(best[1] & 1), 'loads_in_flight': 8 if best[1] & 2 else 4,
+                             'workgroups_per_cu': best[2]}
+    return out
 
 
 def fused_algorithmic_bytes(info) -> float:
@@ -1099,10 +1135,16 @@ def main():
             if _live_traffic is not None else
             'committed profile (profiles/r05_pmc_bench.json, same command and workload)')
     if dom:  # the same launch against what a plain device copy reaches on THIS box
-        copy_gbs = measured_copy_bandwidth(dev)
+        cp = measured_copy_bandwidth(dev)
+        copy_gbs = max(cp['torch_copy'], cp['probe'])
         roofline['copy_bandwidth'] = {
             'measured': round(copy_gbs, 1), 'unit': 'GB/s',
-            'what': 'device-to-device copy of 1 GiB (read + written bytes), HIP events, this run',
+            'what': 'fastest device-to-device copy of 1 GiB on this box (read + written bytes), '
+                    'HIP events, this run',
+            'torch_copy': round(cp['torch_copy'], 1), 'lab_copy': round(cp['probe'], 1),
+            'lab_schedule': cp['probe_schedule'],
+            'lab_read_only': round(cp['read'], 1), 'lab_read_schedule': cp['read_schedule'],
+            'frac_of_read': round(roofline['achieved'] / cp['read'], 4),
             'frac_of_copy': round(roofline['achieved'] / copy_gbs, 4)}
     roofline['share_of_step'] = round(tot_ms.get(dom, 0.0) / (elapsed * 1e3), 4) if dom else None
     roofline['others'] = {k: round(tot_ms[k] / args.steps, 3) for k in sorted(tot_ms) if k != dom}

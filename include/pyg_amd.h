@@ -398,10 +398,10 @@ PYGAMD_API int pygamd_relu_backward_colsum(const float* grad, int64_t ldg, const
 PYGAMD_API int pygamd_segment_matmul_tile_rows(void);
 /* `n_groups` = number of weight matrices (segments * blocks).  `workspace` (device, 16-byte
  * aligned, pygamd_segment_matmul_workspace_bytes(n_groups, K, N); may be NULL): with it, in
- * PYGAMD_GEMM_SPLIT_BF16 mode, for dense weights (w_stride_n == 1, w_stride_k == N,
- * w_seg_stride == K * N) with K <= 128, K % 4 == 0 and 16-byte-aligned rows of x, the product
- * runs on the convert-once split kernel (csrc/segmm.hip: the weights' bf16 term planes are
- * written there by a pre-pass, every call); otherwise on the exact fp32 kernel (ABI 9).        */
+ * PYGAMD_GEMM_SPLIT_BF16 mode, for K <= 128, K % 4 == 0 and 16-byte-aligned rows of x (weights
+ * in any strides: W^T is read where it lies), the product runs on the convert-once split kernel
+ * (csrc/segmm.hip: the weights' bf16 term planes are written there by a pre-pass, every call);
+ * otherwise on the exact fp32 kernel (ABI 9).                                                  */
 PYGAMD_API int pygamd_segment_matmul_workspace_bytes(int64_t n_groups, int64_t K, int64_t N,
                                                      size_t* bytes /*[host]*/);
 /* `x_rows` / `g_rows` (device int64, or NULL): operand row r is x[x_rows[r]] (g[g_rows[r]]) — the

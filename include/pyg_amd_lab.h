@@ -40,6 +40,16 @@ PYGAMD_API int pygamd_lab_sage_layer_fused(const pygamd_spmm_args* graph,
  *              emits unforced; same results).                                                  */
 PYGAMD_API int pygamd_lab_set_wgrad_variant(int variant);
 
+/* Streaming device-to-device copy of n_bytes (a multiple of 16, both pointers 16-byte aligned):
+ * the measured HBM copy rate bench.py reports next to the 8 TB/s specification (SURVEY 8(d)'s
+ * secondary denominator).  variant bit 0 = non-temporal loads and stores, bit 1 = eight instead
+ * of four 16-byte loads in flight per lane, bit 2 = the read half alone (the loads are summed per
+ * lane and nothing is written for finite data: n_bytes of traffic instead of 2 n_bytes; dst needs
+ * 4 KiB); blocks_per_cu workgroups of 256 lanes per compute unit walk the buffers grid-stride.
+ * A measurement probe, never on the product path.                                              */
+PYGAMD_API int pygamd_lab_copy(const void* src, void* dst, int64_t n_bytes, int variant,
+                               int blocks_per_cu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,6 +191,7 @@ LAB_SIGNATURES = {
     'pygamd_lab_sage_layer_fused': (c_int, [POINTER(SpmmArgs), POINTER(SageFusedArgs), c_int,
                                             c_int, _P, c_size_t, _P]),
     'pygamd_lab_set_wgrad_variant': (c_int, [c_int]),
+    'pygamd_lab_copy': (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
 }
 
 _lib = None

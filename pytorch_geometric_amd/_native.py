@@ -1477,24 +1477,26 @@ def segment_matmul(x: Tensor, w: Tensor, plan, transpose_w: bool = False,
     lib = _lib.load()
     tiles, n_tiles = plan[0], plan[1]
     x2 = _f32_rows(x, 'x')
-    if transpose_w:
-        # materialise W^T once (tiny next to the activations): the kernel then streams weight
-        # rows with coalesced 128-byte loads instead of gathering a column per lane
-        w = w.transpose(1, 2)
     w = w.contiguous()
-    G, Kw, Nw = w.shape
-    K, N, sk, sn = Kw, Nw, Nw, 1
+    if transpose_w:
+        w = w.transpose(1, 2)
+    G, K, N = w.shape
+    # the bf16 term planes of the weights (split arithmetic, K <= 128: csrc/segmm.hip)
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_segment_matmul_workspace_bytes(G, K, N, ctypes.byref(nbytes)))
+    split = nbytes.value > 0 and get_gemm_mode() == 'split'
+    if transpose_w and not split:
+        # the general kernel streams weight rows with coalesced 128-byte loads: materialise W^T
+        # (the split kernel's pre-pass reads the transposed view where it lies)
+        w = w.contiguous()
+    seg_stride, sk, sn = w.stride()
     if x2.size(1) != blocks * K:
         raise ValueError(f"'inputs' has {x2.size(1)} columns but the weights expect "
                          f"{blocks * K}")
     n_out = x2.size(0) if x_rows is None else x_rows.numel()
     out = torch.empty(n_out, blocks * N, dtype=torch.float32, device=x.device)
-    # the bf16 term planes of the weights (split arithmetic, K <= 128: csrc/segmm.hip)
-    nbytes = ctypes.c_size_t(0)
-    check(lib.pygamd_segment_matmul_workspace_bytes(G, K, N, ctypes.byref(nbytes)))
-    ws = (torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
-          if nbytes.value > 0 and get_gemm_mode() == 'split' else None)
-    check(lib.pygamd_segment_matmul(_p(x2), _ld(x2), _p(x_rows), _p(w), Kw * Nw, sk, sn, G,
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device) if split else None
+    check(lib.pygamd_segment_matmul(_p(x2), _ld(x2), _p(x_rows), _p(w), seg_stride, sk, sn, G,
                                     _p(tiles),
                                     n_tiles, K, N, blocks, _p(out), _ld(out), _p(ws),
                                     0 if ws is None else nbytes.value, _stream(x)),

@@ -601,9 +601,86 @@ static int launch_lab(const SageFusedArgs<IdxT>& a, bool streamed, hipStream_t s
   return PYGAMD_OK;
 }
 
+// Streaming copy probe (pygamd_lab_copy): every lane moves 16 bytes per step, `unroll` loads in
+// flight before the first store, grid-stride so a fixed number of workgroups per CU covers any size.
+typedef float lab_f4 __attribute__((ext_vector_type(4)));
+
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void lab_copy_kernel(const lab_f4* __restrict__ src,
+                                                       lab_f4* __restrict__ dst, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    lab_f4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+      else dst[i + u * stride] = v[u];
+    }
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// the read half alone: the same loads summed per lane; the store never happens for finite data
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void lab_read_kernel(const lab_f4* __restrict__ src,
+                                                       lab_f4* __restrict__ dst, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  lab_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    lab_f4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc += v[u];
+  }
+  for (; i < n; i += stride) acc += src[i];
+  if (acc.x + acc.y + acc.z + acc.w == __builtin_inff()) dst[threadIdx.x] = acc;
+}
+
 }  // namespace pygamd
 
 using namespace pygamd;
+
+extern "C" int pygamd_lab_copy(const void* src, void* dst, int64_t n_bytes, int variant,
+                               int blocks_per_cu, void* stream) {
+  if (n_bytes < 0 || (n_bytes & 15) || blocks_per_cu < 1) return PYGAMD_ERR_INVALID_ARG;
+  if ((n_bytes && (!src || !dst)) || variant < 0 || variant > 7) return PYGAMD_ERR_INVALID_ARG;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0)
+    return PYGAMD_ERR_INVALID_ARG;
+  if (n_bytes == 0) return PYGAMD_OK;
+  hipStream_t st = as_stream(stream);
+  int dev = 0, cus = 256;
+  PYGAMD_HIP_CHECK(hipGetDevice(&dev));
+  PYGAMD_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int64_t n = n_bytes / 16;
+  const int64_t want = ceil_div(n, 256);
+  const unsigned grid = static_cast<unsigned>(
+      want < static_cast<int64_t>(cus) * blocks_per_cu ? want
+                                                        : static_cast<int64_t>(cus) * blocks_per_cu);
+  const lab_f4* s = static_cast<const lab_f4*>(src);
+  lab_f4* d = static_cast<lab_f4*>(dst);
+#define PYGAMD_LAB_COPY(K, U, NT) \
+  hipLaunchKernelGGL((K<U, NT>), dim3(grid), dim3(256), 0, st, s, d, n)
+  switch (variant) {
+    case 0: PYGAMD_LAB_COPY(lab_copy_kernel, 4, false); break;
+    case 1: PYGAMD_LAB_COPY(lab_copy_kernel, 4, true); break;
+    case 2: PYGAMD_LAB_COPY(lab_copy_kernel, 8, false); break;
+    case 3: PYGAMD_LAB_COPY(lab_copy_kernel, 8, true); break;
+    case 4: PYGAMD_LAB_COPY(lab_read_kernel, 4, false); break;
+    case 5: PYGAMD_LAB_COPY(lab_read_kernel, 4, true); break;
+    case 6: PYGAMD_LAB_COPY(lab_read_kernel, 8, false); break;
+    default: PYGAMD_LAB_COPY(lab_read_kernel, 8, true); break;
+  }
+#undef PYGAMD_LAB_COPY
+  PYGAMD_LAUNCH_CHECK();
+  return PYGAMD_OK;
+}
 
 extern "C" int pygamd_lab_sage_layer_fused(const pygamd_spmm_args* graph,
                                            const pygamd_sage_fused_args* f, int variant,

@@ -313,9 +313,14 @@ __device__ __forceinline__ SegFrag seg_split8(const f32x4& v0, const f32x4& v1) 
   return f;
 }
 
-// planes[((g * 3 + term) * KG + kg) * N + n] (16 bytes) = bf16 term `term` of W[g][8 kg .. + 7][n]
+// planes[((g * 3 + term) * KG + kg) * N + n] (16 bytes) = bf16 term `term` of W[g][8 kg .. + 7][n],
+// W[g][k][n] at w[g * seg_stride + k * sk + n * sn]: a transposed view (sk == 1, the input
+// gradient's W^T) is read where it lies — neighbouring lanes then read 32-byte pieces of rows whose
+// other pieces the kg-neighbours (N lanes further) read, so every line is fetched once — instead of
+// being copied into a [G, N, K] tensor first (0.10 ms per layer at the FB15k-237 shape).
 __global__ void __launch_bounds__(kBlock)
-    segmm_split_weights_kernel(const float* __restrict__ w, int K, int N, int KG, int64_t total,
+    segmm_split_weights_kernel(const float* __restrict__ w, int64_t seg_stride, int64_t sk,
+                               int64_t sn, int K, int N, int KG, int64_t total,
                                u32x4* __restrict__ planes) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;   // (g, kg, n)
   if (i >= total) return;
@@ -323,10 +328,17 @@ __global__ void __launch_bounds__(kBlock)
   const int64_t gk = i / N;
   const int kg = static_cast<int>(gk % KG);
   const int64_t g = gk / KG;
-  const float* __restrict__ wc = w + (g * K + 8 * kg) * N + n;
+  const float* __restrict__ wc = w + g * seg_stride + 8 * kg * sk + n * sn;
   float v[8];
+  if (sk == 1 && 8 * kg + 8 <= K && ((reinterpret_cast<uintptr_t>(wc) & 15u) == 0)) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(wc);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(wc + 4);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = 8 * kg + e < K ? wc[static_cast<int64_t>(e) * N] : 0.f;
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 8 * kg + e < K ? wc[static_cast<int64_t>(e) * sk] : 0.f;
+  }
   u32x4 pw[3];
 #pragma unroll
   for (int p4 = 0; p4 < 4; ++p4) {
@@ -703,12 +715,11 @@ extern "C" {
 
 int pygamd_segment_matmul_tile_rows(void) { return kTM; }
 
-static bool segmm_split_ok(const float* x, int64_t ldx, int64_t w_seg_stride, int64_t w_stride_k,
-                           int64_t w_stride_n, int64_t K, int64_t N) {
-  // 16-byte rows (K % 4, ldx % 4, aligned base) and dense weights [G, K, N] with K <= 128
+static bool segmm_split_ok(const float* x, int64_t ldx, int64_t K, int64_t N) {
+  // 16-byte rows (K % 4, ldx % 4, aligned base) and K <= 128; the weights in any strides (the
+  // pre-pass reads them once)
   return pygamd_get_gemm_mode() == PYGAMD_GEMM_SPLIT_BF16 && K >= 4 && K <= kSK && K % 4 == 0 &&
-         N >= 1 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 &&
-         w_stride_n == 1 && w_stride_k == N && w_seg_stride == K * N;
+         N >= 1 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
 }
 
 int pygamd_segment_matmul_workspace_bytes(int64_t n_groups, int64_t K, int64_t N, size_t* bytes) {
@@ -738,13 +749,14 @@ int pygamd_segment_matmul(const float* x, int64_t ldx, const int64_t* x_rows, co
   // fp32 kernel (exact products: never less accurate).
   if (workspace && need > 0 && workspace_bytes >= need &&
       (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0 &&
-      segmm_split_ok(x, ldx, w_seg_stride, w_stride_k, w_stride_n, K, N)) {
+      segmm_split_ok(x, ldx, K, N)) {
     u32x4* planes = static_cast<u32x4*>(workspace);
     const int KG = static_cast<int>(ceil_div(K, 8));
     const int64_t total = n_groups * KG * N;
     hipLaunchKernelGGL(segmm_split_weights_kernel,
                        dim3(static_cast<unsigned>(ceil_div(total, kBlock))), dim3(kBlock), 0, st, w,
-                       static_cast<int>(K), static_cast<int>(N), KG, total, planes);
+                       w_seg_stride, w_stride_k, w_stride_n, static_cast<int>(K),
+                       static_cast<int>(N), KG, total, planes);
     PYGAMD_LAUNCH_CHECK();
     const int n_halves = static_cast<int>(ceil_div(N, kSN));
     const int64_t n_items = n_tiles * n_halves;
