@@ -335,22 +335,23 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // 16-byte variant for F % 4 == 0 (the layer widths): a thread owns 4 consecutive columns, a
-// 256-thread block covers 1024 / F rows per pass with full-width coalesced accesses.
-template <bool MASK>
-__global__ void __launch_bounds__(kBlock)
+// BLOCK-thread workgroup covers 4 BLOCK / F rows per pass with full-width coalesced accesses.
+constexpr int kColsumBlock = 1024;
+
+template <bool MASK, int U, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
     colsum_vec4_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ act,
                        int64_t lda, float* __restrict__ y, int64_t ldy, int64_t n_rows, int64_t F,
                        float* __restrict__ out) {
-  __shared__ float part[kBlock][4];
+  __shared__ float part[BLOCK][4];
   const int units = static_cast<int>(F / 4);          // 16-byte pieces per row (<= 256 here)
-  const int groups = kBlock / units;                   // rows per pass
+  const int groups = BLOCK / units;                    // rows per pass
   const int u = threadIdx.x % units;
   const int rg = threadIdx.x / units;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (rg < groups) {
     // four row groups in flight per thread (one 16-byte load per operand at a time left the pass
     // latency-bound: 0.42 ms for a [169 k, 256] block, 2.5 x its traffic time)
-    constexpr int U = 4;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * groups;
     for (int64_t r0 = static_cast<int64_t>(blockIdx.x) * groups + rg; r0 < n_rows;
          r0 += U * stride) {
@@ -481,18 +482,22 @@ static int launch_colsum(const float* x, int64_t ldx, const float* act, int64_t 
   const bool v4 = (F % 4 == 0) && (F / 4 <= kBlock) && (ldx % 4 == 0) && aligned16(x) &&
                   (!act || ((lda % 4 == 0) && (ldy % 4 == 0) && aligned16(act) && aligned16(y)));
   if (v4) {
-    const int groups = kBlock / static_cast<int>(F / 4);
-    // (every block ends in F atomics on the same F addresses: 1024 blocks, not 4096)
+    // Every workgroup ends in F atomics on the same F addresses and the workgroups of a resident
+    // grid finish together: with 1024 workgroups of 256 lanes that burst was half of the launch
+    // ([169 k, 256]: 181 us with the ReLU mask, 128 us without; 118 / 57 us with 256 workgroups).
+    // One workgroup of 1024 lanes per CU keeps the loads in flight and a quarter of the atomics:
+    // 117 / 55 us, and 26 instead of 56 us for a [14.5 k, 500] block.
+    const int groups = kColsumBlock / static_cast<int>(F / 4);
     int64_t blocks = ceil_div(n_rows, static_cast<int64_t>(groups) * 16);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
     const dim3 grid(static_cast<unsigned>(blocks));
     if (act) {
-      hipLaunchKernelGGL(colsum_vec4_kernel<true>, grid, dim3(kBlock), 0, st, x, ldx, act, lda, y,
-                         ldy, n_rows, F, out);
+      hipLaunchKernelGGL((colsum_vec4_kernel<true, 4, kColsumBlock>), grid, dim3(kColsumBlock), 0,
+                         st, x, ldx, act, lda, y, ldy, n_rows, F, out);
     } else {
-      hipLaunchKernelGGL(colsum_vec4_kernel<false>, grid, dim3(kBlock), 0, st, x, ldx, act, lda,
-                         y, ldy, n_rows, F, out);
+      hipLaunchKernelGGL((colsum_vec4_kernel<false, 4, kColsumBlock>), grid, dim3(kColsumBlock), 0,
+                         st, x, ldx, act, lda, y, ldy, n_rows, F, out);
     }
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
@@ -500,7 +505,7 @@ static int launch_colsum(const float* x, int64_t ldx, const float* act, int64_t 
   const int width = static_cast<int>(F < kBlock ? F : kBlock);
   const int groups = kBlock / width;
   int64_t blocks = ceil_div(n_rows, static_cast<int64_t>(groups) * 16);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 256) blocks = 256;  // (the same burst of closing atomics as above)
   if (blocks < 1) blocks = 1;
   const dim3 grid(static_cast<unsigned>(blocks));
   if (act) {

@@ -230,58 +230,85 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // grad_x[n,f] = ga[n,h(f)] att_a[f] + gb[n,h(f)] att_b[f];  grad_att_a[f] = sum_n ga[n,h(f)] x[n,f]
-// Thread t of a 256-thread block owns column f = f0 + t for a strip of rows (coalesced row reads
-// and writes, four rows in flight per thread); the two column sums leave the block through
-// atomics (grad_att_* zeroed by the host wrapper; the strips are long, so few atomics meet).
-__global__ void __launch_bounds__(kBlock)
+// Lane t of a 256-lane group owns column f = f0 + t for a strip of rows (coalesced row reads and
+// writes, four rows in flight per lane); four such groups share a workgroup, their column sums
+// meet in LDS and leave through one set of atomics (grad_att_* zeroed by the host wrapper).
+constexpr int kHdSub = 4;  // row sub-strips per workgroup (kBlock lanes each)
+
+__global__ void __launch_bounds__(kBlock * kHdSub)
     head_dot_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ att_a,
                         const float* __restrict__ att_b, const float* __restrict__ ga,
                         const float* __restrict__ gb, int64_t n_rows, int H, int C,
                         int64_t rows_per_block, float* __restrict__ grad_x, int64_t ldg,
                         int accumulate, float* __restrict__ grad_att_a,
                         float* __restrict__ grad_att_b) {
+  __shared__ float red[2][kHdSub][kBlock];
   const int64_t F = static_cast<int64_t>(H) * C;
-  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
-  int64_t r1 = r0 + rows_per_block;
-  if (r1 > n_rows) r1 = n_rows;
-  for (int64_t f = threadIdx.x; f < F; f += kBlock) {
-    const int h = static_cast<int>(f / C);
-    const float wa = att_a[f];
-    const float wb = att_b ? att_b[f] : 0.f;
+  const int tid = threadIdx.x % kBlock, sub = threadIdx.x / kBlock;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  int64_t b1 = b0 + rows_per_block;
+  if (b1 > n_rows) b1 = n_rows;
+  // the workgroup's strip in kHdSub pieces: as many rows in flight as four small workgroups, one
+  // set of closing atomics (all workgroups of a resident grid finish together: 1024 workgroups x
+  // 2 F atomics on the same addresses were a quarter of the launch)
+  const int64_t piece = (b1 - b0 + kHdSub - 1) / kHdSub;
+  const int64_t r0 = b0 + sub * piece;
+  int64_t r1 = r0 + piece;
+  if (r1 > b1) r1 = b1;
+  for (int64_t fb = 0; fb < F; fb += kBlock) {
+    const int64_t f = fb + tid;
+    const bool live = f < F;
     float sa = 0.f, sb = 0.f;
-    int64_t n = r0;
-    for (; n + 4 <= r1; n += 4) {
-      float xv[4], va[4], vb[4], old[4];
+    if (live) {
+      const int h = static_cast<int>(f / C);
+      const float wa = att_a[f];
+      const float wb = att_b ? att_b[f] : 0.f;
+      int64_t n = r0;
+      for (; n + 4 <= r1; n += 4) {
+        float xv[4], va[4], vb[4], old[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        xv[u] = x[(n + u) * ldx + f];
-        va[u] = ga[(n + u) * H + h];
-        vb[u] = gb ? gb[(n + u) * H + h] : 0.f;
-        // (the values to add to, loaded with the operands: four rows in flight, not a
-        // read-modify-write per row)
-        old[u] = (grad_x && accumulate) ? grad_x[(n + u) * ldg + f] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+          xv[u] = x[(n + u) * ldx + f];
+          va[u] = ga[(n + u) * H + h];
+          vb[u] = gb ? gb[(n + u) * H + h] : 0.f;
+          // (the values to add to, loaded with the operands: four rows in flight, not a
+          // read-modify-write per row)
+          old[u] = (grad_x && accumulate) ? grad_x[(n + u) * ldg + f] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          sa = fmaf(va[u], xv[u], sa);
+          sb = fmaf(vb[u], xv[u], sb);
+          if (grad_x) grad_x[(n + u) * ldg + f] = old[u] + (va[u] * wa + vb[u] * wb);
+        }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        sa = fmaf(va[u], xv[u], sa);
-        sb = fmaf(vb[u], xv[u], sb);
-        if (grad_x) grad_x[(n + u) * ldg + f] = old[u] + (va[u] * wa + vb[u] * wb);
+      for (; n < r1; ++n) {
+        const float xv = x[n * ldx + f];
+        const float va = ga[n * H + h];
+        const float vb = gb ? gb[n * H + h] : 0.f;
+        sa = fmaf(va, xv, sa);
+        sb = fmaf(vb, xv, sb);
+        if (grad_x) {
+          float* gp = grad_x + n * ldg + f;
+          const float v = va * wa + vb * wb;
+          *gp = accumulate ? *gp + v : v;
+        }
       }
     }
-    for (; n < r1; ++n) {
-      const float xv = x[n * ldx + f];
-      const float va = ga[n * H + h];
-      const float vb = gb ? gb[n * H + h] : 0.f;
-      sa = fmaf(va, xv, sa);
-      sb = fmaf(vb, xv, sb);
-      if (grad_x) {
-        float* gp = grad_x + n * ldg + f;
-        const float v = va * wa + vb * wb;
-        *gp = accumulate ? *gp + v : v;
+    red[0][sub][tid] = sa;
+    red[1][sub][tid] = sb;
+    __syncthreads();
+    if (sub == 0 && live) {
+      float ta = 0.f, tb = 0.f;
+#pragma unroll
+      for (int q = 0; q < kHdSub; ++q) {
+        ta += red[0][q][tid];
+        tb += red[1][q][tid];
       }
+      atomicAdd(grad_att_a + f, ta);
+      if (grad_att_b) atomicAdd(grad_att_b + f, tb);
     }
-    atomicAdd(grad_att_a + f, sa);
-    if (grad_att_b) atomicAdd(grad_att_b + f, sb);
+    __syncthreads();
   }
 }
 
@@ -503,10 +530,11 @@ int pygamd_head_dot_backward(const float* x, int64_t ldx, const float* att_a, co
   if (n_rows == 0) return PYGAMD_OK;
   if (!x || !grad_a || (grad_x && ldg < H * C)) return PYGAMD_ERR_INVALID_ARG;
   int64_t blocks = ceil_div(n_rows, 64);
-  if (blocks > 1024) blocks = 1024;   // 4 per CU: long strips keep the atomics on grad_att rare
+  if (blocks > 256) blocks = 256;   // one 1024-lane workgroup per CU: few closing atomics
   const int64_t rows_per_block = ceil_div(n_rows, blocks);
   blocks = ceil_div(n_rows, rows_per_block);
-  hipLaunchKernelGGL(head_dot_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(head_dot_bwd_kernel, dim3(static_cast<unsigned>(blocks)),
+                     dim3(kBlock * kHdSub), 0,
                      st, x, ldx, att_a, att_b, grad_a, grad_b, n_rows, static_cast<int>(H),
                      static_cast<int>(C), rows_per_block, grad_x, ldg, accumulate ? 1 : 0,
                      grad_att_a, grad_att_b);
