@@ -1134,8 +1134,13 @@ def main():
             '(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch'
             if _live_traffic is not None else
             'committed profile (profiles/r05_pmc_bench.json, same command and workload)')
-    if dom:  # the same launch against what a plain device copy reaches on THIS box
-        cp = measured_copy_bandwidth(dev)
+    cp = None
+    if dom and rank == 0:  # the same launch against what plain device copies reach on THIS box
+        try:
+            cp = measured_copy_bandwidth(dev)
+        except RuntimeError as exc:  # (a side figure: never at the price of the bench line)
+            roofline['copy_bandwidth'] = {'error': str(exc)[:200]}
+    if cp is not None:
         copy_gbs = max(cp['torch_copy'], cp['probe'])
         roofline['copy_bandwidth'] = {
             'measured': round(copy_gbs, 1), 'unit': 'GB/s',
