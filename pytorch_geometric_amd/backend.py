@@ -24,7 +24,10 @@ modules.  ``install()`` therefore
    the same input tensors (no values are compared, no host sync);
 6. routes ``torch_geometric.nn.GraphSAGE.forward`` (models/basic_gnn.py:175-270) to the fused
    whole-stack schedule (``nn/models/_fused_sage.py``) when that computes exactly the same thing
-   — plain mean/sum ``SAGEConv`` layers, ReLU, Identity norms, no dropout in effect.
+   — plain mean/sum ``SAGEConv`` layers, ReLU, Identity norms, no dropout in effect — and a
+   single ``SAGEConv.forward`` (nn/conv/sage_conv.py:118-139) of ANY model to the one-kernel layer
+   (aggregation + ``lin_l`` + ``lin_r`` + bias as one kernel and one autograd node) for a square
+   graph given as a plain ``edge_index`` tensor.
 
 Every wrapper STEPS ASIDE to the original reference function for anything that is not a float32
 HIP tensor, under ``torch.compile`` / TorchScript, or when ``backend.use_mi355x`` is False —
@@ -375,6 +378,27 @@ def _wrap_graphsage_forward(cls) -> Callable:
     return forward
 
 
+def _wrap_sageconv_forward(cls) -> Callable:
+    """The reference's ``SAGEConv.forward`` (nn/conv/sage_conv.py:118-139: ``propagate`` ->
+    ``lin_l`` -> ``+ lin_r(x_r)`` -> optional L2 normalisation) as the one-kernel layer when the
+    call is what that kernel computes (square graph, float32 device features, mean / sum, plain
+    tensor ``edge_index``: ``_fused_sage.layer_eligible``); every other call runs the original,
+    whose ``propagate`` is wrapped above."""
+    orig = cls.forward
+
+    def forward(self, x, edge_index, size=None):
+        from .nn.models import _fused_sage
+        if (_enabled() and isinstance(x, torch.Tensor)
+                and _fused_sage.layer_eligible(self, x, edge_index, size)):
+            h = _fused_sage.run_layer(self, x, edge_index)
+            return torch.nn.functional.normalize(h, p=2.0, dim=-1) if self.normalize else h
+        return orig(self, x, edge_index, size)
+
+    forward.__wrapped__ = orig
+    forward.__doc__ = orig.__doc__
+    return forward
+
+
 def _wrap_propagate(cls) -> Callable:
     orig = cls.propagate
 
@@ -499,6 +523,11 @@ def install() -> None:
     prev = GraphSAGE.__dict__.get('forward')
     GraphSAGE.forward = _wrap_graphsage_forward(GraphSAGE)
     _state['forwards'].append((GraphSAGE, had_own, prev))
+    # ... and a single SAGEConv layer of any model
+    had_own = 'forward' in SAGEConv.__dict__
+    prev = SAGEConv.__dict__.get('forward')
+    SAGEConv.forward = _wrap_sageconv_forward(SAGEConv)
+    _state['forwards'].append((SAGEConv, had_own, prev))
 
     # the reference's own dense layer (nn/dense/linear.py:121-127: F.linear) on the fp32-MFMA
     # kernels for float32 device inputs of >= OWN_GEMM_MIN_ROWS rows; everything else unchanged

@@ -17,8 +17,11 @@ class SAGEConv(MessagePassing):
     semantics of ``torch_geometric.nn.SAGEConv`` (torch_geometric/nn/conv/sage_conv.py:68-152),
     so ``state_dict``s interchange.
 
-    The neighbourhood reduction runs at the INPUT width as one CSR SpMM launch
-    (``message_and_aggregate``); the linear maps are library GEMMs.
+    On a square graph with float32 device features the whole layer is ONE kernel and one autograd
+    node (``nn/models/_fused_sage.py:layer_eligible``; ``fuse = False`` on the layer opts out).
+    Otherwise (bipartite pairs, ``project=True``, hooks on ``propagate``, other dtypes) the
+    neighbourhood reduction runs at the INPUT width as one CSR SpMM launch
+    (``message_and_aggregate``) and the linear maps on the repo's GEMM kernels.
     """
 
     def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int,
@@ -49,6 +52,12 @@ class SAGEConv(MessagePassing):
 
     def forward(self, x: PairOrTensor, edge_index,
                 size: Optional[Tuple[int, int]] = None) -> Tensor:
+        if isinstance(x, Tensor):
+            from ..models import _fused_sage
+            if _fused_sage.layer_eligible(self, x, edge_index, size):
+                # aggregation, both linear maps and the bias in one kernel; one autograd node
+                h = _fused_sage.run_layer(self, x, edge_index)
+                return F.normalize(h, p=2.0, dim=-1) if self.normalize else h
         x_src, x_dst = (x, x) if isinstance(x, Tensor) else x
         if self.project:
             x_src = self.lin(x_src).relu()

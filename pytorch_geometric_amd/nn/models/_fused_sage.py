@@ -486,30 +486,78 @@ def eligible(model, x, edge_index, trim: bool) -> bool:
         return False
     aggr = None
     for conv in model.convs:
-        if type(conv).__name__ != 'SAGEConv' or not getattr(conv, 'fuse', True):
+        if conv.normalize or not _conv_ok(conv, x):
             return False
-        if conv.aggr not in ('mean', 'sum', 'add') or not conv.root_weight:
-            return False
-        if conv.normalize or conv.project or conv.flow != 'source_to_target':
-            return False
-        if getattr(conv, 'explain', False) or getattr(conv, 'decomposed_layers', 1) != 1:
-            return False
-        if (getattr(conv, '_propagate_forward_pre_hooks', None)
-                or getattr(conv, '_propagate_forward_hooks', None)
-                or conv._forward_hooks or conv._forward_pre_hooks):
+        if conv._forward_hooks or conv._forward_pre_hooks:
             return False
         if aggr is not None and conv.aggr != aggr:
             return False
         aggr = conv.aggr
-        if not params_ready(conv, x):
-            return False
+    return _graph_ok(edge_index, x.size(0))
+
+
+def _conv_ok(conv, x: Tensor) -> bool:
+    """A plain mean / sum ``SAGEConv`` with a root weight whose ``propagate`` nobody observes."""
+    if type(conv).__name__ != 'SAGEConv' or not getattr(conv, 'fuse', True):
+        return False
+    if conv.aggr not in ('mean', 'sum', 'add') or not conv.root_weight:
+        return False
+    if conv.project or conv.flow != 'source_to_target':
+        return False
+    if getattr(conv, 'explain', False) or getattr(conv, 'decomposed_layers', 1) != 1:
+        return False
+    if (getattr(conv, '_propagate_forward_pre_hooks', None)
+            or getattr(conv, '_propagate_forward_hooks', None)
+            or getattr(conv, '_message_and_aggregate_forward_pre_hooks', None)
+            or getattr(conv, '_message_and_aggregate_forward_hooks', None)
+            or getattr(conv, '_message_forward_pre_hooks', None)
+            or getattr(conv, '_message_forward_hooks', None)
+            or getattr(conv, '_aggregate_forward_pre_hooks', None)
+            or getattr(conv, '_aggregate_forward_hooks', None)):
+        return False
+    return params_ready(conv, x)
+
+
+def _graph_ok(edge_index, n: int) -> bool:
     if isinstance(edge_index, EdgeIndex):
         if edge_index.atomic_backward:  # single-use batch handle: keep the no-sort layer path
             return False
-        return edge_index.sparse_size == (x.size(0), x.size(0))
+        return edge_index.sparse_size == (n, n)
     return (isinstance(edge_index, Tensor) and type(edge_index) is Tensor and edge_index.is_cuda
             and not edge_index.is_sparse and edge_index.dim() == 2 and edge_index.size(0) == 2
             and edge_index.dtype in (torch.int32, torch.int64))
+
+
+# One SAGEConv layer of ANY model (the usual PyG script builds its network from conv layers, not
+# from `GraphSAGE`) as a one-layer stack: aggregation + both linear maps + bias in the one-kernel
+# layer, the backward as the one-launch input gradient + one weight-gradient GEMM over
+# `[agg | x]` — instead of SpMM + two GEMMs + an add forward and their five backward launches.
+# PYGAMD_SAGE_LAYER_NODE=0 (or `conv.fuse = False`) keeps the propagate + Linear path.
+LAYER_NODE = os.environ.get('PYGAMD_SAGE_LAYER_NODE', '1') != '0'
+
+
+def layer_eligible(conv, x, edge_index, size) -> bool:
+    """``conv(x, edge_index)`` is what a one-layer :class:`FusedSageStack` computes (duck-typed:
+    ``backend.install()`` routes the reference's ``SAGEConv.forward`` here as well)."""
+    if not LAYER_NODE or not FUSE_LAYER or GEMM_BACKEND != 'own':
+        return False
+    if not (isinstance(x, Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return False
+    if x.size(0) == 0 or torch.is_autocast_enabled() or torch.compiler.is_compiling():
+        return False
+    if torch.jit.is_scripting() or torch.cuda.is_current_stream_capturing():
+        return False
+    if size is not None and tuple(size) != (x.size(0), x.size(0)):
+        return False
+    return _conv_ok(conv, x) and _graph_ok(edge_index, x.size(0))
+
+
+def run_layer(conv, x: Tensor, edge_index) -> Tensor:
+    from ...edge_index import as_edge_index
+    graph = as_edge_index(edge_index, x.size(0), x.size(0))
+    aggr = 'sum' if conv.aggr == 'add' else conv.aggr
+    return FusedSageStack.apply(x, graph, aggr, True, conv.lin_l.weight, conv.lin_l.bias,
+                                conv.lin_r.weight)
 
 
 def run(model, x: Tensor, edge_index) -> Tensor:

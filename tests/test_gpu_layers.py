@@ -150,6 +150,64 @@ def test_bipartite_and_handle_input(dev):
     assert_close(out, ref2.detach())
 
 
+def test_sage_conv_layer_runs_as_one_kernel_node(dev, monkeypatch):
+    """A model built from SAGEConv layers (not the GraphSAGE class): every eligible layer is ONE
+    autograd node over the one-kernel layer (nn/models/_fused_sage.py:layer_eligible) and computes
+    what propagate -> lin_l -> + lin_r(x) (sage_conv.py:118-139) computes; pairs, other
+    aggregations, opted-out layers and hooked layers keep the propagate path."""
+    from pytorch_geometric_amd.nn import SAGEConv
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    from tests._util import random_graph
+    g = gen(12)
+    n, e = 3000, 40000
+    ei = random_graph(n, n, e, seed=12).to(dev)
+    x = torch.randn(n, 36, generator=g).to(dev)
+    w_out = torch.randn(n, 10, generator=g).to(dev)
+    torch.manual_seed(3)
+    convs = [SAGEConv(36, 64).to(dev), SAGEConv(64, 64, aggr='sum', normalize=True).to(dev),
+             SAGEConv(64, 10, bias=False).to(dev)]   # (the last one: narrow -> transform first)
+
+    def run():
+        for c in convs:
+            c.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        h = xg
+        for c in convs[:-1]:
+            h = c(h, ei).relu()
+        out = convs[-1](h, ei)
+        (out * w_out).sum().backward()
+        return out, xg.grad, [p.grad.clone() for c in convs for p in c.parameters()]
+
+    out, gx, gp = run()
+    assert 'FusedSageStack' in out.grad_fn.name()
+    monkeypatch.setattr(_fused_sage, 'LAYER_NODE', False)
+    ref_out, ref_gx, ref_gp = run()
+    assert 'FusedSageStack' not in ref_out.grad_fn.name()
+    monkeypatch.setattr(_fused_sage, 'LAYER_NODE', True)
+    assert_close_scaled(out, ref_out.detach().cpu(), what='out')
+    assert_close_scaled(gx, ref_gx.cpu(), what='grad_x')
+    for a, b in zip(gp, ref_gp):
+        assert_close_scaled(a, b.cpu(), what='param grad')
+    # who steps aside
+    conv = convs[0]
+    assert not _fused_sage.layer_eligible(conv, x, ei, (n, n - 1))
+    assert _fused_sage.layer_eligible(conv, x, ei, (n, n))
+    assert not _fused_sage.layer_eligible(conv, x.double(), ei, None)
+    assert not _fused_sage.layer_eligible(SAGEConv(36, 8, aggr='max').to(dev), x, ei, None)
+    assert not _fused_sage.layer_eligible(SAGEConv(36, 8, project=True).to(dev), x, ei, None)
+    assert not _fused_sage.layer_eligible(SAGEConv(36, 8, root_weight=False).to(dev), x, ei, None)
+    conv.fuse = False
+    assert not _fused_sage.layer_eligible(conv, x, ei, None)
+    conv.fuse = True
+    pair = SAGEConv((36, 36), 8).to(dev)((x, x[:100]), ei[:, ei[1] < 100])
+    assert 'FusedSageStack' not in pair.grad_fn.name()
+    handle = conv.register_propagate_forward_pre_hook(lambda m, a: None)
+    assert not _fused_sage.layer_eligible(conv, x, ei, None)
+    handle.remove()
+    with torch.no_grad():
+        assert_close_scaled(conv(x, ei), convs[0](x.clone().requires_grad_(True), ei).detach().cpu())
+
+
 def test_out_of_range_edge_index(dev):
     """test_message_passing.py:201-213: IndexError on invalid indices (unfused path)."""
     from pytorch_geometric_amd.nn import SAGEConv

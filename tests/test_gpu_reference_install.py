@@ -103,6 +103,12 @@ def test_reference_convs_take_the_hip_path_and_match_their_cpu_results(pyg, inst
             assert_close(a, b, rtol=1e-5, atol=2e-5, what=f'{name} grad input')
         for a, b in zip(gp, ref_gp):
             assert_close_scaled(a, b, tol=2e-5, what=f'{name} grad param')
+    # the reference's SAGEConv.forward on a square graph = the one-kernel layer, one autograd node
+    dconv = copy.deepcopy(cases[0][1]).to(dev)
+    assert 'FusedSageStack' in dconv(x.to(dev), ei.to(dev)).grad_fn.name()
+    installed.uninstall()
+    assert 'FusedSageStack' not in dconv(x.to(dev), ei.to(dev)).grad_fn.name()
+    installed.install()
 
 
 def test_reference_layers_do_not_resort_the_graph_every_forward(pyg, installed, launches, dev):
@@ -163,13 +169,23 @@ def test_reference_graphsage_model_runs_the_fused_stack(pyg, installed, launches
     assert_close_scaled(gin[0], ref_gin[0], tol=2e-5, what='GraphSAGE grad x')
     for a, b in zip(gp, ref_gp):
         assert_close_scaled(a, b, tol=2e-5, what='GraphSAGE grad param')
-    # switched off: the reference's own layer loop runs (one fused propagate per layer at the
-    # layer's INPUT width), same numbers
+    # switched off: the reference's own layer loop runs, every SAGEConv.forward as a one-kernel
+    # layer node (the same six aggregation widths, the ReLUs as ATen passes), same numbers
     dmodel.fuse_stack = False
     del launches['sink'][:]
     out2, _, _ = _fwd_bwd(dmodel, _to(dev, (x, ei)), go)
-    assert sorted(i['F'] for i, _, _ in launches['sink'] if 'F' in i) == [20, 20, 64, 64, 64, 64]
+    assert sorted(i['F'] for i, _, _ in launches['sink'] if 'F' in i) == widths
     assert_close(out2, ref_out, rtol=1e-5, atol=2e-5, what='GraphSAGE layer loop')
+    # ... and without the layer nodes: one fused propagate per layer at the layer's INPUT width
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    _fused_sage.LAYER_NODE = False
+    try:
+        del launches['sink'][:]
+        out3, _, _ = _fwd_bwd(dmodel, _to(dev, (x, ei)), go)
+    finally:
+        _fused_sage.LAYER_NODE = True
+    assert sorted(i['F'] for i, _, _ in launches['sink'] if 'F' in i) == [20, 20, 64, 64, 64, 64]
+    assert_close(out3, ref_out, rtol=1e-5, atol=2e-5, what='GraphSAGE propagate loop')
 
 
 def test_reference_edge_index_matmul_on_device(pyg, installed, launches, dev):
