@@ -27,7 +27,8 @@ modules.  ``install()`` therefore
    — plain mean/sum ``SAGEConv`` layers, ReLU, Identity norms, no dropout in effect — and a
    single ``SAGEConv.forward`` (nn/conv/sage_conv.py:118-139) of ANY model to the one-kernel layer
    (aggregation + ``lin_l`` + ``lin_r`` + bias as one kernel and one autograd node) for a square
-   graph given as a plain ``edge_index`` tensor.
+   graph given as a plain ``edge_index`` tensor; an unweighted ``GraphConv.forward``
+   (nn/conv/graph_conv.py:77-92) is the same layer and takes the same route.
 
 Every wrapper STEPS ASIDE to the original reference function for anything that is not a float32
 HIP tensor, under ``torch.compile`` / TorchScript, or when ``backend.use_mi355x`` is False —
@@ -399,6 +400,23 @@ def _wrap_sageconv_forward(cls) -> Callable:
     return forward
 
 
+def _wrap_graphconv_forward(cls) -> Callable:
+    """The reference's ``GraphConv.forward`` (nn/conv/graph_conv.py:77-92) without edge weights: the
+    same layer as SAGEConv under the names ``lin_rel`` / ``lin_root``."""
+    orig = cls.forward
+
+    def forward(self, x, edge_index, edge_weight=None, size=None):
+        from .nn.models import _fused_sage
+        if (_enabled() and edge_weight is None and isinstance(x, torch.Tensor)
+                and _fused_sage.layer_eligible(self, x, edge_index, size)):
+            return _fused_sage.run_layer(self, x, edge_index)
+        return orig(self, x, edge_index, edge_weight, size)
+
+    forward.__wrapped__ = orig
+    forward.__doc__ = orig.__doc__
+    return forward
+
+
 def _wrap_propagate(cls) -> Callable:
     orig = cls.propagate
 
@@ -528,6 +546,10 @@ def install() -> None:
     prev = SAGEConv.__dict__.get('forward')
     SAGEConv.forward = _wrap_sageconv_forward(SAGEConv)
     _state['forwards'].append((SAGEConv, had_own, prev))
+    had_own = 'forward' in GraphConv.__dict__
+    prev = GraphConv.__dict__.get('forward')
+    GraphConv.forward = _wrap_graphconv_forward(GraphConv)
+    _state['forwards'].append((GraphConv, had_own, prev))
 
     # the reference's own dense layer (nn/dense/linear.py:121-127: F.linear) on the fp32-MFMA
     # kernels for float32 device inputs of >= OWN_GEMM_MIN_ROWS rows; everything else unchanged

@@ -32,6 +32,11 @@ class GraphConv(MessagePassing):
 
     def forward(self, x, edge_index, edge_weight: Optional[Tensor] = None,
                 size: Optional[Tuple[int, int]] = None) -> Tensor:
+        if isinstance(x, Tensor) and edge_weight is None:
+            from ..models import _fused_sage
+            if _fused_sage.layer_eligible(self, x, edge_index, size):
+                # the SAGE layer under other names: aggregation + both maps + bias in one kernel
+                return _fused_sage.run_layer(self, x, edge_index)
         pair = (x, x) if isinstance(x, Tensor) else x
         out = self.lin_rel(self.propagate(edge_index, x=pair, edge_weight=edge_weight,
                                           size=size))

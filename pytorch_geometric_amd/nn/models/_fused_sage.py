@@ -451,11 +451,19 @@ class FusedSageStack(Function):
         return (grad_x, None, None, None, *grads)
 
 
+def _linears(conv):
+    """(neighbour map, root map): ``SAGEConv.lin_l / lin_r`` (sage_conv.py:101-107) or
+    ``GraphConv.lin_rel / lin_root`` (graph_conv.py:63-64) — the same layer up to names."""
+    if type(conv).__name__ == 'GraphConv':
+        return conv.lin_rel, conv.lin_root
+    return conv.lin_l, conv.lin_r
+
+
 def params_ready(conv, x: Tensor) -> bool:
     """The layer's weights exist (a lazily initialised ``SAGEConv(-1, ...)`` materialises them in
     its first ORIGINAL forward, nn/dense/linear.py:139-150 in the reference), are fp32 and live on
     ``x``'s device."""
-    for lin in (conv.lin_l, conv.lin_r):
+    for lin in _linears(conv):
         ps = [lin.weight] + ([lin.bias] if getattr(lin, 'bias', None) is not None else [])
         for p in ps:
             if isinstance(p, torch.nn.parameter.UninitializedParameter):
@@ -486,7 +494,7 @@ def eligible(model, x, edge_index, trim: bool) -> bool:
         return False
     aggr = None
     for conv in model.convs:
-        if conv.normalize or not _conv_ok(conv, x):
+        if not _conv_ok(conv, x) or conv.normalize:
             return False
         if conv._forward_hooks or conv._forward_pre_hooks:
             return False
@@ -496,13 +504,15 @@ def eligible(model, x, edge_index, trim: bool) -> bool:
     return _graph_ok(edge_index, x.size(0))
 
 
-def _conv_ok(conv, x: Tensor) -> bool:
-    """A plain mean / sum ``SAGEConv`` with a root weight whose ``propagate`` nobody observes."""
-    if type(conv).__name__ != 'SAGEConv' or not getattr(conv, 'fuse', True):
+def _conv_ok(conv, x: Tensor, kinds=('SAGEConv', )) -> bool:
+    """A plain mean / sum ``SAGEConv`` with a root weight (or, for a single layer, an unweighted
+    ``GraphConv``) whose ``propagate`` nobody observes."""
+    kind = type(conv).__name__
+    if kind not in kinds or not getattr(conv, 'fuse', True):
         return False
-    if conv.aggr not in ('mean', 'sum', 'add') or not conv.root_weight:
+    if conv.aggr not in ('mean', 'sum', 'add') or conv.flow != 'source_to_target':
         return False
-    if conv.project or conv.flow != 'source_to_target':
+    if kind == 'SAGEConv' and (not conv.root_weight or conv.project):
         return False
     if getattr(conv, 'explain', False) or getattr(conv, 'decomposed_layers', 1) != 1:
         return False
@@ -538,7 +548,8 @@ LAYER_NODE = os.environ.get('PYGAMD_SAGE_LAYER_NODE', '1') != '0'
 
 def layer_eligible(conv, x, edge_index, size) -> bool:
     """``conv(x, edge_index)`` is what a one-layer :class:`FusedSageStack` computes (duck-typed:
-    ``backend.install()`` routes the reference's ``SAGEConv.forward`` here as well)."""
+    ``backend.install()`` routes the reference's ``SAGEConv.forward`` / ``GraphConv.forward``
+    here as well; a ``GraphConv`` call with edge weights is not asked)."""
     if not LAYER_NODE or not FUSE_LAYER or GEMM_BACKEND != 'own':
         return False
     if not (isinstance(x, Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
@@ -549,15 +560,15 @@ def layer_eligible(conv, x, edge_index, size) -> bool:
         return False
     if size is not None and tuple(size) != (x.size(0), x.size(0)):
         return False
-    return _conv_ok(conv, x) and _graph_ok(edge_index, x.size(0))
+    return _conv_ok(conv, x, ('SAGEConv', 'GraphConv')) and _graph_ok(edge_index, x.size(0))
 
 
 def run_layer(conv, x: Tensor, edge_index) -> Tensor:
     from ...edge_index import as_edge_index
     graph = as_edge_index(edge_index, x.size(0), x.size(0))
     aggr = 'sum' if conv.aggr == 'add' else conv.aggr
-    return FusedSageStack.apply(x, graph, aggr, True, conv.lin_l.weight, conv.lin_l.bias,
-                                conv.lin_r.weight)
+    lin_l, lin_r = _linears(conv)
+    return FusedSageStack.apply(x, graph, aggr, True, lin_l.weight, lin_l.bias, lin_r.weight)
 
 
 def run(model, x: Tensor, edge_index) -> Tensor:

@@ -206,6 +206,34 @@ def test_sage_conv_layer_runs_as_one_kernel_node(dev, monkeypatch):
     handle.remove()
     with torch.no_grad():
         assert_close_scaled(conv(x, ei), convs[0](x.clone().requires_grad_(True), ei).detach().cpu())
+    # widths that are no multiple of four, and GraphConv (the same layer as lin_rel / lin_root;
+    # with edge weights it keeps the weighted SpMM)
+    from pytorch_geometric_amd.nn import GraphConv
+    x5 = torch.randn(n, 5, generator=g).to(dev)
+    torch.manual_seed(4)
+    odd = [SAGEConv(5, 7).to(dev), GraphConv(7, 9).to(dev), GraphConv(9, 3, aggr='mean').to(dev)]
+
+    def run_odd():
+        for c in odd:
+            c.zero_grad()
+        h = x5.clone().requires_grad_(True)
+        first = h
+        for c in odd:
+            h = c(h, ei).tanh()
+        h.sum().backward()
+        return h, first.grad, [p.grad.clone() for c in odd for p in c.parameters()]
+
+    got = run_odd()
+    assert 'FusedSageStack' in odd[1](x5.new_zeros(n, 7), ei).grad_fn.name()
+    monkeypatch.setattr(_fused_sage, 'LAYER_NODE', False)
+    want = run_odd()
+    monkeypatch.setattr(_fused_sage, 'LAYER_NODE', True)
+    assert_close_scaled(got[0], want[0].detach().cpu(), what='odd out')
+    assert_close_scaled(got[1], want[1].cpu(), what='odd grad_x')
+    for a, b in zip(got[2], want[2]):
+        assert_close_scaled(a, b.cpu(), what='odd param grad')
+    w = torch.rand(ei.size(1), generator=g).to(dev)
+    assert 'FusedSageStack' not in odd[1](x5.new_zeros(n, 7), ei, w).grad_fn.name()
 
 
 def test_out_of_range_edge_index(dev):

@@ -106,6 +106,11 @@ def test_reference_convs_take_the_hip_path_and_match_their_cpu_results(pyg, inst
     # the reference's SAGEConv.forward on a square graph = the one-kernel layer, one autograd node
     dconv = copy.deepcopy(cases[0][1]).to(dev)
     assert 'FusedSageStack' in dconv(x.to(dev), ei.to(dev)).grad_fn.name()
+    gconv = GraphConv(16, 12).to(dev)   # (unweighted: the same layer under other names)
+    assert 'FusedSageStack' in gconv(x.to(dev), ei.to(dev)).grad_fn.name()
+    assert 'FusedSageStack' not in gconv(x.to(dev), ei.to(dev), w.to(dev)).grad_fn.name()
+    assert_close(gconv(x.to(dev), ei.to(dev)), copy.deepcopy(gconv).cpu()(x, ei).detach(),
+                 rtol=1e-5, atol=2e-5, what='graphconv unweighted')
     installed.uninstall()
     assert 'FusedSageStack' not in dconv(x.to(dev), ei.to(dev)).grad_fn.name()
     installed.install()
