@@ -49,6 +49,51 @@ def test_gcn_conv_golden(dev, golden, fuse):
         _run_layer(conv, L[name], gr['x'], dev, *args)
 
 
+def test_gcn_conv_aggregates_at_the_narrower_width(dev, monkeypatch):
+    """A (X W) = (A X) W: a GCNConv whose input is narrower than its output aggregates first (the
+    reference transforms first, gcn_conv.py:260-264) — same values, and no transposed aggregation
+    in the backward when ``x`` takes no gradient; ``aggregate_first = False`` keeps the order."""
+    from pytorch_geometric_amd import _native
+    from pytorch_geometric_amd.nn import GCNConv
+    from tests._util import random_graph
+    g = gen(21)
+    n = 2000
+    ei = random_graph(n, n, 24000, seed=21).to(dev)
+    x = torch.randn(n, 12, generator=g).to(dev)
+    go = torch.randn(n, 40, generator=g).to(dev)
+    torch.manual_seed(5)
+    conv = GCNConv(12, 40).to(dev)
+    sink = []
+    monkeypatch.setattr(_native, 'timing_sink', sink)
+
+    def run(first, x_grad):
+        conv.aggregate_first = first
+        conv.zero_grad()
+        xg = x.clone().requires_grad_(x_grad)
+        del sink[:]
+        out = conv(xg, ei)
+        out.backward(go)
+        widths = sorted(i['F'] for i, _, _ in sink if 'F' in i)
+        return out.detach(), xg.grad, [p.grad.clone() for p in conv.parameters()], widths
+
+    a = run(True, True)
+    b = run(False, True)
+    assert a[3] == [12, 12] and b[3] == [40, 40], (a[3], b[3])
+    assert_close_scaled(a[0], b[0].cpu(), what='out')
+    assert_close_scaled(a[1], b[1].cpu(), what='grad x')
+    for p, q in zip(a[2], b[2]):
+        assert_close_scaled(p, q.cpu(), what='grad param')
+    c = run(True, False)
+    assert c[3] == [12], c[3]          # forward only: nothing to aggregate on the way back
+    for p, q in zip(c[2], b[2]):
+        assert_close_scaled(p, q.cpu(), what='grad param (x without gradient)')
+    assert run(False, False)[3] == [40, 40]
+    wide = GCNConv(40, 12).to(dev)      # the input is the wider side: the reference's order
+    del sink[:]
+    wide(torch.randn(n, 40, device=dev), ei)
+    assert [i['F'] for i, _, _ in sink if 'F' in i] == [12]
+
+
 def test_gcn_norm_golden(dev, golden):
     from pytorch_geometric_amd.nn import gcn_norm
     gr, lp = golden['graph'], golden['loops']
