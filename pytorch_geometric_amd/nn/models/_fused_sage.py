@@ -560,7 +560,9 @@ def layer_eligible(conv, x, edge_index, size) -> bool:
         return False
     if size is not None and tuple(size) != (x.size(0), x.size(0)):
         return False
-    return _conv_ok(conv, x, ('SAGEConv', 'GraphConv')) and _graph_ok(edge_index, x.size(0))
+    if not _conv_ok(conv, x, ('SAGEConv', 'GraphConv')) or not _graph_ok(edge_index, x.size(0)):
+        return False
+    return edge_index.size(1) > 0  # (an edgeless graph: nothing to fuse, the general path knows it)
 
 
 def run_layer(conv, x: Tensor, edge_index) -> Tensor:
