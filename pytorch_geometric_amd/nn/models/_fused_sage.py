@@ -528,9 +528,19 @@ def _conv_ok(conv, x: Tensor, kinds=('SAGEConv', )) -> bool:
     return params_ready(conv, x)
 
 
-def _graph_ok(edge_index, n: int) -> bool:
+# A single-use batch handle (the loader's, `EdgeIndex.from_sorted_batch`) never reaches the
+# whole-stack schedule (hop-aware batches have their own, `_fused_sage_hops`); a single LAYER takes
+# it from this many edges on: the by-source sort of the batch (once per handle, shared by the
+# layers that use it) and its hub plan (one host read) against the atomic backward of every layer
+# — a 3-layer SAGEConv model on whole [15, 10, 5] subgraphs of 0.6 M nodes / 0.69 M edges:
+# 16.0 -> 10.3 ms per batch step (scripts/time_minibatch_layers.py); small batches keep the atomics.
+SINGLE_USE_MIN_EDGES = 1 << 16
+
+
+def _graph_ok(edge_index, n: int, single_use: bool = False) -> bool:
     if isinstance(edge_index, EdgeIndex):
-        if edge_index.atomic_backward:  # single-use batch handle: keep the no-sort layer path
+        if edge_index.atomic_backward and not (
+                single_use and edge_index.size(1) >= SINGLE_USE_MIN_EDGES):
             return False
         return edge_index.sparse_size == (n, n)
     return (isinstance(edge_index, Tensor) and type(edge_index) is Tensor and edge_index.is_cuda
@@ -560,7 +570,8 @@ def layer_eligible(conv, x, edge_index, size) -> bool:
         return False
     if size is not None and tuple(size) != (x.size(0), x.size(0)):
         return False
-    if not _conv_ok(conv, x, ('SAGEConv', 'GraphConv')) or not _graph_ok(edge_index, x.size(0)):
+    if (not _conv_ok(conv, x, ('SAGEConv', 'GraphConv'))
+            or not _graph_ok(edge_index, x.size(0), single_use=True)):
         return False
     return edge_index.size(1) > 0  # (an edgeless graph: nothing to fuse, the general path knows it)
 

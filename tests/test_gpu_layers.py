@@ -251,6 +251,33 @@ def test_sage_conv_layer_runs_as_one_kernel_node(dev, monkeypatch):
     handle.remove()
     with torch.no_grad():
         assert_close_scaled(conv(x, ei), convs[0](x.clone().requires_grad_(True), ei).detach().cpu())
+    # a single-use batch handle (the loader's): the layer node from SINGLE_USE_MIN_EDGES edges on
+    # (it sorts the batch by source once), the atomic backward below that
+    import pytorch_geometric_amd as pga
+    order = ei[1].argsort(stable=True)
+    batch = pga.EdgeIndex.from_sorted_batch(ei[:, order].contiguous(), n,
+                                            max_in_degree=int(ei[1].bincount().max()))
+    assert batch.atomic_backward and not _fused_sage.layer_eligible(conv, x, batch, None)
+    monkeypatch.setattr(_fused_sage, 'SINGLE_USE_MIN_EDGES', 1000)
+    assert _fused_sage.layer_eligible(conv, x, batch, None)
+
+    def run_batch():
+        conv.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        o = conv(xg, batch)
+        (o * w_out[:, :1]).sum().backward()
+        return o, xg.grad, [p.grad.clone() for p in conv.parameters()]
+
+    got = run_batch()
+    assert 'FusedSageStack' in got[0].grad_fn.name()
+    monkeypatch.setattr(_fused_sage, 'LAYER_NODE', False)
+    want = run_batch()
+    monkeypatch.setattr(_fused_sage, 'LAYER_NODE', True)
+    assert 'FusedSageStack' not in want[0].grad_fn.name()
+    assert_close_scaled(got[0], want[0].detach().cpu(), what='batch out')
+    assert_close_scaled(got[1], want[1].cpu(), what='batch grad_x')
+    for a, b in zip(got[2], want[2]):
+        assert_close_scaled(a, b.cpu(), what='batch param grad')
     # widths that are no multiple of four, and GraphConv (the same layer as lin_rel / lin_root;
     # with edge weights it keeps the weighted SpMM)
     from pytorch_geometric_amd.nn import GraphConv
