@@ -24,6 +24,24 @@ def test_no_cpu_fallback():
         pga.utils.segment_matmul(torch.randn(4, 3), [0, 4], torch.randn(1, 3, 2))
 
 
+def test_layer_nodes_step_aside_off_the_device():
+    """The one-kernel layer route of SAGEConv / GraphConv / the aggregate-first order of GCNConv
+    are taken for float32 DEVICE features only: on CPU tensors the layers keep their general path,
+    which raises (no CPU fallback) — nothing is computed on the host."""
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd.nn.models import _fused_sage
+    x = torch.randn(4, 3)
+    ei = torch.tensor([[0, 1, 2], [1, 0, 3]])
+    for conv in (pga.nn.SAGEConv(3, 8), pga.nn.GraphConv(3, 8)):
+        assert not _fused_sage.layer_eligible(conv, x, ei, None)
+        with pytest.raises(pga.PygAmdError, match='no CPU fallback'):
+            conv(x, ei)
+    gcn = pga.nn.GCNConv(3, 8)
+    assert not gcn._aggregate_first(x)
+    with pytest.raises(pga.PygAmdError, match='no CPU fallback'):
+        gcn(x, ei)
+
+
 def test_product_never_imports_the_oracle():
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
