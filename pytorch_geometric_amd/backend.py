@@ -28,7 +28,9 @@ modules.  ``install()`` therefore
    single ``SAGEConv.forward`` (nn/conv/sage_conv.py:118-139) of ANY model to the one-kernel layer
    (aggregation + ``lin_l`` + ``lin_r`` + bias as one kernel and one autograd node) for a square
    graph given as a plain ``edge_index`` tensor; an unweighted ``GraphConv.forward``
-   (nn/conv/graph_conv.py:77-92) is the same layer and takes the same route.
+   (nn/conv/graph_conv.py:77-92) is the same layer and takes the same route;
+   ``GCNConv.forward`` (nn/conv/gcn_conv.py:226-266) aggregates BEFORE it transforms when its input
+   is the narrower side (``A (X W) = (A X) W``).
 
 Every wrapper STEPS ASIDE to the original reference function for anything that is not a float32
 HIP tensor, under ``torch.compile`` / TorchScript, or when ``backend.use_mi355x`` is False —
@@ -417,6 +419,50 @@ def _wrap_graphconv_forward(cls) -> Callable:
     return forward
 
 
+def _wrap_gcnconv_forward(cls) -> Callable:
+    """The reference's ``GCNConv.forward`` (nn/conv/gcn_conv.py:226-266) transforms first and
+    aggregates second whatever the widths.  ``A (X W) = (A X) W``: when the input is the NARROWER
+    side (100 -> 256, 128 -> 256) the same layer as ``lin(propagate(x))`` gathers that much less
+    and, for a first layer whose ``x`` takes no gradient, has no aggregation in its backward.
+    Taken for a plain ``edge_index`` tensor and float32 device features when nobody observes the
+    message flow (hooks, explain); the normalisation and its cache are the layer's own
+    (``gcn_norm`` looked up in the reference's module: the identity memo of step 5 applies)."""
+    orig = cls.forward
+
+    def forward(self, x, edge_index, edge_weight=None):
+        if not (_enabled() and _ours(x) and x.dim() == 2 and _ours_index(edge_index)
+                and x.size(-1) < self.out_channels and getattr(self, 'aggregate_first', True)
+                and not getattr(self, 'explain', False)
+                and getattr(self, 'decomposed_layers', 1) == 1
+                and not any(getattr(self, name, None) for name in _FLOW_HOOKS)):
+            return orig(self, x, edge_index, edge_weight)
+        import torch_geometric.nn.conv.gcn_conv as gcn_mod
+        if self.normalize:
+            cache = self._cached_edge_index
+            if cache is None:
+                edge_index, edge_weight = gcn_mod.gcn_norm(
+                    edge_index, edge_weight, x.size(self.node_dim), self.improved,
+                    self.add_self_loops, self.flow, x.dtype)
+                if self.cached:
+                    self._cached_edge_index = (edge_index, edge_weight)
+            else:
+                edge_index, edge_weight = cache[0], cache[1]
+        out = self.lin(self.propagate(edge_index, x=x, edge_weight=edge_weight))
+        return out if self.bias is None else out + self.bias
+
+    forward.__wrapped__ = orig
+    forward.__doc__ = orig.__doc__
+    return forward
+
+
+_FLOW_HOOKS = ('_propagate_forward_pre_hooks', '_propagate_forward_hooks',
+               '_message_forward_pre_hooks', '_message_forward_hooks',
+               '_aggregate_forward_pre_hooks', '_aggregate_forward_hooks',
+               '_message_and_aggregate_forward_pre_hooks',
+               '_message_and_aggregate_forward_hooks', '_edge_update_forward_pre_hooks',
+               '_edge_update_forward_hooks')
+
+
 def _wrap_propagate(cls) -> Callable:
     orig = cls.propagate
 
@@ -550,6 +596,11 @@ def install() -> None:
     prev = GraphConv.__dict__.get('forward')
     GraphConv.forward = _wrap_graphconv_forward(GraphConv)
     _state['forwards'].append((GraphConv, had_own, prev))
+    # ... and GCNConv aggregates before it transforms when its input is the narrower side
+    had_own = 'forward' in GCNConv.__dict__
+    prev = GCNConv.__dict__.get('forward')
+    GCNConv.forward = _wrap_gcnconv_forward(GCNConv)
+    _state['forwards'].append((GCNConv, had_own, prev))
 
     # the reference's own dense layer (nn/dense/linear.py:121-127: F.linear) on the fp32-MFMA
     # kernels for float32 device inputs of >= OWN_GEMM_MIN_ROWS rows; everything else unchanged

@@ -87,6 +87,7 @@ def test_reference_convs_take_the_hip_path_and_match_their_cpu_results(pyg, inst
         ('sage-sum-t2s', SAGEConv(16, 12, aggr='sum', flow='target_to_source'), (x, ei)),
         ('gcn', GCNConv(16, 12), (x, ei)),
         ('gcn-weighted', GCNConv(16, 12, improved=True), (x, ei, w)),
+        ('gcn-wide', GCNConv(16, 40), (x, ei)),   # input narrower: aggregated before lin
         ('graphconv', GraphConv(16, 12, aggr='mean'), (x, ei, w)),
         ('gat', GATConv(16, 4, heads=3), (x, ei)),
         ('gat-mean-heads', GATConv(16, 6, heads=2, concat=False), (x, ei)),
@@ -98,6 +99,9 @@ def test_reference_convs_take_the_hip_path_and_match_their_cpu_results(pyg, inst
         before = len(launches['sink'])
         out, gin, gp = _fwd_bwd(dconv, _to(dev, args), go)
         assert len(launches['sink']) > before, f'{name}: no SpMM launch — reference path taken'
+        if name == 'gcn-wide':  # forward and backward aggregation at the INPUT width
+            fs = [i['F'] for i, _, _ in launches['sink'][before:] if 'F' in i]
+            assert fs.count(16) >= 2 and 40 not in fs, fs
         assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what=f'{name} out')
         for a, b in zip(gin, ref_gin):
             assert_close(a, b, rtol=1e-5, atol=2e-5, what=f'{name} grad input')
