@@ -658,7 +658,12 @@ def spmm_node(x: Tensor, w: Optional[Tensor], graph: EdgeIndex, reduce: str,
     """``SpmmFunction.apply`` semantics; sum / mean with no gradient asked for the weights run as
     the C++ autograd node."""
     C = _cpp_nodes()
+    # The C++ node takes BOTH sorted forms up front.  The by-source one (a transposed sort + a hub
+    # plan with a host read, per fresh graph) only serves the gradient of `x`: inference under
+    # no_grad and first layers whose `x` takes no gradient keep the Python node, which builds it
+    # inside backward() when needs_input_grad[0] says so (ADVICE r5).
     if (C is not None and reduce in ('sum', 'mean') and _plain_f32(x, w) and x.dim() >= 2
+            and torch.is_grad_enabled() and x.requires_grad
             and x.numel() > 0 and x.size(0) == graph.num_src_nodes and not graph.atomic_backward
             and (w is None or (w.dim() == 1 and not w.requires_grad
                                and w.numel() == graph.num_edges))):

@@ -814,6 +814,16 @@ def poll_index_errors(wait: bool = False, device=None):
 
 def _raise_out_of_range(index: Tensor, size: int, what: str, style=None):
     lo, hi = index_minmax(index)
+    if style == 'edge_index':  # the texts of MessagePassing._index_select_safe
+        if lo < 0:
+            raise IndexError(
+                f"Found negative indices in 'edge_index' (got {lo}). Please ensure that all "
+                f"indices in 'edge_index' point to valid indices in the interval [0, {size}) in "
+                f"your node feature matrix and try again.")
+        raise IndexError(
+            f"Found indices in 'edge_index' that are larger than {size - 1} (got {hi}). Please "
+            f"ensure that all indices in 'edge_index' point to valid indices in the interval "
+            f"[0, {size}) in your node feature matrix and try again.")
     if style == 'dim_size' and size <= hi:
         raise ValueError(f"Encountered invalid 'dim_size' (got '{size}' but expected "
                          f">= '{hi + 1}')")
@@ -828,11 +838,20 @@ def _raise_if_flagged(err: Tensor, index: Tensor, size: int, what: str):
     if torch.cuda.is_current_stream_capturing():
         return
     if int(err.item()) != 0:
-        _raise_out_of_range(index, size, what)
+        style = _error_style.value
+        _raise_out_of_range(index, size, what, style if style == 'edge_index' else None)
 
 
-def gather_rows(x: Tensor, index: Tensor, check_bounds: bool = False) -> Tensor:
+def gather_rows(x: Tensor, index: Tensor, check_bounds=False) -> Tensor:
+    """``x[index]`` for float32 rows.  ``check_bounds``: ``False`` (the caller vouches for the
+    index), ``True`` (one blocking flag read, IndexError at the call) or ``'edge_index'`` — the
+    gather of ``MessagePassing._index_select``: the reference's IndexError texts
+    (message_passing.py:269-290), delivered as ``INDEX_CHECK`` says (async flag ring / blocking
+    read / not at all); flagged rows are skipped by the kernel in every mode."""
     _require_device(x, index)
+    as_edges = check_bounds == 'edge_index'
+    if as_edges and INDEX_CHECK == 'off':
+        as_edges = check_bounds = False
     C = _compiled.ops()
     if C is not None and not check_bounds and _plain(x) \
             and index.dtype in (torch.int32, torch.int64):
@@ -842,9 +861,20 @@ def gather_rows(x: Tensor, index: Tensor, check_bounds: bool = False) -> Tensor:
     index = index.contiguous()
     n, F = index.numel(), x2.size(1)
     out = torch.empty(n, F, dtype=torch.float32, device=x.device)
-    err = torch.zeros(1, dtype=torch.int32, device=x.device) if check_bounds else None
+    ring = slot = None
+    if as_edges:
+        ring, slot, err = _index_flag(x.device, n > 0 and F > 0)
+    else:
+        err = torch.zeros(1, dtype=torch.int32, device=x.device) if check_bounds else None
     check(lib.pygamd_gather_rows(_p(x2), _ld(x2), x2.size(0), _p(index), _idx_dtype(index), n, F,
                                  _p(out), _ld(out), _p(err), _stream(x)), 'gather_rows')
+    if as_edges:
+        prev = set_error_style('edge_index')
+        try:
+            _index_flag_done(ring, slot, err, 'gather', x2.size(0), index)
+        finally:
+            set_error_style(prev)
+        return out
     if check_bounds and int(err.item()) != 0:
         lo, hi = index_minmax(index)
         raise IndexError(

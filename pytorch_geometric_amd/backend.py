@@ -82,6 +82,83 @@ def _ours_index(t: Any) -> bool:
             and t.dim() == 2 and t.size(0) == 2 and t.dtype in (torch.int32, torch.int64))
 
 
+def _is_ref_edge_index(t: Any) -> bool:
+    """The reference's own ``EdgeIndex`` (edge_index.py:173: a wrapper subclass over ``_data``)."""
+    mod = sys.modules.get('torch_geometric.edge_index')
+    return mod is not None and isinstance(t, mod.EdgeIndex)
+
+
+def _plain_index(t: Any) -> Any:
+    """The plain ``[2, E]`` tensor under any of the three graph arguments a layer may be handed: a
+    tensor, this package's handle, or the reference's ``EdgeIndex``."""
+    from .edge_index import EdgeIndex as Handle
+    if isinstance(t, Handle):
+        return t.edge_index
+    if _is_ref_edge_index(t):
+        return t._data
+    return t
+
+
+def _adopt(edge_index, n_src, n_dst, flip: bool = False):
+    """This package's handle for a reference ``EdgeIndex`` living on the device (None when it
+    cannot stand in: sizes that disagree, a CPU tensor).  The reference object already KNOWS its
+    order and may hold the sorted forms — ``_indptr`` and the transposed ``_T_perm / _T_index /
+    _T_indptr`` (edge_index.py:589-663) — so the handle is built with that ``sort_order`` (no
+    sortedness re-check, no sort for the forward) and, for the non-flipped case, seeded with the
+    cached transposed form; it is cached by the identity of ``_data`` like any plain tensor's
+    handle, so the by-source sort of the backward happens once per graph object."""
+    from .edge_index import CSR, adopt_sorted
+    data = edge_index._data
+    if not (data.is_cuda and data.dim() == 2 and data.dtype in (torch.int32, torch.int64)):
+        return None
+    rows, cols = edge_index._sparse_size   # sizes of data[0] / data[1]; entries may be None
+    want = (n_dst, n_src) if flip else (n_src, n_dst)
+    if (rows is not None and rows != want[0]) or (cols is not None and cols != want[1]):
+        return None
+    order = edge_index.sort_order
+    if flip:
+        order = {'row': 'col', 'col': 'row'}.get(order)
+    handle, fresh = adopt_sorted(data, n_src, n_dst, flip, order)
+    if fresh and not flip and order is not None:
+        E = data.size(1)
+        ptr = edge_index._indptr
+        t_perm, t_idx, t_ptr = edge_index._T_perm, edge_index._T_index, edge_index._T_indptr
+        same = lambda t: t is not None and t.dtype == data.dtype and t.is_contiguous()
+        if order == 'col':   # sorted by destination: `_indptr` over data[1], transposed = by source
+            if same(ptr) and ptr.numel() == n_dst + 1 and handle._csr is None:
+                handle._csr = CSR(ptr, data[0].contiguous(),
+                                  torch.arange(E, dtype=data.dtype, device=data.device),
+                                  n_dst, n_src)
+            if (same(t_perm) and same(t_ptr) and same(t_idx[1]) and t_ptr.numel() == n_src + 1):
+                handle._csc = CSR(t_ptr, t_idx[1], t_perm, n_src, n_dst)
+        else:                # sorted by source: `_indptr` over data[0], transposed = by destination
+            if same(ptr) and ptr.numel() == n_src + 1 and handle._csc is None:
+                handle._csc = CSR(ptr, data[1].contiguous(),
+                                  torch.arange(E, dtype=data.dtype, device=data.device),
+                                  n_src, n_dst)
+            if (same(t_perm) and same(t_ptr) and same(t_idx[0]) and t_ptr.numel() == n_dst + 1):
+                handle._csr = CSR(t_ptr, t_idx[0], t_perm, n_dst, n_src)
+    return handle
+
+
+def _device_graph(t: Any) -> bool:
+    """A graph argument the layer routes take: a plain device ``[2, E]`` index tensor, this
+    package's handle, or the reference's ``EdgeIndex`` over a device tensor."""
+    return _ours_index(_plain_index(t))
+
+
+def _square_graph(edge_index, n: int, s2t: bool = True):
+    """``edge_index`` as the layer / stack routes want it for a square graph over ``n`` nodes: a
+    reference ``EdgeIndex`` becomes this package's handle (:func:`_adopt`); anything else — and
+    anything handed to a ``target_to_source`` layer, which those routes decline — is returned
+    unchanged."""
+    if s2t and _is_ref_edge_index(edge_index):
+        got = _adopt(edge_index, n, n)
+        if got is not None:
+            return got
+    return edge_index
+
+
 def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
     from . import utils as U
 
@@ -198,12 +275,13 @@ def _fused_propagate(conv, edge_index, size, kwargs):
     fuse = True if type(conv).__name__ == 'GATConv' else getattr(conv, 'fuse', True)
     if not (_enabled() and fuse) or getattr(conv, 'explain', False):
         return NotImplemented
-    # this package's handle (a Tensor subclass) keeps its sorted forms; any other subclass (the
-    # reference's own EdgeIndex) stays on the reference path
+    # this package's handle (a Tensor subclass) keeps its sorted forms; the reference's own
+    # EdgeIndex is adopted below (once the sizes are known) with the order and caches it carries
     handle = edge_index if isinstance(edge_index, Handle) else None
     if handle is not None and not (handle.is_cuda and conv.flow == 'source_to_target'):
         return NotImplemented
-    if handle is None and not _ours_index(edge_index):
+    ref_ei = handle is None and _is_ref_edge_index(edge_index)
+    if handle is None and not ref_ei and not _ours_index(edge_index):
         return NotImplemented
     if conv._propagate_forward_pre_hooks or conv._propagate_forward_hooks:
         return NotImplemented
@@ -252,6 +330,10 @@ def _fused_propagate(conv, edge_index, size, kwargs):
         if handle.sparse_size != (n_src, n_dst):
             return NotImplemented
         graph = handle
+    elif ref_ei:
+        graph = _adopt(edge_index, n_src, n_dst, flip=not s2t)
+        if graph is None:
+            return NotImplemented
     else:
         graph = as_edge_index(edge_index, n_src, n_dst, flip=not s2t)
     reduce = 'sum' if aggr == 'add' else aggr
@@ -316,6 +398,8 @@ class _IdentityMemo:
 
 
 def _memoisable(edge_index, edge_attr) -> bool:
+    """(callers pass the PLAIN tensor under a handle / reference ``EdgeIndex``: the rewrites
+    append self-loops, so the result is a new unsorted edge list whatever the input's class)"""
     return (_ours_index(edge_index) and _enabled()
             and (edge_attr is None or (isinstance(edge_attr, Tensor) and edge_attr.is_cuda
                                        and not edge_attr.requires_grad)))
@@ -333,21 +417,24 @@ def _make_graph_rewrite_memos(gcn_mod, gat_mod) -> List[Tuple[Any, str, Callable
 
     def gcn_norm(edge_index, edge_weight=None, num_nodes=None, improved=False,
                  add_self_loops=True, flow='source_to_target', dtype=None):
-        if (_memoisable(edge_index, edge_weight) and dtype in (None, torch.float32)
+        plain = _plain_index(edge_index)
+        if (_memoisable(plain, edge_weight) and dtype in (None, torch.float32)
                 and (edge_weight is None or (edge_weight.dtype == torch.float32
                                              and edge_weight.dim() == 1))):
-            return memo_norm((edge_index, edge_weight),
+            return memo_norm((plain, edge_weight),
                              (num_nodes, bool(improved), bool(add_self_loops), flow, dtype))
         return orig_norm(edge_index, edge_weight, num_nodes, improved, add_self_loops, flow, dtype)
 
     def remove_self_loops(edge_index, edge_attr=None):
-        if edge_attr is None and _memoisable(edge_index, None):
-            return memo_rm((edge_index, ), ())
+        plain = _plain_index(edge_index)
+        if edge_attr is None and _memoisable(plain, None):
+            return memo_rm((plain, ), ())
         return orig_rm(edge_index, edge_attr)
 
     def add_self_loops(edge_index, edge_attr=None, fill_value=None, num_nodes=None):
-        if edge_attr is None and _memoisable(edge_index, None) and isinstance(num_nodes, int):
-            return memo_add((edge_index, ), (num_nodes, ))
+        plain = _plain_index(edge_index)
+        if edge_attr is None and _memoisable(plain, None) and isinstance(num_nodes, int):
+            return memo_add((plain, ), (num_nodes, ))
         return orig_add(edge_index, edge_attr, fill_value, num_nodes)
 
     for fn, o in ((gcn_norm, orig_norm), (remove_self_loops, orig_rm), (add_self_loops, orig_add)):
@@ -370,9 +457,10 @@ def _wrap_graphsage_forward(cls) -> Callable:
                 num_sampled_edges_per_hop=None):
         from .nn.models import _fused_sage
         if (_enabled() and edge_weight is None and edge_attr is None
-                and _fused_sage.eligible(self, x, edge_index,
-                                         num_sampled_nodes_per_hop is not None)):
-            return _fused_sage.run(self, x, edge_index)
+                and isinstance(x, Tensor) and num_sampled_nodes_per_hop is None):
+            graph = _square_graph(edge_index, x.size(0))
+            if _fused_sage.eligible(self, x, graph, False):
+                return _fused_sage.run(self, x, graph)
         return orig(self, x, edge_index, edge_weight, edge_attr, batch, batch_size,
                     num_sampled_nodes_per_hop, num_sampled_edges_per_hop)
 
@@ -391,10 +479,11 @@ def _wrap_sageconv_forward(cls) -> Callable:
 
     def forward(self, x, edge_index, size=None):
         from .nn.models import _fused_sage
-        if (_enabled() and isinstance(x, torch.Tensor)
-                and _fused_sage.layer_eligible(self, x, edge_index, size)):
-            h = _fused_sage.run_layer(self, x, edge_index)
-            return torch.nn.functional.normalize(h, p=2.0, dim=-1) if self.normalize else h
+        if _enabled() and isinstance(x, torch.Tensor):
+            graph = _square_graph(edge_index, x.size(0), self.flow == 'source_to_target')
+            if _fused_sage.layer_eligible(self, x, graph, size):
+                h = _fused_sage.run_layer(self, x, graph)
+                return torch.nn.functional.normalize(h, p=2.0, dim=-1) if self.normalize else h
         return orig(self, x, edge_index, size)
 
     forward.__wrapped__ = orig
@@ -409,9 +498,10 @@ def _wrap_graphconv_forward(cls) -> Callable:
 
     def forward(self, x, edge_index, edge_weight=None, size=None):
         from .nn.models import _fused_sage
-        if (_enabled() and edge_weight is None and isinstance(x, torch.Tensor)
-                and _fused_sage.layer_eligible(self, x, edge_index, size)):
-            return _fused_sage.run_layer(self, x, edge_index)
+        if _enabled() and edge_weight is None and isinstance(x, torch.Tensor):
+            graph = _square_graph(edge_index, x.size(0), self.flow == 'source_to_target')
+            if _fused_sage.layer_eligible(self, x, graph, size):
+                return _fused_sage.run_layer(self, x, graph)
         return orig(self, x, edge_index, edge_weight, size)
 
     forward.__wrapped__ = orig
@@ -424,17 +514,18 @@ def _wrap_gcnconv_forward(cls) -> Callable:
     aggregates second whatever the widths.  ``A (X W) = (A X) W``: when the input is the NARROWER
     side (100 -> 256, 128 -> 256) the same layer as ``lin(propagate(x))`` gathers that much less
     and, for a first layer whose ``x`` takes no gradient, has no aggregation in its backward.
-    Taken for a plain ``edge_index`` tensor and float32 device features when nobody observes the
-    message flow (hooks, explain); the normalisation and its cache are the layer's own
+    Taken for float32 device features when the aggregation is linear (``add`` / ``sum`` / ``mean``
+    with the stock ``message``: ``GCNConv(16, 64, aggr='max')`` and subclasses overriding the
+    message keep the reference's order) and nobody observes the message flow (hooks, explain);
+    the normalisation and its cache are the layer's own
     (``gcn_norm`` looked up in the reference's module: the identity memo of step 5 applies)."""
     orig = cls.forward
 
     def forward(self, x, edge_index, edge_weight=None):
-        if not (_enabled() and _ours(x) and x.dim() == 2 and _ours_index(edge_index)
+        from .nn.conv.gcn_conv import linear_message_flow
+        if not (_enabled() and _ours(x) and x.dim() == 2 and _device_graph(edge_index)
                 and x.size(-1) < self.out_channels and getattr(self, 'aggregate_first', True)
-                and not getattr(self, 'explain', False)
-                and getattr(self, 'decomposed_layers', 1) == 1
-                and not any(getattr(self, name, None) for name in _FLOW_HOOKS)):
+                and getattr(self, 'fuse', True) and linear_message_flow(self, cls)):
             return orig(self, x, edge_index, edge_weight)
         import torch_geometric.nn.conv.gcn_conv as gcn_mod
         if self.normalize:
@@ -469,12 +560,232 @@ def _wrap_propagate(cls) -> Callable:
     def propagate(self, edge_index, size=None, **kwargs):
         res = _fused_propagate(self, edge_index, size, kwargs)
         if res is NotImplemented:
-            return orig(self, edge_index, size, **kwargs)
+            # (`size` by keyword: a layer object built BEFORE install() has left the generated
+            # `propagate(self, edge_index, x, ..., size=None)` on its class, propagate.jinja:19)
+            return orig(self, edge_index, size=size, **kwargs)
         return res
 
     propagate.__wrapped__ = orig
     propagate.__module__ = getattr(orig, '__module__', propagate.__module__)
     return propagate
+
+
+def _capturing(t: Tensor) -> bool:
+    """The routes below read sizes back to the host (segment pointers, hub plans, index checks):
+    not inside a hipGraph capture."""
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
+def _quiet(conv) -> bool:
+    """Nobody observes this layer's message flow: no hooks of any kind on ``propagate`` /
+    ``message`` / ``aggregate`` / ``edge_update``, no explain mode, no decomposed layers."""
+    return (not getattr(conv, 'explain', False) and getattr(conv, 'decomposed_layers', 1) == 1
+            and not any(getattr(conv, name, None) for name in _FLOW_HOOKS))
+
+
+def _stock(conv, base, names) -> bool:
+    """``conv``'s class takes these methods from ``base`` unchanged (a subclass that overrides
+    ``message`` inherits the wrapped ``forward`` too and must keep the reference's route)."""
+    kind = type(conv)
+    return all(getattr(kind, n, None) is getattr(base, n, None) for n in names)
+
+
+def _make_index_select(orig: Callable) -> Callable:
+    """Replacement for ``MessagePassing._index_select`` (nn/conv/message_passing.py:263-290) — the
+    gather behind every ``x_j`` / ``x_i`` / ``alpha_j`` of the general (un-fused) route, in the
+    Python ``_collect`` and in the generated ``collect`` alike (collect.jinja:124-137): float32
+    device rows go through ``pygamd_gather_rows``, whose backward is the sorted scatter (one cached
+    radix sort of the index instead of one atomic per element — profiles/r05_unfused_propagate.md).
+    Out-of-range / negative indices raise the reference's ``IndexError`` texts; WHEN follows
+    ``PYGAMD_CHECK_INDEX`` (``sync``: at the call, as the reference's CPU path does; ``async``,
+    the default: at the next checked launch, as the reference's GPU path — a device assert —
+    does).  Everything else runs the original."""
+    def _index_select(self, src, index):
+        if (_ours(src) and _enabled() and isinstance(index, Tensor) and index.dim() == 1
+                and index.dtype in (torch.int32, torch.int64) and src.dim() >= 1):
+            from ._functions import GatherFunction
+            if hasattr(index, '_data'):   # the reference's `Index` (a row of its EdgeIndex)
+                index = index._data
+            if type(index) is Tensor and index.is_cuda:
+                d = self.node_dim + src.dim() if self.node_dim < 0 else self.node_dim
+                s0 = src if d == 0 else src.movedim(d, 0).contiguous()
+                out = GatherFunction.apply(s0, index, 'edge_index')
+                return out if d == 0 else out.movedim(0, d)
+        return orig(self, src, index)
+
+    _index_select.__wrapped__ = orig
+    _index_select.__doc__ = orig.__doc__
+    return _index_select
+
+
+def _wrap_gatconv_forward(cls) -> Callable:
+    """The reference's ``GATConv.forward`` (nn/conv/gat_conv.py:254-385) as projection + ONE
+    autograd node for node terms, edge softmax and aggregation (``GatAttendFunction``: three
+    forward kernels, the two gradients of the projected features meeting inside one backward
+    kernel) when nothing in between is observable: one shared projection (``lin``), no edge
+    features, no dropout in effect, nobody asking for the coefficients, no hooks.  Every other
+    call runs the original, whose ``propagate`` / ``softmax`` / ``_index_select`` are served by
+    this backend too."""
+    orig = cls.forward
+
+    def forward(self, x, edge_index, edge_attr=None, size=None, return_attention_weights=None):
+        if not (_enabled() and _ours(x) and x.dim() == 2 and x.size(0) > 0
+                and edge_attr is None and size is None
+                and return_attention_weights is None and self.lin is not None
+                and self.edge_dim is None and self.flow == 'source_to_target'
+                and getattr(self, 'fuse_attention', True)
+                and isinstance(self.aggr, str) and self.aggr in ('add', 'sum')
+                and not (self.training and self.dropout > 0) and _device_graph(edge_index)
+                and _quiet(self)
+                and _stock(self, cls, ('message', 'edge_update', 'aggregate', 'update'))
+                and _ours(self.att_src) and not torch.is_autocast_enabled()
+                and not _capturing(x)):
+            return orig(self, x, edge_index, edge_attr, size, return_attention_weights)
+        import torch_geometric.nn.conv.gat_conv as gat_mod
+        from ._functions import GatAttendFunction, bias_act
+        from .edge_index import as_edge_index
+        H, C, n = self.heads, self.out_channels, x.size(0)
+        res = self.res(x) if getattr(self, 'res', None) is not None else None
+        x_src = self.lin(x).view(-1, H, C)
+        if self.add_self_loops:
+            # (the identity memos of step 5: the same tensors for the same input, so the handle
+            # below is found again on the next forward)
+            ei, _ = gat_mod.remove_self_loops(edge_index, None)
+            ei, _ = gat_mod.add_self_loops(ei, None, fill_value=self.fill_value, num_nodes=n)
+            graph = as_edge_index(ei, n, n)
+        else:
+            graph = _square_graph(edge_index, n)
+            if _is_ref_edge_index(graph):   # (sizes that disagree with `x`)
+                return orig(self, x, edge_index, edge_attr, size, return_attention_weights)
+            graph = as_edge_index(graph, n, n)
+        out = GatAttendFunction.apply(x_src, self.att_src, self.att_dst, graph,
+                                      self.negative_slope, n)
+        out = out.reshape(-1, H * C) if self.concat else out.mean(dim=1)
+        if res is not None:
+            out = out + res
+        return bias_act(out, self.bias, False) if self.bias is not None else out
+
+    forward.__wrapped__ = orig
+    forward.__doc__ = orig.__doc__
+    return forward
+
+
+def _rgcn_args_ok(conv, x, edge_index, edge_type) -> bool:
+    x_l = x[0] if isinstance(x, tuple) else x
+    x_r = x[1] if isinstance(x, tuple) else x_l
+    w = conv.weight
+    if not (_ours(w) and isinstance(edge_type, Tensor) and edge_type.is_cuda
+            and edge_type.dim() == 1 and edge_type.dtype in (torch.int32, torch.int64)
+            and _device_graph(edge_index)):
+        return False
+    if edge_type.numel() != _plain_index(edge_index).size(1) or edge_type.numel() == 0:
+        return False
+    for t in (x_l, x_r):
+        if t is None:
+            continue
+        if not (isinstance(t, Tensor) and t.is_cuda):
+            return False
+        if t.is_floating_point() and not (t.dtype == torch.float32 and t.dim() == 2):
+            return False
+        if not t.is_floating_point() and t.dim() != 1:
+            return False
+    if isinstance(x, tuple) and (x_l is None or x_r is None):
+        return False
+    return (isinstance(conv.aggr, str) and conv.aggr in ('mean', 'add', 'sum', 'max', 'min')
+            and conv.flow == 'source_to_target' and _quiet(conv)
+            and not torch.is_autocast_enabled()
+            and not _capturing(w))
+
+
+def _wrap_rgcn_forward(cls, fast: bool) -> Callable:
+    """The reference's ``RGCNConv.forward`` — a Python loop of masked ``propagate`` calls, 474
+    iterations at the FB15k-237 shape (nn/conv/rgcn_conv.py:243-282) — and ``FastRGCNConv.forward``
+    (one ``bmm`` over per-edge weight copies, rgcn_conv.py:302-374) on this package's sorted,
+    segmented schedule (``nn/conv/rgcn_conv.py``: one sort per graph, one SpMM per
+    (relation, destination) pair segment, one grouped fp32-MFMA GEMM = the ``segment_matmul``
+    of seam S2, one SpMM back onto the nodes).  Same parameters, same result as the loop (the
+    per-relation mean included); dense / ``num_bases`` / ``num_blocks`` weights, feature and
+    node-index inputs.  Note the reference's OWN ``segment_matmul`` branch (rgcn_conv.py:264-271,
+    only with pyg-lib) normalises ``aggr='mean'`` over all relations together (its TODO at
+    :286): this route follows the loop, which is what the reference computes on the CPU."""
+    orig = cls.forward
+    names = ('message', 'aggregate', 'update', 'message_and_aggregate')
+
+    def forward(self, x, edge_index, edge_type=None):
+        if (_enabled() and edge_type is not None and _stock(self, cls, names)
+                and _rgcn_args_ok(self, x, edge_index, edge_type)
+                and getattr(self, 'fuse_relations', True)):
+            from .nn.conv import rgcn_conv as own
+            ei = _plain_index(edge_index)
+            run = own.fast_rgcn_forward if fast else own.rgcn_forward
+            return run(self, x, ei, edge_type)
+        return orig(self, x, edge_index, edge_type)
+
+    forward.__wrapped__ = orig
+    forward.__doc__ = orig.__doc__
+    return forward
+
+
+def _wrap_heterolinear_forward(cls) -> Callable:
+    """The reference's ``HeteroLinear.forward`` (nn/dense/linear.py:287-329: a Python loop of
+    per-type ``matmul`` calls unless pyg-lib's ``segment_matmul`` is importable) as sort by type ->
+    ONE grouped fp32-MFMA GEMM -> per-type bias -> original order, for float32 device rows."""
+    orig = cls.forward
+
+    def forward(self, x, type_vec):
+        w = self.weight
+        if (_enabled() and _ours(x) and x.dim() == 2 and x.size(0) > 0
+                and not isinstance(w, torch.nn.parameter.UninitializedParameter) and _ours(w)
+                and isinstance(type_vec, Tensor) and type_vec.is_cuda and type_vec.dim() == 1
+                and type_vec.dtype in (torch.int32, torch.int64)
+                and type_vec.numel() == x.size(0) and x.size(1) == w.size(1)
+                and not torch.is_autocast_enabled()
+                and not _capturing(x)):
+            from .nn.dense.linear import hetero_linear_forward
+            return hetero_linear_forward(self, x, type_vec)
+        return orig(self, x, type_vec)
+
+    forward.__wrapped__ = orig
+    forward.__doc__ = orig.__doc__
+    return forward
+
+
+class _SegmentMatmulOps:
+    """``pyg_lib.ops`` as far as seam S2 goes: ``segment_matmul(inputs, ptr,
+    other)`` with pyg-lib's contract (call sites nn/conv/rgcn_conv.py:288, nn/dense/linear.py:255)
+    on the grouped fp32-MFMA GEMM.  Device float32 only — there is no host computation here."""
+
+    @staticmethod
+    def segment_matmul(inputs, ptr, other):
+        from .utils import segment_matmul
+        if not (_ours(inputs) and _ours(other)):
+            raise NotImplementedError(
+                "pytorch_geometric_amd serves 'segment_matmul' for float32 HIP tensors only "
+                f"(got {inputs.dtype} on {inputs.device})")
+        return segment_matmul(inputs, ptr, other)
+
+
+class _PygLibShim:
+    ops = _SegmentMatmulOps
+
+
+def _bind_segment_matmul(mods) -> List[Tuple[Any, str, Any]]:
+    """Binds the ``pyg_lib`` NAME the reference's two call sites resolve at call time
+    (``pyg_lib.ops.segment_matmul``: rgcn_conv.py:13-19,288; linear.py:16,255) when pyg-lib itself
+    is absent.  The flag that sends the reference there, ``torch_geometric.typing.WITH_SEGMM``
+    (typing.py:47-63), stays as it is: it is process-global and read for CPU tensors as well,
+    which this backend does not compute — the layer wrappers above take the float32 device calls
+    before the flag is looked at; a user who sets it gets this kernel from the reference's own
+    branches."""
+    import torch_geometric.typing as pyg_typing
+    if getattr(pyg_typing, 'WITH_PYG_LIB', False):
+        return []
+    done = []
+    for mod in mods:
+        if hasattr(mod, 'pyg_lib'):
+            done.append((mod, 'pyg_lib', mod.pyg_lib))
+            mod.pyg_lib = _PygLibShim
+    return done
 
 
 _sampler_cls = None
@@ -601,6 +912,32 @@ def install() -> None:
     prev = GCNConv.__dict__.get('forward')
     GCNConv.forward = _wrap_gcnconv_forward(GCNConv)
     _state['forwards'].append((GCNConv, had_own, prev))
+
+    # ... GATConv as projection + one attention node
+    had_own = 'forward' in GATConv.__dict__
+    prev = GATConv.__dict__.get('forward')
+    GATConv.forward = _wrap_gatconv_forward(GATConv)
+    _state['forwards'].append((GATConv, had_own, prev))
+    # ... the relational layers on the sorted, segmented schedule (BASELINE config 5), HeteroLinear
+    # as one grouped GEMM, and the `pyg_lib.ops.segment_matmul` name of seam S2
+    from torch_geometric.nn.conv import FastRGCNConv, RGCNConv
+    from torch_geometric.nn.dense.linear import HeteroLinear as PygHeteroLinear
+    for kls, wrap in ((RGCNConv, _wrap_rgcn_forward(RGCNConv, False)),
+                      (FastRGCNConv, _wrap_rgcn_forward(FastRGCNConv, True)),
+                      (PygHeteroLinear, _wrap_heterolinear_forward(PygHeteroLinear))):
+        had_own = 'forward' in kls.__dict__
+        prev = kls.__dict__.get('forward')
+        kls.forward = wrap
+        _state['forwards'].append((kls, had_own, prev))
+    import torch_geometric.nn.conv.rgcn_conv as pyg_rgcn_mod
+    import torch_geometric.nn.dense.linear as pyg_linear_mod
+    _state['rebinds'] += _bind_segment_matmul((pyg_rgcn_mod, pyg_linear_mod))
+
+    # the gather of the general route: every `x_j` / `x_i` / `alpha_j` of any MessagePassing layer
+    from torch_geometric.nn.conv import MessagePassing as PygMessagePassing
+    orig_select = PygMessagePassing.__dict__['_index_select']
+    PygMessagePassing._index_select = _make_index_select(orig_select)
+    _state['rebinds'].append((PygMessagePassing, '_index_select', orig_select))
 
     # the reference's own dense layer (nn/dense/linear.py:121-127: F.linear) on the fp32-MFMA
     # kernels for float32 device inputs of >= OWN_GEMM_MIN_ROWS rows; everything else unchanged

@@ -761,15 +761,13 @@ int pygamd_segment_matmul(const float* x, int64_t ldx, const int64_t* x_rows, co
     const int n_halves = static_cast<int>(ceil_div(N, kSN));
     const int64_t n_items = n_tiles * n_halves;
     const unsigned sgrid = static_cast<unsigned>(round_up(n_items, 8));
-    static bool attr_set[5] = {false, false, false, false, false};
     const int nc = static_cast<int>(ceil_div(K, 32));
     auto launch = [&](auto kernel) -> int {
-      if (!attr_set[nc]) {  // (once per instantiation: the planes need more than 64 KB)
-        PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             static_cast<int>(kSegSplitLds)));
-        attr_set[nc] = true;
-      }
+      // (the planes need more than 64 KB; set on every launch like gemm.hip / sage_fused.hip: the
+      // attribute belongs to the current device's code object, a process may drive several GPUs)
+      PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(kSegSplitLds)));
       hipLaunchKernelGGL(kernel, dim3(sgrid), dim3(kBlock), kSegSplitLds, st, x, ldx, x_rows,
                          planes, tiles, n_items, n_halves, static_cast<int>(K), static_cast<int>(N),
                          static_cast<int>(blocks), out, ldo);
@@ -811,13 +809,9 @@ int pygamd_segment_matmul_wgrad(const float* x, int64_t ldx, const float* g, int
   const dim3 grid(static_cast<unsigned>(n_chunks), static_cast<unsigned>(ceil_div(K, kWT)),
                   static_cast<unsigned>(ceil_div(N, kWT)));
   if (pygamd_get_gemm_mode() == PYGAMD_GEMM_SPLIT_BF16) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(segmm_wgrad_split_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(kWgSplitLds)));
-      attr_set = true;
-    }
+    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(segmm_wgrad_split_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(kWgSplitLds)));
     hipLaunchKernelGGL(segmm_wgrad_split_kernel, grid, dim3(kBlock), kWgSplitLds, st, x, ldx, g,
                        ldg, g_rows, chunks, static_cast<int>(K), static_cast<int>(N),
                        static_cast<int>(blocks), grad_w);

@@ -81,7 +81,9 @@ class EdgeIndex(Tensor):
             like ``maybe_num_nodes`` in the reference.
         sort_order: ``'row'`` if ``edge_index[0]`` is already sorted, ``'col'`` if ``edge_index[1]``
             is, else ``None`` (same vocabulary as the reference's ``EdgeIndex``).
-        validate: range-check the indices against ``sparse_size`` once (two host syncs).
+        validate: range-check the indices against ``sparse_size`` once (two host syncs) and check
+            a claimed ``sort_order`` (one more); ``'range'``: the range check only (the caller
+            vouches for the order, as the reference's ``EdgeIndex`` does for its own flag).
     """
 
     # every torch operation on a handle sees (and returns) a plain tensor
@@ -116,7 +118,7 @@ class EdgeIndex(Tensor):
             sparse_size = (n if given[0] is None else given[0],
                            n if given[1] is None else given[1])
         self.sparse_size = (int(sparse_size[0]), int(sparse_size[1]))
-        if validate and edge_index.numel() > 0:
+        if validate in (True, 'range') and edge_index.numel() > 0:
             # the reference raises IndexError from index_select (message_passing.py:269-290);
             # the fused kernels never bounds-check, so the handle does it once, up front
             for row, n in ((0, self.sparse_size[0]), (1, self.sparse_size[1])):
@@ -132,7 +134,7 @@ class EdgeIndex(Tensor):
                         f"{hi}). Please ensure that all indices in 'edge_index' point to valid "
                         f"indices in the interval [0, {n}) in your node feature matrix and try "
                         f"again.")
-        if validate and sort_order is not None and edge_index.size(1) > 1:
+        if validate is True and sort_order is not None and edge_index.size(1) > 1:
             key = edge_index[0] if sort_order == 'row' else edge_index[1]
             if not bool((key[1:] >= key[:-1]).all()):
                 raise ValueError(f"'edge_index' is not sorted by {sort_order} although "
@@ -379,27 +381,37 @@ def as_edge_index(edge_index, num_src: Optional[int] = None, num_dst: Optional[i
                   flip: bool = False) -> EdgeIndex:
     """Handle for a raw ``[2, E]`` tensor, cached per (tensor identity, version, sizes, flip).
     ``flip=True`` swaps the two rows first (``flow='target_to_source'``)."""
+    return adopt_sorted(edge_index, num_src, num_dst, flip, None)[0]
+
+
+def adopt_sorted(edge_index, num_src: Optional[int], num_dst: Optional[int], flip: bool,
+                 sort_order: Optional[str]) -> Tuple[EdgeIndex, bool]:
+    """``as_edge_index`` for a tensor whose owner vouches for ``sort_order`` (of the handle's rows,
+    i.e. AFTER the flip) — the data of a reference ``EdgeIndex``: the indices are still
+    range-checked once, the order is taken on trust.  Returns ``(handle, fresh)``; ``fresh`` says
+    the handle was built by this call (the caller may seed its sorted forms)."""
     if isinstance(edge_index, EdgeIndex):
         if flip:
             raise ValueError("an EdgeIndex handle is always 'source_to_target'; pass a raw "
                              "tensor to use flow='target_to_source'")
-        return edge_index
+        return edge_index, False
     if not isinstance(edge_index, Tensor):
         raise ValueError(f"'edge_index' must be a Tensor or EdgeIndex (got {type(edge_index)})")
 
     def make():
         ei = edge_index.flip(0).contiguous() if flip else edge_index
-        return EdgeIndex(ei, (num_src, num_dst))
+        return EdgeIndex(ei, (num_src, num_dst), sort_order=sort_order,
+                         validate=True if sort_order is None else 'range')
 
     if not _cache_enabled:
-        return make()
+        return make(), True
     key = (id(edge_index), flip)
     hit = _cache.get(key)
     if hit is not None:
         ref, version, size, handle = hit
         if (ref() is edge_index and version == edge_index._version
                 and size == (num_src, num_dst)):
-            return handle
+            return handle, False
     handle = make()
     if len(_cache) >= MAX_CACHE_ENTRIES:
         _cache.pop(next(iter(_cache)))
@@ -408,4 +420,4 @@ def as_edge_index(edge_index, num_src: Optional[int] = None, num_dst: Optional[i
         _cache.pop(key, None)
 
     _cache[key] = (weakref.ref(edge_index, _drop), edge_index._version, (num_src, num_dst), handle)
-    return handle
+    return handle, True

@@ -37,6 +37,32 @@ def gcn_norm(edge_index: Tensor, edge_weight: Optional[Tensor] = None,
     return edge_index, inv_sqrt[edge_index[0]] * edge_weight * inv_sqrt[edge_index[1]]
 
 
+_FLOW_HOOKS = ('_propagate_forward_pre_hooks', '_propagate_forward_hooks',
+               '_message_forward_pre_hooks', '_message_forward_hooks',
+               '_aggregate_forward_pre_hooks', '_aggregate_forward_hooks',
+               '_message_and_aggregate_forward_pre_hooks',
+               '_message_and_aggregate_forward_hooks', '_edge_update_forward_pre_hooks',
+               '_edge_update_forward_hooks')
+
+
+def linear_message_flow(conv, base) -> bool:
+    """``A (X W) = (A X) W`` holds for this layer object: a LINEAR aggregation (``add`` / ``sum`` /
+    ``mean`` given as a string — ``GCNConv(16, 64, aggr='max')`` is a valid layer and is not),
+    the stock ``message`` / ``aggregate`` / ``message_and_aggregate`` / ``update`` of ``base`` (a
+    subclass that overrides one of them inherits ``forward`` too), and nobody observing the flow
+    (hooks, explain mode, decomposed layers).  ``base``: the ``GCNConv`` class ``conv`` derives
+    from — this package's or, through ``backend.install()``, the reference's."""
+    if not (isinstance(conv.aggr, str) and conv.aggr in ('add', 'sum', 'mean')):
+        return False
+    kind = type(conv)
+    for name in ('message', 'aggregate', 'message_and_aggregate', 'update'):
+        if getattr(kind, name, None) is not getattr(base, name, None):
+            return False
+    if getattr(conv, 'explain', False) or getattr(conv, 'decomposed_layers', 1) != 1:
+        return False
+    return not any(getattr(conv, name, None) for name in _FLOW_HOOKS)
+
+
 class GCNConv(MessagePassing):
     r"""Graph convolution ``X' = D^-1/2 (A + I) D^-1/2 X W + b`` with the constructor arguments,
     parameters (``lin.weight`` glorot, ``bias`` zeros) and the normalise -> transform -> propagate
@@ -118,8 +144,9 @@ class GCNConv(MessagePassing):
 
     def _aggregate_first(self, x: Tensor) -> bool:
         """Aggregation before the linear map: only where it is the same computation seen from
-        outside (float32 device features on the fused route, nobody hooked into the message
-        flow) and the input is the narrower side.  ``aggregate_first = False`` on the layer keeps
+        outside (float32 device features on the fused route, a linear aggregation with the
+        stock message, nobody hooked into the message flow: :func:`linear_message_flow`) and the
+        input is the narrower side.  ``aggregate_first = False`` on the layer keeps
         the reference's order."""
         if not getattr(self, 'aggregate_first', True) or not self.fuse:
             return False
@@ -127,11 +154,13 @@ class GCNConv(MessagePassing):
             return False
         if x.size(-1) >= self.out_channels:
             return False
-        return not (self._propagate_forward_pre_hooks or self._propagate_forward_hooks)
+        return linear_message_flow(self, GCNConv)
 
     def message(self, x_j: Tensor, edge_weight: Optional[Tensor]) -> Tensor:
         return x_j if edge_weight is None else edge_weight.view(-1, 1) * x_j
 
     def message_and_aggregate(self, graph: EdgeIndex, x: Tensor,
                               edge_weight: Optional[Tensor]) -> Tensor:
-        return spmm_node(x, edge_weight, graph, 'sum', 'coo')
+        # (the layer's OWN aggregation: `GCNConv(..., aggr='mean' | 'max')` are valid layers,
+        # gcn_conv.py:181 only sets a default)
+        return spmm_node(x, edge_weight, graph, {'add': 'sum'}.get(self.aggr, self.aggr), 'coo')

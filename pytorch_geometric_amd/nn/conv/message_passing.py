@@ -217,7 +217,9 @@ class MessagePassing(torch.nn.Module):
         if self.flow != 'source_to_target' and any(isinstance(v, (tuple, list))
                                                    for v in kwargs.values()):
             return False  # (src, dst) pairs swap roles; take the general path
-        return self.aggr in ('sum', 'add', 'mean', 'min', 'max')
+        if self.aggr in ('min', 'max') and kwargs.get('edge_weight') is not None:
+            return False  # the SpMM kernels weight sums and means only: max_j (w_e x_j) takes
+        return self.aggr in ('sum', 'add', 'mean', 'min', 'max')  # the gather -> message route
 
     def edge_updater(self, edge_index, size: Optional[Tuple[int, int]] = None, **kwargs):
         r"""Computes per-edge features via ``edge_update`` (message_passing.py:620-665)."""

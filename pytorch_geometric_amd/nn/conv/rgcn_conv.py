@@ -84,6 +84,114 @@ class RelationalHandle:
         return self._edge_graph
 
 
+def _relational_handle(conv, edge_index: Tensor, edge_type: Tensor, n_src: int,
+                       n_dst: int) -> RelationalHandle:
+    """The layer's handle for this ``(edge_index, edge_type)`` pair, cached on the layer by tensor
+    identity + in-place version (one sort per graph, not per call).  ``conv`` is duck-typed: the
+    reference's ``RGCNConv`` objects are served through ``backend.install()``."""
+    hit = conv.__dict__.get('_handle_cache')
+    if hit is not None:
+        r_ei, r_et, v_ei, v_et, size, handle = hit
+        if (r_ei() is edge_index and r_et() is edge_type and v_ei == edge_index._version
+                and v_et == edge_type._version and size == (n_src, n_dst)):
+            return handle
+    handle = RelationalHandle(edge_index, edge_type, n_src, n_dst, conv.num_relations)
+    conv.__dict__['_handle_cache'] = (weakref.ref(edge_index), weakref.ref(edge_type),
+                                      edge_index._version, edge_type._version, (n_src, n_dst),
+                                      handle)
+    return handle
+
+
+def _index_inputs(conv, x_l, x_r, edge_index, edge_type, weight, by_node_id=False):
+    """Node-index ("featureless") inputs, rgcn_conv.py:262-268: the message of edge (j, i, r)
+    is the embedding row ``weight[r, x_l[j]]``.  One differentiable row gather builds all
+    messages, one SpMM reduces them per (relation, destination) pair and one sums the pairs
+    of every destination — instead of one masked propagate per relation."""
+    ei = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
+    n_src, n_dst = x_l.size(0), x_r.size(0)
+    look = ei[0] if by_node_id else x_l[ei[0]]
+    rows = edge_type.to(torch.int64) * weight.size(1) + look.to(torch.int64)
+    msg = GatherFunction.apply(weight.reshape(-1, conv.out_channels), rows, True)
+    h = _relational_handle(conv, ei, edge_type, n_src, n_dst)
+    reduce = 'sum' if conv.aggr == 'add' else conv.aggr
+    per_pair = SpmmFunction.apply(msg, None, h.edge_graph, reduce, 'coo')
+    return SpmmFunction.apply(per_pair, None, h.out_graph, 'sum', 'coo')
+
+
+def _composed_weight(conv) -> Tensor:
+    weight = conv.weight
+    if conv.num_bases is not None:  # basis decomposition (rgcn_conv.py:203-205)
+        weight = (conv.comp @ weight.view(conv.num_bases, -1)).view(
+            conv.num_relations, conv.in_channels_l, conv.out_channels)
+    return weight
+
+
+def _root_bias(conv, out: Tensor, x_r: Tensor) -> Tensor:
+    root = conv.root
+    if root is not None:
+        if not torch.is_floating_point(x_r):
+            out = out + root[x_r]
+        else:
+            out = out + linear(x_r, root.t())
+    fa = requested_activation(conv)  # (BasicGNN-style ReLU stacks: bias + ReLU in one pass)
+    if fa is not None or (conv.bias is not None and out.is_cuda):
+        return bias_act(out, conv.bias, fa == 'relu')
+    if conv.bias is not None:
+        out = out + conv.bias
+    return out
+
+
+def rgcn_forward(conv, x, edge_index, edge_type: Optional[Tensor]) -> Tensor:
+    """``RGCNConv.forward`` (rgcn_conv.py:164-282, the per-relation loop's result) on the sorted,
+    segmented schedule of the class docstring below.  ``conv``: this package's layer or the
+    reference's (same parameter names and shapes, rgcn_conv.py:92-162)."""
+    x_l = x[0] if isinstance(x, tuple) else x
+    if x_l is None:
+        x_l = torch.arange(conv.in_channels_l, device=conv.weight.device)
+    x_r = x[1] if isinstance(x, tuple) else x_l
+    assert edge_type is not None
+    if not torch.is_floating_point(x_r) and conv.num_blocks is not None:
+        raise ValueError('Block-diagonal decomposition not supported '
+                         'for non-continuous input features.')
+    weight = _composed_weight(conv)
+    if not torch.is_floating_point(x_l):
+        # node-index inputs: the per-relation embedding lookup weight[r, x_j]
+        out = _index_inputs(conv, x_l, x_r, edge_index, edge_type, weight)
+    else:
+        n_src, n_dst = x_l.size(0), x_r.size(0)
+        ei = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
+        h = _relational_handle(conv, ei, edge_type, n_src, n_dst)
+        reduce = 'sum' if conv.aggr == 'add' else conv.aggr
+        # (1) per-(relation, destination) neighbourhood reduce at the input width
+        agg = SpmmFunction.apply(x_l, None, h.pair_graph, reduce, 'coo')  # [S, F_in]
+        # (2) relation-segmented transform (block b of a pair row times weight[r, b]: column
+        # blocks in place, one launch) and (3) the sum of the pair rows of every destination,
+        # as one autograd node: the backward of (3) is a row gather that the gradient launches
+        # of (2) do themselves
+        out = segment_matmul_sum(agg, h.rel_ptr, weight, h.out_graph)
+    return _root_bias(conv, out, x_r)
+
+
+def fast_rgcn_forward(conv, x, edge_index, edge_type: Optional[Tensor]) -> Tensor:
+    """``FastRGCNConv.forward`` (rgcn_conv.py:301-374): the same operator restricted to ``aggr`` in
+    ``add`` / ``sum`` / ``mean``; index inputs are looked up by SOURCE NODE id
+    (rgcn_conv.py:357-359)."""
+    assert conv.aggr in ['add', 'sum', 'mean']
+    x_l = x[0] if isinstance(x, tuple) else x
+    if x_l is not None and torch.is_floating_point(x_l):
+        return rgcn_forward(conv, x, edge_index, edge_type)
+    assert edge_type is not None
+    if conv.num_blocks is not None:
+        raise ValueError('Block-diagonal decomposition not supported '
+                         'for non-continuous input features.')
+    if x_l is None:
+        x_l = torch.arange(conv.in_channels_l, device=conv.weight.device)
+    x_r = x[1] if isinstance(x, tuple) else x_l
+    out = _index_inputs(conv, x_l, x_r, edge_index, edge_type, _composed_weight(conv),
+                        by_node_id=True)
+    return _root_bias(conv, out, x_r)
+
+
 class RGCNConv(MessagePassing):
     r"""Relational graph convolution
     ``x_i' = root x_i + sum_r mean_{j in N_r(i)} W_r x_j + b`` — constructor, parameters
@@ -135,7 +243,6 @@ class RGCNConv(MessagePassing):
             self.bias = Parameter(torch.empty(out_channels))
         else:
             self.register_parameter('bias', None)
-        self._handle_cache = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -145,77 +252,9 @@ class RGCNConv(MessagePassing):
         glorot(self.root)
         zeros(self.bias)
 
-    def _handle(self, edge_index: Tensor, edge_type: Tensor, n_src: int,
-                n_dst: int) -> RelationalHandle:
-        hit = self._handle_cache
-        if hit is not None:
-            r_ei, r_et, v_ei, v_et, size, handle = hit
-            if (r_ei() is edge_index and r_et() is edge_type and v_ei == edge_index._version
-                    and v_et == edge_type._version and size == (n_src, n_dst)):
-                return handle
-        handle = RelationalHandle(edge_index, edge_type, n_src, n_dst, self.num_relations)
-        self._handle_cache = (weakref.ref(edge_index), weakref.ref(edge_type),
-                              edge_index._version, edge_type._version, (n_src, n_dst), handle)
-        return handle
-
     def forward(self, x: Union[Optional[Tensor], Tuple[Optional[Tensor], Tensor]], edge_index,
                 edge_type: Optional[Tensor] = None) -> Tensor:
-        x_l = x[0] if isinstance(x, tuple) else x
-        if x_l is None:
-            x_l = torch.arange(self.in_channels_l, device=self.weight.device)
-        x_r = x[1] if isinstance(x, tuple) else x_l
-        assert edge_type is not None
-        if not torch.is_floating_point(x_r) and self.num_blocks is not None:
-            raise ValueError('Block-diagonal decomposition not supported '
-                             'for non-continuous input features.')
-        weight = self.weight
-        if self.num_bases is not None:  # basis decomposition (rgcn_conv.py:203-205)
-            weight = (self.comp @ weight.view(self.num_bases, -1)).view(
-                self.num_relations, self.in_channels_l, self.out_channels)
-
-        if not torch.is_floating_point(x_l):
-            # node-index inputs: the per-relation embedding lookup weight[r, x_j]
-            out = self._index_inputs(x_l, x_r, edge_index, edge_type, weight)
-        else:
-            n_src, n_dst = x_l.size(0), x_r.size(0)
-            ei = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
-            h = self._handle(ei, edge_type, n_src, n_dst)
-            reduce = 'sum' if self.aggr == 'add' else self.aggr
-            # (1) per-(relation, destination) neighbourhood reduce at the input width
-            agg = SpmmFunction.apply(x_l, None, h.pair_graph, reduce, 'coo')  # [S, F_in]
-            # (2) relation-segmented transform (block b of a pair row times weight[r, b]: column
-            # blocks in place, one launch) and (3) the sum of the pair rows of every destination,
-            # as one autograd node: the backward of (3) is a row gather that the gradient launches
-            # of (2) do themselves
-            out = segment_matmul_sum(agg, h.rel_ptr, weight, h.out_graph)
-
-        root = self.root
-        if root is not None:
-            if not torch.is_floating_point(x_r):
-                out = out + root[x_r]
-            else:
-                out = out + linear(x_r, root.t())
-        fa = requested_activation(self)  # (BasicGNN-style ReLU stacks: bias + ReLU in one pass)
-        if fa is not None or (self.bias is not None and out.is_cuda):
-            return bias_act(out, self.bias, fa == 'relu')
-        if self.bias is not None:
-            out = out + self.bias
-        return out
-
-    def _index_inputs(self, x_l, x_r, edge_index, edge_type, weight, by_node_id=False):
-        """Node-index ("featureless") inputs, rgcn_conv.py:262-268: the message of edge (j, i, r)
-        is the embedding row ``weight[r, x_l[j]]``.  One differentiable row gather builds all
-        messages, one SpMM reduces them per (relation, destination) pair and one sums the pairs
-        of every destination — instead of one masked propagate per relation."""
-        ei = edge_index.edge_index if isinstance(edge_index, EdgeIndex) else edge_index
-        n_src, n_dst = x_l.size(0), x_r.size(0)
-        look = ei[0] if by_node_id else x_l[ei[0]]
-        rows = edge_type.to(torch.int64) * weight.size(1) + look.to(torch.int64)
-        msg = GatherFunction.apply(weight.reshape(-1, self.out_channels), rows, True)
-        h = self._handle(ei, edge_type, n_src, n_dst)
-        reduce = 'sum' if self.aggr == 'add' else self.aggr
-        per_pair = SpmmFunction.apply(msg, None, h.edge_graph, reduce, 'coo')
-        return SpmmFunction.apply(per_pair, None, h.out_graph, 'sum', 'coo')
+        return rgcn_forward(self, x, edge_index, edge_type)
 
     def message(self, x_j: Tensor) -> Tensor:
         return x_j
@@ -239,28 +278,4 @@ class FastRGCNConv(RGCNConv):
     ``in_channels == num_nodes``."""
 
     def forward(self, x, edge_index, edge_type: Optional[Tensor] = None) -> Tensor:
-        assert self.aggr in ['add', 'sum', 'mean']
-        x_l = x[0] if isinstance(x, tuple) else x
-        if x_l is not None and torch.is_floating_point(x_l):
-            return super().forward(x, edge_index, edge_type)
-        assert edge_type is not None
-        if self.num_blocks is not None:
-            raise ValueError('Block-diagonal decomposition not supported '
-                             'for non-continuous input features.')
-        if x_l is None:
-            x_l = torch.arange(self.in_channels_l, device=self.weight.device)
-        x_r = x[1] if isinstance(x, tuple) else x_l
-        weight = self.weight
-        if self.num_bases is not None:
-            weight = (self.comp @ weight.view(self.num_bases, -1)).view(
-                self.num_relations, self.in_channels_l, self.out_channels)
-        out = self._index_inputs(x_l, x_r, edge_index, edge_type, weight, by_node_id=True)
-        if self.root is not None:
-            out = out + (self.root[x_r] if not torch.is_floating_point(x_r)
-                         else linear(x_r, self.root.t()))
-        fa = requested_activation(self)  # (BasicGNN-style ReLU stacks: bias + ReLU in one pass)
-        if fa is not None or (self.bias is not None and out.is_cuda):
-            return bias_act(out, self.bias, fa == 'relu')
-        if self.bias is not None:
-            out = out + self.bias
-        return out
+        return fast_rgcn_forward(self, x, edge_index, edge_type)

@@ -71,6 +71,35 @@ class Linear(torch.nn.Module):
                 f'bias={self.bias is not None})')
 
 
+def hetero_linear_forward(mod, x: Tensor, type_vec: Tensor) -> Tensor:
+    """``HeteroLinear.forward`` (nn/dense/linear.py:287-329): sort the rows by type (stable HIP
+    radix sort) unless ``is_sorted``, ONE grouped fp32-MFMA GEMM (``segment_matmul``), the per-type
+    bias, the original order restored.  ``mod``: this package's layer or the reference's (same
+    parameter names and shapes, linear.py:213-246) through ``backend.install()``."""
+    from ... import _native
+    from ..._functions import GatherFunction
+    from ...utils import segment_matmul
+    perm = None
+    if type_vec.numel() > 0:
+        # (the grouped GEMM reads the segment pointer on the host anyway: one more tiny sync)
+        lo, hi = _native.index_minmax(type_vec)
+        if lo < 0 or hi >= mod.num_types:
+            raise IndexError(f"'type_vec' must lie in [0, {mod.num_types}) "
+                             f"(got values in [{lo}, {hi}])")
+    if not mod.is_sorted:
+        type_vec, perm = _native.index_sort(type_vec, max_value=mod.num_types)
+        x = GatherFunction.apply(x, perm, False)
+    type_ptr = _native.index2ptr(type_vec, mod.num_types)
+    out = segment_matmul(x, type_ptr, mod.weight)
+    if mod.bias is not None:
+        out = out + GatherFunction.apply(mod.bias, type_vec, False)
+    if perm is not None:  # restore the original order
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        out = GatherFunction.apply(out, inv, False)
+    return out
+
+
 class HeteroLinear(torch.nn.Module):
     r"""One linear map per node/edge type: ``out[k] = x[k] @ W[type_vec[k]] + b[type_vec[k]]`` —
     constructor, parameters (``weight [T, in, out]``, ``bias [T, out]``) and forward of
@@ -117,28 +146,7 @@ class HeteroLinear(torch.nn.Module):
                 raise RuntimeError(f"Bias initializer '{self.bias_initializer}' not supported")
 
     def forward(self, x: Tensor, type_vec: Tensor) -> Tensor:
-        from ... import _native
-        from ..._functions import GatherFunction
-        from ...utils import segment_matmul
-        perm = None
-        if type_vec.numel() > 0:
-            # (the grouped GEMM reads the segment pointer on the host anyway: one more tiny sync)
-            lo, hi = _native.index_minmax(type_vec)
-            if lo < 0 or hi >= self.num_types:
-                raise IndexError(f"'type_vec' must lie in [0, {self.num_types}) "
-                                 f"(got values in [{lo}, {hi}])")
-        if not self.is_sorted:
-            type_vec, perm = _native.index_sort(type_vec, max_value=self.num_types)
-            x = GatherFunction.apply(x, perm, False)
-        type_ptr = _native.index2ptr(type_vec, self.num_types)
-        out = segment_matmul(x, type_ptr, self.weight)
-        if self.bias is not None:
-            out = out + GatherFunction.apply(self.bias, type_vec, False)
-        if perm is not None:  # restore the original order
-            inv = torch.empty_like(perm)
-            inv[perm] = torch.arange(perm.numel(), device=perm.device)
-            out = GatherFunction.apply(out, inv, False)
-        return out
+        return hetero_linear_forward(self, x, type_vec)
 
     def __repr__(self) -> str:
         return (f'{self.__class__.__name__}({self.in_channels}, {self.out_channels}, '

@@ -198,7 +198,8 @@ def test_fused_propagate_glue_matches_the_reference(installed, oracle_kernels):
         (GATConv(8, 4, heads=2, concat=False), (x, ei), {}),
     ]
     for conv, args, kw in cases:
-        before = oracle_kernels['spmm']
+        conv.fuse_attention = False  # (GATConv: keep the propagate glue under test here; the
+        before = oracle_kernels['spmm']  # one-node attention route only exists on the device)
         out = conv(*args, **kw)
         assert oracle_kernels['spmm'] == before + 1, f'{conv}: fused route not taken'
         ref = _reference_result(installed, lambda: conv(*args, **kw))
@@ -266,3 +267,60 @@ def test_oracle_segment_logsumexp_matches_the_reference():
         (ref * w).sum().backward()
         (got * w).sum().backward()
         assert torch.allclose(b.grad, a.grad, atol=1e-6)
+
+
+def test_round6_bindings_step_aside_on_the_cpu_and_are_restored(installed):
+    """RGCNConv / FastRGCNConv / HeteroLinear / GATConv forwards, `MessagePassing._index_select`
+    and the `pyg_lib` name of seam S2: bound by install(), the reference's own code for CPU
+    tensors (also for layers built BEFORE install() and for the reference's EdgeIndex), restored
+    by uninstall()."""
+    import torch_geometric.nn.conv.rgcn_conv as rgcn_mod
+    import torch_geometric.nn.dense.linear as lin_mod
+    from torch_geometric import EdgeIndex
+    from torch_geometric.nn import (FastRGCNConv, GATConv, GCNConv, HeteroLinear, MessagePassing,
+                                    RGCNConv, SAGEConv)
+    installed.uninstall()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(20, 8, generator=g)
+    ei = torch.randint(0, 20, (2, 60), generator=g)
+    et = torch.randint(0, 3, (60, ), generator=g)
+    tv = torch.randint(0, 3, (20, ), generator=g)
+    adj = EdgeIndex(ei, sparse_size=(20, 20)).sort_by('col').values
+    mods = [(RGCNConv(8, 4, 3), (x, ei, et)), (FastRGCNConv(8, 4, 3, num_bases=2), (x, ei, et)),
+            (RGCNConv(8, 4, 3, num_blocks=2), (x, ei, et)), (GATConv(8, 4, heads=2), (x, ei)),
+            (HeteroLinear(8, 4, 3), (x, tv)), (GCNConv(8, 16, aggr='max'), (x, ei)),
+            (SAGEConv(8, 4), (x, adj)), (GCNConv(8, 4), (x, adj)), (GATConv(8, 4), (x, adj))]
+    refs = [m(*a) for m, a in mods]
+    assert not hasattr(RGCNConv.forward, '__wrapped__')
+    installed.install()
+    for cls in (RGCNConv, FastRGCNConv, HeteroLinear, GATConv):
+        assert hasattr(cls.forward, '__wrapped__'), cls
+    assert hasattr(MessagePassing._index_select, '__wrapped__')
+    assert rgcn_mod.pyg_lib is lin_mod.pyg_lib and hasattr(rgcn_mod.pyg_lib.ops, 'segment_matmul')
+    with pytest.raises(NotImplementedError):  # no host computation behind the name
+        rgcn_mod.pyg_lib.ops.segment_matmul(x, torch.tensor([0, 20]), torch.randn(1, 8, 4))
+    for (m, a), r in zip(mods, refs):
+        assert torch.allclose(m(*a), r, atol=1e-6), type(m).__name__
+    installed.uninstall()
+    assert not hasattr(RGCNConv.forward, '__wrapped__')
+    assert not hasattr(MessagePassing._index_select, '__wrapped__')
+    assert rgcn_mod.pyg_lib is object or not hasattr(rgcn_mod.pyg_lib, 'ops') \
+        or rgcn_mod.pyg_lib.__name__ == 'pyg_lib'
+    installed.install()
+
+
+def test_linear_message_flow_guard():
+    """aggregate-before-transform only for linear aggregations with the stock message."""
+    from pytorch_geometric_amd.nn.conv.gcn_conv import GCNConv, linear_message_flow
+
+    class Squared(GCNConv):
+        def message(self, x_j, edge_weight):
+            return x_j * x_j
+
+    assert linear_message_flow(GCNConv(4, 8), GCNConv)
+    assert linear_message_flow(GCNConv(4, 8, aggr='mean'), GCNConv)
+    assert not linear_message_flow(GCNConv(4, 8, aggr='max'), GCNConv)
+    assert not linear_message_flow(Squared(4, 8), GCNConv)
+    hooked = GCNConv(4, 8)
+    hooked.register_propagate_forward_pre_hook(lambda *a: None)
+    assert not linear_message_flow(hooked, GCNConv)

@@ -484,3 +484,411 @@ def test_reference_convs_accept_this_packages_edge_index_handle(pyg, installed, 
         assert_close(got[0], want[0], rtol=1e-5, atol=2e-5, what=f'{name} out')
         for a, b in zip(got[1] + got[2], want[1] + want[2]):
             assert_close_scaled(a, b, tol=2e-5, what=f'{name} grads')
+
+
+# ---- round 6: the rest of the drop-in boundary (VERDICT r5 "what's missing" 1-4) ----------------
+@pytest.fixture()
+def segmm_calls(monkeypatch):
+    """Counts the grouped-GEMM launches that reach the HIP library."""
+    from pytorch_geometric_amd import _native
+    rec = {'fwd': 0, 'wgrad': 0}
+    real, real_w = _native.segment_matmul, _native.segment_matmul_wgrad
+
+    def fwd(*a, **k):
+        rec['fwd'] += 1
+        return real(*a, **k)
+
+    def wgrad(*a, **k):
+        rec['wgrad'] += 1
+        return real_w(*a, **k)
+
+    monkeypatch.setattr(_native, 'segment_matmul', fwd)
+    monkeypatch.setattr(_native, 'segment_matmul_wgrad', wgrad)
+    return rec
+
+
+def _relational_graph(n, e, n_rel, seed):
+    g = gen(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    # a skewed relation histogram with empty relations (FB15k-237 has both)
+    et = (torch.rand(e, generator=g).pow(3) * (n_rel - 2)).long()
+    return g, ei, et
+
+
+def test_reference_rgcn_layers_run_the_segmented_schedule(pyg, installed, segmm_calls, dev):
+    """torch_geometric.nn.{RGCNConv, FastRGCNConv} + install(): the reference's own classes leave
+    their per-relation Python loop (rgcn_conv.py:243-282) for the sorted, segmented schedule — one
+    grouped GEMM forward, one per gradient — and return what the loop returns on the CPU: dense,
+    basis-decomposed and block-diagonal weights, mean / add / max, feature and node-index inputs,
+    (source, destination) feature pairs."""
+    from torch_geometric.nn import FastRGCNConv, RGCNConv
+    n, e, n_rel = 220, 5000, 13
+    g, ei, et = _relational_graph(n, e, n_rel, 41)
+    x = torch.randn(n, 24, generator=g)
+    torch.manual_seed(3)
+    cases = [
+        ('dense-mean', RGCNConv(24, 16, n_rel), (x, ei, et)),
+        ('dense-add', RGCNConv(24, 16, n_rel, aggr='add'), (x, ei, et)),
+        ('dense-max', RGCNConv(24, 16, n_rel, aggr='max'), (x, ei, et)),
+        ('bases', RGCNConv(24, 16, n_rel, num_bases=4), (x, ei, et)),
+        ('blocks', RGCNConv(24, 16, n_rel, num_blocks=4), (x, ei, et)),
+        ('no-root-no-bias', RGCNConv(24, 16, n_rel, root_weight=False, bias=False), (x, ei, et)),
+        ('fast-dense', FastRGCNConv(24, 16, n_rel), (x, ei, et)),
+        ('fast-blocks-add', FastRGCNConv(24, 16, n_rel, num_blocks=2, aggr='add'), (x, ei, et)),
+        ('fast-bases', FastRGCNConv(24, 16, n_rel, num_bases=3), (x, ei, et)),
+    ]
+    for name, conv, args in cases:
+        go = torch.randn(n, 16, generator=g)
+        ref_out, ref_gin, ref_gp = _fwd_bwd(conv, args, go)   # CPU: the reference's own loop
+        dconv = copy.deepcopy(conv).to(dev)
+        before = dict(segmm_calls)
+        out, gin, gp = _fwd_bwd(dconv, _to(dev, args), go)
+        assert segmm_calls['fwd'] - before['fwd'] == 2, (name, segmm_calls)   # forward + d input
+        assert segmm_calls['wgrad'] - before['wgrad'] == 1, (name, segmm_calls)
+        assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what=f'{name} out')
+        assert_close(gin[0], ref_gin[0], rtol=1e-5, atol=2e-5, what=f'{name} grad x')
+        for a, b in zip(gp, ref_gp):
+            assert_close_scaled(a, b, tol=2e-5, what=f'{name} grad param')
+    # node-index ("featureless") inputs: x = None -> one embedding row per (relation, node)
+    for name, conv in [('index', RGCNConv(n, 16, n_rel)), ('index-bases', RGCNConv(n, 16, n_rel, num_bases=3)),
+                       ('fast-index', FastRGCNConv(n, 16, n_rel, aggr='add'))]:
+        go = torch.randn(n, 16, generator=g)
+        ref_out, _, ref_gp = _fwd_bwd(conv, (None, ei, et), go)
+        dconv = copy.deepcopy(conv).to(dev)
+        out, _, gp = _fwd_bwd(dconv, (None, ei.to(dev), et.to(dev)), go)
+        assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what=f'{name} out')
+        for a, b in zip(gp, ref_gp):
+            assert_close_scaled(a, b, tol=2e-5, what=f'{name} grad param')
+    # (source, destination) pairs: a bipartite relation graph
+    n_dst = 90
+    ei2 = torch.stack([ei[0], ei[1] % n_dst])
+    xs, xd = torch.randn(n, 24, generator=g), torch.randn(n_dst, 10, generator=g)
+    conv = RGCNConv((24, 10), 16, n_rel)
+    go = torch.randn(n_dst, 16, generator=g)
+    ref_out, ref_gin, ref_gp = _fwd_bwd(conv, ((xs, xd), ei2, et), go)
+    dconv = copy.deepcopy(conv).to(dev)
+    before = segmm_calls['fwd']
+    out, _, gp = _fwd_bwd(dconv, ((xs.to(dev), xd.to(dev)), ei2.to(dev), et.to(dev)), go)
+    assert segmm_calls['fwd'] > before
+    assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what='bipartite out')
+    for a, b in zip(gp, ref_gp):
+        assert_close_scaled(a, b, tol=2e-5, what='bipartite grad param')
+    # a subclass that overrides `message` keeps the reference's loop (no grouped GEMM)
+
+    class Scaled(RGCNConv):
+        def message(self, x_j, edge_type_ptr):
+            return 2.0 * x_j
+
+    torch.manual_seed(4)
+    conv = Scaled(24, 16, 4)
+    et4 = et % 4
+    ref = conv(x, ei, et4).detach()
+    before = segmm_calls['fwd']
+    out = copy.deepcopy(conv).to(dev)(x.to(dev), ei.to(dev), et4.to(dev))
+    assert segmm_calls['fwd'] == before
+    assert_close(out, ref, rtol=1e-5, atol=2e-5, what='overridden message')
+
+
+def test_reference_hetero_linear_is_one_grouped_gemm(pyg, installed, segmm_calls, dev):
+    """torch_geometric.nn.HeteroLinear + install() (nn/dense/linear.py:287-329): the per-type
+    Python loop becomes sort -> one grouped GEMM -> restore, for sorted and unsorted type vectors
+    and with empty types; pinned against the reference's `forward_naive` route on the CPU."""
+    from torch_geometric.nn import HeteroLinear
+    g = gen(17)
+    n, n_types = 3000, 7
+    x = torch.randn(n, 20, generator=g)
+    tv = torch.randint(0, n_types - 1, (n, ), generator=g)   # the last type stays empty
+    go = torch.randn(n, 12, generator=g)
+    torch.manual_seed(5)
+    for name, mod, types in [('unsorted', HeteroLinear(20, 12, n_types), tv),
+                             ('sorted', HeteroLinear(20, 12, n_types, is_sorted=True),
+                              tv.sort().values),
+                             ('no-bias', HeteroLinear(20, 12, n_types, bias=False), tv)]:
+        ref_out, ref_gin, ref_gp = _fwd_bwd(mod, (x, types), go)
+        dmod = copy.deepcopy(mod).to(dev)
+        before = segmm_calls['fwd']
+        out, gin, gp = _fwd_bwd(dmod, (x.to(dev), types.to(dev)), go)
+        assert segmm_calls['fwd'] - before == 2, name
+        assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what=f'{name} out')
+        assert_close(gin[0], ref_gin[0], rtol=1e-5, atol=2e-5, what=f'{name} grad x')
+        for a, b in zip(gp, ref_gp):
+            assert_close_scaled(a, b, tol=2e-5, what=f'{name} grad param')
+    # seam S2 by name: the reference's two call sites resolve `pyg_lib.ops.segment_matmul` here
+    import torch_geometric.nn.conv.rgcn_conv as rgcn_mod
+    import torch_geometric.nn.dense.linear as lin_mod
+    ptr = torch.tensor([0, 5, 5, 40, 100])
+    w = torch.randn(4, 20, 6, generator=g)
+    want = torch.cat([x[ptr[i]:ptr[i + 1]] @ w[i] for i in range(4)])
+    for mod in (rgcn_mod, lin_mod):
+        got = mod.pyg_lib.ops.segment_matmul(x[:100].to(dev), ptr.to(dev), w.to(dev))
+        assert_close(got, want, rtol=1e-5, atol=2e-5, what='pyg_lib.ops.segment_matmul')
+    with pytest.raises(NotImplementedError):   # no host computation behind the name
+        rgcn_mod.pyg_lib.ops.segment_matmul(x[:100], ptr, w)
+
+
+def test_custom_message_passing_layer_gathers_through_the_hip_kernel(pyg, installed, dev):
+    """A user's MessagePassing subclass with `message(x_i, x_j, edge_attr)`: install() serves the
+    gather behind every `_i` / `_j` argument (`MessagePassing._index_select`,
+    message_passing.py:263-290) and the scatter behind the aggregation; out-of-range indices
+    raise the reference's IndexError texts."""
+    from torch_geometric.nn import MessagePassing
+
+    class EdgeConvLike(MessagePassing):
+        def __init__(self, aggr):
+            super().__init__(aggr=aggr)
+            self.lin = torch.nn.Linear(2 * 8 + 3, 8)
+
+        def forward(self, x, edge_index, edge_attr):
+            return self.propagate(edge_index, x=x, edge_attr=edge_attr)
+
+        def message(self, x_i, x_j, edge_attr):
+            return self.lin(torch.cat([x_i, x_j - x_i, edge_attr], dim=-1))
+
+    g = gen(8)
+    n, e = 400, 6000
+    x = torch.randn(n, 8, generator=g)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ea = torch.randn(e, 3, generator=g)
+    for aggr in ('add', 'max', 'mean'):
+        torch.manual_seed(1)
+        conv = EdgeConvLike(aggr)
+        go = torch.randn(n, 8, generator=g)
+        ref_out, ref_gin, ref_gp = _fwd_bwd(conv, (x, ei, ea), go)
+        dconv = copy.deepcopy(conv).to(dev)
+        out, gin, gp = _fwd_bwd(dconv, _to(dev, (x, ei, ea)), go)
+        assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what=f'{aggr} out')
+        for a, b in zip(gin, ref_gin):
+            assert_close(a, b, rtol=1e-5, atol=5e-5, what=f'{aggr} grad input')
+        for a, b in zip(gp, ref_gp):
+            assert_close_scaled(a, b, tol=2e-5, what=f'{aggr} grad param')
+
+    # the gather itself is this package's autograd node (and only for float32 device rows)
+    seen = []
+
+    class Probe(MessagePassing):
+        def forward(self, x, edge_index):
+            return self.propagate(edge_index, x=x)
+
+        def message(self, x_j):
+            seen.append(x_j.grad_fn.name() if x_j.grad_fn is not None else None)
+            return x_j
+
+    probe = Probe(aggr='add')
+    xd = x.to(dev).requires_grad_(True)
+    probe(xd, ei.to(dev))
+    probe(x.clone().requires_grad_(True), ei)
+    assert 'GatherFunction' in seen[0] and 'GatherFunction' not in seen[1], seen
+    installed.uninstall()
+    probe(xd, ei.to(dev))
+    installed.install()
+    assert 'GatherFunction' not in seen[2], seen
+
+    from pytorch_geometric_amd import _native
+    bad = ei.clone()
+    bad[0, 7] = n + 3
+    neg = ei.clone()
+    neg[1, 9] = -1
+    _native.INDEX_CHECK = 'sync'
+    try:
+        with pytest.raises(IndexError, match=f'larger than {n - 1}'):
+            probe(xd, bad.to(dev))
+        with pytest.raises(IndexError, match='negative indices'):
+            EdgeConvLike('add').to(dev)(xd, neg.to(dev), ea.to(dev))
+    finally:
+        _native.INDEX_CHECK = 'async'
+    # default mode: the flag arrives behind the launch (as the reference's device assert does)
+    # — at the next checked launch (the scatter of the same propagate, when the flag has already
+    # landed) or at check_index_errors() at the latest
+    with pytest.raises(IndexError, match=f'larger than {n - 1}'):
+        probe(xd, bad.to(dev))
+        _native.check_index_errors()
+
+
+def test_reference_edge_index_as_the_graph_argument(pyg, installed, launches, dev):
+    """The reference's own EdgeIndex (edge_index.py:173) handed to its own layers: SAGE / GCN /
+    GAT / GraphConv reach the fused kernels on the order and caches it carries — sorted by
+    destination: no sort for the forward; `fill_cache_()` done: no sort at all."""
+    from torch_geometric import EdgeIndex
+    from torch_geometric.nn import GATConv, GCNConv, GraphConv, GraphSAGE, SAGEConv
+    g = gen(23)
+    n, e = 350, 5000
+    x = torch.randn(n, 16, generator=g)
+    raw = torch.randint(0, n, (2, e), generator=g)
+    loops = (raw[0] == raw[1]).nonzero().view(-1)
+    raw[1, loops] = (raw[1, loops] + 1) % n
+    by_col = EdgeIndex(raw, sparse_size=(n, n)).sort_by('col').values
+    by_row = EdgeIndex(raw, sparse_size=(n, n)).sort_by('row').values
+    unsorted = EdgeIndex(raw, sparse_size=(n, n))
+    torch.manual_seed(6)
+    layers = [('sage', SAGEConv(16, 12)), ('sage-max', SAGEConv(16, 12, aggr='max')),
+              ('graphconv', GraphConv(16, 12)), ('gcn', GCNConv(16, 12)),
+              ('gcn-raw', GCNConv(16, 12, normalize=False)), ('gat', GATConv(16, 4, heads=2))]
+    for name, conv in layers:
+        go = torch.randn(n, conv(x, raw).size(1), generator=g)
+        for kind, adj in (('col', by_col), ('row', by_row), ('none', unsorted)):
+            want = _fwd_bwd(conv, (x, adj.as_tensor()), go)       # CPU, plain tensor
+            dconv = copy.deepcopy(conv).to(dev)
+            dadj = adj.to(dev)
+            assert type(dadj).__name__ == 'EdgeIndex' and dadj.is_cuda
+            before = len(launches['sink'])
+            got = _fwd_bwd(dconv, (x.to(dev), dadj), go)
+            assert len(launches['sink']) > before, f'{name}/{kind}: no SpMM launch'
+            assert_close(got[0], want[0], rtol=1e-5, atol=2e-5, what=f'{name}/{kind} out')
+            for a, b in zip(got[1] + got[2], want[1] + want[2]):
+                assert_close_scaled(a, b, tol=2e-5, what=f'{name}/{kind} grads')
+    # the one-kernel layer is reached with the reference's graph object too
+    dconv = copy.deepcopy(layers[0][1]).to(dev)
+    assert 'FusedSageStack' in dconv(x.to(dev), by_col.to(dev)).grad_fn.name()
+    # sort counts: destination-sorted input = no sort forward, one (by source) for the backward
+    from pytorch_geometric_amd import edge_index as own_ei
+    own_ei.clear_cache()
+    dadj, xd = by_col.to(dev), x.to(dev).requires_grad_(True)
+    conv = SAGEConv(16, 12, aggr='max').to(dev)    # (max: the propagate route, not the layer node)
+    s0 = launches['sorts']
+    out = conv(xd, dadj)
+    assert launches['sorts'] == s0, 'a destination-sorted EdgeIndex was sorted again'
+    out.sum().backward()
+    s1 = launches['sorts']
+    assert s1 - s0 <= 1
+    conv(xd, dadj).sum().backward()
+    assert launches['sorts'] == s1, 'the adopted handle was not found again'
+    # ... and with the reference's cache filled beforehand, none at all
+    own_ei.clear_cache()
+    dadj = by_col.to(dev)
+    dadj.fill_cache_()
+    s2 = launches['sorts']
+    conv(xd, dadj).sum().backward()
+    assert launches['sorts'] == s2, 'the cached transposed form of the EdgeIndex was not used'
+    ref = copy.deepcopy(conv).cpu()(x, by_col.as_tensor()).detach()
+    assert_close(conv(xd, dadj), ref, rtol=1e-5, atol=2e-5, what='seeded handle')
+    # the whole model
+    torch.manual_seed(7)
+    model = GraphSAGE(16, 32, num_layers=2, out_channels=5)
+    go = torch.randn(n, 5, generator=g)
+    want = _fwd_bwd(model, (x, raw), go)
+    got = _fwd_bwd(copy.deepcopy(model).to(dev), (x.to(dev), by_col.to(dev)), go)
+    assert_close(got[0], want[0], rtol=1e-5, atol=2e-5, what='GraphSAGE on EdgeIndex')
+    for a, b in zip(got[2], want[2]):
+        assert_close_scaled(a, b, tol=2e-5, what='GraphSAGE on EdgeIndex grads')
+
+
+def test_reference_gatconv_runs_the_fused_attention_node(pyg, installed, launches, dev):
+    """torch_geometric.nn.GATConv + install(): projection + ONE autograd node (node terms, edge
+    softmax, aggregation) when nothing in between is observable; dropout on the coefficients,
+    `return_attention_weights`, edge features or bipartite inputs keep the reference's own
+    sequence (whose pieces are served too)."""
+    from torch_geometric.nn import GAT, GATConv
+    g = gen(31)
+    n, e = 500, 7000
+    x = torch.randn(n, 16, generator=g)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    loops = (ei[0] == ei[1]).nonzero().view(-1)
+    ei[1, loops] = (ei[1, loops] + 1) % n
+    torch.manual_seed(8)
+
+    def nodes(out):
+        seen, todo = set(), [out.grad_fn]
+        while todo:
+            f = todo.pop()
+            if f is None or f in seen:
+                continue
+            seen.add(f)
+            todo += [nf for nf, _ in f.next_functions]
+        return {f.name() for f in seen}
+
+    for name, conv in [('concat', GATConv(16, 8, heads=4)),
+                       ('mean-heads', GATConv(16, 8, heads=3, concat=False)),
+                       ('residual', GATConv(16, 8, heads=2, residual=True)),
+                       ('no-loops-no-bias', GATConv(16, 8, heads=2, add_self_loops=False,
+                                                    bias=False))]:
+        go = torch.randn(n, conv(x, ei).size(1), generator=g)
+        want = _fwd_bwd(conv, (x, ei), go)
+        dconv = copy.deepcopy(conv).to(dev)
+        out = dconv(x.to(dev), ei.to(dev))
+        assert any('GatAttend' in f for f in nodes(out)), (name, nodes(out))
+        got = _fwd_bwd(dconv, (x.to(dev), ei.to(dev)), go)
+        assert_close(got[0], want[0], rtol=1e-5, atol=2e-5, what=f'{name} out')
+        for a, b in zip(got[1] + got[2], want[1] + want[2]):
+            assert_close_scaled(a, b, tol=2e-5, what=f'{name} grads')
+    # observable coefficients: the reference's own sequence, same numbers
+    conv = GATConv(16, 8, heads=2)
+    dconv = copy.deepcopy(conv).to(dev)
+    ref_out, (ref_ei, ref_alpha) = conv(x, ei, return_attention_weights=True)
+    out, (d_ei, alpha) = dconv(x.to(dev), ei.to(dev), return_attention_weights=True)
+    assert not any('GatAttend' in f for f in nodes(out))
+    assert torch.equal(d_ei.cpu(), ref_ei)
+    assert_close(out, ref_out, rtol=1e-5, atol=2e-5, what='with attention weights')
+    assert_close(alpha, ref_alpha, rtol=1e-5, atol=2e-5, what='attention weights')
+    conv = GATConv(16, 8, heads=2, dropout=0.5).to(dev)      # training: dropout is in effect
+    assert not any('GatAttend' in f for f in nodes(conv(x.to(dev), ei.to(dev))))
+    conv.eval()
+    assert any('GatAttend' in f for f in nodes(conv(x.to(dev).requires_grad_(True), ei.to(dev))))
+    # the reference's GAT model (BASELINE config 3's class) end to end
+    torch.manual_seed(9)
+    model = GAT(16, 32, num_layers=3, out_channels=6, heads=4)
+    go = torch.randn(n, 6, generator=g)
+    want = _fwd_bwd(model, (x, ei), go)
+    dmodel = copy.deepcopy(model).to(dev)
+    got = _fwd_bwd(dmodel, (x.to(dev), ei.to(dev)), go)
+    assert_close(got[0], want[0], rtol=1e-5, atol=2e-5, what='GAT out')
+    for a, b in zip(got[1] + got[2], want[1] + want[2]):
+        assert_close_scaled(a, b, tol=2e-5, what='GAT grads')
+
+
+def test_reference_gcnconv_keeps_its_order_for_nonlinear_aggregations(pyg, installed, launches,
+                                                                      dev):
+    """`A (X W) = (A X) W` only for linear aggregations with the stock message.
+    GCNConv(16, 40, aggr='max') — input narrower than output — and a subclass overriding
+    `message` must transform first, as the reference does."""
+    from torch_geometric.nn import GCNConv
+    g = gen(19)
+    n, e = 300, 4000
+    x = torch.randn(n, 16, generator=g)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    loops = (ei[0] == ei[1]).nonzero().view(-1)
+    ei[1, loops] = (ei[1, loops] + 1) % n
+
+    class Squared(GCNConv):
+        def message(self, x_j, edge_weight):
+            return edge_weight.view(-1, 1) * x_j * x_j
+
+    torch.manual_seed(2)
+    for name, conv in [('max', GCNConv(16, 40, aggr='max')), ('min', GCNConv(16, 40, aggr='min')),
+                       ('mean', GCNConv(16, 40, aggr='mean')), ('squared', Squared(16, 40))]:
+        go = torch.randn(n, 40, generator=g)
+        want = _fwd_bwd(conv, (x, ei), go)
+        got = _fwd_bwd(copy.deepcopy(conv).to(dev), (x.to(dev), ei.to(dev)), go)
+        assert_close(got[0], want[0], rtol=1e-5, atol=2e-5, what=f'{name} out')
+        for a, b in zip(got[1] + got[2], want[1] + want[2]):
+            assert_close_scaled(a, b, tol=2e-5, what=f'{name} grads')
+    # the same guard on this package's own layer
+    import pytorch_geometric_amd.nn as own
+    torch.manual_seed(2)
+    ref = GCNConv(16, 40, aggr='max')
+    mine = own.GCNConv(16, 40, aggr='max').to(dev)
+    mine.load_state_dict(ref.state_dict())
+    assert_close(mine(x.to(dev), ei.to(dev)), ref(x, ei).detach(), rtol=1e-5, atol=2e-5,
+                 what='own GCNConv aggr=max')
+
+
+def test_layers_built_before_install_keep_working(pyg, dev):
+    """A layer object constructed BEFORE install() has left the generated `propagate(self,
+    edge_index, x, ..., size=None)` on its class (propagate.jinja:19); the wrapper must hand
+    `size` over by keyword."""
+    from pytorch_geometric_amd import backend
+    from torch_geometric.nn import GATConv, SAGEConv
+    backend.uninstall()
+    g = gen(3)
+    x = torch.randn(50, 8, generator=g)
+    ei = torch.randint(0, 50, (2, 300), generator=g)
+    torch.manual_seed(0)
+    convs = [SAGEConv(8, 4, aggr='max'), GATConv(8, 4, heads=2, dropout=0.0)]
+    refs = [c(x, ei).detach() for c in convs]
+    backend.install()
+    try:
+        for c, r in zip(convs, refs):
+            assert_close(c(x, ei), r, rtol=1e-6, atol=1e-6, what='CPU after install')
+            assert_close(copy.deepcopy(c).to(dev)(x.to(dev), ei.to(dev)), r, rtol=1e-5,
+                         atol=2e-5, what='device after install')
+    finally:
+        backend.uninstall()
