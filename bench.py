@@ -457,6 +457,14 @@ def parity_cached(dev):
     return {k: (float(f'{v:.3e}') if isinstance(v, float) else v) for k, v in errs.items()}
 
 
+def _print_line(result: dict) -> None:
+    print(json.dumps(result), flush=True)
+
+
+# where run_minibatch() hands its result line (bench_configs.config4 collects it instead)
+EMIT = _print_line
+
+
 def run_minibatch(args, rank, local_rank, world, dev):
     """BASELINE config 4 (informational second mode; the default mode is the metric's config):
     GraphSAGE(128, 256, 3 layers, 172 classes) + NeighborLoader [15, 10, 5], batch 1024 per rank,
@@ -555,7 +563,7 @@ def run_minibatch(args, rank, local_rank, world, dev):
         t[0] = tm[0]
     elapsed, total_edges = float(t[0]), float(t[1])
     if rank == 0:
-        print(json.dumps({
+        EMIT({
             'metric': 'edges/sec (fwd+bwd) 3-layer SAGE + NeighborLoader [15,10,5], '
                       'papers100M shape (BASELINE config 4, informational)',
             'value': total_edges / elapsed, 'unit': 'edges/s',
@@ -577,7 +585,7 @@ def run_minibatch(args, rank, local_rank, world, dev):
                                                 'ranks': [round(v, 3) for v in per_rank_ms]},
                        'graph_build_s': round(t_gen, 1),
                        'hbm_gb_allocated': round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
-                       'gemm': gemm_desc(False)}}), flush=True)
+                       'gemm': gemm_desc(False)}})
 
 
 def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, scale, N, E, t_gen):
@@ -735,7 +743,7 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
         caps = [B]
         for k in fan:
             caps.append(caps[-1] * k)
-        print(json.dumps({
+        EMIT({
             'metric': 'edges/sec (fwd+bwd) 3-layer SAGE + NeighborLoader [15,10,5], '
                       'papers100M shape (BASELINE config 4, informational)',
             'value': total_edges / elapsed, 'unit': 'edges/s',
@@ -773,7 +781,7 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
                                    'bytes over the step time: the step is latency-bound, not '
                                    'bandwidth-bound)',
                          'algorithmic_bytes_per_batch': round(
-                             (agg_bytes + gather_bytes) / args.steps)}}), flush=True)
+                             (agg_bytes + gather_bytes) / args.steps)}})
 
 
 def gemm_desc(tuned: bool) -> str:
@@ -934,6 +942,9 @@ def main():
     ap.add_argument('--no-side-figures', action='store_true',
                     help='full-batch mode: skip the short re-timings printed beside the headline '
                          '(exact fp32 instruction, dense loss)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the other_configs block (BASELINE configs 1/3/4/5 and the '
+                         'reference-class headline, bench_configs.py; after the timed region)')
     ap.add_argument('--no-live-pmc', action='store_true',
                     help='full-batch mode: do not run the two rocprofv3 --pmc passes that give '
                          'roofline.traffic for THIS run (the committed profile serves instead)')
@@ -1254,6 +1265,12 @@ def main():
             # (the leg an N > 1 line carries instead, run here too so that it is exercised on
             # every round's single-GPU box)
             result['parity_cached_sample'] = parity_cached(dev)
+            if not args.no_other_configs and not args.no_side_figures:
+                # BASELINE configs 1 / 3 / 4 / 5 and this step written with the REFERENCE's
+                # GraphSAGE + install(), after the timed region (bench_configs.py); scalars only
+                import bench_configs
+                result['other_configs'] = bench_configs.run(
+                    dev, headline=(x, ei, train_idx, y_train, num_classes, ms_per_step))
         elif not args.no_cpu_baseline:
             # N > 1: no live CPU run of the reference (rank 0 only, the other ranks wait at the
             # barrier below); the GPU leg against the committed reference sample

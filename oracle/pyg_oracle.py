@@ -410,6 +410,45 @@ def rgcn_conv_blocks(x, edge_index, edge_type, weight, root, bias, aggr='mean'):
     return out if bias is None else out + bias
 
 
+def rgcn_conv_blocks_pairs(x, edge_index, edge_type, weight, root, bias, aggr='mean'):
+    """:func:`rgcn_conv_blocks` (nn/conv/rgcn_conv.py:207-220) evaluated only on the rows that can
+    be non-zero.  The reference multiplies, per relation r, ALL N rows of ``h = propagate_r(x)`` by
+    ``weight[r]`` — N x R x B block products, 0.7 TFLOP per layer at the FB15k-237 shape, 474
+    saved [N, F] tensors for the backward — although ``h`` is zero outside the destinations that
+    relation r reaches.  Here the same sums are taken over the (relation, destination) PAIRS that
+    exist: ``out[i] = sum_{r: (r,i) exists} aggr_{j in N_r(i)} x_j @ weight[r]``.  Identical math
+    (a zero row times a matrix is a zero row), seconds instead of minutes at the timed shape of
+    BASELINE config 5; pinned against the golden vectors generated by the reference itself and
+    against :func:`rgcn_conv_blocks` in tests/test_oracle_golden.py.  ``weight``: [R, B, K, N]
+    (or [R, K, N] for the dense branch, rgcn_conv.py:243-282)."""
+    if weight.dim() == 3:
+        weight = weight.unsqueeze(1)
+    N = x.size(0)
+    R, B, K, Nn = weight.shape
+    key = edge_type.long() * N + edge_index[1].long()
+    uniq, inv = torch.unique(key, return_inverse=True)   # ascending: grouped by relation
+    S = uniq.numel()
+    agg = scatter(x.index_select(0, edge_index[0]), inv, 0, S, 'sum' if aggr == 'add' else aggr)
+    rel, dst = uniq // N, uniq % N
+    ptr = index2ptr(rel, R).tolist()
+    # (split, not slices: one concatenation in the backward instead of one [S, F] zero-filled
+    # tensor per relation)
+    chunks = torch.split(agg, [ptr[r + 1] - ptr[r] for r in range(R)])
+    mats = weight.unbind(0)   # (likewise: one stack in the backward)
+    parts = []
+    for r in range(R):
+        if chunks[r].size(0) == 0:
+            continue
+        h = chunks[r].reshape(-1, B, K)
+        parts.append(torch.einsum('abc,bcd->abd', h, mats[r]).reshape(-1, B * Nn))
+    out = x.new_zeros(N, B * Nn)
+    if parts:
+        out = out.index_add(0, dst, torch.cat(parts))
+    if root is not None:
+        out = out + x @ root
+    return out if bias is None else out + bias
+
+
 def rgcn_weight_from_bases(comp, bases, in_channels, out_channels):
     """nn/conv/rgcn_conv.py:203-205: weight[r] = sum_b comp[r, b] * bases[b]."""
     return (comp @ bases.view(bases.size(0), -1)).view(comp.size(0), in_channels, out_channels)

@@ -268,7 +268,7 @@ def _sweep(old: Callable, new: Callable) -> List[Tuple[Any, str, Callable]]:
 def _fused_propagate(conv, edge_index, size, kwargs):
     """Returns the aggregated tensor, or NotImplemented when this call must take the reference
     path."""
-    from ._functions import SpmmFunction
+    from ._functions import spmm_node
     from .edge_index import EdgeIndex as Handle, as_edge_index
     # `fuse` is False for layers without `message_and_aggregate` (GATConv,
     # message_passing.py:154); for the others it stays the user's off switch
@@ -339,7 +339,9 @@ def _fused_propagate(conv, edge_index, size, kwargs):
     reduce = 'sum' if aggr == 'add' else aggr
     if weight is not None and weight.dim() == 1 and x_src.dim() > 2:
         return NotImplemented
-    out = SpmmFunction.apply(x_src, weight, graph, reduce, order)
+    # (sum / mean with plain operands: the C++ autograd node — an eager, launch-bound step such as
+    # GCN on the Cora shape spends most of its host time in the Python Functions)
+    out = spmm_node(x_src, weight, graph, reduce, order)
     return conv.update(out)
 
 
@@ -844,12 +846,12 @@ def _wrap_linear_forward(cls):
     orig = cls.forward
 
     def forward(self, x):
-        from ._functions import LinearFunction, own_linear_eligible
+        from ._functions import linear, own_linear_eligible
         w = self.weight
         if (_enabled() and isinstance(x, Tensor)
                 and not isinstance(w, torch.nn.parameter.UninitializedParameter)
                 and w.device == x.device and own_linear_eligible(x, w)):
-            return LinearFunction.apply(x, w, self.bias)
+            return linear(x, w, self.bias)   # (the C++ node for plain operands)
         return orig(self, x)
 
     forward.__wrapped__ = orig

@@ -746,3 +746,67 @@ def test_segment_matmul_row_index_operands(dev, mode, K, N, blocks):
                      what='grad weights')
     finally:
         _native.set_gemm_mode(prev)
+
+
+def test_split_nonfinite_matches_reference(dev):
+    """Non-finite operands.  The reference's `F.linear` gives `w * Inf = +-Inf`
+    (and NaN for `0 * Inf`, `Inf - Inf`, NaN operands).  The default arithmetic — every fp32 operand
+    as x1 + x2 + x3 in bf16 — cannot represent Inf that way (`Inf - bf16(Inf)` is NaN), so an
+    output that DEPENDS on a non-finite operand comes out NaN where the reference says +-Inf.
+    What is guaranteed, and checked here against `F.linear` on the CPU:
+      * outputs that do not depend on a non-finite operand are unaffected (same values as a clean
+        run) — a poisoned row / column never spreads;
+      * every output the reference makes non-finite is non-finite here too (NaN or the same Inf):
+        `isfinite` masks agree exactly, so `torch.isfinite(out).all()` guards behave the same;
+      * `set_gemm_mode('fp32')` (the exact `v_mfma_f32_32x32x2_f32` kernels) reproduces the
+        reference's class element by element: +-Inf where it says +-Inf, NaN where it says NaN."""
+    from pytorch_geometric_amd import _native
+    g = gen(77)
+    M, K, N = 3000, 96, 40
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    go = torch.randn(M, N, generator=g)
+    clean = torch.nn.functional.linear(x, w, b)
+    xb = x.clone()
+    xb[5, 3] = float('inf')
+    xb[17, 0] = float('-inf')
+    xb[40, 9] = float('nan')
+    xb[99, 1], xb[99, 2] = float('inf'), float('-inf')       # Inf - Inf in one row
+    wb = w.clone()
+    wb[7, 11] = float('inf')
+    wb[8, 3] = 0.0                                            # 0 * Inf for row 5
+    ref = torch.nn.functional.linear(xb, wb, b)
+    ref_dg = go @ wb
+    ref_wg = go.t() @ xb
+    for mode in ('split', 'fp32'):
+        prev = _native.set_gemm_mode(mode)
+        try:
+            out = _native.linear_forward(xb.to(dev), wb.to(dev), b.to(dev)).cpu()
+            dg = _native.linear_dgrad(go.to(dev), wb.t().contiguous().to(dev)).cpu()
+            wg = _native.linear_wgrad(go.to(dev), xb.to(dev)).cpu()
+        finally:
+            _native.set_gemm_mode(prev)
+        for got, want, what in ((out, ref, 'forward'), (dg, ref_dg, 'dgrad'), (wg, ref_wg, 'wgrad')):
+            fin = torch.isfinite(want)
+            assert torch.equal(torch.isfinite(got), fin), f'{mode} {what}: finite masks differ'
+            assert_close(got[fin], want[fin], rtol=1e-5, atol=1e-4, what=f'{mode} {what} finite part')
+            if mode == 'fp32':   # the reference's class exactly
+                assert torch.equal(torch.isnan(got), torch.isnan(want)), f'{what}: NaN class'
+                inf = torch.isinf(want)
+                assert torch.equal(got[inf], want[inf]), f'{what}: signed infinities'
+        if mode == 'split':     # clean rows / columns are bit-identical to a clean run
+            ok_rows = torch.ones(M, dtype=torch.bool)
+            ok_rows[[5, 17, 40, 99]] = False
+            ok_cols = torch.ones(N, dtype=torch.bool)
+            ok_cols[7] = False
+            prev = _native.set_gemm_mode('split')
+            try:
+                base = _native.linear_forward(x.to(dev), w.to(dev), b.to(dev)).cpu()
+            finally:
+                _native.set_gemm_mode(prev)
+            # (column 8 of the clean run differs by the zeroed weight: compare the rest)
+            ok_cols8 = ok_cols.clone()
+            ok_cols8[8] = False
+            assert torch.equal(out[ok_rows][:, ok_cols8], base[ok_rows][:, ok_cols8])
+            assert_close(base, clean, rtol=1e-5, atol=1e-4, what='clean split run')

@@ -238,6 +238,25 @@ def test_fast_rgcn_and_index_inputs(golden, golden_rgcn):
     _check_layer(L['fast_add'], lambda x, w, r, b: O.rgcn_conv(x, ei, et, w, r, b, 'add'), names)
     _check_layer(L['fast_blocks'], lambda x, w, r, b: O.rgcn_conv_blocks(x, ei, et, w, r, b),
                  names)
+    # the pair-row evaluation used at BASELINE config 5's timed shape (tests/test_gpu_configs.py):
+    # against the reference's own results (dense and block weights, mean and add) ...
+    _check_layer(L['fast'], lambda x, w, r, b: O.rgcn_conv_blocks_pairs(x, ei, et, w, r, b), names)
+    _check_layer(L['fast_add'],
+                 lambda x, w, r, b: O.rgcn_conv_blocks_pairs(x, ei, et, w, r, b, 'add'), names)
+    _check_layer(L['fast_blocks'],
+                 lambda x, w, r, b: O.rgcn_conv_blocks_pairs(x, ei, et, w, r, b), names)
+    # ... and against the loop restatement, incl. max and relations without edges
+    g = torch.Generator().manual_seed(3)
+    n, R = 40, 9
+    ei2 = torch.randint(0, n, (2, 300), generator=g)
+    et2 = torch.randint(0, R - 2, (300, ), generator=g)
+    x2 = torch.randn(n, 12, generator=g, dtype=torch.float64)
+    w2 = torch.randn(R, 3, 4, 5, generator=g, dtype=torch.float64)
+    r2 = torch.randn(12, 15, generator=g, dtype=torch.float64)
+    for aggr in ('mean', 'add', 'max'):
+        close(O.rgcn_conv_blocks_pairs(x2, ei2, et2, w2, r2, None, aggr),
+              O.rgcn_conv_blocks(x2.float(), ei2, et2, w2.float(), r2.float(), None,
+                                 aggr).double(), 1e-5)
     _check_layer(L['fast_bases'],
                  lambda x, w, c, r, b: O.rgcn_conv(
                      x, ei, et, O.rgcn_weight_from_bases(c, w, 16, 10), r, b),
