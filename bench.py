@@ -175,7 +175,7 @@ def measured_copy_bandwidth(dev, n_bytes: int = 1 << 30, reps: int = 5) -> dict:
         return 2.0 * n_bytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     def probe(variant, per_cu):
-        rc = _lib.load().pygamd_lab_copy(src.data_ptr(), dst.data_ptr(), n_bytes, variant, per_cu,
+        rc = _lib.load_lab().pygamd_lab_copy(src.data_ptr(), dst.data_ptr(), n_bytes, variant, per_cu,
                                         stream)
         if rc:
             raise RuntimeError(f'pygamd_lab_copy: {rc}')

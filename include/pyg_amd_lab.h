@@ -1,8 +1,11 @@
-/* pyg_amd_lab.h — LABORATORY entry points of libpyg_amd.so.  NOT part of the drop-in boundary
- * (include/pyg_amd.h): schedules that were measured and not adopted, and the timing probes of the
- * production kernels, kept runnable for scripts/fused_probe.py and for the parity tests that pin
- * them to the production results.  Nothing a maintainer binds lives here; signatures may change
- * without an ABI bump.                                                                           */
+/* pyg_amd_lab.h — LABORATORY entry points, exported by libpyg_amd_lab.so ONLY (a second build of
+ * the library's sources plus csrc/sage_fused_lab.hip and the weight-gradient probes of gemm.hip
+ * under -DPYGAMD_LAB; pytorch_geometric_amd/_build.py).  NOT part of the drop-in boundary
+ * (include/pyg_amd.h) and not in the product library libpyg_amd.so: schedules that were measured
+ * and not adopted, and the timing probes of the production kernels, kept runnable for scripts/,
+ * for the parity tests that pin them to the production results and for the copy-rate side figure
+ * of bench.py.  Nothing a maintainer binds lives here; signatures may change without an ABI
+ * bump.                                                                                          */
 #ifndef PYG_AMD_LAB_H
 #define PYG_AMD_LAB_H
 #include "pyg_amd.h"

@@ -44,10 +44,12 @@ def check_index_errors() -> None:
 
 
 def build(force: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into ``lib/libpyg_amd.so`` and the compiled PyTorch
-    binding (csrc/torch_binding.cpp) into ``lib/libpyg_amd_torch.so`` (both in-tree)."""
+    """Compile the HIP sources for gfx950 into ``lib/libpyg_amd.so``, the compiled PyTorch binding
+    (csrc/torch_binding.cpp) into ``lib/libpyg_amd_torch.so`` and the laboratory build
+    (``lib/libpyg_amd_lab.so``: scripts / tests / bench side figure only) — all in-tree."""
     path = _build.build_library(force=force)
     _build.build_torch_binding(force=force)
+    _build.build_lab_library(force=force)
     return path
 
 

@@ -1,10 +1,15 @@
-"""In-tree build of the C-ABI library ``lib/libpyg_amd.so`` (hipcc, gfx950 only) and of the compiled
-PyTorch binding ``lib/libpyg_amd_torch.so`` (csrc/torch_binding.cpp: host code only, links the C-ABI
-library and libtorch).
+"""In-tree build of the C-ABI library ``lib/libpyg_amd.so`` (hipcc, gfx950 only), of its laboratory
+twin ``lib/libpyg_amd_lab.so`` and of the compiled PyTorch binding ``lib/libpyg_amd_torch.so``
+(csrc/torch_binding.cpp: host code only, links the C-ABI library and libtorch).
 
-The C-ABI library is plain HIP + rocPRIM headers; it does not link against torch.  Objects go to
-``build/`` (git-ignored), the shared objects stay in-tree next to the package so that they travel
-with a repo snapshot to a GPU box (``*.so`` is git-ignored but not gpurun-ignored).
+The C-ABI library is hand-written HIP and nothing else: no rocPRIM / hipCUB / rocBLAS / hipBLASLt
+and no torch in it (the radix sort, the scans and the GEMMs are its own kernels).  The laboratory
+library is the same objects plus ``csrc/sage_fused_lab.hip`` and ``gemm.hip`` compiled with
+``-DPYGAMD_LAB=1`` (schedules measured and not adopted, timing probes: include/pyg_amd_lab.h); it is
+loaded by scripts/, by the tests that pin those schedules to the production results and by the
+copy-rate side figure of bench.py — never by the product path.  Objects go to ``build/``
+(git-ignored), the shared objects stay in-tree next to the package so that they travel with a repo
+snapshot to a GPU box (``*.so`` is git-ignored but not gpurun-ignored).
 """
 import os
 import shutil
@@ -16,9 +21,12 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, 'csrc')
 LIB_DIR = os.path.join(PKG_DIR, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpyg_amd.so')
+LAB_LIB_PATH = os.path.join(LIB_DIR, 'libpyg_amd_lab.so')
 BUILD_DIR = os.path.join(os.path.dirname(PKG_DIR), 'build', 'pyg_amd')
 SOURCES = ['capi.hip', 'graph.hip', 'spmm.hip', 'scatter.hip', 'softmax.hip', 'segmm.hip',
-           'sample.hip', 'minibatch.hip', 'gemm.hip', 'sage_fused.hip', 'sage_fused_lab.hip']
+           'sample.hip', 'minibatch.hip', 'gemm.hip', 'sage_fused.hip']
+LAB_SOURCES = SOURCES + ['sage_fused_lab.hip']
+LAB_FLAGS = {'gemm.hip': ['-DPYGAMD_LAB=1']}   # the weight-gradient variants and probes
 ARCH = 'gfx950'
 FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
@@ -36,6 +44,7 @@ def find_hipcc():
 
 
 STAMP_PATH = LIB_PATH + '.stamp'
+LAB_STAMP_PATH = LAB_LIB_PATH + '.stamp'
 
 
 BINDING_SRC = os.path.join(CSRC_DIR, 'torch_binding.cpp')
@@ -68,10 +77,28 @@ def is_stale():
         return f.read().strip() != source_hash()
 
 
+def lab_is_stale():
+    if not (os.path.exists(LAB_LIB_PATH) and os.path.exists(LAB_STAMP_PATH)):
+        return True
+    with open(LAB_STAMP_PATH) as f:
+        return f.read().strip() != source_hash()
+
+
 def build_library(force=False, verbose=True):
-    """Compile every HIP source for gfx950 and link ``libpyg_amd.so``. Returns its path."""
+    """Compile every product HIP source for gfx950 and link ``libpyg_amd.so``. Returns its path."""
     if not force and not is_stale():
         return LIB_PATH
+    return _build(SOURCES, {}, LIB_PATH, STAMP_PATH, force, verbose)
+
+
+def build_lab_library(force=False, verbose=True):
+    """``libpyg_amd_lab.so``: the product objects (re-used) + the laboratory sources."""
+    if not force and not lab_is_stale():
+        return LAB_LIB_PATH
+    return _build(LAB_SOURCES, LAB_FLAGS, LAB_LIB_PATH, LAB_STAMP_PATH, force, verbose)
+
+
+def _build(sources, more_flags, lib_path, stamp_path, force, verbose):
     hipcc = find_hipcc()
     if hipcc is None:
         raise RuntimeError('hipcc not found: cannot build libpyg_amd.so')
@@ -86,12 +113,13 @@ def build_library(force=False, verbose=True):
         src_path = os.path.join(CSRC_DIR, src)
         # (objects are kept per flag set: a lab build must not pick up the default build's)
         import hashlib
-        tag = hashlib.sha1(' '.join(FLAGS + EXTRA_FLAGS.get(src, [])).encode()).hexdigest()[:8]
+        flags = FLAGS + EXTRA_FLAGS.get(src, []) + more_flags.get(src, [])
+        tag = hashlib.sha1(' '.join(flags).encode()).hexdigest()[:8]
         obj = os.path.join(BUILD_DIR, src.replace('.hip', f'.{tag}.o'))
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src_path), headers_mtime)):
             return obj
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', src_path, '-o', obj]
+        cmd = [hipcc] + flags + ['-c', src_path, '-o', obj]
         if verbose:
             print('[pyg_amd build]', ' '.join(cmd), file=sys.stderr, flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)
@@ -99,27 +127,26 @@ def build_library(force=False, verbose=True):
             raise RuntimeError(f'hipcc failed for {src}:\n{res.stdout}\n{res.stderr}')
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    tmp = LIB_PATH + '.tmp'
+    with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources))
+    tmp = lib_path + '.tmp'
     cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
         print('[pyg_amd build]', ' '.join(cmd), file=sys.stderr, flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f'link failed:\n{res.stdout}\n{res.stderr}')
-    os.replace(tmp, LIB_PATH)
-    with open(STAMP_PATH, 'w') as f:
+    os.replace(tmp, lib_path)
+    with open(stamp_path, 'w') as f:
         f.write(source_hash())
-    return LIB_PATH
+    return lib_path
 
 
 def binding_hash():
     import hashlib
     import torch
     h = hashlib.sha1()
-    for p in (BINDING_SRC, os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h'),
-              os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd_lab.h')):
+    for p in (BINDING_SRC, os.path.join(os.path.dirname(PKG_DIR), 'include', 'pyg_amd.h')):
         with open(p, 'rb') as f:
             h.update(f.read())
     h.update(torch.__version__.encode())
@@ -167,4 +194,5 @@ def build_torch_binding(force=False, verbose=True):
 
 if __name__ == '__main__':
     print(build_library(force='--force' in sys.argv))
+    print(build_lab_library(force='--force' in sys.argv))
     print(build_torch_binding(force='--force' in sys.argv))

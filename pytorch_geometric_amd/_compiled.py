@@ -43,6 +43,8 @@ def _register_fakes():
 
 
 def ops():
+    if _lib.lab_active():  # a laboratory schedule is selected: every call through ctypes into
+        return None        # libpyg_amd_lab.so (the binding is linked against the product library)
     if _state['tried']:
         return _state['ns']
     _state['tried'] = True

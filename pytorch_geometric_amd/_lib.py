@@ -186,7 +186,8 @@ SIGNATURES = {
                                                  c_int64, c_float, _P, _P, _P]),
 }
 
-# include/pyg_amd_lab.h: schedules measured and not adopted + timing probes (NOT the boundary)
+# include/pyg_amd_lab.h: schedules measured and not adopted + timing probes (NOT the boundary;
+# exported by libpyg_amd_lab.so only)
 LAB_SIGNATURES = {
     'pygamd_lab_sage_layer_fused': (c_int, [POINTER(SpmmArgs), POINTER(SageFusedArgs), c_int,
                                             c_int, _P, c_size_t, _P]),
@@ -194,7 +195,9 @@ LAB_SIGNATURES = {
     'pygamd_lab_copy': (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
 }
 
-_lib = None
+_lib = None       # libpyg_amd.so: the product library (include/pyg_amd.h, nothing else)
+_lab = None       # libpyg_amd_lab.so: the same sources + the laboratory entry points
+_use_lab = False  # route load() to the laboratory build (tests / scripts that select a variant)
 
 
 def lib_path():
@@ -204,9 +207,33 @@ def lib_path():
 GEMM_MODES = {'fp32': 0, 'split': 1}  # PYGAMD_GEMM_FP32 / PYGAMD_GEMM_SPLIT_BF16
 
 
+def _open(path, signatures):
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in signatures:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.pygamd_abi_version() != ABI_VERSION:
+        raise PygAmdError(f'ABI mismatch: {path} reports {lib.pygamd_abi_version()}')
+    return lib
+
+
+def _default_mode():
+    # 'split' (round 4): error against fp64 at or below the fp32 matrix instruction's on the same
+    # inputs (tests/test_gpu_split_accept.py, test_gpu_gemm.py), 2.7 x fewer matrix-pipe cycles;
+    # PYGAMD_GEMM_MODE=fp32 selects the exact instruction (bitwise an fmaf chain)
+    mode = os.environ.get('PYGAMD_GEMM_MODE', 'split')
+    if mode not in GEMM_MODES:
+        raise PygAmdError(f"PYGAMD_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got '{mode}'")
+    return GEMM_MODES[mode]
+
+
 def load():
-    """Load (building first if the in-tree .so is missing/stale and hipcc exists)."""
+    """The product library (building first if the in-tree .so is missing/stale and hipcc
+    exists) — or the laboratory build while :func:`use_lab` routes there."""
     global _lib
+    if _use_lab:
+        return load_lab()
     if _lib is not None:
         return _lib
     path = _build.LIB_PATH
@@ -218,22 +245,50 @@ def load():
                 f"{path} is missing and hipcc is unavailable: run "
                 f"`python -c 'import __graft_entry__ as g; g.build()'` on a machine with ROCm. "
                 f"There is no CPU fallback for the pytorch_geometric_amd kernels.")
-    lib = ctypes.CDLL(path)
-    for name, (restype, argtypes) in list(SIGNATURES.items()) + list(LAB_SIGNATURES.items()):
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
-        fn.restype = restype
-        fn.argtypes = argtypes
-    if lib.pygamd_abi_version() != ABI_VERSION:
-        raise PygAmdError(f'ABI mismatch: library reports {lib.pygamd_abi_version()}')
-    # 'split' (round 4): error against fp64 at or below the fp32 matrix instruction's on the same
-    # inputs (tests/test_gpu_split_accept.py, test_gpu_gemm.py), 2.7 x fewer matrix-pipe cycles;
-    # PYGAMD_GEMM_MODE=fp32 selects the exact instruction (bitwise an fmaf chain)
-    mode = os.environ.get('PYGAMD_GEMM_MODE', 'split')
-    if mode not in GEMM_MODES:
-        raise PygAmdError(f"PYGAMD_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got '{mode}'")
-    lib.pygamd_set_gemm_mode(GEMM_MODES[mode])
+    lib = _open(path, list(SIGNATURES.items()))
+    lib.pygamd_set_gemm_mode(_default_mode())
     _lib = lib
     return lib
+
+
+def load_lab():
+    """``libpyg_amd_lab.so``: the product sources plus csrc/sage_fused_lab.hip and the weight-
+    gradient probes (include/pyg_amd_lab.h) — schedules measured and not adopted, timing probes,
+    the copy-rate probe of bench.py's side figure.  Loaded by scripts/, the tests that pin those
+    schedules to the production results, and that side figure; never by the product path."""
+    global _lab
+    if _lab is not None:
+        return _lab
+    path = _build.LAB_LIB_PATH
+    if _build.lab_is_stale():
+        if _build.find_hipcc() is not None and os.environ.get('PYG_AMD_NO_BUILD') != '1':
+            _build.build_lab_library(verbose=False)
+        elif not os.path.exists(path):
+            raise PygAmdError(f"{path} is missing and hipcc is unavailable (the laboratory "
+                              f"build: `python -m pytorch_geometric_amd._build`)")
+    lab = _open(path, list(SIGNATURES.items()) + list(LAB_SIGNATURES.items()))
+    # (its own copy of the process-wide switches: start from the product library's mode)
+    lab.pygamd_set_gemm_mode(_lib.pygamd_get_gemm_mode() if _lib is not None else _default_mode())
+    _lab = lab
+    return lab
+
+
+def use_lab(flag: bool) -> None:
+    global _use_lab
+    _use_lab = bool(flag)
+    if _use_lab:
+        load_lab()
+
+
+def lab_active() -> bool:
+    return _use_lab
+
+
+def loaded():
+    """The library objects that are open (for process-wide switches kept per library)."""
+    if _lib is None and _lab is None:
+        load()
+    return [l for l in (_lib, _lab) if l is not None]
 
 
 def check(rc, what=''):

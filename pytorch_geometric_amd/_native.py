@@ -1192,7 +1192,9 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     (int32 ``[n_rows, compressed_pitch(Fo)]``) receives ``out`` once more in that layout."""
     _require_device(rowptr, col, x_gather, x_root, w, bias, agg, out, relu_bits, mask_bits,
                     row_scale, out_scaled, compressed_out)
-    C = _compiled.ops()
+    variant = SAGE_FUSED_VARIANT if variant is None else variant
+    lab = bool(variant or SAGE_FUSED_PROBE)  # a laboratory schedule / probe: libpyg_amd_lab.so
+    C = None if lab else _compiled.ops()
     if (C is not None and gather_width is None and compressed_out is None and rowend is None
             and _plain(x_gather, x_root, w, agg, out, out_scaled)):
         n_rows, F, Fo = rowptr.numel() - 1, x_gather.size(1), w.size(0)
@@ -1217,10 +1219,9 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
                     h_rows, h_cptr, n_hub, n_chunks,
                     HUB_THRESHOLD if hub_threshold is None else hub_threshold,
                     HUB_CHUNK if hub_chunk is None else hub_chunk, save_agg, relu_bits,
-                    mask_bits, row_scale, out_scaled,
-                    SAGE_FUSED_VARIANT if variant is None else variant, SAGE_FUSED_PROBE)
+                    mask_bits, row_scale, out_scaled)
             return out
-    lib = _lib.load()
+    lib = _lib.load_lab() if lab else _lib.load()
     xr, w2 = _f32_rows(x_root, 'x_root'), _f32_rows(w, 'weight')
     if gather_width is None:
         xg = _f32_rows(x_gather, 'x')
@@ -1293,8 +1294,7 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
                                                       ctypes.byref(nbytes)))
     ws_bytes = nbytes.value
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xg.device) if ws_bytes else None
-    variant = SAGE_FUSED_VARIANT if variant is None else variant
-    if variant or SAGE_FUSED_PROBE:
+    if lab:
         check(lib.pygamd_lab_sage_layer_fused(ctypes.byref(a), ctypes.byref(f), variant or 1,
                                               SAGE_FUSED_PROBE, _p(ws), ws_bytes, _stream(xg)),
               'sage_layer_forward (lab schedule)')
@@ -1323,14 +1323,19 @@ def set_gemm_mode(mode: str) -> str:
     if mode not in _lib.GEMM_MODES:
         raise ValueError(f"mode must be one of {sorted(_lib.GEMM_MODES)}, got '{mode}'")
     prev = get_gemm_mode()
-    check(lib.pygamd_set_gemm_mode(_lib.GEMM_MODES[mode]), 'set_gemm_mode')
+    for each in _lib.loaded():  # (the laboratory build keeps its own copy of the switch)
+        check(each.pygamd_set_gemm_mode(_lib.GEMM_MODES[mode]), 'set_gemm_mode')
     return prev
 
 
 def lab_set_wgrad_variant(variant: int) -> None:
-    """LAB (include/pyg_amd_lab.h): 0 = production split weight gradient (operands split once on
-    their way into LDS), 1 = round 3's in-register schedule.  Tests and probes only."""
-    check(_lib.load().pygamd_lab_set_wgrad_variant(int(variant)), 'lab_set_wgrad_variant')
+    """LAB (include/pyg_amd_lab.h, libpyg_amd_lab.so): 0 = production split weight gradient
+    (operands split once on their way into LDS), 1 = round 3's in-register schedule, further
+    values = timing probes.  While a variant is selected EVERY call of this module goes to the
+    laboratory library (a superset build of the product library) through ctypes; 0 switches back
+    to the product library.  Tests and probes only."""
+    check(_lib.load_lab().pygamd_lab_set_wgrad_variant(int(variant)), 'lab_set_wgrad_variant')
+    _lib.use_lab(int(variant) != 0)
 
 
 def get_gemm_mode() -> str:

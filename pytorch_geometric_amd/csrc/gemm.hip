@@ -1130,7 +1130,11 @@ static int launch_nt(GemmNT p, bool vec, hipStream_t st) {
 }
 
 static int g_gemm_mode = 0;  // pygamd_set_gemm_mode
-static int g_wgrad_variant = 0;  // pygamd_lab_set_wgrad_variant
+#ifdef PYGAMD_LAB
+static int g_wgrad_variant = 0;  // pygamd_lab_set_wgrad_variant (libpyg_amd_lab.so only)
+#else
+constexpr int g_wgrad_variant = 0;  // the product library has the production schedule only
+#endif
 
 // Shape of an NT launch: the tile and the number of K slices.  Outputs with >= kFillTiles tiles of
 // the large shape fill the chip by their rows alone (the full-batch layers); below that — sampled
@@ -1205,12 +1209,14 @@ int pygamd_set_gemm_mode(int mode) {
 
 int pygamd_get_gemm_mode(void) { return g_gemm_mode; }
 
+#ifdef PYGAMD_LAB
 int pygamd_lab_set_wgrad_variant(int variant) {
   if (variant < 0 || variant > 63 || ((variant & 1) && variant != 1))
     return PYGAMD_ERR_INVALID_ARG;
   g_wgrad_variant = variant;
   return PYGAMD_OK;
 }
+#endif
 
 int pygamd_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
                           const float* bias, int64_t M, int64_t K, int64_t N, int relu,
@@ -1353,7 +1359,8 @@ int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ld
     const bool vx = p.vec_x && p.vec_x2;
     kern = p.vec_g ? (vx ? gemm_tn_split_kernel<true, true> : gemm_tn_split_kernel<true, false>)
                    : (vx ? gemm_tn_split_kernel<false, true> : gemm_tn_split_kernel<false, false>);
-    switch (g_wgrad_variant) {  // lab: timing probes of the all-vector variant
+#ifdef PYGAMD_LAB
+    switch (g_wgrad_variant) {  // timing probes of the all-vector variant
       case 2: kern = gemm_tn_split_kernel<true, true, 2>; break;
       case 4: kern = gemm_tn_split_kernel<true, true, 4>; break;
       case 6: kern = gemm_tn_split_kernel<true, true, 6>; break;
@@ -1365,10 +1372,13 @@ int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ld
       case 40: kern = gemm_tn_split_kernel<true, true, 40>; break;
       default: break;
     }
+#endif
     lds = kTnSplitLds;
     threads = kTnThreads;
-  } else if (g_gemm_mode == PYGAMD_GEMM_SPLIT_BF16) {  // lab: operands split in registers
+#ifdef PYGAMD_LAB
+  } else if (g_gemm_mode == PYGAMD_GEMM_SPLIT_BF16) {  // round 3: operands split in registers
     kern = vec ? gemm_tn_kernel<true, true> : gemm_tn_kernel<false, true>;
+#endif
   } else {
     kern = vec ? gemm_tn_kernel<true, false> : gemm_tn_kernel<false, false>;
   }

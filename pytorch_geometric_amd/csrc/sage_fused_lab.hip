@@ -1,7 +1,7 @@
 // sage_fused_lab.hip — LABORATORY schedules of the one-kernel SAGEConv layer (sage_fused.hip holds the
-// production ones).  Built into the library so that scripts/fused_probe.py and the parity tests can
-// run them on the device, but NOT part of the boundary: the entry point below is declared in
-// include/pyg_amd_lab.h, not in include/pyg_amd.h, and nothing in the package's product path calls it.
+// production ones).  Built into libpyg_amd_lab.so ONLY (not into the product library libpyg_amd.so)
+// so that scripts/fused_probe.py and the parity tests can run them on the device; the entry point
+// below is declared in include/pyg_amd_lab.h, not in include/pyg_amd.h.
 //   variant 2      the gather phase as a software-pipelined stream (bitwise the production kernel);
 //   variant 1      the production fp32 schedule with its probe bits honoured;
 //   variant 5 / 6  the production kernels themselves (split arithmetic / fp32 instruction),

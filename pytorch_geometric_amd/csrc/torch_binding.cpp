@@ -21,7 +21,6 @@
 #include <torch/library.h>
 
 #include "../../include/pyg_amd.h"
-#include "../../include/pyg_amd_lab.h"
 
 namespace {
 
@@ -257,8 +256,7 @@ void sage_layer_fused(const Tensor& rowptr, const OptTensor& col, const Tensor& 
                         const OptTensor& hub_rows, const OptTensor& hub_cptr, int64_t n_hub,
                         int64_t n_chunks, int64_t hub_threshold, int64_t hub_chunk, bool save_agg,
                         const OptTensor& relu_bits, const OptTensor& mask_bits,
-                        const OptTensor& row_scale, const OptTensor& out_scaled, int64_t variant,
-                        int64_t probe) {
+                        const OptTensor& row_scale, const OptTensor& out_scaled) {
   const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(rowptr.device());
   check_index(rowptr, rowptr, "rowptr");
   check_index(col, rowptr, "col");
@@ -330,12 +328,6 @@ void sage_layer_fused(const Tensor& rowptr, const OptTensor& col, const Tensor& 
   Tensor ws;
   if (ws_bytes > 0)
     ws = at::empty({static_cast<int64_t>(ws_bytes)}, xg.options().dtype(at::kByte));
-  if (variant != 0 || probe != 0) {  // include/pyg_amd_lab.h: not the boundary
-    check(pygamd_lab_sage_layer_fused(&a, &f, variant != 0 ? static_cast<int>(variant) : 1,
-                                      static_cast<int>(probe), ptr(ws), ws_bytes, cur_stream(xg)),
-          "sage_layer_forward (lab schedule)");
-    return;
-  }
   check(pygamd_sage_layer_fused(&a, &f, ptr(ws), ws_bytes, cur_stream(xg)), "sage_layer_forward");
 }
 
@@ -627,7 +619,7 @@ TORCH_LIBRARY(pyg_amd_c, m) {
       "Tensor? bias, int reduce, bool relu, Tensor(a!) agg, Tensor(b!) out, Tensor? hub_rows, "
       "Tensor? hub_cptr, int n_hub, int n_chunks, int hub_threshold, int hub_chunk, "
       "bool save_agg, Tensor(c!)? relu_bits, Tensor? mask_bits, Tensor? row_scale, "
-      "Tensor(d!)? out_scaled, int variant, int probe) -> ()");
+      "Tensor(d!)? out_scaled) -> ()");
   m.def("index2ptr(Tensor index, int size) -> Tensor");
   m.def("ptr2index(Tensor ptr, int n) -> Tensor");
   m.def("gather_rows(Tensor x, Tensor index) -> Tensor");

@@ -157,7 +157,7 @@ def test_config5_at_the_timed_shape(dev):
     gradient, against the oracle evaluated in float64 (`rgcn_conv_blocks_pairs`: the reference's
     per-relation loop restricted to the rows that can be non-zero, pinned on the reference's own
     vectors in tests/test_oracle_golden.py).  Tolerance: 2e-5 of each tensor's largest magnitude
-    (north_star's 1e-5 on the aggregation, doubled for two stacked layers)."""
+    (north_star's 1e-5 on the aggregation, doubled for two stacked layers), no outlier allowance."""
     from pytorch_geometric_amd.nn import RGCNConv
     g = gen(4)
     n, e, R = 14_541, 544_230, 474
@@ -170,40 +170,44 @@ def test_config5_at_the_timed_shape(dev):
     for c in convs:
         with torch.no_grad():
             c.bias.uniform_(-0.1, 0.1)   # (zeros at init: give the bias path something to do)
-    # float64 oracle
-    e64 = emb.double().requires_grad_(True)
-    p64 = [[p.detach().double().requires_grad_(True) for p in (c.weight, c.root, c.bias)]
-           for c in convs]
-    h = O.rgcn_conv_blocks_pairs(e64, ei, et, *p64[0]).relu()
-    h = O.rgcn_conv_blocks_pairs(h, ei, et, *p64[1])
-    h.backward(go.double())
     # device
     emb_d = torch.nn.Parameter(emb.to(dev))
     eid, etd = ei.to(dev), et.to(dev)
     for c in convs:
         c.to(dev)
-    out = convs[1](convs[0](emb_d, eid, etd).relu(), eid, etd)
+    hid = convs[0](emb_d, eid, etd).relu()
+    out = convs[1](hid, eid, etd)
     out.backward(go.to(dev))
+    # float64 oracle ON THE DEVICE'S ACTIVATION PATTERN: of the 7.3 M hidden units a handful sit
+    # within float32 rounding of 0 and would take the other ReLU branch in float64 — one such unit
+    # moves ~4 k elements of the embedding gradient by 1e-3 (seen: 4.7e-4 of the elements), which
+    # says nothing about a kernel.  The oracle therefore applies the mask the device produced, and
+    # the mask itself is checked: it may differ from the float64 one only where the pre-activation
+    # is within 1e-5 of the tensor's scale of zero.
+    e64 = emb.double().requires_grad_(True)
+    p64 = [[p.detach().cpu().double().requires_grad_(True) for p in (c.weight, c.root, c.bias)]
+           for c in convs]
+    pre = O.rgcn_conv_blocks_pairs(e64, ei, et, *p64[0])
+    mask = (hid.detach() > 0).cpu()
+    flipped = mask != (pre.detach() > 0)
+    assert int(flipped.sum()) <= 64, f'{int(flipped.sum())} hidden units on the other ReLU branch'
+    if bool(flipped.any()):
+        assert float(pre.detach()[flipped].abs().max()) <= 1e-5 * float(pre.detach().abs().max())
+    h = O.rgcn_conv_blocks_pairs(pre * mask.double(), ei, et, *p64[1])
+    h.backward(go.double())
 
-    def check(got, ref, what, tol=2e-5, kinks=0.0):
-        """max |diff| <= tol x the tensor's largest magnitude.  `kinks`: the share of elements
-        allowed beyond it (and then within 5 %) in tensors BEHIND the ReLU — of the 7.3 M hidden
-        units a handful sit within float32 rounding of 0 and take the other branch in float64,
-        which moves the gradients that pass through them."""
+    def check(got, ref, what, tol=2e-5):
         scale = max(float(ref.abs().max()), 1.0)
-        err = (got.detach().cpu().double() - ref).abs() / scale
-        assert bool(torch.isfinite(got).all()), f'{what}: non-finite values'
-        frac = float((err > tol).double().mean())
-        assert frac <= kinks and float(err.max()) <= (0.05 if kinks else tol), \
-            f'{what}: max {float(err.max()):.2e} of the scale, {frac:.2e} of the elements > {tol:g}'
+        err = float((got.detach().cpu().double() - ref).abs().max()) / scale
+        assert bool(torch.isfinite(got).all()) and err <= tol, f'{what}: {err:.2e} of the scale'
 
+    check(hid, (pre * mask.double()).detach(), 'hidden layer')
     check(out, h.detach(), 'out')
-    check(emb_d.grad, e64.grad, 'grad embedding', kinks=1e-4)
+    check(emb_d.grad, e64.grad, 'grad embedding')
     for li, (c, ps) in enumerate(zip(convs, p64)):
-        behind_relu = 1e-4 if li == 0 else 0.0
-        check(c.weight.grad, ps[0].grad, f'layer {li} grad block weights', kinks=behind_relu)
-        check(c.root.grad, ps[1].grad, f'layer {li} grad root', kinks=behind_relu)
-        check(c.bias.grad, ps[2].grad, f'layer {li} grad bias', kinks=behind_relu)
+        check(c.weight.grad, ps[0].grad, f'layer {li} grad block weights')
+        check(c.root.grad, ps[1].grad, f'layer {li} grad root')
+        check(c.bias.grad, ps[2].grad, f'layer {li} grad bias')
     # relations without edges keep an exactly-zero weight gradient
     empty = torch.bincount(et, minlength=R) == 0
     if bool(empty.any()):
