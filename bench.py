@@ -70,7 +70,7 @@ def pmc_traffic(args, N, E, kernel: str):
     if _live_traffic is not None:   # this run's own counter passes (live_pmc_traffic)
         return _live_traffic.get(kernel)
     d = None
-    for name in ('r05_pmc_bench.json', 'r04_pmc_bench.json', 'r03_pmc_bench.json'):  # newest file that knows the kernel
+    for name in ('r06_pmc_bench.json', 'r05_pmc_bench.json', 'r04_pmc_bench.json', 'r03_pmc_bench.json'):  # newest file that knows the kernel
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 cand = json.load(f)
@@ -1144,7 +1144,7 @@ def main():
             '--kernel-trace only) over this command with 2 steps, run by this process; '
             '(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch'
             if _live_traffic is not None else
-            'committed profile (profiles/r05_pmc_bench.json, same command and workload)')
+            'committed profile (profiles/r06_pmc_bench.json, same command and workload)')
     cp = None
     if dom and rank == 0:  # the same launch against what plain device copies reach on THIS box
         try:
