@@ -593,8 +593,7 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
     capacities, feature gather, the padded hop-aware GraphSAGE stack forward + backward, Adam — as
     ONE captured hipGraph (the eager path is bound by ~145 launches per batch).
     Only the seed ids change between replays (one device-to-device copy) plus a device-side RNG
-    word.  With a process group the gradient all-reduce and the optimizer step stay outside the
-    graph (fwd + bwd captured)."""
+    word.  With a process group over RCCL the gradient all-reduce is captured too (see below)."""
     import torch.distributed as dist
 
     from pytorch_geometric_amd.slots import run_slot_stack
@@ -627,21 +626,36 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
                 if seeds.numel() == B:
                     yield seeds
 
+    # With a process group over RCCL the gradient all-reduce and the optimizer step are recorded
+    # INTO the graph as well (RCCL launches are stream-ordered kernels:
+    # tests/test_gpu_nccl.py::test_rccl_all_reduce_and_adam_capture_into_one_hipgraph): an 8-rank
+    # run replays ONE graph per batch, exactly like the one-GPU run.  gloo (the shared-GPU test
+    # mode) cannot be captured: there the two stay behind the graph.
+    in_graph = (use_dist and dist.get_backend() == 'nccl'
+                and os.environ.get('PYGAMD_CAPTURE_COLLECTIVE', '1') != '0')
+
+    def whole_step_dist():
+        fwd_bwd()
+        bucket.all_reduce_mean(force=True)
+        opt.step()
+
+    outside = use_dist and not in_graph   # all-reduce + Adam issued eagerly behind the graph
+    body = whole_step_dist if in_graph else (fwd_bwd if use_dist else whole_step)
     it = plan()
     seeds_buf.copy_(next(it))
     from pytorch_geometric_amd.hipgraph import CapturedStep
     if os.environ.get('PYGAMD_CAPTURE', '1') == '0':  # the same static-shape step, eagerly
-        captured = fwd_bwd if use_dist else whole_step   # (per-kernel times for a profile)
+        captured = body                                # (per-kernel times for a profile)
         for _ in range(3):
             captured()
     else:
-        captured = CapturedStep(fwd_bwd if use_dist else whole_step, warmup=3)
+        captured = CapturedStep(body, warmup=3)
     ar_events = []
 
     def step():
         seeds_buf.copy_(next(it))
         captured()
-        if use_dist:
+        if outside:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             bucket.all_reduce_mean(force=True)
@@ -681,7 +695,7 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
         mark()
         captured()
         mark()
-        if use_dist:
+        if outside:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             bucket.all_reduce_mean(force=True)
@@ -759,7 +773,8 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
                                    f'synthetic papers100M shape x {scale:g} (N={N}, E={E}) '
                                    f'replicated per GPU',
                        'captured': ('sampling + gather + forward + backward' +
-                                    ('' if use_dist else ' + Adam') + ' = one hipGraph per batch'),
+                                    (' + RCCL all-reduce + Adam' if in_graph else
+                                     '' if use_dist else ' + Adam') + ' = one hipGraph per batch'),
                        'parallelism': f'dp{world} (seed sharding, one flat-bucket '
                                       f'all-reduce/step)',
                        'allreduce_ms_per_step': round(

@@ -51,6 +51,49 @@ print('NCCL_WORLD1_OK')
 '''
 
 
+_CAPTURE_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from pytorch_geometric_amd.data_parallel import FlatGradBucket
+from pytorch_geometric_amd.hipgraph import CapturedStep
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1)
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(0)
+x = torch.randn(512, 32, generator=g).to(dev)
+y = torch.randn(512, 8, generator=g).to(dev)
+
+def make():
+    torch.manual_seed(1)
+    m = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8)).to(dev)
+    b = FlatGradBucket(m)
+    o = torch.optim.Adam(m.parameters(), lr=1e-2, capturable=True, fused=True)
+    def step():
+        b.zero_()
+        torch.nn.functional.mse_loss(m(x), y).backward()
+        b.all_reduce_mean(force=True)      # RCCL all-reduce of the flat bucket, stream-ordered
+        o.step()
+    return m, b, step
+
+m_eager, _, step_eager = make()
+for _ in range(6):
+    step_eager()
+m_cap, bucket, step_cap = make()
+replay = CapturedStep(step_cap, warmup=3)   # 3 eager steps, then ONE graph: fwd + bwd + all-reduce + Adam
+for _ in range(3):
+    replay()
+torch.cuda.synchronize()
+assert bucket.check_views()
+for a, b in zip(m_eager.parameters(), m_cap.parameters()):
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
+dist.barrier()
+dist.destroy_process_group()
+print('NCCL_CAPTURE_OK')
+'''
+
+
 def _free_port():
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
@@ -74,6 +117,17 @@ def test_rccl_collectives_on_one_rank():
     assert res.returncode == 0 and 'NCCL_WORLD1_OK' in res.stdout, res.stderr[-3000:]
 
 
+@pytest.mark.timeout(300)
+def test_rccl_all_reduce_and_adam_capture_into_one_hipgraph():
+    """What the 8-rank mini-batch step replays: forward + backward + the RCCL
+    all-reduce of the flat gradient bucket + the fused Adam update recorded into ONE hipGraph
+    (RCCL launches are stream-ordered kernels: they capture like any other), replayed, and equal
+    to the same steps issued eagerly."""
+    res = subprocess.run([sys.executable, '-c', _CAPTURE_WORKER, ROOT], capture_output=True,
+                         text=True, env=_env(), timeout=280, cwd=ROOT)
+    assert res.returncode == 0 and 'NCCL_CAPTURE_OK' in res.stdout, res.stderr[-3000:]
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize('mode', ['fullbatch', 'minibatch'])
 def test_bench_step_under_torchrun_with_rccl(mode):
@@ -93,6 +147,25 @@ def test_bench_step_under_torchrun_with_rccl(mode):
     assert out['config']['allreduce_ms_per_step'] > 0      # the collective really ran
     if mode == 'fullbatch':
         assert out['config']['process_group'] == 'nccl'
+
+
+@pytest.mark.timeout(600)
+def test_captured_minibatch_step_holds_the_collective_under_rccl():
+    """`bench.py --mode minibatch --capture` with a process group over RCCL: sampling, gather,
+    forward, backward, the gradient all-reduce and Adam replay as ONE hipGraph per batch — what
+    every rank of an 8-GPU run executes."""
+    e = _env()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', e['MASTER_PORT'],
+           os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--init-dist', '--mode', 'minibatch',
+           '--capture', '--steps', '4', '--warmup', '2', '--scale', '0.02', '--no-cpu-baseline']
+    res = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=560, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 1 and out['value'] > 0
+    assert 'RCCL all-reduce + Adam = one hipGraph' in out['config']['captured'], out['config']
 
 
 @pytest.mark.timeout(900)
