@@ -31,7 +31,7 @@
 //
 // (B) PYGAMD_GEMM_SPLIT_BF16 — `sage_fused_split_kernel` (round 4).  At the products shape the fp32
 // transform phase costs 6.0-6.4 ms of a 13.4 ms launch whose gather phase alone takes 10.1-11.5 ms,
-// and a CU that runs the fp32 matrix pipe next to a bandwidth-bound gather slows both (DESIGN.md
+// and a CU that runs the fp32 matrix pipe next to a bandwidth-bound gather slows both (CHANGELOG.md
 // §5a).  The split arithmetic (split_bf16.h: every fp32 operand as the exact sum of three bf16
 // terms, the six leading cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation) needs 6 x 32
 // instead of 8 x 64 matrix-pipe cycles per 16 k — IF the conversion does not eat the gain: done per

@@ -8,7 +8,7 @@
 //                  independent of pygamd_set_gemm_mode; 5 honours probe bits 0 and 1;
 //   variant 3 / 4  one persistent 1024-thread workgroup per CU whose 12 / 8 gather waves feed 4 / 8
 //                  transform waves through LDS tiles with LDS counters instead of barriers.
-// Both were measured slower than the production schedule at the products shape.
+// Both were measured slower than the production schedule at the products shape (CHANGELOG.md §5a).
 // `probe` bits (timing only): see SageFusedArgs::probe.
 #include "sage_fused_device.h"
 #include "../../include/pyg_amd_lab.h"

@@ -45,7 +45,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t (&t)[3])
 // The same with the residual subtractions pinned to single v_sub_f32.  hipcc packs the two
 // subtractions of a pair into one v_pk_add_f32, and a packed fp32 instruction stalls the matrix
 // instructions of the OTHER waves on its SIMD: in the weight-gradient kernel, where one wave group
-// converts while its partner multiplies, that serialised the two.  The kernels
+// converts while its partner multiplies, that serialised the two (CHANGELOG.md §5c).  The kernels
 // that convert and multiply in the same wave, or whose products hide under a gather (gemm_nt,
 // the one-kernel layer), measured the same with either form and keep the compiler's.
 __device__ __forceinline__ float sub_f32_single(float a, float b) {

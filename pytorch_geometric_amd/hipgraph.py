@@ -5,7 +5,7 @@ and the step is bound by launch latency, not by HBM or MFMA.  Everything this pa
 to the current stream with outputs from torch's allocator and, once the sorted graph handles are
 cached, without any host synchronisation — so a whole step can be recorded once and replayed
 (``hipGraphLaunch``) instead of re-issuing every kernel: 0.48 -> 0.12 ms per step on the Cora-shaped
-GCN."""
+GCN (CHANGELOG.md §6b)."""
 from typing import Any, Callable
 
 import torch

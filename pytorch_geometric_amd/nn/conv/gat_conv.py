@@ -112,7 +112,7 @@ class GATConv(MessagePassing):
                 return_attention_weights: Optional[bool] = None):
         H, C = self.heads, self.out_channels
         x_src, x_dst, res = self._project(x)
-        # The kernels compute in float32.  Half / bf16 projected features — a half
+        # The kernels compute in float32 (CHANGELOG.md §4).  Half / bf16 projected features — a half
         # model, or an autocast region whose `Linear` ran in bf16 — are widened HERE and take the
         # same native path; outside autocast the result is handed back in their dtype.  (They used
         # to reach float32-only kernels as they were and raise: ADVICE r4.)

@@ -66,7 +66,7 @@ OVERLAP_WGS = int(os.environ.get('PYGAMD_OVERLAP_WGS', '1'))  # workgroups per C
 # (products shape: 16.8 ms against 12.9 ms for the layer that gathers, +0.8 ms for the layer that
 # writes): decoding a row is ~35 VALU instructions per lane against 4 adds, and the mask word has to
 # arrive before the values can be addressed (two dependent loads per source row with 4 waves per
-# SIMD).  DESIGN.md §5a.
+# SIMD).  CHANGELOG.md §5a.
 COMPRESS_ROWS = os.environ.get('PYGAMD_COMPRESS_ROWS', '0') != '0'
 # backward of a 'pre' layer: find the all-zero rows of the incoming gradient in the pass that lays
 # it out and skip them in the transposed aggregation (PYGAMD_SPARSE_GRAD=0: read every row)

@@ -75,7 +75,7 @@ if fetch and write:
             res['per_launch'][key] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w,
                                       'hbm_bytes': (2 * f + w) * 1024}
     F = 256
-    # gathered rows + indices + row pointers + root rows + saved aggregated rows + output
+    # CHANGELOG.md §3: gathered rows + indices + row pointers + root rows + saved aggregated rows + output
     alg = E * (4 * F + 8) + (N + 1) * 8 + N * 4 * F + N * 4 * F + N * 4 * F
     dom = [v for k, v in res['per_launch'].items() if k.startswith('sage_fused_fwd_F256')]
     if dom:

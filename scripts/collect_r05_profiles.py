@@ -86,7 +86,7 @@ if fetch and write:
             by_symbol[sym] = (2 * fv + wv) * 1024
             detail[sym] = {'FETCH_SIZE_KiB': fv, 'WRITE_SIZE_KiB': wv}
     F = 256
-    # DESIGN §3 / bench.py fused_algorithmic_bytes: the forward launch (aggregated rows stored) and
+    # CHANGELOG.md §3 / bench.py fused_algorithmic_bytes: the forward launch (aggregated rows stored) and
     # the input-gradient launch (row-scaled second output instead); the counters average over both
     fwd = E * (4 * F + 8) + (N + 1) * 8 + 3 * N * 4 * F + N * 4 * (F // 32)
     bwd = E * (4 * F + 8) + (N + 1) * 8 + 3 * N * 4 * F + N * 4 * (F // 32)

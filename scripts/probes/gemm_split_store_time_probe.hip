@@ -1,5 +1,5 @@
 // gemm_split_store_time_probe.hip — stand-alone probe (NOT part of the library) of the split-mode NT
-// GEMM that converts at LDS-store time (DESIGN.md §3 "experiment recorded", §9 item 1):
+// GEMM that converts at LDS-store time (CHANGELOG.md §3 "experiment recorded", §9 item 1):
 //   C[M, N] = relu?(A[M, K] @ B[N, K]^T + bias), fp32 in / out, every operand as three bf16 terms,
 //   six v_mfma_f32_32x32x16_bf16 products per 16 k values, fp32 accumulation.
 // It includes the library's gemm.hip for the shared pieces (argument block, tile numbering, the
