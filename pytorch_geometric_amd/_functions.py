@@ -161,7 +161,7 @@ SORTED_SCATTER_MIN_ELEMS = 1 << 23
 SORTED_SCATTER_ALWAYS_ROWS = 1 << 20
 SCATTER_PLAN_CACHE_BYTES = int(os.environ.get('PYGAMD_SCATTER_PLAN_BYTES', str(1 << 30)))
 SCATTER_SEEN_ENTRIES = 64
-_scatter_plans = collections.OrderedDict()  # key -> [weakref(base), version, plan, nbytes, hub?]
+_scatter_plans = collections.OrderedDict()  # key -> [weakref(base), version, plan, nbytes, hub?, oob]
 _scatter_seen = collections.OrderedDict()   # key -> (weakref(base), version): met once, no plan
 _INT32_MAX = (1 << 31) - 1
 
@@ -174,13 +174,20 @@ def _index_key(index: Tensor, dim_size: int):
                   int(dim_size))
 
 
-def _build_scatter_plan(index: Tensor, dim_size: int):
+def _build_scatter_plan(index: Tensor, dim_size: int, oob: list):
+    """``oob``: a one-element list the flag ring sets to True when the guard's flag arrives
+    raised — a CACHED plan then re-reports its out-of-range entries on every later hit (the
+    kernels skip such rows either way; without the marker only the first use would say so)."""
     n = index.numel()
     small = n < _INT32_MAX and dim_size + 1 < _INT32_MAX
     ring, slot, err = _native._index_flag(index.device, True)
     keys = _native.index_guard(index, dim_size, err,
                                dtype=torch.int32 if small else torch.int64)
-    _native._index_flag_done(ring, slot, err, 'scatter', dim_size, index)
+
+    def mark():
+        oob[0] = True
+
+    _native._index_flag_done(ring, slot, err, 'scatter', dim_size, index, on_flag=mark)
     sorted_keys, perm = _native.index_sort(keys, max_value=dim_size)
     # group `dim_size` = the out-of-range entries: it has a pointer entry and no output row
     ptr = _native.index2ptr(sorted_keys, dim_size + 1)[:dim_size + 1]
@@ -201,6 +208,9 @@ def _sorted_scatter_plan(index: Tensor, dim_size: int, force: bool = True):
     hit = _scatter_plans.get(key)
     if hit is not None and hit[0]() is base and hit[1] == index._version:
         _scatter_plans.move_to_end(key)
+        if hit[5][0] and _native.INDEX_CHECK != 'off':  # known bad since an earlier use: say so
+            _native._raise_out_of_range(index, dim_size, 'scatter',   # again, at the call
+                                        _native._error_style.value)
         if not hit[4]:  # reused: now the hub split pays (one host read, once)
             ptr, perm, _ = hit[2]
             hit[2], hit[4] = (ptr, perm, _native.hub_plan(ptr)), True
@@ -216,7 +226,8 @@ def _sorted_scatter_plan(index: Tensor, dim_size: int, force: bool = True):
                 _scatter_seen.popitem(last=False)
             return None
     _scatter_seen.pop(key, None)
-    ptr, perm = _build_scatter_plan(index, dim_size)
+    oob = [False]
+    ptr, perm = _build_scatter_plan(index, dim_size, oob)
     plan = (ptr, perm, None)
     nbytes = _plan_bytes(ptr, perm)
     if nbytes <= SCATTER_PLAN_CACHE_BYTES:
@@ -224,7 +235,7 @@ def _sorted_scatter_plan(index: Tensor, dim_size: int, force: bool = True):
         while _scatter_plans and held + nbytes > SCATTER_PLAN_CACHE_BYTES:
             held -= _scatter_plans.popitem(last=False)[1][3]
         _scatter_plans[key] = [weakref.ref(base, lambda _, k=key: _scatter_plans.pop(k, None)),
-                               index._version, plan, nbytes, False]
+                               index._version, plan, nbytes, False, oob]
     return plan
 
 

@@ -724,15 +724,18 @@ class _FlagRing:
             self.poll()
         return slot
 
-    def publish(self, slot: int, what: str, size: int, index: Tensor):
+    def publish(self, slot: int, what: str, size: int, index: Tensor, on_flag=None):
+        """``on_flag``: called (before the error is raised) when this launch turns out flagged —
+        lets the owner of a CACHED object built from ``index`` (a sorted-scatter plan) remember
+        it, so that later uses of the cache report the same indices again."""
         self.host[slot:slot + 1].copy_(self.dev[slot:slot + 1], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev.device))
-        self.pending.append((slot, ev, what, size, index, _error_style.value))
+        self.pending.append((slot, ev, what, size, index, _error_style.value, on_flag))
 
     def poll(self, wait: bool = False):
         while self.pending:
-            slot, ev, what, size, index, style = self.pending[0]
+            slot, ev, what, size, index, style, on_flag = self.pending[0]
             if wait:
                 ev.synchronize()
             elif not ev.query():
@@ -741,6 +744,8 @@ class _FlagRing:
             if int(self.host[slot]) != 0:
                 self.host[slot] = 0
                 self.dev[slot:slot + 1].zero_()
+                if on_flag is not None:
+                    on_flag()
                 _raise_out_of_range(index, size, what, style)
 
 
@@ -790,11 +795,16 @@ def _index_flag(device, active: bool):
     return None, None, torch.zeros(1, dtype=torch.int32, device=device)
 
 
-def _index_flag_done(ring, slot, err, what: str, size: int, index: Tensor):
+def _index_flag_done(ring, slot, err, what: str, size: int, index: Tensor, on_flag=None):
     if ring is not None:
-        ring.publish(slot, what, size, index)
+        ring.publish(slot, what, size, index, on_flag)
     elif err is not None and INDEX_CHECK == 'sync':
-        _raise_if_flagged(err, index, size, what)
+        try:
+            _raise_if_flagged(err, index, size, what)
+        except IndexError:
+            if on_flag is not None:
+                on_flag()
+            raise
 
 
 def poll_index_errors(wait: bool = False, device=None):

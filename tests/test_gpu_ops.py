@@ -1268,6 +1268,12 @@ def test_large_unsorted_scatter_takes_the_sorted_route(dev, monkeypatch):
     with pytest.raises(IndexError, match='out of bounds'):
         pga.check_index_errors()
     pga.check_index_errors()
+    # the plan of `bad` is cached: a LATER use of the same tensor reports its entries again, at
+    # the call and without device work (only the first use used to say so)
+    with pytest.raises(IndexError, match='out of bounds'):
+        scatter(src, bad, 0, n, 'sum')
+    assert sorts['n'] == 5
+    pga.check_index_errors()
     _native.INDEX_CHECK = 'sync'
     try:
         with pytest.raises(IndexError, match='out of bounds'):
