@@ -11,9 +11,16 @@ from typing import Iterator, List, Optional
 import torch
 from torch import Tensor
 
+import os
+
 from . import _native
 from .edge_index import EdgeIndex
 from .sampler import NeighborSampler
+
+# collate_slots: layer 0 of the slot stack gathers its neighbours' rows straight from the feature
+# matrix (only the destination rows of a batch are copied) — slots.SlotSampler.gather(direct=True).
+# PYGAMD_SLOTS_DIRECT=0 copies every row of the batch first, as rounds 4-5 did.
+SLOTS_DIRECT = os.environ.get('PYGAMD_SLOTS_DIRECT', '1') != '0'
 
 
 @dataclass
@@ -142,7 +149,7 @@ class NeighborLoader:
             plan = SlotPlan(seeds.numel(), smp.num_neighbors, self.x.device)
             self._slots = SlotSampler(smp.colptr, smp.row, self.num_nodes, plan, seed=smp.seed)
         b = self._slots.sample(seeds, epoch_dev)
-        b.x = self._slots.gather(self.x, b)
+        b.x = self._slots.gather(self.x, b, direct=SLOTS_DIRECT and len(smp.num_neighbors) > 0)
         b.y = None if self.y is None else self.y[seeds]
         return b
 

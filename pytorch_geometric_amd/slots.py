@@ -11,7 +11,10 @@ hipGraph — with as few, as fat kernels as the path allows (round 3: 181 kernel
 
 * sampling: 1 launch for the seeds + 2 per hop (``SlotSampler.sample``); the duplicate-resolving
   node map is never reset (epoch-stamped claims);
-* feature gather: 1 launch, straight into the right half of the first ``[agg | x]`` buffer;
+* feature gather: 1 launch, straight into the right half of the first ``[agg | x]`` buffer —
+  round 6: of the DESTINATION rows only; layer 0 gathers its neighbours' rows (the last hop: 80 % of
+  the batch) from the graph's feature matrix by graph node id (``gather(direct=True)``: 1.18 ->
+  1.09 ms per captured batch at the papers100M shape);
 * forward: ONE launch per layer — the one-kernel SAGE layer (gather -> LDS -> MFMA, bias + ReLU +
   ReLU bits in the epilogue) over all destination blocks of the layer at once (``rowptr`` =
   the static ``row_begin``, ``rowend`` = the sampler's ``row_end``);
@@ -66,6 +69,9 @@ class SlotPlan:
         begin = [(self.bases[b + 1] - self.B) + torch.arange(cap[b], dtype=torch.int64) * k
                  for b, k in enumerate(self.fanouts)]
         self.row_begin = torch.cat(begin).to(torch.int32).to(self.device)
+        # (the same pointer as int64: layer 0 in DIRECT mode gathers from the graph's feature
+        # matrix by graph node id, SlotBatch.x_global)
+        self.row_begin64 = self.row_begin.to(torch.int64)
         # transposed CSR c serves the backward of layer c + 1: hops 0 .. L - c - 2
         self.n_csr = self.L - 1
         self.t_slots = [self.bases[self.L - c] - self.B for c in range(self.n_csr)]
@@ -87,6 +93,12 @@ class SlotBatch:
     t_col: List[Tensor]  # per transposed CSR: [slots] int32 (filled prefix = ptr[-1])
     x: Optional[Tensor] = None   # [R, 2 F] = [ (aggregation target) | x[node_g] ]
     y: Optional[Tensor] = None
+    # DIRECT mode (SlotSampler.gather(direct=True)): `x` holds the DESTINATION rows only
+    # ([R_dst, 2 F]) and layer 0 gathers its neighbours straight from the graph's feature matrix
+    # `x_global` through `src_g` (graph node ids) — the rows of the last hop, 80 % of the batch,
+    # are then read once by the layer instead of being copied into the batch first and read back.
+    x_global: Optional[Tensor] = None
+    row_end64: Optional[Tensor] = None
     # The index tensors above are the SAMPLER's buffers, overwritten by its next `sample()`:
     # `stamp` is the sampler's call counter when this batch was drawn, `owner` the sampler.  The
     # stack's backward reads `t_ptr / t_col / inv_cnt` again and refuses a batch whose sampler has
@@ -182,15 +194,25 @@ class SlotSampler:
                          self.t_ptr, self.t_col, stamp=self.calls, owner=weakref.ref(self))
 
     @torch.no_grad()
-    def gather(self, x: Tensor, batch: SlotBatch, out: Optional[Tensor] = None) -> Tensor:
+    def gather(self, x: Tensor, batch: SlotBatch, out: Optional[Tensor] = None,
+               direct: bool = False) -> Tensor:
         """``[R, 2 F]`` with ``x[node_g]`` in the right half (holes: zero rows); the left half is
-        where layer 0 stores its aggregated rows."""
+        where layer 0 stores its aggregated rows.  ``direct``: only the ``R_dst`` rows that are ever
+        a destination are copied (``[R_dst, 2 F]``) and the batch remembers ``x`` itself
+        (``x_global``) and an int64 ``row_end``: layer 0 of the stack then reads its neighbours'
+        rows from ``x`` by graph node id."""
         p = self.plan
         F = x.size(1)
+        rows = p.R_dst if direct else p.R
+        if direct:
+            if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+                raise ValueError("'x' must be a float32 [N, F] matrix with unit inner stride")
+            batch.x_global = x
+            batch.row_end64 = batch.row_end.to(torch.int64)
         if out is None:
-            out = torch.empty(p.R, 2 * F, dtype=torch.float32, device=x.device)
+            out = torch.empty(rows, 2 * F, dtype=torch.float32, device=x.device)
         check(_lib.load().pygamd_slots_gather(
-            _i64p(x), _native._ld(x), F, _i64p(batch.node_g), p.R,
+            _i64p(x), _native._ld(x), F, _i64p(batch.node_g), rows,
             ctypes.c_void_p(out.data_ptr() + 4 * F), _native._ld(out), _native._stream(x)),
             'slots_gather')
         return out
@@ -209,8 +231,13 @@ class FusedSageSlotStack(Function):
         L = len(params) // 3
         if L != p.L:
             raise ValueError(f'{L} layers on a batch of {p.L} hops')
-        if cat0.shape[0] != p.R or cat0.dtype != torch.float32 or cat0.size(1) % 2:
-            raise ValueError(f"'x' must be the float32 [{p.R}, 2 F] buffer of SlotSampler.gather")
+        direct = batch.x_global is not None
+        rows0 = p.R_dst if direct else p.R
+        if cat0.shape[0] != rows0 or cat0.dtype != torch.float32 or cat0.size(1) % 2:
+            raise ValueError(f"'x' must be the float32 [{rows0}, 2 F] buffer of "
+                             f"SlotSampler.gather")
+        if direct and batch.x_global.size(1) != cat0.size(1) // 2:
+            raise ValueError("'x_global' and the gathered buffer disagree about the width")
         dev = cat0.device
         Fi = cat0.size(1) // 2
         cat = cat0
@@ -233,9 +260,18 @@ class FusedSageSlotStack(Function):
                 nxt = torch.empty(m, 2 * Fo, dtype=torch.float32, device=dev)
                 dst = nxt[:, Fo:]
                 rb = _native.relu_bits_like(m, Fo, dev)
-            _native.sage_layer_forward(batch.plan.row_begin, batch.src_id, cat[:, Fi:],
-                                       cat[:m, Fi:], wmat, b, aggr, not last, cat[:m, :Fi], dst,
-                                       save_agg=True, relu_bits=rb, rowend=batch.row_end)
+            if l == 0 and direct:
+                # neighbours by GRAPH node id from the feature matrix itself (slots past a row's
+                # end hold -1 and are never dereferenced; a duplicate's slot names the same graph
+                # node as the row `src_id` points at: same features)
+                _native.sage_layer_forward(p.row_begin64, batch.src_g, batch.x_global,
+                                           cat[:m, Fi:], wmat, b, aggr, not last, cat[:m, :Fi],
+                                           dst, save_agg=True, relu_bits=rb,
+                                           rowend=batch.row_end64)
+            else:
+                _native.sage_layer_forward(p.row_begin, batch.src_id, cat[:, Fi:], cat[:m, Fi:],
+                                           wmat, b, aggr, not last, cat[:m, :Fi], dst,
+                                           save_agg=True, relu_bits=rb, rowend=batch.row_end)
             cats.append(cat)
             wmats.append(wmat)
             bits.append(rb)
@@ -274,12 +310,12 @@ class FusedSageSlotStack(Function):
                 break
             c = l - 1                                # this layer's transposed CSR
             r_in = p.bases[L - l + 1]                # rows of the layer input = rows layer l-1 made
-            w_t = wmat.t()                           # [2 Fi, Fo]
-            scale = batch.inv_cnt[:m] if aggr == 'mean' else None
-            gagg = _native.linear_dgrad(g, w_t[:Fi].contiguous(), row_scale=scale,
+            w_t = wmat.t().contiguous()              # [2 Fi, Fo]: ONE transpose, both halves
+            scale = batch.inv_cnt[:m] if aggr == 'mean' else None   # are row blocks of it
+            gagg = _native.linear_dgrad(g, w_t[:Fi], row_scale=scale,
                                         n_scaled=Fi if scale is not None else 0)
             g_in = torch.empty(r_in, Fi, dtype=torch.float32, device=g.device)
-            _native.linear_dgrad(g, w_t[Fi:].contiguous(), out=g_in[:m])
+            _native.linear_dgrad(g, w_t[Fi:], out=g_in[:m])
             # g_in = relu'(h) * (A^T gagg + [groot ; 0]): rows past m have no root part
             _native.spmm_csr(batch.t_ptr[c], batch.t_col[c], gagg, 'sum', n_rows=r_in, out=g_in,
                              accumulate=True, accumulate_rows=m, relu_bits=bits[l - 1])

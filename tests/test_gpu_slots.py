@@ -139,11 +139,14 @@ def _reference_stack(plan, b, x_rows, params, aggr):
     return h
 
 
+@pytest.mark.parametrize('direct', [False, True])
 @pytest.mark.parametrize('aggr', ['mean', 'sum'])
 @pytest.mark.parametrize('dims,fan,B', [((16, 32, 32, 8), [4, 3, 2], 50),
                                         ((128, 256, 256, 172), [5, 4, 3], 33),
                                         ((12, 20, 6), [6, 2], 70)])
-def test_slot_stack_matches_plain_pytorch(dev, aggr, dims, fan, B):
+def test_slot_stack_matches_plain_pytorch(dev, aggr, dims, fan, B, direct):
+    """``direct``: only the destination rows of the batch are copied; layer 0 gathers its
+    neighbours from the graph's feature matrix by graph node id (SlotSampler.gather(direct=True))."""
     import pytorch_geometric_amd as pga
     from pytorch_geometric_amd.nn import GraphSAGE
     from pytorch_geometric_amd.slots import SlotPlan, SlotSampler, run_slot_stack
@@ -157,10 +160,13 @@ def test_slot_stack_matches_plain_pytorch(dev, aggr, dims, fan, B):
     seeds = torch.randperm(n, generator=g)[:B]
     epoch = torch.ones(1, dtype=torch.int64, device=dev)
     b = smp.sample(seeds.to(dev), epoch)
-    b.x = smp.gather(x.to(dev), b)
+    x_dev = x.to(dev)
+    b.x = smp.gather(x_dev, b, direct=direct)
     node_g = b.node_g.cpu()
     x_rows = torch.where((node_g >= 0).view(-1, 1), x[node_g.clamp(min=0)], torch.zeros(1))
-    assert torch.equal(b.x[:, dims[0]:].cpu(), x_rows)      # holes: zero rows
+    if direct:
+        assert b.x.size(0) == plan.R_dst < plan.R and b.x_global is x_dev
+    assert torch.equal(b.x[:, dims[0]:].cpu(), x_rows[:b.x.size(0)])      # holes: zero rows
     torch.manual_seed(4)
     model = GraphSAGE(dims[0], dims[1], num_layers=len(fan), out_channels=dims[-1], aggr=aggr)
     if len(dims) == 4:
