@@ -14,6 +14,8 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 * ``tests/test_gpu_reference_install.py`` runs the reference's OWN ``nn.conv.*`` / ``EdgeIndex`` /
   ``utils.*`` on HIP tensors through ``pytorch_geometric_amd.backend.install()`` and compares with
   the reference's CPU results;
+* ``tests/test_gpu_reference_suite.py`` runs the reference's own TEST modules for the path (packed
+  under ``reference_tests/``) with and without ``install()`` and compares the outcomes;
 * ``bench.py`` times the unmodified reference on the host cores (``cpu_baseline.kind =
   "reference"``).
 
@@ -33,6 +35,23 @@ DST = os.path.join(HERE, '_ref')
 ARCHIVE = os.path.join(DST, 'torch_geometric.tar.gz')
 MANIFEST = os.path.join(DST, 'MANIFEST.json')
 KEEP = ('.py', '.jinja', '.typed')
+# The reference's OWN test modules for the rows of SURVEY.md §8 (+ the conftest that holds their
+# fixtures): packed next to the package under `reference_tests/`, so that on the GPU box they run
+# against `backend.install()` with their `@withDevice` / `@withCUDA` cases on HIP tensors
+# (tests/test_gpu_reference_suite.py).  Data, never edited: any assertion that fails there fails
+# as the reference wrote it.
+TEST_FILES = (
+    'conftest.py',
+    'utils/test_scatter.py', 'utils/test_segment.py', 'utils/test_softmax.py',
+    'utils/test_spmm.py', 'utils/test_index_sort.py', 'utils/test_sort_edge_index.py',
+    'utils/test_coalesce.py', 'utils/test_loop.py', 'utils/test_degree.py',
+    'utils/test_trim_to_layer.py', 'utils/test_undirected.py',
+    'test_edge_index.py', 'test_index.py',
+    'nn/aggr/test_basic.py', 'nn/aggr/test_fused.py', 'nn/aggr/test_multi.py',
+    'nn/conv/test_message_passing.py', 'nn/conv/test_sage_conv.py', 'nn/conv/test_gcn_conv.py',
+    'nn/conv/test_gat_conv.py', 'nn/conv/test_rgcn_conv.py', 'nn/conv/test_graph_conv.py',
+    'nn/dense/test_linear.py', 'nn/models/test_basic_gnn.py',
+)
 
 
 def staged_path():
@@ -53,10 +72,16 @@ def stage(force: bool = False):
         for n in sorted(names):
             if n.endswith(KEEP):
                 files.append(os.path.relpath(os.path.join(base, n), src))
+    tsrc = os.path.join(REF_ROOT, 'test')
+    tests = [t for t in TEST_FILES if os.path.isfile(os.path.join(tsrc, t))]
     h = hashlib.sha1()
     for rel in files:
         h.update(rel.encode())
         with open(os.path.join(src, rel), 'rb') as f:
+            h.update(f.read())
+    for rel in tests:
+        h.update(('test/' + rel).encode())
+        with open(os.path.join(tsrc, rel), 'rb') as f:
             h.update(f.read())
     digest = h.hexdigest()
     if not force and os.path.exists(MANIFEST) and staged_path():
@@ -73,6 +98,8 @@ def stage(force: bool = False):
     with tarfile.open(tmp, 'w:gz') as tar:
         for rel in files:
             tar.add(os.path.join(src, rel), arcname=os.path.join('torch_geometric', rel))
+        for rel in tests:
+            tar.add(os.path.join(tsrc, rel), arcname=os.path.join('reference_tests', rel))
     os.replace(tmp, ARCHIVE)
     with open(MANIFEST, 'w') as f:
         json.dump({'source': src, 'files': len(files), 'sha1': digest}, f)
@@ -92,6 +119,20 @@ def _unpacked_dir():
         with open(marker, 'w') as f:
             f.write(digest)
     return root
+
+
+def reference_tests():
+    """(directory, [test files]) of the reference's own test modules for the path: the mounted
+    ``<reference>/test`` in the build container, else the staged copies."""
+    if os.path.isdir(os.path.join(REF_ROOT, 'test')):
+        root = os.path.join(REF_ROOT, 'test')
+    elif staged_path() and os.path.exists(MANIFEST):
+        root = os.path.join(_unpacked_dir(), 'reference_tests')
+    else:
+        raise ImportError('no reference tests: neither /root/reference/test nor a staged archive')
+    files = [os.path.join(root, t) for t in TEST_FILES
+             if t != 'conftest.py' and os.path.isfile(os.path.join(root, t))]
+    return root, files
 
 
 def import_reference():

@@ -159,6 +159,66 @@ def _square_graph(edge_index, n: int, s2t: bool = True):
     return edge_index
 
 
+def _stand_in(impl: Callable, orig: Callable) -> Callable:
+    """The function object that is bound in ``orig``'s place: calling it runs ``impl`` (this
+    backend's route, which falls back to ``orig`` itself), while everything that INSPECTS it finds
+    ``orig`` — its source (``inspect`` follows ``__wrapped__``), its signature, its name and module,
+    its attributes (TorchScript modifiers) and, because the stand-in's code runs in ``orig``'s
+    module globals, the names its source refers to.  That is what TorchScript needs to "step
+    aside": ``torch.jit.script(conv)`` / ``torch.jit.script(softmax)`` compile the ORIGINAL body
+    (reference tests: test_gcn_conv.py:75, test_softmax.py:24, test_linear.py:135-180) exactly as
+    without install(), instead of failing on a Python closure it cannot resolve.  The trampoline
+    itself touches no global name (only its closure cell)."""
+    import functools
+    import types
+
+    def call(*args, **kwargs):
+        return impl(*args, **kwargs)
+
+    fn = types.FunctionType(call.__code__, getattr(orig, '__globals__', call.__globals__),
+                            getattr(orig, '__name__', 'call'), None, call.__closure__)
+    try:
+        functools.update_wrapper(fn, orig)      # __module__, __name__, __qualname__, __doc__, __dict__
+    except (AttributeError, TypeError):         # pragma: no cover  (exotic callables)
+        pass
+    fn.__wrapped__ = orig
+    fn._pygamd_impl = impl
+    _share_script_overloads(fn, orig)
+    return fn
+
+
+_overload_names: List[str] = []
+
+
+def _share_script_overloads(fn: Callable, orig: Callable) -> None:
+    """``add_self_loops``, ``remove_self_loops``, ``coalesce`` and ``sort_edge_index`` are
+    ``@torch.jit._overload``-ed in the reference (utils/loop.py:203-373, _coalesce.py:23-59, …).
+    TorchScript keeps the uncompiled overload declarations per QUALIFIED NAME, compiles them for
+    the first function object of that name it meets and then drops them (torch/jit/_script.py
+    ``_get_overloads``): a stand-in and its original sharing one name would leave whichever comes
+    second without overloads (seen as "Arguments for call are not valid" in a later
+    ``torch.jit.script(GCNConv(...))``).  The stand-in therefore carries its own qualified name and
+    its own copy of the declarations (or of the compiled set, if the original was scripted before
+    install()).  Private torch registries: guarded, a torch that lacks them is left alone."""
+    try:
+        import torch._jit_internal as ji
+        from torch.jit import _state as jit_state
+        qual = ji._qualified_name(orig)
+        decls = ji._get_fn_overloads(qual)
+        done = jit_state._jit_function_overload_caching.get(orig, None)
+        if not decls and not done:
+            return
+        mine = qual + '__pygamd'
+        fn._jit_override_qualname = mine
+        if decls:
+            ji._overloaded_fns[mine] = list(decls)
+            _overload_names.append(mine)
+        if done:
+            jit_state._jit_function_overload_caching[fn] = list(done)
+    except Exception:  # pragma: no cover
+        pass
+
+
 def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
     from . import utils as U
 
@@ -216,9 +276,23 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
         return orig['scatter_argmax'](src, index, dim, dim_size)
 
     def spmm(src, other, reduce='sum'):
+        # sum / mean only: for min / max over a `torch.sparse` matrix the reference's own device
+        # path raises NotImplementedError("... not yet supported ...") (utils/_spmm.py:92-99, pinned
+        # by its test_spmm.py:50-82) — the call is left to it.  (This package's own
+        # `utils.spmm` does take unit-valued min / max.)
         if (isinstance(src, Tensor) and type(src) is Tensor and src.is_cuda and _ours(other)
                 and src.layout in (torch.sparse_csr, torch.sparse_coo, torch.sparse_csc)
+                and reduce in ('sum', 'add', 'mean')
                 and src.dim() == 2 and src.values().dim() == 1 and _enabled()):
+            # the conversion the reference warns about happens here too (the handle is built from
+            # a CSR view of the matrix): same warning, same conditions (utils/_spmm.py:101-118)
+            if src.layout == torch.sparse_coo or (src.layout == torch.sparse_csc
+                                                  and not other.requires_grad):
+                import warnings
+                warnings.warn(f"Converting sparse tensor to CSR format for more "
+                              f"efficient processing. Consider converting your "
+                              f"sparse tensor to CSR format beforehand to avoid "
+                              f"repeated conversion (got '{src.layout}')", stacklevel=3)
             return U.spmm(src, other, reduce)
         return orig['spmm'](src, other, reduce)
 
@@ -243,11 +317,7 @@ def _make_dispatchers(orig: Dict[str, Callable]) -> Dict[str, Callable]:
                softmax=softmax, index_sort=index_sort,
                scatter_argmax=scatter_argmax, spmm=spmm, sort_edge_index=sort_edge_index,
                coalesce=coalesce)
-    for name, fn in new.items():
-        fn.__wrapped__ = orig[name]
-        fn.__doc__ = orig[name].__doc__
-        fn.__name__ = name
-    return new
+    return {name: _stand_in(fn, orig[name]) for name, fn in new.items()}
 
 
 def _sweep(old: Callable, new: Callable) -> List[Tuple[Any, str, Callable]]:
@@ -356,7 +426,9 @@ def _make_edge_index_spmm(orig: Callable) -> Callable:
         from .edge_index import as_edge_index
         ok = (_ours(other) and other.dim() == 2 and _enabled()
               and reduce in ('sum', 'add', 'mean', 'min', 'max')
-              and (value is None or (_ours(value) and value.dim() == 1))
+              and (value is None or (_ours(value) and value.dim() == 1
+                                     and reduce not in ('min', 'max')))  # (weighted
+              # extrema: the reference's own scatter route, edge_index.py:1903-1922)
               and (input.is_sorted_by_col if transpose else input.is_sorted_by_row))
         if not ok:
             return orig(input, other, value, reduce, transpose)
@@ -369,8 +441,7 @@ def _make_edge_index_spmm(orig: Callable) -> Callable:
         return SpmmFunction.apply(other, value, graph, 'sum' if reduce == 'add' else reduce,
                                   'coo')
 
-    _spmm.__wrapped__ = orig
-    return _spmm
+    return _stand_in(_spmm, orig)
 
 
 class _IdentityMemo:
@@ -439,12 +510,9 @@ def _make_graph_rewrite_memos(gcn_mod, gat_mod) -> List[Tuple[Any, str, Callable
             return memo_add((plain, ), (num_nodes, ))
         return orig_add(edge_index, edge_attr, fill_value, num_nodes)
 
-    for fn, o in ((gcn_norm, orig_norm), (remove_self_loops, orig_rm), (add_self_loops, orig_add)):
-        fn.__wrapped__ = o
-        fn.__doc__ = o.__doc__
-    gcn_mod.gcn_norm = gcn_norm
-    gat_mod.remove_self_loops = remove_self_loops
-    gat_mod.add_self_loops = add_self_loops
+    gcn_mod.gcn_norm = _stand_in(gcn_norm, orig_norm)
+    gat_mod.remove_self_loops = _stand_in(remove_self_loops, orig_rm)
+    gat_mod.add_self_loops = _stand_in(add_self_loops, orig_add)
     return [(gcn_mod, 'gcn_norm', orig_norm), (gat_mod, 'remove_self_loops', orig_rm),
             (gat_mod, 'add_self_loops', orig_add)]
 
@@ -466,9 +534,7 @@ def _wrap_graphsage_forward(cls) -> Callable:
         return orig(self, x, edge_index, edge_weight, edge_attr, batch, batch_size,
                     num_sampled_nodes_per_hop, num_sampled_edges_per_hop)
 
-    forward.__wrapped__ = orig
-    forward.__doc__ = orig.__doc__
-    return forward
+    return _stand_in(forward, orig)
 
 
 def _wrap_sageconv_forward(cls) -> Callable:
@@ -488,9 +554,7 @@ def _wrap_sageconv_forward(cls) -> Callable:
                 return torch.nn.functional.normalize(h, p=2.0, dim=-1) if self.normalize else h
         return orig(self, x, edge_index, size)
 
-    forward.__wrapped__ = orig
-    forward.__doc__ = orig.__doc__
-    return forward
+    return _stand_in(forward, orig)
 
 
 def _wrap_graphconv_forward(cls) -> Callable:
@@ -506,9 +570,7 @@ def _wrap_graphconv_forward(cls) -> Callable:
                 return _fused_sage.run_layer(self, x, graph)
         return orig(self, x, edge_index, edge_weight, size)
 
-    forward.__wrapped__ = orig
-    forward.__doc__ = orig.__doc__
-    return forward
+    return _stand_in(forward, orig)
 
 
 def _wrap_gcnconv_forward(cls) -> Callable:
@@ -543,9 +605,7 @@ def _wrap_gcnconv_forward(cls) -> Callable:
         out = self.lin(self.propagate(edge_index, x=x, edge_weight=edge_weight))
         return out if self.bias is None else out + self.bias
 
-    forward.__wrapped__ = orig
-    forward.__doc__ = orig.__doc__
-    return forward
+    return _stand_in(forward, orig)
 
 
 _FLOW_HOOKS = ('_propagate_forward_pre_hooks', '_propagate_forward_hooks',
@@ -567,9 +627,9 @@ def _wrap_propagate(cls) -> Callable:
             return orig(self, edge_index, size=size, **kwargs)
         return res
 
-    propagate.__wrapped__ = orig
-    propagate.__module__ = getattr(orig, '__module__', propagate.__module__)
-    return propagate
+    fn = _stand_in(propagate, orig)   # (__module__ = orig's: `_set_jittable_templates` looks at it)
+    fn._pygamd_propagate = True
+    return fn
 
 
 def _capturing(t: Tensor) -> bool:
@@ -615,9 +675,7 @@ def _make_index_select(orig: Callable) -> Callable:
                 return out if d == 0 else out.movedim(0, d)
         return orig(self, src, index)
 
-    _index_select.__wrapped__ = orig
-    _index_select.__doc__ = orig.__doc__
-    return _index_select
+    return _stand_in(_index_select, orig)
 
 
 def _wrap_gatconv_forward(cls) -> Callable:
@@ -667,9 +725,7 @@ def _wrap_gatconv_forward(cls) -> Callable:
             out = out + res
         return bias_act(out, self.bias, False) if self.bias is not None else out
 
-    forward.__wrapped__ = orig
-    forward.__doc__ = orig.__doc__
-    return forward
+    return _stand_in(forward, orig)
 
 
 def _rgcn_args_ok(conv, x, edge_index, edge_type) -> bool:
@@ -699,6 +755,25 @@ def _rgcn_args_ok(conv, x, edge_index, edge_type) -> bool:
             and not _capturing(w))
 
 
+def _note_segment_matmul_heuristic(conv) -> None:
+    """The reference's forward leaves `_use_segment_matmul_heuristic_output` on the layer
+    (rgcn_conv.py:246-260: a bool once a forward has run with `backend.use_segment_matmul = None`);
+    TorchScript types the attribute from that value (`torch.jit.script(conv)` after a forward:
+    test_rgcn_conv.py:84).  Same inputs — the relation histogram's maximum comes from the cached
+    handle — same helper, once per handle."""
+    import torch_geometric.backend as pyg_backend
+    if pyg_backend.use_segment_matmul is not None:
+        return
+    hit = conv.__dict__.get('_handle_cache')
+    handle = hit[-1] if hit is not None else None
+    if handle is None or getattr(handle, '_heuristic_for', None) is conv:
+        return
+    conv._use_segment_matmul_heuristic_output = pyg_backend.use_segment_matmul_heuristic(
+        num_segments=conv.num_relations, max_segment_size=handle.max_edges_per_relation,
+        in_channels=conv.weight.size(1), out_channels=conv.weight.size(2))
+    handle._heuristic_for = conv
+
+
 def _wrap_rgcn_forward(cls, fast: bool) -> Callable:
     """The reference's ``RGCNConv.forward`` — a Python loop of masked ``propagate`` calls, 474
     iterations at the FB15k-237 shape (nn/conv/rgcn_conv.py:243-282) — and ``FastRGCNConv.forward``
@@ -720,12 +795,13 @@ def _wrap_rgcn_forward(cls, fast: bool) -> Callable:
             from .nn.conv import rgcn_conv as own
             ei = _plain_index(edge_index)
             run = own.fast_rgcn_forward if fast else own.rgcn_forward
-            return run(self, x, ei, edge_type)
+            out = run(self, x, ei, edge_type)
+            if not fast and self.num_blocks is None:
+                _note_segment_matmul_heuristic(self)
+            return out
         return orig(self, x, edge_index, edge_type)
 
-    forward.__wrapped__ = orig
-    forward.__doc__ = orig.__doc__
-    return forward
+    return _stand_in(forward, orig)
 
 
 def _wrap_heterolinear_forward(cls) -> Callable:
@@ -747,9 +823,7 @@ def _wrap_heterolinear_forward(cls) -> Callable:
             return hetero_linear_forward(self, x, type_vec)
         return orig(self, x, type_vec)
 
-    forward.__wrapped__ = orig
-    forward.__doc__ = orig.__doc__
-    return forward
+    return _stand_in(forward, orig)
 
 
 class _SegmentMatmulOps:
@@ -854,8 +928,7 @@ def _wrap_linear_forward(cls):
             return linear(x, w, self.bias)   # (the C++ node for plain operands)
         return orig(self, x)
 
-    forward.__wrapped__ = orig
-    return forward
+    return _stand_in(forward, orig)
 
 
 def install() -> None:
@@ -890,6 +963,35 @@ def install() -> None:
         prev = cls.__dict__.get('propagate')
         cls.propagate = _wrap_propagate(cls)
         _state['classes'].append((cls, had_own, prev))
+
+    # A layer object renders its TorchScript-able `propagate` from a template when it is BUILT
+    # (`_set_jittable_templates`, message_passing.py:926-1000) — unless its class carries a custom
+    # `propagate`, which the stand-in above would look like.  So for the wrapped classes that step
+    # runs against the class as the reference left it, and the stand-in goes back on top of
+    # whatever it produced (the generated function: its module name and globals are the stand-in's
+    # too, so later objects skip the rendering and TorchScript compiles the generated body).
+    from torch_geometric.nn.conv import MessagePassing as _MP
+    orig_templates = _MP.__dict__['_set_jittable_templates']
+
+    def _set_jittable_templates(self, raise_on_error=False):
+        cls = type(self)
+        at = next((i for i, r in enumerate(_state['classes']) if r[0] is cls), None)
+        if at is None or not getattr(cls.__dict__.get('propagate'), '_pygamd_propagate', False):
+            return orig_templates(self, raise_on_error)
+        _, had_own, prev = _state['classes'][at]
+        if had_own:
+            cls.propagate = prev
+        else:
+            delattr(cls, 'propagate')
+        try:
+            return orig_templates(self, raise_on_error)
+        finally:
+            had_now, now = 'propagate' in cls.__dict__, cls.__dict__.get('propagate')
+            cls.propagate = _wrap_propagate(cls)
+            _state['classes'][at] = (cls, had_now, now)
+
+    _MP._set_jittable_templates = _stand_in(_set_jittable_templates, orig_templates)
+    _state['rebinds'].append((_MP, '_set_jittable_templates', orig_templates))
 
     import torch_geometric.nn.conv.gat_conv as pyg_gat_mod
     import torch_geometric.nn.conv.gcn_conv as pyg_gcn_mod
@@ -985,6 +1087,12 @@ def uninstall() -> None:
     for attr in ('mi355x', 'use_mi355x'):
         if hasattr(pyg_backend, attr):
             delattr(pyg_backend, attr)
+    try:  # the stand-ins' copies of TorchScript overload declarations (_share_script_overloads)
+        import torch._jit_internal as ji
+        while _overload_names:
+            ji._overloaded_fns.pop(_overload_names.pop(), None)
+    except Exception:  # pragma: no cover
+        pass
     _state.update(installed=False, rebinds=[], classes=[], forwards=[])
 
 

@@ -67,6 +67,14 @@ class RelationalHandle:
                                     sort_order='col', validate=False)
         self._perm, self._pair_of_edge, self._edge_graph = perm, pair_of_edge, None
         self.rel_ptr = tuple(_native.index2ptr(pair_rel, num_relations).tolist())
+        # the relation histogram's maximum (what the reference's `use_segment_matmul_heuristic`
+        # looks at, rgcn_conv.py:246-257): pairs per relation are on the host already, the edges
+        # per pair are `seg_ptr`'s differences — one more small read, once per handle
+        if E > 0:
+            edge_ptr = seg_ptr[torch.tensor(self.rel_ptr, device=dev)]
+            self.max_edges_per_relation = int((edge_ptr[1:] - edge_ptr[:-1]).max())
+        else:
+            self.max_edges_per_relation = 0
         # pairs -> destination nodes
         self.out_graph = EdgeIndex(torch.stack([torch.arange(S, device=dev), pair_dst]),
                                    (S, num_dst), sort_order='row', validate=False)
