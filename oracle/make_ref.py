@@ -40,18 +40,22 @@ KEEP = ('.py', '.jinja', '.typed')
 # against `backend.install()` with their `@withDevice` / `@withCUDA` cases on HIP tensors
 # (tests/test_gpu_reference_suite.py).  Data, never edited: any assertion that fails there fails
 # as the reference wrote it.
-TEST_FILES = (
-    'conftest.py',
-    'utils/test_scatter.py', 'utils/test_segment.py', 'utils/test_softmax.py',
-    'utils/test_spmm.py', 'utils/test_index_sort.py', 'utils/test_sort_edge_index.py',
-    'utils/test_coalesce.py', 'utils/test_loop.py', 'utils/test_degree.py',
-    'utils/test_trim_to_layer.py', 'utils/test_undirected.py',
-    'test_edge_index.py', 'test_index.py',
-    'nn/aggr/test_basic.py', 'nn/aggr/test_fused.py', 'nn/aggr/test_multi.py',
-    'nn/conv/test_message_passing.py', 'nn/conv/test_sage_conv.py', 'nn/conv/test_gcn_conv.py',
-    'nn/conv/test_gat_conv.py', 'nn/conv/test_rgcn_conv.py', 'nn/conv/test_graph_conv.py',
-    'nn/dense/test_linear.py', 'nn/models/test_basic_gnn.py',
-)
+TEST_FILES = ('conftest.py', 'test_edge_index.py', 'test_index.py',
+              'nn/models/test_basic_gnn.py')
+# ... and every module of these directories: all 60-odd conv layers (the ones without a dedicated
+# route ride on `MessagePassing._index_select` + `scatter`), every aggregation, the dense layers,
+# the utils
+TEST_DIRS = ('nn/conv', 'nn/aggr', 'nn/dense', 'utils')
+
+
+def _test_files(tsrc):
+    found = [t for t in TEST_FILES if os.path.isfile(os.path.join(tsrc, t))]
+    for d in TEST_DIRS:
+        full = os.path.join(tsrc, d)
+        if os.path.isdir(full):
+            found += [os.path.join(d, n) for n in sorted(os.listdir(full))
+                      if n.endswith('.py') and (n.startswith('test_') or n == 'conftest.py')]
+    return found
 
 
 def staged_path():
@@ -73,7 +77,7 @@ def stage(force: bool = False):
             if n.endswith(KEEP):
                 files.append(os.path.relpath(os.path.join(base, n), src))
     tsrc = os.path.join(REF_ROOT, 'test')
-    tests = [t for t in TEST_FILES if os.path.isfile(os.path.join(tsrc, t))]
+    tests = _test_files(tsrc)
     h = hashlib.sha1()
     for rel in files:
         h.update(rel.encode())
@@ -130,8 +134,8 @@ def reference_tests():
         root = os.path.join(_unpacked_dir(), 'reference_tests')
     else:
         raise ImportError('no reference tests: neither /root/reference/test nor a staged archive')
-    files = [os.path.join(root, t) for t in TEST_FILES
-             if t != 'conftest.py' and os.path.isfile(os.path.join(root, t))]
+    files = [os.path.join(root, t) for t in _test_files(root)
+             if os.path.basename(t) != 'conftest.py']
     return root, files
 
 
