@@ -17,15 +17,27 @@ class CapturedStep:
     read its inputs from fixed buffers (update them in place between replays), keep ``.grad``
     tensors allocated (``zero_grad(set_to_none=False)``) and must not synchronise with the host."""
 
-    def __init__(self, fn: Callable[[], Any], warmup: int = 3):
+    def __init__(self, fn: Callable[[], Any], warmup: int = 3, capture_error_mode: str = None):
+        """``capture_error_mode``: hipStreamCaptureMode of the recording (``torch.cuda.graph``'s
+        argument).  Default: ``'global'`` — except when a ``torch.distributed`` process group
+        exists: its watchdog thread polls events of earlier collectives while this thread records,
+        which a GLOBAL capture reports as an illegal call from another thread (seen as an
+        intermittent ``ProcessGroupNCCL`` watchdog abort when the step's all-reduce is recorded
+        too); such steps record ``'thread_local'``."""
+        if capture_error_mode is None:
+            import torch.distributed as dist
+            pg = dist.is_available() and dist.is_initialized()
+            capture_error_mode = 'thread_local' if pg else 'global'
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 1)):
                 fn()
         torch.cuda.current_stream().wait_stream(side)
+        if capture_error_mode != 'global':
+            torch.cuda.synchronize()   # the warm-up collectives are done before recording starts
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             self.output = fn()
 
     def __call__(self):
