@@ -642,14 +642,30 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
     outside = use_dist and not in_graph   # all-reduce + Adam issued eagerly behind the graph
     body = whole_step_dist if in_graph else (fwd_bwd if use_dist else whole_step)
     it = plan()
-    seeds_buf.copy_(next(it))
-    from pytorch_geometric_amd.hipgraph import CapturedStep
-    if os.environ.get('PYGAMD_CAPTURE', '1') == '0':  # the same static-shape step, eagerly
-        captured = body                                # (per-kernel times for a profile)
-        for _ in range(3):
-            captured()
+    eager = os.environ.get('PYGAMD_CAPTURE', '1') == '0'  # the same static-shape step, eagerly
+    # Round 6: the step is slots.SlotTrainer's — parameters in one flat buffer in the layer
+    # kernels' layout, loss + its gradient and Adam as ONE launch each, no per-parameter
+    # concatenation / transpose / accumulation launch (PYGAMD_SLOT_TRAINER=0: the round-5 step
+    # through autograd + F.cross_entropy + torch's fused Adam, for an A/B on the same box).
+    use_trainer = os.environ.get('PYGAMD_SLOT_TRAINER', '1') != '0'
+    if use_trainer:
+        from pytorch_geometric_amd.slots import SlotTrainer
+        trainer = SlotTrainer(model, loader, lr=1e-3, capture=not eager,
+                              collective_in_graph=in_graph if use_dist else None)
+        seeds_buf, epoch, loss_buf = trainer.seeds, trainer.epoch, trainer.loss
+        seeds_buf.copy_(next(it))
+        captured = trainer.step          # (records itself on the first call)
+        captured()
+        outside = False                  # (a gloo group: the trainer reduces behind its graph)
     else:
-        captured = CapturedStep(body, warmup=3)
+        seeds_buf.copy_(next(it))
+        from pytorch_geometric_amd.hipgraph import CapturedStep
+        if eager:
+            captured = body                                # (per-kernel times for a profile)
+            for _ in range(3):
+                captured()
+        else:
+            captured = CapturedStep(body, warmup=3)
     ar_events = []
 
     def step():
@@ -769,7 +785,9 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
                                    f'{B} seeds/rank, fan-out {fan}, hop-aware (trim_to_layer) '
                                    f'stack on STATIC-shape SLOT batches (csrc/minibatch.hip; block '
                                    f'capacities {caps}; one fused-layer launch per layer forward, '
-                                   f'dgrad GEMMs + transposed SpMM backward), '
+                                   f'dgrad GEMMs + transposed SpMM backward'
+                                   + ('; slots.SlotTrainer: flat parameters, one-launch loss and '
+                                      'Adam' if use_trainer else '') + '), '
                                    f'synthetic papers100M shape x {scale:g} (N={N}, E={E}) '
                                    f'replicated per GPU',
                        'captured': ('sampling + gather + forward + backward' +

@@ -30,7 +30,7 @@ extern "C" {
 
 #define PYGAMD_API __attribute__((visibility("default")))
 
-#define PYGAMD_ABI_VERSION 9
+#define PYGAMD_ABI_VERSION 10
 
 typedef enum {
   PYGAMD_OK = 0,
@@ -736,6 +736,45 @@ PYGAMD_API int pygamd_slots_transpose(const int64_t* src_g, const int32_t* src_i
                                       int32_t* const* cursor /*[host]*/,
                                       int32_t* const* ptr /*[host]*/,
                                       int32_t* const* col /*[host]*/, void* stream);
+
+/* ---- f1c: the loss and optimizer ends of a captured batch step — csrc/train.hip ----------------------
+ * The reference's mini-batch loop (examples/multi_gpu/distributed_sampling.py:104-117) ends every
+ * batch with `loss = F.cross_entropy(out, batch.y[:batch.batch_size]); loss.backward();
+ * optimizer.step()` (torch.optim.Adam).  Inside a hipGraph every launch costs ~5 us, so these two
+ * ends are ONE launch each here (before: 7 ATen launches for the loss of 1024 rows, 42 us of
+ * multi-tensor Adam for 0.2 M parameters, a concatenation / transpose launch per weight use).
+ *
+ * pygamd_cross_entropy_step: loss[0] = mean_r (logsumexp(logits[r, :]) - logits[r, label_r]),
+ * grad[r, c] = (softmax(logits[r, :])[c] - [c == label_r]) / B — F.cross_entropy (reduction
+ * 'mean', no class weights, no label smoothing) and its backward for an upstream gradient of 1.
+ * label_r = y[label_idx[r]] (label_idx NULL: y[r]) — the seeds' labels are read from the graph's
+ * label vector, no gathered copy.  A label outside [0, C) sets *err_flag (device int32, optional)
+ * and contributes neither loss nor gradient (no ignore_index: the mean divides by B).  The row
+ * losses are added up in row order (deterministic).  Workspace: ..._workspace_bytes(B); its first
+ * 16 bytes must be ZERO before the first launch (the kernel re-arms them itself).                 */
+PYGAMD_API int pygamd_cross_entropy_step_workspace_bytes(int64_t B, size_t* bytes /*[host]*/);
+PYGAMD_API int pygamd_cross_entropy_step(const float* logits, int64_t ld, int64_t B, int64_t C,
+                                         const int64_t* y, const int64_t* label_idx, float* grad,
+                                         int64_t ldg, float* loss, void* workspace,
+                                         size_t workspace_bytes, int32_t* err_flag, void* stream);
+/* pygamd_adam_step: torch.optim.Adam (amsgrad / maximize off; weight_decay = the L2 form) over ONE
+ * flat float32 buffer of n parameters with gradients `grad * grad_scale` (grad_scale = 1 / world
+ * size after a SUM all-reduce).  The step count is read from the device: step = *step_dev -
+ * step_base >= 1 (a captured step bumps *step_dev itself; bias corrections in float32 as the
+ * capturable optimizer evaluates them).  `transposed` (optional): for each of n_segments (<=
+ * PYGAMD_ADAM_MAX_SEGMENTS) row-major blocks param[seg_off .. + rows * cols) the updated values
+ * are also stored transposed at transposed[seg_t_off + c * rows + r] — the W^T operand of
+ * pygamd_linear_dgrad, kept current without a transpose launch per use.                          */
+#define PYGAMD_ADAM_MAX_SEGMENTS 8
+PYGAMD_API int pygamd_adam_step(float* param, const float* grad, float* exp_avg,
+                                float* exp_avg_sq, int64_t n, const int64_t* step_dev,
+                                int64_t step_base, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, double grad_scale,
+                                float* transposed, int n_segments,
+                                const int64_t* seg_off /*[host]*/,
+                                const int32_t* seg_rows /*[host]*/,
+                                const int32_t* seg_cols /*[host]*/,
+                                const int64_t* seg_t_off /*[host]*/, void* stream);
 
 /* ---- f3: SAGEConv layer forward in one kernel ----------------------------------------------------
  * y[i, :] = act([aggr_{j->i} x[j] | x_root[i]] @ w[Fo, 2F]^T + bias) — `propagate` + `lin_l(agg)

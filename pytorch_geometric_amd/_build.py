@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(LIB_DIR, 'libpyg_amd.so')
 LAB_LIB_PATH = os.path.join(LIB_DIR, 'libpyg_amd_lab.so')
 BUILD_DIR = os.path.join(os.path.dirname(PKG_DIR), 'build', 'pyg_amd')
 SOURCES = ['capi.hip', 'graph.hip', 'spmm.hip', 'scatter.hip', 'softmax.hip', 'segmm.hip',
-           'sample.hip', 'minibatch.hip', 'gemm.hip', 'sage_fused.hip']
+           'sample.hip', 'minibatch.hip', 'train.hip', 'gemm.hip', 'sage_fused.hip']
 LAB_SOURCES = SOURCES + ['sage_fused_lab.hip']
 LAB_FLAGS = {'gemm.hip': ['-DPYGAMD_LAB=1']}   # the weight-gradient variants and probes
 ARCH = 'gfx950'

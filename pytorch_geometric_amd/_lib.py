@@ -5,12 +5,12 @@ fallback: if the library is missing (and cannot be built) or a call fails, we ra
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
-                    c_uint64, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_uint64, c_void_p)
 
 from . import _build
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 X_DENSE, X_COMPRESSED = 0, 1  # pygamd_x_format  # PYGAMD_ABI_VERSION of include/pyg_amd.h
 IDX_I32, IDX_I64 = 0, 1
 SUM, MEAN, MIN, MAX, MUL, ANY = 0, 1, 2, 3, 4, 5
@@ -146,6 +146,12 @@ SIGNATURES = {
                                      _P]),
     'pygamd_slots_gather': (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
     'pygamd_slots_transpose': (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    'pygamd_cross_entropy_step_workspace_bytes': (c_int, [c_int64, _P]),
+    'pygamd_cross_entropy_step': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P,
+                                          _P, c_size_t, _P, _P]),
+    'pygamd_adam_step': (c_int, [_P, _P, _P, _P, c_int64, _P, c_int64, c_double, c_double,
+                                 c_double, c_double, c_double, c_double, _P, c_int, _P, _P, _P,
+                                 _P, _P]),
     'pygamd_edge_key': (c_int, [_P, _P, c_int, c_int64, c_int64, c_int, _P, _P]),
     'pygamd_run_flags': (c_int, [_P, c_int64, _P, _P]),
     'pygamd_edge_unkey': (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P]),

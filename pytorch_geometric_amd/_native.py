@@ -1420,13 +1420,19 @@ def linear_dgrad(g: Tensor, w_t: Tensor, row_scale: Optional[Tensor] = None, n_s
 
 def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
                  accumulate: bool = False, wgs_per_cu: int = 0, bias_grad: bool = False,
-                 x2: Optional[Tensor] = None):
+                 x2: Optional[Tensor] = None, bias_out: Optional[Tensor] = None):
     """``g [M, N].T @ x [M, K]`` -> ``[N, K]`` (deterministic split reduction over M).
     ``wgs_per_cu=1`` halves the launch's footprint (for running under a bandwidth-bound kernel
     on another stream).  ``bias_grad=True`` also returns ``g.sum(0)`` — taken from the same pass
     over ``g`` — as ``(grad_w, grad_b)``.  ``x2`` (``[M, K2]``): the gradient against
-    ``[x | x2]`` -> ``[N, K + K2]`` without concatenating the two."""
-    _require_device(g, x, out, x2)
+    ``[x | x2]`` -> ``[N, K + K2]`` without concatenating the two.  ``bias_out`` (contiguous
+    float32 ``[N]``, with ``bias_grad``): where the bias gradient is written (e.g. its slot of a
+    flat gradient buffer) instead of a fresh tensor."""
+    _require_device(g, x, out, x2, bias_out)
+    if bias_out is not None and (not bias_grad or bias_out.dtype != torch.float32
+                                 or bias_out.shape != (g.size(1), )
+                                 or not bias_out.is_contiguous()):
+        raise ValueError("'bias_out' needs bias_grad=True and a contiguous float32 [N] tensor")
     C = _compiled.ops()
     if C is not None and _plain(g, x, x2, out) and x.size(0) == g.size(0) \
             and (x2 is None or (x2.size(0) == g.size(0) and x.size(1) > 0 and x2.size(1) > 0)):
@@ -1434,7 +1440,10 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
         if K > 0 and (out is None or (out.shape == (N, K) and (K <= 1 or out.stride(1) == 1))):
             if out is None:
                 out = torch.empty(N, K, dtype=torch.float32, device=g.device)
-            gb = torch.empty(N, dtype=torch.float32, device=g.device) if bias_grad else None
+            gb = None
+            if bias_grad:
+                gb = bias_out if bias_out is not None else \
+                    torch.empty(N, dtype=torch.float32, device=g.device)
             with _timed({'kind': 'gemm', 'op': 'wgrad', 'M': g.size(0), 'N': N, 'K': K}, g):
                 C.linear_wgrad(g, x, out, accumulate, wgs_per_cu, gb, x2)
             return (out, gb) if bias_grad else out
@@ -1458,8 +1467,10 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
     gb = None
     if bias_grad:
         if K == 0:  # no weight tile passes over g
-            return out, colsum(g2)
-        gb = torch.empty(N, dtype=torch.float32, device=g.device)
+            cs = colsum(g2)
+            return out, (cs if bias_out is None else bias_out.copy_(cs))
+        gb = bias_out if bias_out is not None else \
+            torch.empty(N, dtype=torch.float32, device=g.device)
     with _timed({'kind': 'gemm', 'op': 'wgrad', 'M': M, 'N': N, 'K': K}, g):
         check(lib.pygamd_linear_wgrad2(_p(g2), _ld(g2), _p(first), _ld(first), K1, _p(second),
                                        _ld(second) if second is not None else 0, K2, M, N,

@@ -13,7 +13,8 @@ import torch
 
 class CapturedStep:
     """``replay = CapturedStep(fn)`` runs ``fn`` eagerly ``warmup`` times on a side stream (this is
-    where handles get sorted and cached), captures one more call and then replays it.  ``fn`` must
+    where handles get sorted and cached; 0 = the caller has warmed ``fn`` up itself), captures one
+    more call and then replays it.  ``fn`` must
     read its inputs from fixed buffers (update them in place between replays), keep ``.grad``
     tensors allocated (``zero_grad(set_to_none=False)``) and must not synchronise with the host."""
 
@@ -31,7 +32,7 @@ class CapturedStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
+            for _ in range(max(warmup, 0)):
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         if capture_error_mode != 'global':

@@ -132,13 +132,14 @@ class NeighborLoader:
         y = None if self.y is None else self.y[seeds]
         return PaddedBatch(x=x, y=y, hops=p, n_id=n_id, batch_size=seeds.numel())
 
-    def collate_slots(self, seeds: Tensor, epoch_dev: Tensor):
+    def collate_slots(self, seeds: Tensor, epoch_dev: Tensor, with_labels: bool = True):
         """One batch in the static-shape SLOT layout (:mod:`pytorch_geometric_amd.slots`; bounded
         fan-outs, directional, non-disjoint, without replacement): 1 + 2 launches per hop for the
         sampling, 3 for the transposed CSRs of the backward, 1 for the feature gather, no host
         synchronisation.  ``epoch_dev``: int64 [1] on the device, >= 1, growing from batch to batch
         (a captured step bumps it before every replay).  Returns a ``SlotBatch`` with ``x`` = the
-        gathered ``[R, 2 F]`` buffer and ``y`` = the seeds' labels."""
+        gathered ``[R, 2 F]`` buffer and ``y`` = the seeds' labels (``with_labels=False``: none
+        — ``slots.SlotTrainer`` reads them from ``self.y`` inside its loss launch)."""
         from .slots import SlotPlan, SlotSampler
         smp = self.sampler
         if smp.replace or smp.disjoint or smp.subgraph_type != 'directional' \
@@ -150,7 +151,7 @@ class NeighborLoader:
             self._slots = SlotSampler(smp.colptr, smp.row, self.num_nodes, plan, seed=smp.seed)
         b = self._slots.sample(seeds, epoch_dev)
         b.x = self._slots.gather(self.x, b, direct=SLOTS_DIRECT and len(smp.num_neighbors) > 0)
-        b.y = None if self.y is None else self.y[seeds]
+        b.y = None if (self.y is None or not with_labels) else self.y[seeds]
         return b
 
     def _plan(self):

@@ -376,3 +376,282 @@ def run_slot_stack(model, batch: SlotBatch) -> Tensor:
         params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
     aggr = model.convs[0].aggr
     return FusedSageSlotStack.apply(batch.x, batch, 'sum' if aggr == 'add' else aggr, *params)
+
+
+class SlotTrainer:
+    r"""The reference's mini-batch loop for a GraphSAGE (``examples/multi_gpu/
+    distributed_sampling.py:104-117``: sample, ``model(...)``, ``F.cross_entropy``, ``backward()``,
+    ``Adam.step()``, under DDP the gradient all-reduce) as ONE static-shape step per batch that
+    replays as one hipGraph — with every launch that only re-arranged parameters removed:
+
+    * the parameters live in ONE flat buffer in the layout the layer kernels read (per layer the
+      row block ``[W_l | W_r]`` then the bias); ``conv.lin_l.weight`` / ``conv.lin_r.weight`` /
+      ``conv.lin_l.bias`` are re-bound as VIEWS of it (``state_dict`` / checkpoints keep working),
+      their ``.grad`` as views of the flat gradient buffer, which is also the single all-reduce
+      bucket — no concatenation per forward, no ``grad +=`` per parameter, no zero-fill;
+    * the weight-gradient launch of a layer writes its ``[grad W_l | grad W_r]`` and bias gradient
+      straight into that buffer;
+    * ``pygamd_cross_entropy_step``: loss and ``d loss / d logits`` of the seed rows in one launch,
+      labels read from the graph's label vector through the seed ids;
+    * ``pygamd_adam_step``: one launch for all parameters, which also refreshes the transposed
+      weights the input-gradient GEMMs read.
+
+    ``trainer = SlotTrainer(model, loader)``; per batch ``loss = trainer.step(seeds)`` (``seeds``:
+    ``loader.batch_size`` graph node ids on the device; the returned device scalar is the
+    trainer's own buffer).  ``capture=True`` (default) records the step on its first call and
+    replays it afterwards; the recording's warm-up runs leave parameters and optimizer state
+    untouched.  With a ``torch.distributed`` process group the gradients are SUM-all-reduced and
+    divided by the world size inside the optimizer launch (DDP's mean); over RCCL the collective
+    is part of the recorded graph.  Arithmetic: the package's GEMM mode (``set_gemm_mode``);
+    the update is ``torch.optim.Adam``'s (``amsgrad=False``)."""
+
+    def __init__(self, model, loader, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, process_group=None, capture: bool = True,
+                 collective_in_graph: Optional[bool] = None):
+        check_slot_model(model)
+        if loader.y is None:
+            raise ValueError('SlotTrainer needs the loader to hold the label vector (y=...)')
+        if loader.y.dtype != torch.int64 or loader.y.dim() != 1:
+            raise ValueError("'y' must be a 1-D int64 label vector")
+        self.model, self.loader = model, loader
+        self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
+        self.group = process_group
+        convs = list(model.convs)
+        self.L = len(convs)
+        if self.L > _lib.load().pygamd_slots_max_hops():
+            raise ValueError('too many layers')
+        aggr = convs[0].aggr
+        self.aggr = 'sum' if aggr == 'add' else aggr
+        dev = convs[0].lin_l.weight.device
+        self.device = dev
+        _native._require_device(convs[0].lin_l.weight, loader.x, loader.y)
+        # ---- the flat layout: per layer [Fo, 2 Fi] then [Fo] (each block padded to 16 bytes)
+        off, t_off = 0, 0
+        self._shape, self._woff, self._boff, self._toff = [], [], [], []
+        for l, conv in enumerate(convs):
+            Fo, Fi = conv.lin_l.weight.shape
+            if conv.lin_r.weight.shape != (Fo, Fi) or conv.lin_l.weight.dtype != torch.float32:
+                raise ValueError(f'convs[{l}]: lin_l / lin_r must be float32 [{Fo}, {Fi}]')
+            if not _native.sage_layer_forward_supported(Fi, Fo, self.aggr):
+                raise ValueError(f'layer {l} ({Fi} -> {Fo}, {self.aggr}) is outside the one-kernel '
+                                 f'layer (F % 4 == 0, F <= 256, Fo <= 256, sum / mean)')
+            self._shape.append((Fo, Fi))
+            self._woff.append(off)
+            off += -(-(Fo * 2 * Fi) // 4) * 4
+            self._boff.append(off if conv.lin_l.bias is not None else None)
+            if conv.lin_l.bias is not None:
+                off += -(-Fo // 4) * 4
+            self._toff.append(t_off if l > 0 else None)
+            if l > 0:
+                t_off += Fo * 2 * Fi
+        self.n = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.wt_flat = torch.zeros(max(t_off, 1), dtype=torch.float32, device=dev)
+        self.wmat, self.gmat, self.bias, self.gbias, self.wt = [], [], [], [], []
+        with torch.no_grad():
+            for l, conv in enumerate(convs):
+                Fo, Fi = self._shape[l]
+                o = self._woff[l]
+                wm = self.flat[o:o + Fo * 2 * Fi].view(Fo, 2 * Fi)
+                gm = self.grad[o:o + Fo * 2 * Fi].view(Fo, 2 * Fi)
+                wm[:, :Fi].copy_(conv.lin_l.weight)
+                wm[:, Fi:].copy_(conv.lin_r.weight)
+                conv.lin_l.weight.data = wm[:, :Fi]
+                conv.lin_r.weight.data = wm[:, Fi:]
+                conv.lin_l.weight.grad = gm[:, :Fi]
+                conv.lin_r.weight.grad = gm[:, Fi:]
+                self.wmat.append(wm)
+                self.gmat.append(gm)
+                if self._boff[l] is not None:
+                    bo = self._boff[l]
+                    bv, gb = self.flat[bo:bo + Fo], self.grad[bo:bo + Fo]
+                    bv.copy_(conv.lin_l.bias)
+                    conv.lin_l.bias.data = bv
+                    conv.lin_l.bias.grad = gb
+                    self.bias.append(bv)
+                    self.gbias.append(gb)
+                else:
+                    self.bias.append(None)
+                    self.gbias.append(None)
+                if l > 0:
+                    to = self._toff[l]
+                    self.wt.append(self.wt_flat[to:to + Fo * 2 * Fi].view(2 * Fi, Fo))
+                else:
+                    self.wt.append(None)
+        segs = [l for l in range(self.L) if l > 0]
+        self._seg_n = len(segs)
+        n = max(len(segs), 1)
+        self._seg_off = (ctypes.c_int64 * n)(*[self._woff[l] for l in segs])
+        self._seg_rows = (ctypes.c_int32 * n)(*[self._shape[l][0] for l in segs])
+        self._seg_cols = (ctypes.c_int32 * n)(*[2 * self._shape[l][1] for l in segs])
+        self._seg_toff = (ctypes.c_int64 * n)(*[self._toff[l] for l in segs])
+        self.refresh()
+        # ---- per-step state on the device
+        B = loader.batch_size
+        self.B = B
+        self.seeds = torch.zeros(B, dtype=loader.sampler.colptr.dtype, device=dev)
+        self.epoch = torch.zeros(1, dtype=torch.int64, device=dev)   # batch counter = Adam's step
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.label_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        nbytes = ctypes.c_size_t(0)
+        check(_lib.load().pygamd_cross_entropy_step_workspace_bytes(B, ctypes.byref(nbytes)))
+        self._ce_ws = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
+        self._step_base = 0
+        self._capture = bool(capture)
+        self._graph = None
+        import torch.distributed as dist
+        self._dist = dist.is_available() and dist.is_initialized()
+        self._world = dist.get_world_size(process_group) if self._dist else 1
+        if collective_in_graph is None:
+            collective_in_graph = self._dist and dist.get_backend(process_group) == 'nccl'
+        self._collective_in_graph = bool(collective_in_graph) and self._dist
+
+    # ---- host-side maintenance
+    @torch.no_grad()
+    def refresh(self) -> None:
+        """Re-derives the transposed weights from the parameters (call after writing to them from
+        outside: ``load_state_dict``, a manual initialisation)."""
+        for l in range(1, self.L):
+            self.wt[l].copy_(self.wmat[l].t())
+
+    def check_labels(self) -> None:
+        """One host read: raises if a step met a label outside ``[0, out_channels)`` (such rows
+        contribute neither loss nor gradient)."""
+        if int(self.label_err.item()) != 0:
+            self.label_err.zero_()
+            raise IndexError(f'a seed label was outside [0, {self._shape[-1][0]})')
+
+    # ---- the step
+    def _forward_backward(self) -> None:
+        p_lib = _lib.load()
+        self.epoch.add_(1)
+        b = self.loader.collate_slots(self.seeds, self.epoch, with_labels=False)
+        p, L, aggr, dev = b.plan, self.L, self.aggr, self.device
+        b.check_current('SlotTrainer.step')
+        direct = b.x_global is not None
+        cat = b.x
+        Fi = cat.size(1) // 2
+        if Fi != self._shape[0][1]:
+            raise ValueError(f'the loader gathers {Fi} features, the model takes '
+                             f'{self._shape[0][1]}')
+        cats, bits = [], []
+        out = None
+        for l in range(L):
+            Fo = self._shape[l][0]
+            m = p.bases[L - l]
+            last = l == L - 1
+            if last:
+                nxt, dst, rb = None, torch.empty(m, Fo, dtype=torch.float32, device=dev), None
+                out = dst
+            else:
+                nxt = torch.empty(m, 2 * Fo, dtype=torch.float32, device=dev)
+                dst = nxt[:, Fo:]
+                rb = _native.relu_bits_like(m, Fo, dev)
+            if l == 0 and direct:
+                _native.sage_layer_forward(p.row_begin64, b.src_g, b.x_global, cat[:m, Fi:],
+                                           self.wmat[l], self.bias[l], aggr, not last,
+                                           cat[:m, :Fi], dst, save_agg=True, relu_bits=rb,
+                                           rowend=b.row_end64)
+            else:
+                _native.sage_layer_forward(p.row_begin, b.src_id, cat[:, Fi:], cat[:m, Fi:],
+                                           self.wmat[l], self.bias[l], aggr, not last,
+                                           cat[:m, :Fi], dst, save_agg=True, relu_bits=rb,
+                                           rowend=b.row_end)
+            cats.append(cat)
+            bits.append(rb)
+            cat, Fi = nxt, Fo
+        # ---- loss of the seed rows + its gradient
+        C = out.size(1)
+        g = torch.empty(self.B, C, dtype=torch.float32, device=dev)
+        label_idx = self.seeds if self.seeds.dtype == torch.int64 else self.seeds.to(torch.int64)
+        check(p_lib.pygamd_cross_entropy_step(
+            _i64p(out), _native._ld(out), self.B, C, _i64p(self.loader.y), _i64p(label_idx),
+            _i64p(g), _native._ld(g), _i64p(self.loss), _i64p(self._ce_ws),
+            self._ce_ws.numel(), _i64p(self.label_err), _native._stream(out)),
+            'cross_entropy_step')
+        # ---- backward (FusedSageSlotStack.backward with the gradients going to the flat buffer)
+        for l in reversed(range(L)):
+            cat = cats[l]
+            Fi = cat.size(1) // 2
+            m = p.bases[L - l]
+            has_bias = self.bias[l] is not None
+            _native.linear_wgrad(g, cat[:m], out=self.gmat[l], bias_grad=has_bias,
+                                 bias_out=self.gbias[l])
+            if l == 0:
+                break
+            c = l - 1
+            r_in = p.bases[L - l + 1]
+            w_t = self.wt[l]
+            scale = b.inv_cnt[:m] if aggr == 'mean' else None
+            gagg = _native.linear_dgrad(g, w_t[:Fi], row_scale=scale,
+                                        n_scaled=Fi if scale is not None else 0)
+            g_in = torch.empty(r_in, Fi, dtype=torch.float32, device=dev)
+            _native.linear_dgrad(g, w_t[Fi:], out=g_in[:m])
+            _native.spmm_csr(b.t_ptr[c], b.t_col[c], gagg, 'sum', n_rows=r_in, out=g_in,
+                             accumulate=True, accumulate_rows=m, relu_bits=bits[l - 1])
+            g = g_in
+
+    def _all_reduce(self) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _optimizer(self) -> None:
+        check(_lib.load().pygamd_adam_step(
+            _i64p(self.flat), _i64p(self.grad), _i64p(self.exp_avg), _i64p(self.exp_avg_sq),
+            self.n, _i64p(self.epoch), self._step_base, self.lr, self.betas[0], self.betas[1],
+            self.eps, self.weight_decay, 1.0 / self._world,
+            _i64p(self.wt_flat) if self._seg_n else None, self._seg_n, self._seg_off,
+            self._seg_rows, self._seg_cols, self._seg_toff, _native._stream(self.flat)),
+            'adam_step')
+
+    def _body(self) -> None:
+        self._forward_backward()
+        if self._dist and self._collective_in_graph:
+            self._all_reduce()
+        if not self._dist or self._collective_in_graph:
+            self._optimizer()
+
+    def _record(self) -> None:
+        from .hipgraph import CapturedStep
+        warm = 3
+        keep = [t.clone() for t in (self.flat, self.exp_avg, self.exp_avg_sq, self.wt_flat)]
+        # (the warm-up runs are real steps on throw-away state; the epoch keeps growing — the
+        # sampler's claim map needs that — and Adam's count restarts behind them)
+        if self._dist and not self._collective_in_graph:
+            def fn():
+                self._body()
+                self._optimizer()   # (eagerly, so that every rank's warm-up stays finite)
+        else:
+            fn = self._body
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        for t, k in zip((self.flat, self.exp_avg, self.exp_avg_sq, self.wt_flat), keep):
+            t.copy_(k)
+        self._step_base = int(self.epoch.item())
+        self._graph = CapturedStep(self._body, warmup=0)
+
+    def step(self, seeds: Optional[Tensor] = None) -> Tensor:
+        """One training step on ``seeds`` (None: whatever ``self.seeds`` holds).  Returns the
+        loss buffer (a device scalar, overwritten by the next step)."""
+        if seeds is not None:
+            if seeds.numel() != self.B:
+                raise ValueError(f'{self.B} seeds per step (the loader\'s batch size), got '
+                                 f'{seeds.numel()}')
+            self.seeds.copy_(seeds)
+        if self._capture:
+            if self._graph is None:
+                self._record()
+            self._graph()
+        else:
+            self._body()
+        if self._dist and not self._collective_in_graph:
+            self._all_reduce()
+            self._optimizer()
+        return self.loss

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     if _build.is_stale() and _build.find_hipcc() is None:
         pytest.skip('library not built and no hipcc here')
     lib = _lib.load()
-    assert lib.pygamd_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.pygamd_abi_version() == _lib.ABI_VERSION == 10
     assert lib.pygamd_build_arch() == b'gfx950'
     assert lib.pygamd_status_string(0) == b'ok'
     assert lib.pygamd_status_string(3) == b'workspace too small'

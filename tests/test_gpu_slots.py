@@ -313,3 +313,149 @@ def test_slot_stack_refuses_unsupported_models_and_stale_batches(dev):
     ahead.x = smp2.gather(x, ahead)
     out.sum().backward()
     run_slot_stack(m, ahead).sum().backward()
+
+
+def _trainer_setup(dev, n=5000, B=64, fan=(5, 4, 3), feat=32, hidden=48, classes=7, bias=True):
+    from pytorch_geometric_amd.loader import NeighborLoader
+    from pytorch_geometric_amd.nn import GraphSAGE
+    g = gen(8)
+    ei = _graph(n, 80_000, seed=9).to(dev)
+    x = torch.randn(n, feat, generator=g).to(dev)
+    y = torch.randint(0, classes, (n, ), generator=g).to(dev)
+
+    def make():
+        loader = NeighborLoader(x, ei, list(fan), batch_size=B, y=y, seed=1)
+        torch.manual_seed(1)
+        model = GraphSAGE(feat, hidden, num_layers=len(fan), out_channels=classes,
+                          bias=bias).to(dev)
+        return loader, model
+
+    seed_sets = [torch.randperm(n, generator=g)[:B].to(dev) for _ in range(5)]
+    return make, seed_sets
+
+
+@pytest.mark.parametrize('capture', [False, True])
+@pytest.mark.parametrize('bias', [True, False])
+def test_slot_trainer_equals_autograd_cross_entropy_and_torch_adam(dev, capture, bias):
+    """slots.SlotTrainer (flat parameters in the kernels' layout, one-launch loss, one-launch Adam
+    that also refreshes the transposed weights) against the step it replaces — run_slot_stack
+    through autograd, F.cross_entropy, torch.optim.Adam (examples/multi_gpu/
+    distributed_sampling.py:104-117) — on the same batches: losses, gradients and parameters after
+    every step; captured, the recording's warm-up leaves no trace."""
+    from pytorch_geometric_amd.slots import SlotTrainer, run_slot_stack
+    make, seed_sets = _trainer_setup(dev, bias=bias)
+    loader_r, model_r = make()
+    loader_t, model_t = make()
+    opt = torch.optim.Adam(model_r.parameters(), lr=1e-2)
+    trainer = SlotTrainer(model_t, loader_t, lr=1e-2, capture=capture)
+    # the model's parameters are views of the flat buffer now, values unchanged
+    for (k, a), (_, b) in zip(model_t.named_parameters(), model_r.named_parameters()):
+        assert torch.equal(a, b), k
+        assert trainer.flat.data_ptr() <= a.data_ptr() < trainer.flat.data_ptr() + 4 * trainer.n
+    epoch = torch.zeros(1, dtype=torch.int64, device=dev)
+    first_epoch = None
+    for i, seeds in enumerate(seed_sets):
+        loss_t = trainer.step(seeds)
+        if first_epoch is None:   # (captured: the recording's warm-up consumed epochs)
+            first_epoch = int(trainer.epoch.item())
+        epoch.fill_(first_epoch + i)
+        b = loader_r.collate_slots(seeds, epoch)
+        opt.zero_grad()
+        loss_r = torch.nn.functional.cross_entropy(run_slot_stack(model_r, b), b.y)
+        loss_r.backward()
+        assert abs(float(loss_t) - float(loss_r.detach())) <= 1e-5 * max(1.0, abs(float(loss_r.detach()))), i
+        for (k, a), (_, c) in zip(model_t.named_parameters(), model_r.named_parameters()):
+            assert_close_scaled(a.grad, c.grad, tol=2e-5, what=f'step {i}: grad {k}')
+        opt.step()
+        for (k, a), (_, c) in zip(model_t.named_parameters(), model_r.named_parameters()):
+            # Adam divides by sqrt(v): a gradient element near 0 amplifies a 1e-7 difference of
+            # the gradients into a visible one of the update (|update| <= lr): compare at lr scale
+            assert float((a - c).abs().max()) <= 2e-2 * 1e-2, (i, k, float((a - c).abs().max()))
+            assert float((a - c).abs().mean()) <= 1e-3 * 1e-2, (i, k)
+            with torch.no_grad():   # every step is compared from the same parameters (the two
+                c.copy_(a)          # trajectories would drift apart through that amplification)
+    # the transposed copies the input-gradient GEMMs read are current
+    for l in range(1, trainer.L):
+        assert torch.equal(trainer.wt[l], trainer.wmat[l].t())
+    trainer.check_labels()
+    # the re-bound model still evaluates (views) and checkpoints
+    sd = model_t.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values())
+
+
+def test_cross_entropy_step_kernel_vs_torch(dev):
+    """pygamd_cross_entropy_step against F.cross_entropy + autograd: labels through an index,
+    ragged class counts, an out-of-range label (flag, zero row)."""
+    import ctypes
+
+    from pytorch_geometric_amd import _lib, _native
+    from pytorch_geometric_amd._lib import check
+    lib = _lib.load()
+    g = gen(5)
+    for B, C, ld in ((1, 1, 1), (7, 3, 8), (1024, 172, 172), (333, 700, 704)):
+        logits = (torch.randn(B, ld, generator=g) * 3).to(dev)
+        view = logits[:, :C]
+        y_all = torch.randint(0, C, (5000, ), generator=g).to(dev)
+        idx = torch.randint(0, 5000, (B, ), generator=g).to(dev)
+        grad = torch.full((B, ld), 7.0, device=dev)
+        loss = torch.zeros((), device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        nb = ctypes.c_size_t(0)
+        check(lib.pygamd_cross_entropy_step_workspace_bytes(B, ctypes.byref(nb)))
+        ws = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
+        for rep in range(2):   # the ticket re-arms itself
+            check(lib.pygamd_cross_entropy_step(
+                _native._p(view), ld, B, C, _native._p(y_all), _native._p(idx), _native._p(grad),
+                ld, _native._p(loss), _native._p(ws), nb.value, _native._p(err),
+                _native._stream(logits)))
+        ref_in = view.detach().clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(ref_in, y_all[idx])
+        ref.backward()
+        assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref))), (B, C)
+        assert_close(grad[:, :C], ref_in.grad, rtol=1e-5, atol=1e-7, what=f'CE grad {B}x{C}')
+        assert torch.all(grad[:, C:] == 7.0) and int(err) == 0
+    # an out-of-range label: flagged, its row contributes nothing, the mean still divides by B
+    y_bad = y_all.clone()
+    y_bad[idx[0]] = 700
+    check(lib.pygamd_cross_entropy_step(
+        _native._p(view), ld, B, C, _native._p(y_bad), _native._p(idx), _native._p(grad), ld,
+        _native._p(loss), _native._p(ws), nb.value, _native._p(err), _native._stream(logits)))
+    good = (y_bad[idx] < C)
+    rows = torch.nn.functional.cross_entropy(view, y_bad[idx].clamp(max=C - 1), reduction='none')
+    want = float((rows * good).sum() / B)
+    assert int(err) == 1 and abs(float(loss) - want) <= 1e-6 * max(1.0, abs(want))
+    assert torch.all(grad[~good, :C] == 0)
+
+
+def test_adam_step_kernel_vs_torch(dev):
+    """pygamd_adam_step against torch.optim.Adam over several steps (with and without weight
+    decay, a gradient scale), and its transposed copies."""
+    import ctypes
+
+    from pytorch_geometric_amd import _lib, _native
+    from pytorch_geometric_amd._lib import check
+    lib = _lib.load()
+    g = gen(6)
+    n = 3 * 40 + 8 + 5 * 12 + 4
+    for wd, scale in ((0.0, 1.0), (0.01, 0.5)):
+        p0 = torch.randn(n, generator=g).to(dev)
+        flat, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        ref = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([ref], lr=3e-3, betas=(0.8, 0.95), eps=1e-6, weight_decay=wd)
+        step = torch.full((1, ), 10, dtype=torch.int64, device=dev)
+        wt = torch.zeros(3 * 40 + 5 * 12, device=dev)
+        segs = ((0, 3, 40, 0), (128, 5, 12, 120))
+        arr = lambda ty, k: (ty * 2)(*[s[k] for s in segs])   # noqa: E731
+        for it in range(6):
+            grad = torch.randn(n, generator=g).to(dev)
+            step.add_(1)
+            check(lib.pygamd_adam_step(
+                _native._p(flat), _native._p(grad), _native._p(m), _native._p(v), n,
+                _native._p(step), 10, 3e-3, 0.8, 0.95, 1e-6, wd, scale, _native._p(wt), 2,
+                arr(ctypes.c_int64, 0), arr(ctypes.c_int32, 1), arr(ctypes.c_int32, 2),
+                arr(ctypes.c_int64, 3), _native._stream(flat)))
+            ref.grad = grad * scale
+            opt.step()
+            assert_close(flat, ref.detach(), rtol=1e-5, atol=1e-6, what=f'Adam step {it}')
+        assert torch.equal(wt[:120].view(40, 3), flat[:120].view(3, 40).t())
+        assert torch.equal(wt[120:].view(12, 5), flat[128:188].view(5, 12).t())
