@@ -648,9 +648,13 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
     # concatenation / transpose / accumulation launch (PYGAMD_SLOT_TRAINER=0: the round-5 step
     # through autograd + F.cross_entropy + torch's fused Adam, for an A/B on the same box).
     use_trainer = os.environ.get('PYGAMD_SLOT_TRAINER', '1') != '0'
+    piped = False
     if use_trainer:
         from pytorch_geometric_amd.slots import SlotTrainer
-        trainer = SlotTrainer(model, loader, lr=1e-3, capture=not eager,
+        # (PYGAMD_SLOT_PIPELINE=0: the next batch is drawn in front of its own training instead of
+        # beside the previous one's)
+        piped = os.environ.get('PYGAMD_SLOT_PIPELINE', '1') != '0'
+        trainer = SlotTrainer(model, loader, lr=1e-3, capture=not eager, pipeline=piped,
                               collective_in_graph=in_graph if use_dist else None)
         seeds_buf, epoch, loss_buf = trainer.seeds, trainer.epoch, trainer.loss
         seeds_buf.copy_(next(it))
@@ -787,7 +791,10 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
                                    f'capacities {caps}; one fused-layer launch per layer forward, '
                                    f'dgrad GEMMs + transposed SpMM backward'
                                    + ('; slots.SlotTrainer: flat parameters, one-launch loss and '
-                                      'Adam' if use_trainer else '') + '), '
+                                      'Adam' + ('; the NEXT batch is drawn (sampling + gather) as '
+                                                'a parallel branch of the graph that trains on '
+                                                'the current one' if piped else '')
+                                      if use_trainer else '') + '), '
                                    f'synthetic papers100M shape x {scale:g} (N={N}, E={E}) '
                                    f'replicated per GPU',
                        'captured': ('sampling + gather + forward + backward' +

@@ -750,13 +750,16 @@ PYGAMD_API int pygamd_slots_transpose(const int64_t* src_g, const int32_t* src_i
  * label_r = y[label_idx[r]] (label_idx NULL: y[r]) — the seeds' labels are read from the graph's
  * label vector, no gathered copy.  A label outside [0, C) sets *err_flag (device int32, optional)
  * and contributes neither loss nor gradient (no ignore_index: the mean divides by B).  The row
- * losses are added up in row order (deterministic).  Workspace: ..._workspace_bytes(B); its first
+ * losses are added up in row order (deterministic).  step_counter (device int64, optional) is
+ * incremented by one per launch — the optimizer's step count of a captured step (pygamd_adam_step's
+ * step_dev), kept by a launch the step has anyway.  Workspace: ..._workspace_bytes(B); its first
  * 16 bytes must be ZERO before the first launch (the kernel re-arms them itself).                 */
 PYGAMD_API int pygamd_cross_entropy_step_workspace_bytes(int64_t B, size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_cross_entropy_step(const float* logits, int64_t ld, int64_t B, int64_t C,
                                          const int64_t* y, const int64_t* label_idx, float* grad,
                                          int64_t ldg, float* loss, void* workspace,
-                                         size_t workspace_bytes, int32_t* err_flag, void* stream);
+                                         size_t workspace_bytes, int32_t* err_flag,
+                                         int64_t* step_counter, void* stream);
 /* pygamd_adam_step: torch.optim.Adam (amsgrad / maximize off; weight_decay = the L2 form) over ONE
  * flat float32 buffer of n parameters with gradients `grad * grad_scale` (grad_scale = 1 / world
  * size after a SUM all-reduce).  The step count is read from the device: step = *step_dev -

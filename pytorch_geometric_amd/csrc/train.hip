@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(kBlock)
                               const int64_t* __restrict__ label_idx,
                               float* __restrict__ grad, int64_t ldg, float* __restrict__ row_loss,
                               float* __restrict__ loss, unsigned int* __restrict__ ticket,
-                              int32_t* __restrict__ err_flag) {
+                              int32_t* __restrict__ err_flag, int64_t* __restrict__ step_counter) {
   const int lane = lane_id();
   const int64_t r = static_cast<int64_t>(blockIdx.x) * kCeRowsPerBlock + wave_in_block();
   if (r < B) {
@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int t = 0; t < kBlock; ++t) total += part[t];
     *loss = total / static_cast<float>(B);
     *ticket = 0u;  // armed for the next launch
+    if (step_counter) *step_counter += 1;  // the optimizer's step count of a captured step
   }
 }
 
@@ -152,7 +153,7 @@ int pygamd_cross_entropy_step_workspace_bytes(int64_t B, size_t* bytes) {
 int pygamd_cross_entropy_step(const float* logits, int64_t ld, int64_t B, int64_t C,
                               const int64_t* y, const int64_t* label_idx, float* grad,
                               int64_t ldg, float* loss, void* workspace, size_t workspace_bytes,
-                              int32_t* err_flag, void* stream) {
+                              int32_t* err_flag, int64_t* step_counter, void* stream) {
   if (B < 0 || C < 1 || C > (1 << 24) || ld < C || ldg < C) return PYGAMD_ERR_INVALID_ARG;
   if (!loss) return PYGAMD_ERR_INVALID_ARG;
   if (B == 0) return PYGAMD_ERR_INVALID_ARG;  // (the reference's mean over no rows is NaN)
@@ -164,7 +165,7 @@ int pygamd_cross_entropy_step(const float* logits, int64_t ld, int64_t B, int64_
   hipLaunchKernelGGL(cross_entropy_step_kernel,
                      dim3(static_cast<unsigned>(ceil_div(B, kCeRowsPerBlock))), dim3(kBlock), 0,
                      as_stream(stream), logits, ld, B, static_cast<int>(C), y, label_idx, grad,
-                     ldg, row_loss, loss, ticket, err_flag);
+                     ldg, row_loss, loss, ticket, err_flag, step_counter);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;
 }

@@ -122,7 +122,10 @@ class SlotSampler:
     NeighborSampler` (``graph.by_dst()``)."""
 
     def __init__(self, colptr: Tensor, row: Tensor, num_nodes: int, plan: SlotPlan,
-                 seed: int = 0):
+                 seed: int = 0, local: Optional[Tensor] = None):
+        """``local``: the claim map of ANOTHER sampler over the same graph to share (int64
+        ``[num_nodes]``): claims are epoch-stamped, so samplers that are fed one growing epoch
+        sequence between them — the two halves of a double-buffered loop — need only one map."""
         _native._require_device(colptr, row)
         if colptr.dtype != row.dtype or colptr.dtype not in (torch.int32, torch.int64):
             raise ValueError("'colptr' / 'row' must share an int32 / int64 dtype")
@@ -131,11 +134,16 @@ class SlotSampler:
         dev = colptr.device
         p = plan
         # the claim map: zero = "never claimed"; epochs >= 1 always beat it — never reset
-        self.local = torch.zeros(num_nodes, dtype=torch.int64, device=dev)
+        if local is not None and (local.dtype != torch.int64 or local.numel() != num_nodes
+                                  or local.device != dev):
+            raise ValueError("'local' must be an int64 [num_nodes] tensor on the graph's device")
+        self.local = torch.zeros(num_nodes, dtype=torch.int64, device=dev) if local is None \
+            else local
         self.node_g = torch.empty(p.R, dtype=torch.int64, device=dev)
         self.src_g = torch.empty(p.S, dtype=torch.int64, device=dev)
         self.src_id = torch.empty(p.S, dtype=torch.int32, device=dev)
         self.row_end = torch.empty(p.R_dst, dtype=torch.int32, device=dev)
+        self.row_end64 = torch.empty(p.R_dst, dtype=torch.int64, device=dev)  # (direct gather)
         self.inv_cnt = torch.empty(p.R_dst, dtype=torch.float32, device=dev)
         # counts and cursors of every transposed CSR in ONE buffer (one memset per batch)
         self._tbuf = torch.zeros(max(2 * sum(p.t_rows), 1), dtype=torch.int32, device=dev)
@@ -208,7 +216,8 @@ class SlotSampler:
             if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
                 raise ValueError("'x' must be a float32 [N, F] matrix with unit inner stride")
             batch.x_global = x
-            batch.row_end64 = batch.row_end.to(torch.int64)
+            batch.row_end64 = self.row_end64.copy_(batch.row_end)   # (no allocation: a captured
+                                                                    # side branch may run this)
         if out is None:
             out = torch.empty(rows, 2 * F, dtype=torch.float32, device=x.device)
         check(_lib.load().pygamd_slots_gather(
@@ -403,23 +412,36 @@ class SlotTrainer:
     untouched.  With a ``torch.distributed`` process group the gradients are SUM-all-reduced and
     divided by the world size inside the optimizer launch (DDP's mean); over RCCL the collective
     is part of the recorded graph.  Arithmetic: the package's GEMM mode (``set_gemm_mode``);
-    the update is ``torch.optim.Adam``'s (``amsgrad=False``)."""
+    the update is ``torch.optim.Adam``'s (``amsgrad=False``).
+
+    ``pipeline=True``: sampling + feature gather of the NEXT batch run on a second stream (their
+    own recording), beside the forward / backward / optimizer of the current one (two sets of sampler
+    buffers over one claim map; the draws are latency-bound integer work, the training chain is
+    matrix / bandwidth work — what the reference's loader workers overlap from the host).
+    ``step(seeds)`` then trains on the batch drawn from the PREVIOUS call's seeds while it draws
+    the batch of ``seeds``: the first call only draws (its return value is meaningless),
+    :meth:`finish` trains on the last drawn batch."""
 
     def __init__(self, model, loader, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, process_group=None, capture: bool = True,
-                 collective_in_graph: Optional[bool] = None):
+                 collective_in_graph: Optional[bool] = None, pipeline: bool = False):
         check_slot_model(model)
         if loader.y is None:
             raise ValueError('SlotTrainer needs the loader to hold the label vector (y=...)')
         if loader.y.dtype != torch.int64 or loader.y.dim() != 1:
             raise ValueError("'y' must be a 1-D int64 label vector")
+        smp = loader.sampler
+        if smp.replace or smp.disjoint or smp.subgraph_type != 'directional' \
+                or any(k < 1 for k in smp.num_neighbors):
+            raise ValueError('slot batches cover bounded fan-outs, directional, non-disjoint, '
+                             'without replacement')
         self.model, self.loader = model, loader
         self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
         self.group = process_group
         convs = list(model.convs)
         self.L = len(convs)
-        if self.L > _lib.load().pygamd_slots_max_hops():
-            raise ValueError('too many layers')
+        if self.L != len(smp.num_neighbors):
+            raise ValueError(f'{self.L} layers on batches of {len(smp.num_neighbors)} hops')
         aggr = convs[0].aggr
         self.aggr = 'sum' if aggr == 'add' else aggr
         dev = convs[0].lin_l.weight.device
@@ -489,19 +511,43 @@ class SlotTrainer:
         self._seg_cols = (ctypes.c_int32 * n)(*[2 * self._shape[l][1] for l in segs])
         self._seg_toff = (ctypes.c_int64 * n)(*[self._toff[l] for l in segs])
         self.refresh()
-        # ---- per-step state on the device
+        # ---- the samplers: one set of batch buffers, two when the next batch is drawn beside the
+        # current one's training (one claim map between them)
+        from .loader import SLOTS_DIRECT
         B = loader.batch_size
         self.B = B
-        self.seeds = torch.zeros(B, dtype=loader.sampler.colptr.dtype, device=dev)
-        self.epoch = torch.zeros(1, dtype=torch.int64, device=dev)   # batch counter = Adam's step
+        self._pipeline = bool(pipeline)
+        self._direct = SLOTS_DIRECT
+        plan = SlotPlan(B, smp.num_neighbors, dev)
+        first = SlotSampler(smp.colptr, smp.row, loader.num_nodes, plan, seed=smp.seed)
+        self._samplers = [first]
+        if self._pipeline:
+            self._samplers.append(SlotSampler(smp.colptr, smp.row, loader.num_nodes, plan,
+                                              seed=smp.seed, local=first.local))
+        loader._slots = first    # (what `loader.collate_slots` would have built)
+        Fin = self._shape[0][1]
+        if loader.x.dim() != 2 or loader.x.size(1) != Fin:
+            raise ValueError(f'the loader holds {tuple(loader.x.shape)} features, the model takes '
+                             f'{Fin}')
+        rows = plan.R_dst if self._direct else plan.R
+        self._xbuf = [torch.empty(rows, 2 * Fin, dtype=torch.float32, device=dev)
+                      for _ in self._samplers]
+        self._batch = [None] * len(self._samplers)
+        self._cur = 0            # pipeline: the buffer set the next training branch reads
+        self._primed = False
+        self._side = torch.cuda.Stream(dev) if self._pipeline else None
+        # ---- per-step state on the device
+        self.seeds = torch.zeros(B, dtype=smp.colptr.dtype, device=dev)
+        self.epoch = torch.zeros(1, dtype=torch.int64, device=dev)   # stamps / salts the draws
+        self.opt_step = torch.zeros(1, dtype=torch.int64, device=dev)  # Adam's step count
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.label_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._labels_of = [torch.zeros(B, dtype=torch.int64, device=dev) for _ in self._samplers]
         nbytes = ctypes.c_size_t(0)
         check(_lib.load().pygamd_cross_entropy_step_workspace_bytes(B, ctypes.byref(nbytes)))
         self._ce_ws = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
-        self._step_base = 0
         self._capture = bool(capture)
-        self._graph = None
+        self._graphs = None
         import torch.distributed as dist
         self._dist = dist.is_available() and dist.is_initialized()
         self._world = dist.get_world_size(process_group) if self._dist else 1
@@ -524,19 +570,29 @@ class SlotTrainer:
             self.label_err.zero_()
             raise IndexError(f'a seed label was outside [0, {self._shape[-1][0]})')
 
-    # ---- the step
-    def _forward_backward(self) -> None:
-        p_lib = _lib.load()
+    # ---- the two halves of a step
+    @torch.no_grad()
+    def _draw(self, k: int) -> None:
+        """Sampling + feature gather of ``self.seeds`` into buffer set ``k``; allocation-free (it
+        may run as a side branch of a recording)."""
         self.epoch.add_(1)
-        b = self.loader.collate_slots(self.seeds, self.epoch, with_labels=False)
+        smp = self._samplers[k]
+        b = smp.sample(self.seeds, self.epoch)
+        b.x = smp.gather(self.loader.x, b, out=self._xbuf[k], direct=self._direct)
+        self._labels_of[k].copy_(self.seeds)   # the seed ids this batch's labels are read through
+        self._batch[k] = b
+
+    @torch.no_grad()
+    def _train(self, k: int) -> None:
+        """Forward, loss, backward (gradients into the flat buffer), collective, optimizer on the
+        batch in buffer set ``k``."""
+        p_lib = _lib.load()
+        b = self._batch[k]
         p, L, aggr, dev = b.plan, self.L, self.aggr, self.device
         b.check_current('SlotTrainer.step')
         direct = b.x_global is not None
         cat = b.x
         Fi = cat.size(1) // 2
-        if Fi != self._shape[0][1]:
-            raise ValueError(f'the loader gathers {Fi} features, the model takes '
-                             f'{self._shape[0][1]}')
         cats, bits = [], []
         out = None
         for l in range(L):
@@ -563,15 +619,14 @@ class SlotTrainer:
             cats.append(cat)
             bits.append(rb)
             cat, Fi = nxt, Fo
-        # ---- loss of the seed rows + its gradient
+        # ---- loss of the seed rows + its gradient (+ the optimizer's step count)
         C = out.size(1)
         g = torch.empty(self.B, C, dtype=torch.float32, device=dev)
-        label_idx = self.seeds if self.seeds.dtype == torch.int64 else self.seeds.to(torch.int64)
         check(p_lib.pygamd_cross_entropy_step(
-            _i64p(out), _native._ld(out), self.B, C, _i64p(self.loader.y), _i64p(label_idx),
-            _i64p(g), _native._ld(g), _i64p(self.loss), _i64p(self._ce_ws),
-            self._ce_ws.numel(), _i64p(self.label_err), _native._stream(out)),
-            'cross_entropy_step')
+            _i64p(out), _native._ld(out), self.B, C, _i64p(self.loader.y),
+            _i64p(self._labels_of[k]), _i64p(g), _native._ld(g), _i64p(self.loss),
+            _i64p(self._ce_ws), self._ce_ws.numel(), _i64p(self.label_err),
+            _i64p(self.opt_step), _native._stream(out)), 'cross_entropy_step')
         # ---- backward (FusedSageSlotStack.backward with the gradients going to the flat buffer)
         for l in reversed(range(L)):
             cat = cats[l]
@@ -593,6 +648,10 @@ class SlotTrainer:
             _native.spmm_csr(b.t_ptr[c], b.t_col[c], gagg, 'sum', n_rows=r_in, out=g_in,
                              accumulate=True, accumulate_rows=m, relu_bits=bits[l - 1])
             g = g_in
+        if self._dist and self._collective_in_graph:
+            self._all_reduce()
+        if not self._dist or self._collective_in_graph:
+            self._optimizer()
 
     def _all_reduce(self) -> None:
         import torch.distributed as dist
@@ -601,57 +660,104 @@ class SlotTrainer:
     def _optimizer(self) -> None:
         check(_lib.load().pygamd_adam_step(
             _i64p(self.flat), _i64p(self.grad), _i64p(self.exp_avg), _i64p(self.exp_avg_sq),
-            self.n, _i64p(self.epoch), self._step_base, self.lr, self.betas[0], self.betas[1],
+            self.n, _i64p(self.opt_step), 0, self.lr, self.betas[0], self.betas[1],
             self.eps, self.weight_decay, 1.0 / self._world,
             _i64p(self.wt_flat) if self._seg_n else None, self._seg_n, self._seg_off,
             self._seg_rows, self._seg_cols, self._seg_toff, _native._stream(self.flat)),
             'adam_step')
 
-    def _body(self) -> None:
-        self._forward_backward()
-        if self._dist and self._collective_in_graph:
+    def _behind(self) -> None:   # a group that cannot be recorded (gloo): behind the graph
+        if self._dist and not self._collective_in_graph:
             self._all_reduce()
-        if not self._dist or self._collective_in_graph:
             self._optimizer()
+
+    def _body(self, k: int = 0) -> None:
+        """One step on buffer set ``k``.  Plain: draw, then train.  Pipelined: train on set ``k``
+        while a side stream draws ``self.seeds`` into the other set (fork / join — inside a
+        recording the two become parallel branches of the graph)."""
+        if not self._pipeline:
+            self._draw(0)
+            self._train(0)
+            return
+        main = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self._draw(1 - k)
+        self._train(k)
+        main.wait_stream(self._side)
+
+    def _state(self):
+        return (self.flat, self.exp_avg, self.exp_avg_sq, self.wt_flat, self.opt_step)
 
     def _record(self) -> None:
         from .hipgraph import CapturedStep
-        warm = 3
-        keep = [t.clone() for t in (self.flat, self.exp_avg, self.exp_avg_sq, self.wt_flat)]
-        # (the warm-up runs are real steps on throw-away state; the epoch keeps growing — the
-        # sampler's claim map needs that — and Adam's count restarts behind them)
-        if self._dist and not self._collective_in_graph:
-            def fn():
-                self._body()
-                self._optimizer()   # (eagerly, so that every rank's warm-up stays finite)
-        else:
-            fn = self._body
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
+        # (the warm-up runs are real steps on throw-away state: parameters, moments and Adam's
+        # count are put back; the sampling epoch keeps growing — the claim map needs that)
+        keep = [t.clone() for t in self._state()]
+        sets = (0, 1) if self._pipeline else (0, )
+        if self._pipeline:       # every training branch needs a drawn batch to run on
+            self._draw(0)
+            self._draw(1)
+
+        def warm(k):
+            self._body(k)
+            if self._dist and not self._collective_in_graph:
+                self._optimizer()   # (eagerly; no collective: throw-away state)
+
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(warm):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        for t, k in zip((self.flat, self.exp_avg, self.exp_avg_sq, self.wt_flat), keep):
+            for _ in range(2):
+                for k in sets:
+                    warm(k)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        if self._pipeline:
+            # Two recordings per buffer set — the training chain and the draw — replayed on two
+            # STREAMS (round 6: as two branches of one graph they replayed one after the other on
+            # this runtime: 0.959 vs 0.967 ms per batch, DEBUG_HIP_FORCE_GRAPH_QUEUES no help)
+            self._graphs = [(CapturedStep(lambda k=k: self._train(k), warmup=0),
+                             CapturedStep(lambda k=k: self._draw(k), warmup=0)) for k in sets]
+        else:
+            self._graphs = [CapturedStep(lambda: self._body(0), warmup=0)]
+        for t, k in zip(self._state(), keep):
             t.copy_(k)
-        self._step_base = int(self.epoch.item())
-        self._graph = CapturedStep(self._body, warmup=0)
 
     def step(self, seeds: Optional[Tensor] = None) -> Tensor:
         """One training step on ``seeds`` (None: whatever ``self.seeds`` holds).  Returns the
-        loss buffer (a device scalar, overwritten by the next step)."""
+        loss buffer (a device scalar, overwritten by the next step).  Pipelined: see the class
+        docstring (the batch of ``seeds`` is trained on by the NEXT call)."""
         if seeds is not None:
             if seeds.numel() != self.B:
                 raise ValueError(f'{self.B} seeds per step (the loader\'s batch size), got '
                                  f'{seeds.numel()}')
             self.seeds.copy_(seeds)
-        if self._capture:
-            if self._graph is None:
-                self._record()
-            self._graph()
+        if self._capture and self._graphs is None:
+            self._record()
+        if self._pipeline and not self._primed:
+            self._draw(self._cur)     # the first call only draws
+            self._primed = True
+            return self.loss
+        if not self._capture:
+            self._body(self._cur)
+        elif not self._pipeline:
+            self._graphs[0]()
         else:
-            self._body()
-        if self._dist and not self._collective_in_graph:
-            self._all_reduce()
-            self._optimizer()
+            k = self._cur
+            main = torch.cuda.current_stream(self.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self._graphs[1 - k][1]()     # draw `self.seeds` into the other buffer set
+            self._graphs[k][0]()             # train on this one
+            main.wait_stream(self._side)
+        self._behind()
+        if self._pipeline:
+            self._cur = 1 - self._cur
+        return self.loss
+
+    def finish(self) -> Tensor:
+        """Pipelined: trains on the last drawn batch without drawing another one (eagerly)."""
+        if self._pipeline and self._primed:
+            self._train(self._cur)
+            self._behind()
+            self._primed = False
         return self.loss

@@ -334,36 +334,36 @@ def _trainer_setup(dev, n=5000, B=64, fan=(5, 4, 3), feat=32, hidden=48, classes
     return make, seed_sets
 
 
-@pytest.mark.parametrize('capture', [False, True])
-@pytest.mark.parametrize('bias', [True, False])
-def test_slot_trainer_equals_autograd_cross_entropy_and_torch_adam(dev, capture, bias):
+@pytest.mark.parametrize('capture,pipeline,bias', [(False, False, True), (True, False, True),
+                                                   (True, False, False), (False, True, True),
+                                                   (True, True, True)])
+def test_slot_trainer_equals_autograd_cross_entropy_and_torch_adam(dev, capture, pipeline, bias):
     """slots.SlotTrainer (flat parameters in the kernels' layout, one-launch loss, one-launch Adam
-    that also refreshes the transposed weights) against the step it replaces — run_slot_stack
-    through autograd, F.cross_entropy, torch.optim.Adam (examples/multi_gpu/
-    distributed_sampling.py:104-117) — on the same batches: losses, gradients and parameters after
-    every step; captured, the recording's warm-up leaves no trace."""
+    that also refreshes the transposed weights; pipelined: the next batch drawn beside the current
+    one's training) against the step it replaces — run_slot_stack through autograd,
+    F.cross_entropy, torch.optim.Adam (examples/multi_gpu/distributed_sampling.py:104-117) — on the
+    same batches: losses, gradients and parameters after every step; captured, the recording's
+    warm-up leaves no trace."""
     from pytorch_geometric_amd.slots import SlotTrainer, run_slot_stack
     make, seed_sets = _trainer_setup(dev, bias=bias)
     loader_r, model_r = make()
     loader_t, model_t = make()
     opt = torch.optim.Adam(model_r.parameters(), lr=1e-2)
-    trainer = SlotTrainer(model_t, loader_t, lr=1e-2, capture=capture)
+    trainer = SlotTrainer(model_t, loader_t, lr=1e-2, capture=capture, pipeline=pipeline)
     # the model's parameters are views of the flat buffer now, values unchanged
     for (k, a), (_, b) in zip(model_t.named_parameters(), model_r.named_parameters()):
         assert torch.equal(a, b), k
         assert trainer.flat.data_ptr() <= a.data_ptr() < trainer.flat.data_ptr() + 4 * trainer.n
     epoch = torch.zeros(1, dtype=torch.int64, device=dev)
-    first_epoch = None
-    for i, seeds in enumerate(seed_sets):
-        loss_t = trainer.step(seeds)
-        if first_epoch is None:   # (captured: the recording's warm-up consumed epochs)
-            first_epoch = int(trainer.epoch.item())
-        epoch.fill_(first_epoch + i)
+
+    def reference_step(i, seeds, ep, loss_t):
+        epoch.fill_(ep)
         b = loader_r.collate_slots(seeds, epoch)
         opt.zero_grad()
         loss_r = torch.nn.functional.cross_entropy(run_slot_stack(model_r, b), b.y)
         loss_r.backward()
-        assert abs(float(loss_t) - float(loss_r.detach())) <= 1e-5 * max(1.0, abs(float(loss_r.detach()))), i
+        lr_ = float(loss_r.detach())
+        assert abs(float(loss_t) - lr_) <= 1e-5 * max(1.0, abs(lr_)), (i, float(loss_t), lr_)
         for (k, a), (_, c) in zip(model_t.named_parameters(), model_r.named_parameters()):
             assert_close_scaled(a.grad, c.grad, tol=2e-5, what=f'step {i}: grad {k}')
         opt.step()
@@ -374,6 +374,19 @@ def test_slot_trainer_equals_autograd_cross_entropy_and_torch_adam(dev, capture,
             assert float((a - c).abs().mean()) <= 1e-3 * 1e-2, (i, k)
             with torch.no_grad():   # every step is compared from the same parameters (the two
                 c.copy_(a)          # trajectories would drift apart through that amplification)
+
+    drawn = []   # (seeds, epoch of the draw) in the order the trainer drew them
+    for i, seeds in enumerate(seed_sets):
+        loss_t = trainer.step(seeds)
+        drawn.append((seeds, int(trainer.epoch.item())))
+        if not pipeline:
+            reference_step(i, *drawn[i], loss_t)
+        elif i > 0:               # this call trained on the batch of the previous call's seeds
+            reference_step(i - 1, *drawn[i - 1], loss_t)
+    if pipeline:
+        loss_t = trainer.finish()
+        reference_step(len(seed_sets) - 1, *drawn[-1], loss_t)
+    assert int(trainer.opt_step.item()) == len(seed_sets)
     # the transposed copies the input-gradient GEMMs read are current
     for l in range(1, trainer.L):
         assert torch.equal(trainer.wt[l], trainer.wmat[l].t())
@@ -403,23 +416,25 @@ def test_cross_entropy_step_kernel_vs_torch(dev):
         nb = ctypes.c_size_t(0)
         check(lib.pygamd_cross_entropy_step_workspace_bytes(B, ctypes.byref(nb)))
         ws = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
+        counter = torch.full((1, ), 40, dtype=torch.int64, device=dev)
         for rep in range(2):   # the ticket re-arms itself
             check(lib.pygamd_cross_entropy_step(
                 _native._p(view), ld, B, C, _native._p(y_all), _native._p(idx), _native._p(grad),
                 ld, _native._p(loss), _native._p(ws), nb.value, _native._p(err),
-                _native._stream(logits)))
+                _native._p(counter), _native._stream(logits)))
         ref_in = view.detach().clone().requires_grad_(True)
         ref = torch.nn.functional.cross_entropy(ref_in, y_all[idx])
         ref.backward()
         assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref))), (B, C)
         assert_close(grad[:, :C], ref_in.grad, rtol=1e-5, atol=1e-7, what=f'CE grad {B}x{C}')
-        assert torch.all(grad[:, C:] == 7.0) and int(err) == 0
+        assert torch.all(grad[:, C:] == 7.0) and int(err) == 0 and int(counter) == 42
     # an out-of-range label: flagged, its row contributes nothing, the mean still divides by B
     y_bad = y_all.clone()
     y_bad[idx[0]] = 700
     check(lib.pygamd_cross_entropy_step(
         _native._p(view), ld, B, C, _native._p(y_bad), _native._p(idx), _native._p(grad), ld,
-        _native._p(loss), _native._p(ws), nb.value, _native._p(err), _native._stream(logits)))
+        _native._p(loss), _native._p(ws), nb.value, _native._p(err), None,
+        _native._stream(logits)))
     good = (y_bad[idx] < C)
     rows = torch.nn.functional.cross_entropy(view, y_bad[idx].clamp(max=C - 1), reduction='none')
     want = float((rows * good).sum() / B)
