@@ -66,6 +66,7 @@ def one(probe, variant=5):
 
 
 print(f'rows {R_dst}, slots {S}, F {F} -> {Fo}, fill {args.fill}')
+timeit(lambda: one(0), reps=300)   # clocks up (the first timings of a fresh process read ~15 % high)
 for name, probe in (('whole', 0), ('no gather', 1), ('no matrix loop', 2), ('neither', 3)):
     print(f'  split kernel, {name:16s} {timeit(lambda: one(probe)):8.1f} us')
 print(f'  fp32-instruction kernel       {timeit(lambda: one(0, 6)):8.1f} us')
