@@ -741,7 +741,7 @@ PYGAMD_API int pygamd_slots_transpose(const int64_t* src_g, const int32_t* src_i
  * The reference's mini-batch loop (examples/multi_gpu/distributed_sampling.py:104-117) ends every
  * batch with `loss = F.cross_entropy(out, batch.y[:batch.batch_size]); loss.backward();
  * optimizer.step()` (torch.optim.Adam).  Inside a hipGraph every launch costs ~5 us, so these two
- * ends are ONE launch each here (before: 7 ATen launches for the loss of 1024 rows, 42 us of
+ * ends are 2 + 1 launches here (before: 7 ATen launches for the loss of 1024 rows, 42 us of
  * multi-tensor Adam for 0.2 M parameters, a concatenation / transpose launch per weight use).
  *
  * pygamd_cross_entropy_step: loss[0] = mean_r (logsumexp(logits[r, :]) - logits[r, label_r]),
@@ -750,10 +750,11 @@ PYGAMD_API int pygamd_slots_transpose(const int64_t* src_g, const int32_t* src_i
  * label_r = y[label_idx[r]] (label_idx NULL: y[r]) — the seeds' labels are read from the graph's
  * label vector, no gathered copy.  A label outside [0, C) sets *err_flag (device int32, optional)
  * and contributes neither loss nor gradient (no ignore_index: the mean divides by B).  The row
- * losses are added up in row order (deterministic).  step_counter (device int64, optional) is
- * incremented by one per launch — the optimizer's step count of a captured step (pygamd_adam_step's
- * step_dev), kept by a launch the step has anyway.  Workspace: ..._workspace_bytes(B); its first
- * 16 bytes must be ZERO before the first launch (the kernel re-arms them itself).                 */
+ * losses are added up in row order by a second, one-workgroup launch (deterministic; a
+ * last-workgroup-done ticket inside one launch cost 28 us in fences for 1,024 rows).  step_counter
+ * (device int64, optional) is incremented by one per call — the optimizer's step count of a
+ * captured step (pygamd_adam_step's step_dev), kept by a launch the step has anyway.
+ * Workspace: ..._workspace_bytes(B) (the row losses).                                             */
 PYGAMD_API int pygamd_cross_entropy_step_workspace_bytes(int64_t B, size_t* bytes /*[host]*/);
 PYGAMD_API int pygamd_cross_entropy_step(const float* logits, int64_t ld, int64_t B, int64_t C,
                                          const int64_t* y, const int64_t* label_idx, float* grad,
