@@ -25,12 +25,13 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 
 
-for mode in ('split', 'fp32'):
+for mode in (('split', ) if os.environ.get('ONLY_SPLIT') else ('split', 'fp32')):
     _native.set_gemm_mode(mode)
     print('mode', mode)
     for M, K, N in ((169_343, 128, 256), (169_343, 256, 256), (169_343, 256, 320),
                     (169_343, 320, 256), (2_449_029, 96, 256), (2_449_029, 256, 48),
-                    (2_449_029, 256, 256), (14_541, 500, 500)):
+                    (2_449_029, 256, 256), (14_541, 500, 500), (16_384, 256, 256), (1_024, 256, 256),
+                    (100_000, 100, 256)):
         x = torch.randn(M, K, device=dev, generator=g)
         w = torch.randn(N, K, device=dev, generator=g) * 0.05
         out = torch.empty(M, N, device=dev)
