@@ -158,9 +158,10 @@ class NeighborLoader:
         n = self.input_nodes.numel()
         order = (torch.randperm(n, generator=self._gen).to(self.input_nodes.device)
                  if self.shuffle else torch.arange(n, device=self.input_nodes.device))
+        nodes = self.input_nodes[order]   # ONE index launch per epoch; a batch's seeds are a view
         for b in range(len(self)):
-            sel = order[b * self.batch_size:(b + 1) * self.batch_size]
-            yield self.input_nodes[sel], sel
+            lo, hi = b * self.batch_size, (b + 1) * self.batch_size
+            yield nodes[lo:hi], order[lo:hi]
 
     def __iter__(self) -> Iterator[Batch]:
         if self.prefetch <= 0:
