@@ -348,7 +348,8 @@ def parity_at_cpu_scale(sample, dev):
     x, ei = sample['x'].to(dev), sample['ei'].to(dev)
     ti = sample['train_idx'].to(dev)
     out = model(x, ei)
-    loss = F.cross_entropy(out[ti], sample['y'].to(dev)[ti])
+    from pytorch_geometric_amd.nn.functional import cross_entropy as rows_cross_entropy
+    loss = rows_cross_entropy(out, sample['y'].to(dev), ti)   # (the headline step's loss)
     loss.backward()
     torch.cuda.synchronize(dev)
 
@@ -418,7 +419,8 @@ def parity_cached(dev):
     model = model.to(dev)
     ti = train_idx.to(dev)
     out = model(x.to(dev), ei.to(dev))
-    loss = F.cross_entropy(out[ti], y.to(dev)[ti])
+    from pytorch_geometric_amd.nn.functional import cross_entropy as rows_cross_entropy
+    loss = rows_cross_entropy(out, y.to(dev), ti)   # (the headline step's loss)
     loss.backward()
     torch.cuda.synchronize(dev)
 
@@ -979,6 +981,10 @@ def main():
                          "unless PYGAMD_GEMM_MODE says otherwise): 'split' = 3 x bf16 terms per "
                          "fp32 operand, 6 bf16 matrix products, fp32 accumulation; 'fp32' = the "
                          "exact fp32 matrix instruction")
+    ap.add_argument('--torch-loss', action='store_true',
+                    help='the loss of the training rows as F.cross_entropy(out[train_idx], ...) '
+                         '(seven ATen launches) instead of the one-pass '
+                         'pytorch_geometric_amd.nn.functional.cross_entropy')
     ap.add_argument('--no-side-figures', action='store_true',
                     help='full-batch mode: skip the short re-timings printed beside the headline '
                          '(exact fp32 instruction, dense loss)')
@@ -1059,10 +1065,21 @@ def main():
 
     ar_events = []  # (start, end) HIP events around the gradient all-reduce, timed steps only
 
+    # The loss of the training rows: pytorch_geometric_amd.nn.functional.cross_entropy reads the
+    # selected rows of `out` in ONE pass (loss + its gradient; round 6) where
+    # F.cross_entropy(out[train_idx], y_train) is seven ATen launches (0.75 ms here: its nll_loss
+    # reductions run on one workgroup).  --torch-loss keeps the ATen form; the default line prints
+    # that step beside the headline (ms_per_step_torch_cross_entropy).
+    from pytorch_geometric_amd.nn.functional import cross_entropy as rows_cross_entropy
+    fused_loss = [not args.torch_loss]
+
     def step():
         bucket.zero_()
         out = model(x, ei)
-        loss = F.cross_entropy(out[train_idx], y_train)
+        if fused_loss[0]:
+            loss = rows_cross_entropy(out, y, train_idx)
+        else:
+            loss = F.cross_entropy(out[train_idx], y_train)
         loss.backward()
         if dist.is_initialized():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1256,6 +1273,10 @@ def main():
             _fused_sage.SPARSE_GRAD = False
             side['dense_loss_ms_per_step'] = round(quick_ms(), 3)
             _fused_sage.SPARSE_GRAD = True
+        if fused_loss[0]:
+            fused_loss[0] = False
+            side['ms_per_step_torch_cross_entropy'] = round(quick_ms(), 3)
+            fused_loss[0] = True
 
     arithmetic = (
         'fp32 in / fp32 out; products as 3 x bf16 split (x = x1 + x2 + x3 exactly), the 6 leading '
@@ -1274,7 +1295,7 @@ def main():
             'arithmetic': arithmetic, **side,
             'config': {
                 'workload': (f'GraphSAGE(100->256->256->{num_classes}, mean aggr) full-batch '
-                             f'fwd+bwd(CE on an 8% train split)+Adam on a synthetic ogbn-products-shaped graph per GPU '
+                             f'fwd+bwd(CE on an 8% train split' + (', taken by the one-pass pytorch_geometric_amd.nn.functional.cross_entropy' if fused_loss[0] else ', F.cross_entropy on the gathered rows') + ')+Adam on a synthetic ogbn-products-shaped graph per GPU '
                              f'(N={N}, E={E}, {"uniform" if args.uniform else "power-law"} '
                              f'degrees, {args.index_dtype} edge_index, fp32 features)'),
                 'edges_per_step_per_gpu': 3 * E, 'scale': args.scale,
@@ -1310,7 +1331,8 @@ def main():
                 # GraphSAGE + install(), after the timed region (bench_configs.py); scalars only
                 import bench_configs
                 result['other_configs'] = bench_configs.run(
-                    dev, headline=(x, ei, train_idx, y_train, num_classes, ms_per_step))
+                    dev, headline=(x, ei, train_idx, y_train, num_classes,
+                                   side.get('ms_per_step_torch_cross_entropy', ms_per_step)))
         elif not args.no_cpu_baseline:
             # N > 1: no live CPU run of the reference (rank 0 only, the other ranks wait at the
             # barrier below); the GPU leg against the committed reference sample

@@ -748,7 +748,9 @@ PYGAMD_API int pygamd_slots_transpose(const int64_t* src_g, const int32_t* src_i
  * grad[r, c] = (softmax(logits[r, :])[c] - [c == label_r]) / B — F.cross_entropy (reduction
  * 'mean', no class weights, no label smoothing) and its backward for an upstream gradient of 1.
  * label_r = y[label_idx[r]] (label_idx NULL: y[r]) — the seeds' labels are read from the graph's
- * label vector, no gathered copy.  A label outside [0, C) sets *err_flag (device int32, optional)
+ * label vector, no gathered copy.  row_idx (optional): row r of the loss is logits[row_idx[r], :]
+ * (n_logit_rows = the rows `logits` holds) — `F.cross_entropy(out[train_idx], y[train_idx])` of a
+ * full-batch model without the gathered copy of the rows; grad stays compact ([B, C]).  A label outside [0, C) sets *err_flag (device int32, optional)
  * and contributes neither loss nor gradient (no ignore_index: the mean divides by B).  The row
  * losses are added up in row order by a second, one-workgroup launch (deterministic; a
  * last-workgroup-done ticket inside one launch cost 28 us in fences for 1,024 rows).  step_counter
@@ -756,7 +758,8 @@ PYGAMD_API int pygamd_slots_transpose(const int64_t* src_g, const int32_t* src_i
  * captured step (pygamd_adam_step's step_dev), kept by a launch the step has anyway.
  * Workspace: ..._workspace_bytes(B) (the row losses).                                             */
 PYGAMD_API int pygamd_cross_entropy_step_workspace_bytes(int64_t B, size_t* bytes /*[host]*/);
-PYGAMD_API int pygamd_cross_entropy_step(const float* logits, int64_t ld, int64_t B, int64_t C,
+PYGAMD_API int pygamd_cross_entropy_step(const float* logits, int64_t ld, const int64_t* row_idx,
+                                         int64_t n_logit_rows, int64_t B, int64_t C,
                                          const int64_t* y, const int64_t* label_idx, float* grad,
                                          int64_t ldg, float* loss, void* workspace,
                                          size_t workspace_bytes, int32_t* err_flag,

@@ -731,3 +731,48 @@ def bias_act(x: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:
         return BiasActFunction.apply(x, bias, relu)
     out = x if bias is None else x + bias
     return out.relu() if relu else out
+
+
+class CrossEntropyRowsFunction(Function):
+    """``F.cross_entropy(logits[index], target[index])`` — the loss a full-batch model takes on its
+    training split (``examples/ogbn_train.py``-style ``out[train_idx]``) — as ONE pass over the
+    selected rows forward (no gathered copy of the rows, no separate log-softmax / NLL launches)
+    and a row scatter backward: seven ATen launches (0.75 ms at the ogbn-products shape, whose
+    ``nll_loss`` reductions run on one workgroup) become two + three."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, target: Tensor, index: Optional[Tensor]):
+        loss, grad_rows = _native.cross_entropy_rows(logits, target, index)
+        ctx.save_for_backward(grad_rows, index)
+        ctx.shape = logits.shape
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g: Tensor):
+        grad_rows, index = ctx.saved_tensors
+        scaled = grad_rows * g
+        if index is None:
+            return scaled, None, None
+        dense = torch.zeros(ctx.shape, dtype=torch.float32, device=scaled.device)
+        dense.index_add_(0, index, scaled)   # (duplicate indices add up, as out[index] would)
+        return dense, None, None
+
+
+def cross_entropy(logits: Tensor, target: Tensor, index: Optional[Tensor] = None) -> Tensor:
+    """Mean cross entropy of ``logits[index]`` against ``target[index]`` (``index`` None: every
+    row); ``target``: one int64 label per row of ``logits``.  Float32 HIP logits take the one-pass
+    kernel; anything else (CPU tensors, other dtypes, class weights are not offered) runs
+    ``F.cross_entropy`` on the gathered rows."""
+    if (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
+            and logits.size(0) > 0 and logits.size(1) > 0 and logits.stride(1) == 1
+            and target.dtype == torch.int64 and target.dim() == 1
+            and target.numel() == logits.size(0)
+            and (index is None or (index.dtype == torch.int64 and index.dim() == 1
+                                   and index.numel() > 0))
+            and not torch.cuda.is_current_stream_capturing()):
+        return CrossEntropyRowsFunction.apply(
+            logits, target.contiguous(), None if index is None else index.contiguous())
+    if index is None:
+        return torch.nn.functional.cross_entropy(logits, target)
+    return torch.nn.functional.cross_entropy(logits[index], target[index])

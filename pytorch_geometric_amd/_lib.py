@@ -147,8 +147,8 @@ SIGNATURES = {
     'pygamd_slots_gather': (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
     'pygamd_slots_transpose': (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     'pygamd_cross_entropy_step_workspace_bytes': (c_int, [c_int64, _P]),
-    'pygamd_cross_entropy_step': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P,
-                                          _P, c_size_t, _P, _P, _P]),
+    'pygamd_cross_entropy_step': (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P,
+                                          c_int64, _P, _P, c_size_t, _P, _P, _P]),
     'pygamd_adam_step': (c_int, [_P, _P, _P, _P, c_int64, _P, c_int64, c_double, c_double,
                                  c_double, c_double, c_double, c_double, _P, c_int, _P, _P, _P,
                                  _P, _P]),

@@ -1324,6 +1324,40 @@ def sage_layer_forward(rowptr: Tensor, col: Tensor, x_gather: Tensor, x_root: Te
     return out
 
 
+def cross_entropy_rows(logits: Tensor, target: Tensor, index: Optional[Tensor] = None):
+    """``(loss, grad_rows)`` of ``F.cross_entropy(logits[index], target[index])`` (``index`` None: all
+    rows; mean reduction) from ONE pass over the selected rows (``pygamd_cross_entropy_step``):
+    ``loss`` a float32 scalar, ``grad_rows`` ``[B, C]`` = ``d loss / d logits[index]``.  ``target``
+    holds one int64 label per row of ``logits``.  A label outside ``[0, C)`` / an index outside the
+    rows is flagged (``PYGAMD_CHECK_INDEX``) and contributes neither loss nor gradient."""
+    _require_device(logits, target, index)
+    x = _f32_rows(logits, 'logits')
+    N, C = x.shape
+    if target.dtype != torch.int64 or target.dim() != 1 or target.numel() != N \
+            or not target.is_contiguous():
+        raise ValueError(f"'target' must hold one contiguous int64 label per row of 'logits' "
+                         f"({N}), got {target.dtype} {tuple(target.shape)}")
+    if index is not None and (index.dtype != torch.int64 or index.dim() != 1
+                              or not index.is_contiguous()):
+        raise ValueError("'index' must be a contiguous 1-D int64 tensor")
+    B = N if index is None else index.numel()
+    if B == 0 or C == 0:
+        raise ValueError('cross_entropy_rows needs at least one row and one class')
+    lib = _lib.load()
+    grad = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    nbytes = ctypes.c_size_t(0)
+    check(lib.pygamd_cross_entropy_step_workspace_bytes(B, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+    ring, slot, err = _index_flag(x.device, True)
+    check(lib.pygamd_cross_entropy_step(_p(x), _ld(x), _p(index), N, B, C, _p(target), _p(index),
+                                        _p(grad), C, _p(loss), _p(ws), nbytes.value, _p(err),
+                                        None, _stream(x)), 'cross_entropy_rows')
+    _index_flag_done(ring, slot, err, "cross_entropy: a target outside [0, C) (or an 'index' "
+                     "entry outside the rows of the logits)", C, target)
+    return loss, grad
+
+
 def set_gemm_mode(mode: str) -> str:
     """Arithmetic of the dense transform kernels (``pygamd_set_gemm_mode``): ``'fp32'`` (default:
     the fp32 matrix instruction, bitwise an fmaf chain) or ``'split'`` (operands as three bf16

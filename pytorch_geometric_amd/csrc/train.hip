@@ -28,6 +28,7 @@ constexpr int kCeRowsPerBlock = kWavesPerBlock;  // one wave per row
 // (no ignore_index).
 __global__ void __launch_bounds__(kBlock)
     cross_entropy_rows_kernel(const float* __restrict__ logits, int64_t ld, int64_t B, int C,
+                              const int64_t* __restrict__ row_idx, int64_t n_logit_rows,
                               const int64_t* __restrict__ y,
                               const int64_t* __restrict__ label_idx,
                               float* __restrict__ grad, int64_t ldg, float* __restrict__ row_loss,
@@ -35,9 +36,15 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = lane_id();
   const int64_t r = static_cast<int64_t>(blockIdx.x) * kCeRowsPerBlock + wave_in_block();
   if (r >= B) return;
-  const float* __restrict__ row = logits + r * ld;
+  // (row_idx: the loss of a ROW SUBSET of the logits — a full-batch model's training split,
+  // `F.cross_entropy(out[train_idx], y[train_idx])` — without the gathered copy; an index outside
+  // the logits is treated like a bad label)
+  int64_t src = row_idx ? row_idx[r] : r;
+  const bool src_ok = src >= 0 && src < n_logit_rows;
+  src = src_ok ? src : 0;
+  const float* __restrict__ row = logits + src * ld;
   const int64_t lab = y[label_idx ? label_idx[r] : r];
-  const bool lab_ok = lab >= 0 && lab < C;
+  const bool lab_ok = src_ok && lab >= 0 && lab < C;
   float mx = -INFINITY;
   for (int c = lane; c < C; c += kWave) mx = fmaxf(mx, row[c]);
 #pragma unroll
@@ -54,7 +61,7 @@ __global__ void __launch_bounds__(kBlock)
     grow[c] = lab_ok ? (p - (c == lab ? 1.f : 0.f)) * inv_b : 0.f;
   }
   if (lane == 0) {
-    row_loss[r] = lab_ok ? lse - row[lab] : 0.f;
+    row_loss[r] = lab_ok ? lse - row[lab_ok ? lab : 0] : 0.f;
     if (!lab_ok && err_flag) atomicOr(err_flag, 1);
   }
 }
@@ -63,20 +70,22 @@ __global__ void __launch_bounds__(kBlock)
 // the stream.  (One launch with a last-workgroup-done ticket was measured first: the release /
 // acquire fences around the ticket write the L2 back on this chip — 28 us for 1,024 rows against
 // 6 + 5 us for the two launches.)
-__global__ void __launch_bounds__(kBlock)
+constexpr int kCeMeanBlock = 1024;
+__global__ void __launch_bounds__(kCeMeanBlock)
     cross_entropy_mean_kernel(const float* __restrict__ row_loss, int64_t B,
                               float* __restrict__ loss, int64_t* __restrict__ step_counter) {
-  __shared__ float part[kBlock];
-  // thread t owns the contiguous row range [t * per, (t + 1) * per): a fixed order
-  const int64_t per = (B + kBlock - 1) / kBlock;
+  __shared__ float part[kCeMeanBlock];
+  // thread t owns rows t, t + 1024, ... (coalesced reads, a fixed order), then a fixed tree
   float s = 0.f;
-  for (int64_t i = threadIdx.x * per; i < (threadIdx.x + 1) * per && i < B; ++i) s += row_loss[i];
+  for (int64_t i = threadIdx.x; i < B; i += kCeMeanBlock) s += row_loss[i];
   part[threadIdx.x] = s;
   __syncthreads();
+  for (int w = kCeMeanBlock / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    float total = 0.f;
-    for (int t = 0; t < kBlock; ++t) total += part[t];
-    *loss = total / static_cast<float>(B);
+    *loss = part[0] / static_cast<float>(B);
     if (step_counter) *step_counter += 1;  // the optimizer's step count of a captured step
   }
 }
@@ -143,11 +152,13 @@ int pygamd_cross_entropy_step_workspace_bytes(int64_t B, size_t* bytes) {
   return PYGAMD_OK;
 }
 
-int pygamd_cross_entropy_step(const float* logits, int64_t ld, int64_t B, int64_t C,
-                              const int64_t* y, const int64_t* label_idx, float* grad,
+int pygamd_cross_entropy_step(const float* logits, int64_t ld, const int64_t* row_idx,
+                              int64_t n_logit_rows, int64_t B, int64_t C, const int64_t* y,
+                              const int64_t* label_idx, float* grad,
                               int64_t ldg, float* loss, void* workspace, size_t workspace_bytes,
                               int32_t* err_flag, int64_t* step_counter, void* stream) {
-  if (B < 1 || C < 1 || C > (1 << 24) || ld < C || ldg < C) return PYGAMD_ERR_INVALID_ARG;
+  if (B < 1 || C < 1 || C > (1 << 24) || ld < C || ldg < C || n_logit_rows < 1)
+    return PYGAMD_ERR_INVALID_ARG;
   // (B == 0: the reference's mean over no rows is NaN — refused)
   if (!loss || !logits || !y || !grad) return PYGAMD_ERR_INVALID_ARG;
   if (!workspace || workspace_bytes < static_cast<size_t>(B) * sizeof(float))
@@ -156,10 +167,10 @@ int pygamd_cross_entropy_step(const float* logits, int64_t ld, int64_t B, int64_
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(cross_entropy_rows_kernel,
                      dim3(static_cast<unsigned>(ceil_div(B, kCeRowsPerBlock))), dim3(kBlock), 0,
-                     st, logits, ld, B, static_cast<int>(C), y, label_idx, grad, ldg, row_loss,
-                     err_flag);
+                     st, logits, ld, B, static_cast<int>(C), row_idx, n_logit_rows, y, label_idx,
+                     grad, ldg, row_loss, err_flag);
   PYGAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cross_entropy_mean_kernel, dim3(1), dim3(kBlock), 0, st, row_loss, B, loss,
+  hipLaunchKernelGGL(cross_entropy_mean_kernel, dim3(1), dim3(kCeMeanBlock), 0, st, row_loss, B, loss,
                      step_counter);
   PYGAMD_LAUNCH_CHECK();
   return PYGAMD_OK;

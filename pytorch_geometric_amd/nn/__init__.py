@@ -5,6 +5,7 @@ from .conv import (FastRGCNConv, GATConv, GCNConv, GraphConv, MessagePassing, RG
                    gcn_norm)
 from .dense import HeteroLinear, Linear
 from .models import GAT, GCN, BasicGNN, GraphSAGE
+from . import functional  # noqa: F401
 
 __all__ = [
     'Aggregation', 'SumAggregation', 'MeanAggregation', 'MaxAggregation', 'MinAggregation',

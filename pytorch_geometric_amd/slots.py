@@ -623,7 +623,7 @@ class SlotTrainer:
         C = out.size(1)
         g = torch.empty(self.B, C, dtype=torch.float32, device=dev)
         check(p_lib.pygamd_cross_entropy_step(
-            _i64p(out), _native._ld(out), self.B, C, _i64p(self.loader.y),
+            _i64p(out), _native._ld(out), None, self.B, self.B, C, _i64p(self.loader.y),
             _i64p(self._labels_of[k]), _i64p(g), _native._ld(g), _i64p(self.loss),
             _i64p(self._ce_ws), self._ce_ws.numel(), _i64p(self.label_err),
             _i64p(self.opt_step), _native._stream(out)), 'cross_entropy_step')

@@ -958,3 +958,40 @@ def test_gat_takes_half_precision_and_autocast_inputs(dev):
         assert h2._csc is None, 'the one-shot route must not build the by-source form'
     finally:
         gat_mod.GatAttendFunction = keep
+
+
+@pytest.mark.parametrize('with_index', [True, False])
+def test_rows_cross_entropy_equals_torch(dev, with_index):
+    """nn.functional.cross_entropy(out, y, index) — the train-split loss of a full-batch model as
+    one pass over the selected rows — against F.cross_entropy(out[index], y[index]): value,
+    gradient (an upstream factor, duplicate indices, strided logits), the out-of-range flag."""
+    import torch.nn.functional as F
+
+    import pytorch_geometric_amd as pga
+    from pytorch_geometric_amd.nn.functional import cross_entropy
+    g = gen(12)
+    N, C = 5000, 47
+    wide = (torch.randn(N, C + 9, generator=g) * 2).to(dev)
+    y = torch.randint(0, C, (N, ), generator=g).to(dev)
+    idx = None
+    if with_index:
+        idx = torch.randperm(N, generator=g)[:777]
+        idx = torch.cat([idx, idx[:5]]).to(dev)            # a few duplicates
+    for strided in (False, True):   # plain logits, and a row-strided view of a wider buffer
+        base = wide if strided else wide[:, :C].contiguous()
+        x1 = base.detach().clone().requires_grad_(True)
+        x2 = base.detach().clone().requires_grad_(True)
+        l1, l2 = (x1[:, :C], x2[:, :C]) if strided else (x1, x2)
+        got = cross_entropy(l1, y, idx)
+        ref = F.cross_entropy(l2 if idx is None else l2[idx], y if idx is None else y[idx])
+        r = float(ref.detach())
+        assert abs(float(got.detach()) - r) <= 1e-6 * max(1.0, abs(r)), (float(got.detach()), r)
+        (got * 1.7).backward()
+        (ref * 1.7).backward()
+        assert_close(x1.grad, x2.grad, rtol=1e-5, atol=1e-8, what='rows cross entropy: gradient')
+    pga.check_index_errors()
+    bad = y.clone()
+    bad[3 if idx is None else int(idx[0])] = C + 4
+    cross_entropy(wide[:, :C].contiguous(), bad, idx)
+    with pytest.raises(IndexError):
+        pga.check_index_errors()

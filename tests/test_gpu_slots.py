@@ -419,7 +419,8 @@ def test_cross_entropy_step_kernel_vs_torch(dev):
         counter = torch.full((1, ), 40, dtype=torch.int64, device=dev)
         for rep in range(2):   # the ticket re-arms itself
             check(lib.pygamd_cross_entropy_step(
-                _native._p(view), ld, B, C, _native._p(y_all), _native._p(idx), _native._p(grad),
+                _native._p(view), ld, None, B, B, C, _native._p(y_all), _native._p(idx),
+                _native._p(grad),
                 ld, _native._p(loss), _native._p(ws), nb.value, _native._p(err),
                 _native._p(counter), _native._stream(logits)))
         ref_in = view.detach().clone().requires_grad_(True)
@@ -432,7 +433,8 @@ def test_cross_entropy_step_kernel_vs_torch(dev):
     y_bad = y_all.clone()
     y_bad[idx[0]] = 700
     check(lib.pygamd_cross_entropy_step(
-        _native._p(view), ld, B, C, _native._p(y_bad), _native._p(idx), _native._p(grad), ld,
+        _native._p(view), ld, None, B, B, C, _native._p(y_bad), _native._p(idx), _native._p(grad),
+        ld,
         _native._p(loss), _native._p(ws), nb.value, _native._p(err), None,
         _native._stream(logits)))
     good = (y_bad[idx] < C)
