@@ -1052,7 +1052,10 @@ def main():
     model = GraphSAGE(100, 256, num_layers=3, out_channels=num_classes).to(dev)
     broadcast_parameters(model)
     bucket = FlatGradBucket(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    try:  # one multi-tensor launch per step instead of ~10 foreach launches (same update)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    except (RuntimeError, TypeError, ValueError):
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
     # like every full-batch PyG example, the loss is taken on the training split only
     # (ogbn-products: 196,615 of 2,449,029 nodes = 8 %)
