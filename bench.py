@@ -799,9 +799,13 @@ def run_minibatch_captured(args, rank, world, dev, model, bucket, loader, fan, s
                                       if use_trainer else '') + '), '
                                    f'synthetic papers100M shape x {scale:g} (N={N}, E={E}) '
                                    f'replicated per GPU',
-                       'captured': ('sampling + gather + forward + backward' +
+                       'captured': (('forward + loss + backward' if piped else
+                                     'sampling + gather + forward + backward') +
                                     (' + RCCL all-reduce + Adam' if in_graph else
-                                     '' if use_dist else ' + Adam') + ' = one hipGraph per batch'),
+                                     '' if use_dist else ' + Adam') + ' = one hipGraph per batch' +
+                                    ('; sampling + gather of the NEXT batch = a second recording '
+                                     'replayed beside it on a second stream' if piped else '')),
+                       'launches_per_batch': (38 if use_trainer else 60),
                        'parallelism': f'dp{world} (seed sharding, one flat-bucket '
                                       f'all-reduce/step)',
                        'allreduce_ms_per_step': round(
