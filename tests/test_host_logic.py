@@ -199,3 +199,51 @@ def test_edge_index_handle_tensor_protocol_on_the_host():
         assert torch.equal(twin, ei) and twin.data_ptr() != ei.data_ptr()
     assert pga.EdgeIndex(h, (3, 3), validate=False).as_tensor() is ei  # no handle-of-handle
     assert pga.as_edge_index(h) is h
+
+
+def test_rows_cross_entropy_steps_aside_for_cpu_tensors():
+    """nn.functional.cross_entropy: CPU tensors (and anything else outside the one-pass kernel's
+    float32 HIP logits) take F.cross_entropy on the gathered rows — no host computation of ours."""
+    import torch.nn.functional as F
+
+    from pytorch_geometric_amd.nn.functional import cross_entropy
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(40, 6, generator=g, requires_grad=True)
+    y = torch.randint(0, 6, (40, ), generator=g)
+    idx = torch.tensor([3, 9, 9, 31])
+    a = cross_entropy(x, y, idx)
+    b = F.cross_entropy(x[idx], y[idx])
+    assert torch.equal(a, b)
+    ga, = torch.autograd.grad(a, x)
+    gb, = torch.autograd.grad(b, x)
+    assert torch.equal(ga, gb)
+    assert torch.equal(cross_entropy(x, y), F.cross_entropy(x, y))
+
+
+def test_slot_trainer_needs_device_tensors():
+    """slots.SlotTrainer is a device-only path: a CPU model / loader raises at construction."""
+    import pytest
+
+    from pytorch_geometric_amd.nn import GraphSAGE
+    from pytorch_geometric_amd.slots import SlotTrainer
+
+    class FakeSampler:
+        replace = disjoint = False
+        subgraph_type = 'directional'
+        num_neighbors = [3, 2]
+        colptr = torch.zeros(5, dtype=torch.int64)
+        row = torch.zeros(0, dtype=torch.int64)
+        seed = 0
+
+    class FakeLoader:
+        sampler = FakeSampler()
+        x = torch.zeros(4, 8)
+        y = torch.zeros(4, dtype=torch.int64)
+        batch_size, num_nodes = 2, 4
+
+    model = GraphSAGE(8, 16, num_layers=2, out_channels=3)
+    with pytest.raises(Exception):
+        SlotTrainer(model, FakeLoader())
+    FakeLoader.y = None
+    with pytest.raises(ValueError, match='label vector'):
+        SlotTrainer(model, FakeLoader())
