@@ -315,11 +315,12 @@ def test_slot_stack_refuses_unsupported_models_and_stale_batches(dev):
     run_slot_stack(m, ahead).sum().backward()
 
 
-def _trainer_setup(dev, n=5000, B=64, fan=(5, 4, 3), feat=32, hidden=48, classes=7, bias=True):
+def _trainer_setup(dev, n=5000, B=64, fan=(5, 4, 3), feat=32, hidden=48, classes=7, bias=True,
+                   index_dtype=torch.int64):
     from pytorch_geometric_amd.loader import NeighborLoader
     from pytorch_geometric_amd.nn import GraphSAGE
     g = gen(8)
-    ei = _graph(n, 80_000, seed=9).to(dev)
+    ei = _graph(n, 80_000, seed=9).to(dev).to(index_dtype)
     x = torch.randn(n, feat, generator=g).to(dev)
     y = torch.randint(0, classes, (n, ), generator=g).to(dev)
 
@@ -330,7 +331,7 @@ def _trainer_setup(dev, n=5000, B=64, fan=(5, 4, 3), feat=32, hidden=48, classes
                           bias=bias).to(dev)
         return loader, model
 
-    seed_sets = [torch.randperm(n, generator=g)[:B].to(dev) for _ in range(5)]
+    seed_sets = [torch.randperm(n, generator=g)[:B].to(dev).to(index_dtype) for _ in range(5)]
     return make, seed_sets
 
 
@@ -476,3 +477,30 @@ def test_adam_step_kernel_vs_torch(dev):
             assert_close(flat, ref.detach(), rtol=1e-5, atol=1e-6, what=f'Adam step {it}')
         assert torch.equal(wt[:120].view(40, 3), flat[:120].view(3, 40).t())
         assert torch.equal(wt[120:].view(12, 5), flat[128:188].view(5, 12).t())
+
+
+def test_slot_trainer_on_an_int32_graph(dev):
+    """int32 `edge_index` (the reference accepts it, test_message_passing.py:686-703): the sampler
+    runs on int32 pointers, the seeds are int32, the labels are still read through them."""
+    from pytorch_geometric_amd.slots import SlotTrainer, run_slot_stack
+    make, seed_sets = _trainer_setup(dev, fan=(4, 3), index_dtype=torch.int32)
+    loader_r, model_r = make()
+    loader_t, model_t = make()
+    trainer = SlotTrainer(model_t, loader_t, lr=1e-2, capture=True)
+    assert trainer.seeds.dtype == torch.int32
+    epoch = torch.zeros(1, dtype=torch.int64, device=dev)
+    losses = [float(trainer.step(seeds)) for seeds in seed_sets[:3]]   # captured: replays run
+    assert all(v == v and v > 0 for v in losses) and len(set(losses)) == 3
+    # one clean comparison: a fresh pair, one step
+    loader_r, model_r = make()
+    loader_t, model_t = make()
+    trainer = SlotTrainer(model_t, loader_t, lr=1e-2, capture=False)
+    loss_t = float(trainer.step(seed_sets[0]))
+    epoch.fill_(int(trainer.epoch.item()))
+    b = loader_r.collate_slots(seed_sets[0], epoch)
+    loss_r = torch.nn.functional.cross_entropy(run_slot_stack(model_r, b), b.y)
+    loss_r.backward()
+    assert abs(loss_t - float(loss_r.detach())) <= 1e-5 * max(1.0, abs(float(loss_r.detach())))
+    for (k, a), (_, c) in zip(model_t.named_parameters(), model_r.named_parameters()):
+        assert_close_scaled(a.grad, c.grad, tol=2e-5, what=f'int32 graph: grad {k}')
+    trainer.check_labels()
