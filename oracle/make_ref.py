@@ -45,7 +45,8 @@ TEST_FILES = ('conftest.py', 'test_edge_index.py', 'test_index.py',
 # ... and every module of these directories: all 60-odd conv layers (the ones without a dedicated
 # route ride on `MessagePassing._index_select` + `scatter`), every aggregation, the dense layers,
 # the utils
-TEST_DIRS = ('nn/conv', 'nn/aggr', 'nn/dense', 'utils')
+TEST_DIRS = ('nn/conv', 'nn/aggr', 'nn/dense', 'utils', 'nn/models', 'nn/pool', 'nn/norm',
+             'nn/functional', 'nn/kge', 'nn/attention', 'nn/unpool', 'explain', 'transforms')
 
 
 def _test_files(tsrc):
@@ -55,7 +56,7 @@ def _test_files(tsrc):
         if os.path.isdir(full):
             found += [os.path.join(d, n) for n in sorted(os.listdir(full))
                       if n.endswith('.py') and (n.startswith('test_') or n == 'conftest.py')]
-    return found
+    return list(dict.fromkeys(found))   # (a module named above and found in its directory: once)
 
 
 def staged_path():
