@@ -46,7 +46,12 @@ TEST_FILES = ('conftest.py', 'test_edge_index.py', 'test_index.py',
 # route ride on `MessagePassing._index_select` + `scatter`), every aggregation, the dense layers,
 # the utils
 TEST_DIRS = ('nn/conv', 'nn/aggr', 'nn/dense', 'utils', 'nn/models', 'nn/pool', 'nn/norm',
-             'nn/functional', 'nn/kge', 'nn/attention', 'nn/unpool', 'explain', 'transforms')
+             'nn/functional', 'nn/kge', 'nn/attention', 'nn/unpool', 'explain', 'transforms',
+             'nn', 'data', 'sampler', 'metrics')
+# ('loader' too was run once — 331 modules, 4,171 cases passed with the backend, 276 s — and left out
+# of the standing set: its DataLoader-worker modules double the run time; PYGAMD_REFERENCE_TESTS_MORE
+# = a comma-separated list of further directories of <reference>/test for a one-off run)
+TEST_DIRS += tuple(d for d in os.environ.get('PYGAMD_REFERENCE_TESTS_MORE', '').split(',') if d)
 
 
 def _test_files(tsrc):

@@ -5,8 +5,9 @@ reference's authors wrote: every module of test/utils, test/nn/conv (all 60-odd 
 ones without a dedicated route ride on `MessagePassing._index_select` + `scatter`), test/nn/aggr
 and test/nn/dense, plus test_edge_index, test_index and the BasicGNN models — incl. their hook,
 explain and bipartite cases — and (later in round 6) what sits ON TOP of the path: every module of
-test/nn/models, nn/pool, nn/norm, nn/functional, nn/kge, nn/attention, nn/unpool, test/explain and
-test/transforms (275 modules, 3,919 cases).
+test/nn/models, nn/pool, nn/norm, nn/functional, nn/kge, nn/attention, nn/unpool, the top-level
+test/nn modules, test/explain, test/transforms, test/data, test/sampler and test/metrics (313
+modules, 4,141 cases).
 
 The same modules run once WITHOUT the backend in the same environment: a test only counts against
 install() if it passes there (a handful of the reference's tests fail on their own with this torch
@@ -75,10 +76,10 @@ def test_reference_test_modules_pass_with_the_backend_installed():
     on the CPU (tests/test_backend_install.py) — on the device box they triple the run time."""
     from oracle import make_ref
     _, files = make_ref.reference_tests()
-    assert len(files) >= 250, len(files)
+    assert len(files) >= 290, len(files)
     failed, line, out = _run(files, with_backend=True)
     m = re.search(r'(\d+) passed', line)
-    assert m and int(m.group(1)) >= 3700, line
+    assert m and int(m.group(1)) >= 3900, line
     assert 'cuda:0' in out or not failed    # (ids of device cases carry the device name)
     new = sorted(failed)
     if new:
