@@ -1073,6 +1073,229 @@ __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) 
   }
 }
 
+// ---- TN, split arithmetic, NARROW g (N <= 128): the whole [N, 256-column] tile per workgroup -------
+// The last layer of a classifier stack (47 classes, aggregated at the output width: g = [A^T g' |
+// g'] is 96 columns wide) multiplies a narrow g against a wide x.  Under gemm_tn_split_kernel that
+// launch is bound by its LOADS, not by its products (profiles/r06_wgrad_probe.txt: halving the
+// matrix work moved nothing): a 128 x 128 tile re-reads g once per x tile, a quarter of the g
+// loads fetch clamped padding columns, and two register sets per thread are all the 64-register
+// accumulators leave room for.  Here ONE 512-thread workgroup per CU owns every g column and 256
+// x columns: a wave owns one 32-column block of x against all NB <= 4 blocks of g (16 NB
+// accumulator registers), every operand row leaves L2 once, and THREE register sets per staging
+// thread keep three 32-row blocks (45 KB at N = 96) in flight per CU.  One LDS image (the column
+// planes of gemm_tn_split_kernel: [term][column][20 dwords]), two barriers per block; conversion
+// and products alternate — both together are shorter than the block's share of HBM time.
+constexpr int kSkG = 128;                 // staged g columns (N <= 128)
+constexpr int kSkX = 256;                 // x columns per workgroup
+constexpr int kSkCols = kSkG + kSkX;
+constexpr int kSkPlane = kSkCols * kCLD;  // dwords per term plane
+constexpr size_t kTnSkinnyLds = sizeof(uint32_t) * 3 * kSkPlane;
+constexpr int64_t kSkinnyMinRows = 32768;  // below: the tiled kernel with its finer splits
+
+// PROBE (lab, timing only — results undefined): bit 1 = no products, bit 2 = no conversion / LDS
+// stores, bit 3 = no global loads
+template <int NB, int PROBE = 0>
+__global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_skinny_kernel(GemmTN p) {
+  extern __shared__ __align__(16) uint32_t sk_lds[];
+  const int64_t b = blockIdx.x;
+  const int64_t per_xcd = gridDim.x >> 3;
+  const int64_t q = (b & 7) * per_xcd + (b >> 3);
+  const int64_t split = q / p.tiles_k;
+  if (split >= p.splits) return;
+  const int tk = static_cast<int>(q - split * p.tiles_k);
+  const int k0 = tk * kSkX;
+  const int64_t ra = split * p.rows_per_split;
+  int64_t rb = ra + p.rows_per_split;
+  rb = rb < p.M ? rb : p.M;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // staging: waves 0, 1 stage g (tile columns 0..63, 64..127), waves 2..5 stage x (64 columns
+  // each); waves 6, 7 stage g ONCE MORE (the same values to the same LDS words: a benign
+  // duplicate, their loads hit the CU's L1): every wave runs the same instruction stream — a
+  // wave-uniform branch around the staging costs the prefetch (the s_waitcnt pass merges the two
+  // paths at every join and loses one batch of distance per join).  Lane bits as in
+  // gemm_tn_split_kernel: 0 = low bit of the column quad, 1..2 = row group (8 rows), 3..5 = high
+  // bits of the quad.
+  const int sw = wave < 6 ? wave : wave - 6;
+  const bool isx = sw >= 2;
+  const int c4 = (lane & 1) + 2 * (lane >> 3);
+  const int rg = (lane >> 1) & 3;
+  const int sc = 64 * sw + 4 * c4;       // staged column (0..383)
+  const int oc = isx ? sc - kSkG : sc;                     // column inside the operand's tile
+  const float* __restrict__ src = isx ? p.x : p.g;
+  const int64_t sld = isx ? p.ldx : p.ldg;
+  const int col_lim = isx ? p.K - k0 : p.N;                // valid columns (> 0, % 4 == 0)
+  const int col0 = isx ? k0 : 0;
+  const bool cok = oc < col_lim;                           // the whole quad is valid or not
+  const float* const tp = src + (ra + 8 * rg) * sld + col0 + (cok ? oc : 0);
+  auto load_rows = [&](f32x4 (&st)[8], int64_t blk) {
+    if constexpr ((PROBE & 8) != 0) return;
+    const float* bp = tp + blk * kWRows * sld;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) st[r] = *reinterpret_cast<const f32x4*>(bp + r * sld);
+  };
+  auto load_tail = [&](f32x4 (&st)[8], int64_t r0) {  // rows clamped to the split's last one
+    const int64_t last = rb - 1;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int64_t row = r0 + 8 * rg + r;
+      row = row < last ? row : last;
+      st[r] = *reinterpret_cast<const f32x4*>(src + row * sld + col0 + (cok ? oc : 0));
+    }
+  };
+  const bool do_colsum = p.colsum != nullptr && tk == 0;  // workgroup-uniform
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  uint32_t* const wbase = sk_lds + sc * kCLD + 4 * rg;
+  auto convert_store = [&](f32x4 (&st)[8]) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      u32x4 w[3];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        uint32_t tt[3];
+        split_pair_single(st[2 * qq][cc], st[2 * qq + 1][cc], tt);
+        w[0][qq] = tt[0];
+        w[1][qq] = tt[1];
+        w[2][qq] = tt[2];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        *reinterpret_cast<u32x4*>(wbase + k * kSkPlane + cc * kCLD) = w[k];
+    }
+    if (do_colsum && wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] = add_f32_asm(csum[e], st[r][e]);
+      }
+    }
+  };
+  // a full block inside the loop: unconditional (a lane-divergent branch around the conversion
+  // makes the compiler drain every load at the join); padding quads are staged as zeros
+  auto store_rows = [&](f32x4 (&st)[8]) {
+    if constexpr ((PROBE & 4) != 0) return;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st[r][e] = cok ? st[r][e] : 0.f;
+    }
+    convert_store(st);
+  };
+  auto store_tail = [&](f32x4 (&st)[8], int64_t r_end) {  // rows >= r_end are staged as zero
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const bool rok = 8 * rg + r < r_end;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st[r][e] = (rok && cok) ? st[r][e] : 0.f;
+    }
+    convert_store(st);
+  };
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const bool active = k0 + wave * 32 < p.K;  // scalar: this wave's x block is not all padding
+  const uint32_t* const ga = sk_lds + li * kCLD + 4 * lh;
+  const uint32_t* const xb = sk_lds + (kSkG + wave * 32 + li) * kCLD + 4 * lh;
+  auto frag = [&](const uint32_t* base, int s) {
+    SplitFrag f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      f.p[k] = __builtin_bit_cast(bf16x8,
+                                  *reinterpret_cast<const u32x4*>(base + k * kSkPlane + 8 * s));
+    return f;
+  };
+  auto products = [&]() {
+    if constexpr ((PROBE & 2) != 0) return;
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const SplitFrag bx = frag(xb, s);
+        SplitFrag a[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) a[i] = frag(ga + i * 32 * kCLD, s);
+#pragma unroll
+        for (int k = 0; k < kSplitTerms; ++k)
+#pragma unroll
+          for (int i = 0; i < NB; ++i) split_term(k, a[i], bx, acc[i]);
+      }
+    }
+  };
+
+  const int64_t n_rows = rb > ra ? rb - ra : 0;
+  const int64_t n_blocks = n_rows / kWRows;          // full blocks
+  const int64_t n_pipe = n_blocks - n_blocks % 3;    // the pipelined loop takes them three at a time
+  const int64_t last_blk = n_pipe - 1;
+  auto blk_of = [&](int64_t i) { return i < last_blk ? i : last_blk; };  // (re-loads past the end)
+  f32x4 st0[8], st1[8], st2[8];
+  if constexpr ((PROBE & 8) != 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) st0[r] = st1[r] = st2[r] = f32x4{1.f, 2.f, 3.f, 4.f};
+  }
+  // (the three batches in program order, here and in the loop: s_waitcnt counts loads in issue
+  // order and merges the paths into the loop header pessimistically)
+  if (n_pipe > 0) {
+    load_rows(st0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(st1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(st2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int64_t i = 0; i < n_pipe; i += 3) {
+    store_rows(st0);
+    load_rows(st0, blk_of(i + 3));
+    __syncthreads();
+    products();
+    __syncthreads();
+    store_rows(st1);
+    load_rows(st1, blk_of(i + 4));
+    __syncthreads();
+    products();
+    __syncthreads();
+    store_rows(st2);
+    load_rows(st2, blk_of(i + 5));
+    __syncthreads();
+    products();
+    __syncthreads();
+  }
+  // what the pipelined loop left: up to two full blocks and the split's ragged last block
+  for (int64_t r0 = n_pipe * kWRows; r0 < n_rows; r0 += kWRows) {  // (workgroup-uniform)
+    load_tail(st0, ra + r0);
+    const int64_t left = n_rows - r0;
+    store_tail(st0, left < kWRows ? left : kWRows);
+    __syncthreads();
+    products();
+    __syncthreads();
+  }
+  if (do_colsum) {  // (uniform: the barrier is legal; the image is free after the last products)
+    float* const red = reinterpret_cast<float*>(sk_lds);  // [4 row groups][128]
+    if (wave < 2) *reinterpret_cast<f32x4*>(&red[rg * kSkG + sc]) = csum;
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < p.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += red[r * kSkG + threadIdx.x];
+      p.colsum[split * p.N + threadIdx.x] = s;
+    }
+  }
+  if (!active) return;
+  float* __restrict__ slab = p.partial + split * static_cast<int64_t>(p.N) * p.K;
+  const int col = k0 + wave * 32 + li;
+  if (col >= p.K) return;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (row < p.N) slab[static_cast<int64_t>(row) * p.K + col] = acc[i][e];
+    }
+  }
+}
+
 // out[n, k] (+)= sum over splits, in split order (deterministic)
 __global__ void __launch_bounds__(kBlock)
     gemm_tn_reduce_kernel(const float* __restrict__ partial, int splits, int64_t NK, int K,
@@ -1211,7 +1434,7 @@ int pygamd_get_gemm_mode(void) { return g_gemm_mode; }
 
 #ifdef PYGAMD_LAB
 int pygamd_lab_set_wgrad_variant(int variant) {
-  if (variant < 0 || variant > 63 || ((variant & 1) && variant != 1))
+  if (variant < 0 || variant > 127 || ((variant & 1) && variant != 1))
     return PYGAMD_ERR_INVALID_ARG;
   g_wgrad_variant = variant;
   return PYGAMD_OK;
@@ -1351,6 +1574,49 @@ int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ld
   p.vec_g = (N % 4 == 0) && (ldg % 4 == 0) && aligned16p(g);
   p.vec_x = (K1 % 4 == 0) && (ldx % 4 == 0) && aligned16p(x);
   p.vec_x2 = (K2 % 4 == 0) && (ldx2 % 4 == 0) && aligned16p(x2);
+  // a narrow g against one wide x (the classifier layer aggregated at the output width): every g
+  // column and 256 x columns per workgroup, one workgroup per CU (gemm_tn_skinny_kernel)
+  // (lab switch 16: the tiled kernel for this shape too — the A/B of scripts/wgrad_probe.py)
+  if (split_once && !(g_wgrad_variant & 16) && !x2 && N <= kSkG && p.vec_g && p.vec_x &&
+      M >= kSkinnyMinRows) {
+    const int64_t ws_splits = wgrad_splits(M, tiles);  // what the workspace was sized for
+    p.tiles_k = static_cast<int>(ceil_div(K, kSkX));
+    int64_t s = ceil_div(256, p.tiles_k);
+    s = s > ws_splits ? ws_splits : s;
+    p.splits = static_cast<int>(s);
+    p.colsum = bias_grad ? p.partial + static_cast<int64_t>(p.splits) * N * K : nullptr;
+    p.rows_per_split = round_up(ceil_div(M, p.splits), kWRows);
+    void (*sk)(GemmTN) = N <= 32 ? gemm_tn_skinny_kernel<1>
+                         : N <= 64 ? gemm_tn_skinny_kernel<2>
+                         : N <= 96 ? gemm_tn_skinny_kernel<3> : gemm_tn_skinny_kernel<4>;
+#ifdef PYGAMD_LAB
+    if (N > 64 && N <= 96) {  // timing probes of the three-block variant (64 + phase bits)
+      switch (g_wgrad_variant) {
+        case 66: sk = gemm_tn_skinny_kernel<3, 2>; break;
+        case 68: sk = gemm_tn_skinny_kernel<3, 4>; break;
+        case 70: sk = gemm_tn_skinny_kernel<3, 6>; break;
+        case 72: sk = gemm_tn_skinny_kernel<3, 8>; break;
+        case 74: sk = gemm_tn_skinny_kernel<3, 10>; break;
+        case 76: sk = gemm_tn_skinny_kernel<3, 12>; break;
+        case 78: sk = gemm_tn_skinny_kernel<3, 14>; break;
+        default: break;
+      }
+    }
+#endif
+    PYGAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sk),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(kTnSkinnyLds)));
+    const int64_t wgs = round_up(static_cast<int64_t>(p.tiles_k) * p.splits, 8);
+    hipLaunchKernelGGL(sk, dim3(static_cast<unsigned>(wgs)), dim3(kTnThreads), kTnSkinnyLds, st, p);
+    PYGAMD_LAUNCH_CHECK();
+    const int64_t NKs = N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel,
+                       dim3(static_cast<unsigned>(ceil_div(NKs + (bias_grad ? N : 0), kBlock))),
+                       dim3(kBlock), 0, st, p.partial, p.splits, NKs, p.K, out, ldo,
+                       accumulate ? 1 : 0, p.colsum, p.N, bias_grad);
+    PYGAMD_LAUNCH_CHECK();
+    return PYGAMD_OK;
+  }
   const int64_t blocks = round_up(tiles * p.splits, 8);
   size_t lds = sizeof(float) * 4 * kWRows * kWLD;
   int threads = kBlock;

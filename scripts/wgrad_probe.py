@@ -14,6 +14,7 @@ from pytorch_geometric_amd import _native  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--rows', type=int, default=2_449_029)
+ap.add_argument('--skinny-only', action='store_true', help='only the narrow-g A/B at the end')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 M = args.rows
@@ -38,7 +39,7 @@ def timeit(fn, reps=10):
 g = torch.Generator(device=dev).manual_seed(0)
 print('rows, K1 | K2 -> N: fp32 / split in registers (r3) / split once (production) / library ms'
       ' ; production TFLOP/s ; max |production - r3|')
-for rows, K1, K2, N in SHAPES:
+for rows, K1, K2, N in ([] if args.skinny_only else SHAPES):
     x = torch.randn(rows, K1, device=dev, generator=g)
     x2 = torch.randn(rows, K2, device=dev, generator=g)
     go = torch.randn(rows, N, device=dev, generator=g)
@@ -74,3 +75,38 @@ for rows, K1, K2, N in SHAPES:
         _native.set_gemm_mode(prev)
         print('          phases off: ' + ', '.join(parts), flush=True)
     del x, x2, go, cat
+
+# ---- round 6: the narrow-g launch of the bench step's classifier layer (g = [A^T g' | g'] is
+# 96 columns wide, ONE 256-column x): gemm_tn_skinny_kernel against the tiled kernel (lab switch 16)
+print('rows, K -> N (one x operand): tiled split kernel / skinny kernel ms ; GB/s of the skinny one'
+      ' ; max |difference|')
+for rows, K, N in [(M, 256, 96), (M, 256, 128), (M, 512, 48), (180224, 256, 96), (65536, 256, 96)]:
+    x = torch.randn(rows, K, device=dev, generator=g)
+    go = torch.randn(rows, N, device=dev, generator=g)
+    out = torch.empty(N, K, device=dev)
+
+    def own():
+        return _native.linear_wgrad(go, x, out=out, bias_grad=True)
+
+    prev = _native.set_gemm_mode('split')
+    _native.lab_set_wgrad_variant(16)
+    t_old = timeit(own)
+    r_old = own()[0].clone()
+    _native.lab_set_wgrad_variant(0)
+    t_new = timeit(own)
+    r_new = own()[0].clone()
+    _native.set_gemm_mode(prev)
+    gbs = rows * (K + N) * 4 / t_new / 1e6
+    print(f'{rows:8d}, {K} -> {N}: {t_old:7.3f} / {t_new:7.3f} ; {gbs:7.0f} ; '
+          f'{float((r_old - r_new).abs().max()):.3e}', flush=True)
+    if rows == M and N == 96:  # phases of the skinny kernel switched off (lab probes 64 + bits)
+        prev = _native.set_gemm_mode('split')
+        parts = []
+        for bits, what in ((2, 'no products'), (4, 'no conversion'), (8, 'no loads'),
+                           (6, 'loads only'), (12, 'products only'), (10, 'conversion only'),
+                           (14, 'barriers only')):
+            _native.lab_set_wgrad_variant(64 + bits)
+            parts.append(f'{what} {timeit(own):.3f}')
+        _native.lab_set_wgrad_variant(0)
+        _native.set_gemm_mode(prev)
+        print('          phases off: ' + ', '.join(parts), flush=True)
