@@ -1073,14 +1073,14 @@ __global__ void __launch_bounds__(kTnThreads, 1) gemm_tn_split_kernel(GemmTN p) 
   }
 }
 
-// ---- TN, split arithmetic, NARROW g (N <= 128): the whole [N, 256-column] tile per workgroup -------
+// ---- TN, split arithmetic, NARROW g (N <= 96): the whole [N, 256-column] tile per workgroup --------
 // The last layer of a classifier stack (47 classes, aggregated at the output width: g = [A^T g' |
 // g'] is 96 columns wide) multiplies a narrow g against a wide x.  Under gemm_tn_split_kernel that
 // launch is bound by its LOADS, not by its products (profiles/r06_wgrad_probe.txt: halving the
 // matrix work moved nothing): a 128 x 128 tile re-reads g once per x tile, a quarter of the g
 // loads fetch clamped padding columns, and two register sets per thread are all the 64-register
 // accumulators leave room for.  Here ONE 512-thread workgroup per CU owns every g column and 256
-// x columns: a wave owns one 32-column block of x against all NB <= 4 blocks of g (16 NB
+// x columns: a wave owns one 32-column block of x against all NB <= 3 blocks of g (16 NB
 // accumulator registers), every operand row leaves L2 once, and THREE register sets per staging
 // thread keep three 32-row blocks (45 KB at N = 96) in flight per CU.  One LDS image (the column
 // planes of gemm_tn_split_kernel: [term][column][20 dwords]), two barriers per block; conversion
@@ -1090,6 +1090,10 @@ constexpr int kSkX = 256;                 // x columns per workgroup
 constexpr int kSkCols = kSkG + kSkX;
 constexpr int kSkPlane = kSkCols * kCLD;  // dwords per term plane
 constexpr size_t kTnSkinnyLds = sizeof(uint32_t) * 3 * kSkPlane;
+// (N in 97..128 — four blocks of g — and a WIDE form with 256 columns of g + 128 of x per workgroup
+// were built too and measured no faster than the tiled kernel, whose two wave groups overlap
+// conversion and products: profiles/r06_wgrad_probe.txt)
+constexpr int kSkMaxN = 96;
 constexpr int64_t kSkinnyMinRows = 32768;  // below: the tiled kernel with its finer splits
 
 // PROBE (lab, timing only — results undefined): bit 1 = no products, bit 2 = no conversion / LDS
@@ -1577,7 +1581,7 @@ int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ld
   // a narrow g against one wide x (the classifier layer aggregated at the output width): every g
   // column and 256 x columns per workgroup, one workgroup per CU (gemm_tn_skinny_kernel)
   // (lab switch 16: the tiled kernel for this shape too — the A/B of scripts/wgrad_probe.py)
-  if (split_once && !(g_wgrad_variant & 16) && !x2 && N <= kSkG && p.vec_g && p.vec_x &&
+  if (split_once && !(g_wgrad_variant & 16) && !x2 && N <= kSkMaxN && p.vec_g && p.vec_x &&
       M >= kSkinnyMinRows) {
     const int64_t ws_splits = wgrad_splits(M, tiles);  // what the workspace was sized for
     p.tiles_k = static_cast<int>(ceil_div(K, kSkX));
@@ -1588,7 +1592,7 @@ int pygamd_linear_wgrad2(const float* g, int64_t ldg, const float* x, int64_t ld
     p.rows_per_split = round_up(ceil_div(M, p.splits), kWRows);
     void (*sk)(GemmTN) = N <= 32 ? gemm_tn_skinny_kernel<1>
                          : N <= 64 ? gemm_tn_skinny_kernel<2>
-                         : N <= 96 ? gemm_tn_skinny_kernel<3> : gemm_tn_skinny_kernel<4>;
+                                   : gemm_tn_skinny_kernel<3>;
 #ifdef PYGAMD_LAB
     if (N > 64 && N <= 96) {  // timing probes of the three-block variant (64 + phase bits)
       switch (g_wgrad_variant) {

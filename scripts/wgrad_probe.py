@@ -76,17 +76,19 @@ for rows, K1, K2, N in ([] if args.skinny_only else SHAPES):
         print('          phases off: ' + ', '.join(parts), flush=True)
     del x, x2, go, cat
 
-# ---- round 6: the narrow-g launch of the bench step's classifier layer (g = [A^T g' | g'] is
-# 96 columns wide, ONE 256-column x): gemm_tn_skinny_kernel against the tiled kernel (lab switch 16)
-print('rows, K -> N (one x operand): tiled split kernel / skinny kernel ms ; GB/s of the skinny one'
+# ---- round 6: gemm_tn_skinny_kernel (narrow g, N <= 96 — the bench step's classifier layer, g =
+# [A^T g' | g'] 96 columns wide against ONE 256-column x) against the tiled kernel (lab switch 16)
+print('rows, K1 | K2 -> N: tiled split kernel / streamed kernel ms ; GB/s of the streamed one'
       ' ; max |difference|')
-for rows, K, N in [(M, 256, 96), (M, 256, 128), (M, 512, 48), (180224, 256, 96), (65536, 256, 96)]:
+for rows, K, K2, N in [(M, 256, 0, 96), (M, 512, 0, 48), (M, 256, 0, 64), (180224, 256, 0, 96),
+                       (65536, 256, 0, 96)]:
     x = torch.randn(rows, K, device=dev, generator=g)
+    x2 = torch.randn(rows, K2, device=dev, generator=g) if K2 else None
     go = torch.randn(rows, N, device=dev, generator=g)
-    out = torch.empty(N, K, device=dev)
+    out = torch.empty(N, K + K2, device=dev)
 
     def own():
-        return _native.linear_wgrad(go, x, out=out, bias_grad=True)
+        return _native.linear_wgrad(go, x, out=out, bias_grad=True, x2=x2)
 
     prev = _native.set_gemm_mode('split')
     _native.lab_set_wgrad_variant(16)
@@ -96,17 +98,30 @@ for rows, K, N in [(M, 256, 96), (M, 256, 128), (M, 512, 48), (180224, 256, 96),
     t_new = timeit(own)
     r_new = own()[0].clone()
     _native.set_gemm_mode(prev)
-    gbs = rows * (K + N) * 4 / t_new / 1e6
-    print(f'{rows:8d}, {K} -> {N}: {t_old:7.3f} / {t_new:7.3f} ; {gbs:7.0f} ; '
+    gbs = rows * (K + K2 + N) * 4 / t_new / 1e6
+    print(f'{rows:8d}, {K} | {K2} -> {N}: {t_old:7.3f} / {t_new:7.3f} ; {gbs:7.0f} ; '
           f'{float((r_old - r_new).abs().max()):.3e}', flush=True)
-    if rows == M and N == 96:  # phases of the skinny kernel switched off (lab probes 64 + bits)
+    if rows == M and N == 96 and K == 256:
+        # phases of the streamed kernel switched off (lab probes 64 + bits)
         prev = _native.set_gemm_mode('split')
         parts = []
         for bits, what in ((2, 'no products'), (4, 'no conversion'), (8, 'no loads'),
-                           (6, 'loads only'), (12, 'products only'), (10, 'conversion only'),
-                           (14, 'barriers only')):
+                           (12, 'products only'), (10, 'conversion only')):
             _native.lab_set_wgrad_variant(64 + bits)
             parts.append(f'{what} {timeit(own):.3f}')
         _native.lab_set_wgrad_variant(0)
         _native.set_gemm_mode(prev)
         print('          phases off: ' + ', '.join(parts), flush=True)
+        # the same launch on all-zero and on constant operands: what the data's toggling costs
+        for name, fill in (('zeros', 0.0), ('ones', 1.0)):
+            x.fill_(fill)
+            go.fill_(fill)
+            if x2 is not None:
+                x2.fill_(fill)
+            _native.set_gemm_mode('split')
+            print(f'          {name}: streamed {timeit(own):.3f}', end='')
+            _native.lab_set_wgrad_variant(16)
+            print(f', tiled {timeit(own):.3f}', flush=True)
+            _native.lab_set_wgrad_variant(0)
+            _native.set_gemm_mode(prev)
+    del x, x2, go

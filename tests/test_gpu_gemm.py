@@ -481,10 +481,14 @@ def test_split_mode_forward_dgrad_wgrad(dev, split_mode, M, K, N):
     (1, 1, 1, 0), (33, 7, 31, 0), (257, 512, 256, 0), (1000, 36, 130, 20), (4099, 100, 256, 100),
     (70001, 256, 47, 256), (129, 129, 47, 3), (65, 300, 130, 0), (9000, 64, 64, 0),
     (32, 8, 8, 0), (63, 8, 8, 0), (64, 8, 8, 0), (96, 8, 8, 8), (200000, 128, 128, 0),
-    # narrow g against one wide x from 32 k rows: gemm_tn_skinny_kernel (1..4 blocks of g, one and
-    # two x tiles, ragged K, ragged last block, splits with 0 / 1 / 2 blocks behind the pipeline)
+    # from 32 k rows, 16-byte aligned operands: gemm_tn_skinny_kernel — narrow form (1..4 blocks of
+    # g, one and two x tiles, ragged K, ragged last block, splits with 0 / 1 / 2 blocks behind the
+    # pipeline) ...
     (70001, 256, 96, 0), (40003, 300, 128, 0), (33000, 64, 4, 0), (100003, 260, 48, 0),
     (32768, 256, 96, 0), (57345, 512, 36, 0),
+    # wide g from 32 k rows (the tiled kernel; a streamed wide form was measured and dropped)
+    (70001, 256, 256, 256), (40003, 100, 256, 100), (33000, 64, 200, 0), (50000, 300, 132, 20),
+    (65536, 128, 256, 0),
 ])
 def test_split_wgrad_production_schedule_against_the_in_register_one(dev, split_mode, M, K, N,
                                                                      K2):
