@@ -1139,7 +1139,14 @@ def main():
     def symbol(info):
         if info.get('kind') == 'gemm':
             # (csrc/gemm.hip: the weight gradient has its own kernel in the split arithmetic)
+            # (and, from 32 k rows, a narrow g — N <= 96, here the classifier layer's 2 x 48 columns
+            # against ONE x operand — its one-tile-per-workgroup form; the dispatch rule of
+            # pygamd_linear_wgrad2 restated for the label only)
             tn = 'gemm_tn_split_kernel' if pga.get_gemm_mode() == 'split' else 'gemm_tn_kernel'
+            if (tn == 'gemm_tn_split_kernel' and info['op'] == 'wgrad' and info.get('N', 1 << 30) <= 96
+                    and info.get('N', 1) % 4 == 0 and info.get('K', 1) % 4 == 0
+                    and info.get('M', 0) >= 32768 and not info.get('x2')):
+                tn = 'gemm_tn_skinny_kernel'
             return {'wgrad': tn, 'dgrad': 'gemm_nt_kernel', 'forward': 'gemm_nt_kernel'}[info['op']]
         lpr = 4
         while lpr < 64 and lpr * 4 < info['F']:

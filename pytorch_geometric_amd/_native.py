@@ -1478,7 +1478,8 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
             if bias_grad:
                 gb = bias_out if bias_out is not None else \
                     torch.empty(N, dtype=torch.float32, device=g.device)
-            with _timed({'kind': 'gemm', 'op': 'wgrad', 'M': g.size(0), 'N': N, 'K': K}, g):
+            with _timed({'kind': 'gemm', 'op': 'wgrad', 'M': g.size(0), 'N': N, 'K': K,
+                         'x2': x2 is not None}, g):
                 C.linear_wgrad(g, x, out, accumulate, wgs_per_cu, gb, x2)
             return (out, gb) if bias_grad else out
     lib = _lib.load()
@@ -1505,7 +1506,8 @@ def linear_wgrad(g: Tensor, x: Tensor, out: Optional[Tensor] = None,
             return out, (cs if bias_out is None else bias_out.copy_(cs))
         gb = bias_out if bias_out is not None else \
             torch.empty(N, dtype=torch.float32, device=g.device)
-    with _timed({'kind': 'gemm', 'op': 'wgrad', 'M': M, 'N': N, 'K': K}, g):
+    with _timed({'kind': 'gemm', 'op': 'wgrad', 'M': M, 'N': N, 'K': K,
+                 'x2': second is not None}, g):
         check(lib.pygamd_linear_wgrad2(_p(g2), _ld(g2), _p(first), _ld(first), K1, _p(second),
                                        _ld(second) if second is not None else 0, K2, M, N,
                                        int(accumulate), int(wgs_per_cu), _p(out), _ld(out),
