@@ -68,18 +68,31 @@ def _names(node_ids):
     return ' or '.join(sorted({re.sub(r'\[.*', '', t.split('::')[-1]) for t in node_ids}))
 
 
+# The rows of SURVEY.md §8 themselves: every module of test/utils, test/nn/conv, test/nn/aggr,
+# test/nn/dense + test_edge_index, test_index, test_basic_gnn (142 modules, ~3,450 cases, ~2 min).
+# This is what `pytest -m gpu` runs by default; PYGAMD_REFERENCE_SUITE=full adds what sits on top
+# of the path (nn/models, nn/pool, nn/norm, ..., explain, transforms, data, sampler, metrics: 313
+# modules, 4,141 cases, ~4.5 min — profiles/r06_reference_suite.txt holds that run).
+CORE = ('/utils/', '/nn/conv/', '/nn/aggr/', '/nn/dense/', '/test_edge_index.py', '/test_index.py',
+        '/nn/models/test_basic_gnn.py')
+
+
 @pytest.mark.timeout(3500)
 def test_reference_test_modules_pass_with_the_backend_installed():
-    """One pass over all staged modules WITH the backend; whatever fails is run again WITHOUT it (the
+    """One pass over the staged modules WITH the backend; whatever fails is run again WITHOUT it (the
     reference's own failures with this torch version do not count) and once more with it (random
     inputs against default `allclose` tolerances).  The TorchScript-heavy FULL_TEST variants run
     on the CPU (tests/test_backend_install.py) — on the device box they triple the run time."""
     from oracle import make_ref
-    _, files = make_ref.reference_tests()
+    root, files = make_ref.reference_tests()
     assert len(files) >= 290, len(files)
+    full = os.environ.get('PYGAMD_REFERENCE_SUITE', 'core') == 'full'
+    if not full:
+        files = [f for f in files if any(c in '/' + os.path.relpath(f, root) for c in CORE)]
+        assert len(files) >= 135, len(files)
     failed, line, out = _run(files, with_backend=True)
     m = re.search(r'(\d+) passed', line)
-    assert m and int(m.group(1)) >= 3900, line
+    assert m and int(m.group(1)) >= (3900 if full else 3300), line
     assert 'cuda:0' in out or not failed    # (ids of device cases carry the device name)
     new = sorted(failed)
     if new:
