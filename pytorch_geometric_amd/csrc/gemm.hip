@@ -1508,13 +1508,15 @@ int pygamd_linear_nt_workspace_bytes(int64_t M, int64_t N_out, int64_t K_red, si
 
 static int64_t wgrad_splits(int64_t M, int64_t tiles, int wgs_per_cu = 2) {
   // two workgroups per CU (the LDS ring allows no more) = one full wave of workgroups, every
-  // split a multiple of 32 rows and at least 2048 rows (256 below 64 k rows).  wgs_per_cu = 1: half the footprint — the
+  // split a multiple of 32 rows and at least 1024 rows (128 below 64 k rows).  wgs_per_cu = 1: half the footprint — the
   // launch then shares the chip with a bandwidth-bound kernel on another stream (the matrix cores
   // are idle under an SpMM) instead of taking every wave slot.
   int64_t s = ceil_div(256 * (wgs_per_cu == 1 ? 1 : 2), tiles < 1 ? 1 : tiles);
   // (sampled blocks of a few thousand rows: splits of 256 / 64 rows keep the chip busy; their
   // slabs are a few MB)
-  const int64_t max_s = ceil_div(M, M >= 65536 ? 2048 : M >= 8192 ? 256 : 64);
+  // (1024 rather than 2048 rows from 64 k rows: a sampled batch's first layer — 170 k rows, four
+  // tiles — then fills all 256 CUs instead of 168 of them; the full-batch shapes are far from it)
+  const int64_t max_s = ceil_div(M, M >= 65536 ? 1024 : M >= 8192 ? 128 : 64);
   s = s > max_s ? max_s : s;
   return s < 1 ? 1 : s;
 }
