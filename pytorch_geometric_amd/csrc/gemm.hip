@@ -438,7 +438,15 @@ __global__ void __launch_bounds__(kBlock) gemm_nt_splitk_epilogue(GemmNT p) {
   const int64_t row = t / p.N;
   const int col = static_cast<int>(t - row * p.N);
   float v = 0.f;
-  for (int sp = 0; sp < p.ksplits; ++sp) v += p.partial[sp * MN + t];
+  int sp = 0;
+  for (; sp + 4 <= p.ksplits; sp += 4) {  // (four slices' loads in flight, added in slice order)
+    float u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = p.partial[(sp + i) * MN + t];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v += u[i];
+  }
+  for (; sp < p.ksplits; ++sp) v += p.partial[sp * MN + t];
   if (p.bias) v += p.bias[col];
   if (col < p.n_scaled) v *= p.row_scale[row];
   if (p.relu) v = (v > 0.f || v != v) ? v : 0.f;
@@ -1310,13 +1318,38 @@ __global__ void __launch_bounds__(kBlock)
     const int64_t n = t - NK;
     if (bias_grad && n < N) {
       float s = 0.f;
-      for (int sp = 0; sp < splits; ++sp) s += colsum[static_cast<int64_t>(sp) * N + n];
+      int sp = 0;
+      for (; sp + 8 <= splits; sp += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = colsum[static_cast<int64_t>(sp + i) * N + n];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+      }
+      for (; sp < splits; ++sp) s += colsum[static_cast<int64_t>(sp) * N + n];
       bias_grad[n] = s;
     }
     return;
   }
+  // (sixteen slabs' loads in flight, added in split order: the plain loop waits for every load
+  // before it issues the next one — 64 splits were 64 trips to L2, 18 us for 16.8 MB)
   float s = 0.f;
-  for (int sp = 0; sp < splits; ++sp) s += partial[sp * NK + t];
+  int sp = 0;
+  for (; sp + 16 <= splits; sp += 16) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = partial[(sp + i) * NK + t];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+  }
+  for (; sp + 4 <= splits; sp += 4) {
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = partial[(sp + i) * NK + t];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += v[i];
+  }
+  for (; sp < splits; ++sp) s += partial[sp * NK + t];
   const int64_t r = t / K;
   float* dst = out + r * ldo + (t - r * K);
   *dst = accumulate ? *dst + s : s;
