@@ -65,8 +65,13 @@ __global__ void __launch_bounds__(kBlock)
   atomicMax(local + v, slot_key(*epoch, i));
 }
 
-// ---- one hop: a wave per frontier position.  Draws as in sample_neighbors_kernel (sample.hip).
-template <typename IdxT>
+// ---- one hop: G lanes per frontier position (G = 16 / 32 / 64 >= the fan-out), 64 / G positions
+// per wave.  Draws as in sample_neighbors_kernel (sample.hip), a position's lanes numbered from 0.
+// The hop is a chain of four dependent random reads (node id -> colptr -> row -> claim) over the
+// whole graph's arrays: latency, hidden only by positions in flight — a wave per position with a
+// fan-out of 5 kept 5 of 64 lanes busy and 8 k positions in flight per chip (63 us for the 154 k
+// positions of config 4's last hop); four positions per wave are four times as many.
+template <typename IdxT, int G>
 __global__ void __launch_bounds__(kBlock)
     slots_sample_kernel(const IdxT* __restrict__ colptr, const IdxT* __restrict__ row,
                         const int64_t* __restrict__ node_g, int64_t frontier_base,
@@ -74,11 +79,17 @@ __global__ void __launch_bounds__(kBlock)
                         int hop, const int64_t* __restrict__ epoch,
                         long long* __restrict__ local, int64_t* __restrict__ src_g,
                         int32_t* __restrict__ row_end, float* __restrict__ inv_cnt) {
-  const int lane = lane_id();
-  const int64_t f = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block();
-  if (f >= n_frontier) return;
-  const int64_t r = frontier_base + f;
-  const int64_t begin = slot_base + f * k;
+  constexpr int kPer = kWave / G;            // positions per wave
+  const int wl = lane_id();
+  const int sub = wl / G, lane = wl % G;     // position inside the wave, lane inside the position
+  const int64_t f = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kPer + sub;
+  // (no early exit per position: the draws below talk across the wave; the tail positions of the
+  // last wave run on position n_frontier - 1 and store nothing)
+  const bool live = f < n_frontier;
+  if (f - sub >= n_frontier) return;         // (wave-uniform: the whole wave is past the end)
+  const int64_t fc = live ? f : n_frontier - 1;
+  const int64_t r = frontier_base + fc;
+  const int64_t begin = slot_base + fc * k;
   const int64_t v = node_g[r];
   int64_t s = 0, deg = 0;
   if (v >= 0) {
@@ -93,23 +104,28 @@ __global__ void __launch_bounds__(kBlock)
       slot_mix64(slot_mix64(seed ^ slot_mix64(static_cast<uint64_t>(ep) * 0x9E3779B97F4A7C15ull)) +
                  static_cast<uint64_t>(hop));
   int64_t mine = lane;  // deg <= k: every in-neighbour, in storage order
-  if (deg > k) {
-    // Floyd: for j = deg-k .. deg-1: t = U{0..j}; insert t, or j if t is already chosen
-    const uint64_t key = slot_mix64(hop_seed ^ slot_mix64(static_cast<uint64_t>(v)));
-    const int64_t jl = deg - k + lane;
-    int64_t t = 0;
-    if (lane < k) {
-      const uint64_t rr = slot_mix64(key + static_cast<uint64_t>(lane));
-      t = static_cast<int64_t>(__umul64hi(rr, static_cast<uint64_t>(jl + 1)));
-    }
-    mine = -1;
-    for (int c = 0; c < k; ++c) {
-      const int64_t tc = bcast_uniform(t, c);
-      const bool dup = __ballot(lane < c && mine == tc) != 0;
-      if (lane == c) mine = dup ? jl : tc;
-    }
+  // Floyd: for j = deg-k .. deg-1: t = U{0..j}; insert t, or j if t is already chosen.  (Positions
+  // with deg <= k walk the loop too — its cross-lane steps need every lane — and keep `mine`.)
+  const bool draw = deg > k;
+  const uint64_t key = slot_mix64(hop_seed ^ slot_mix64(static_cast<uint64_t>(v)));
+  const int64_t jl = deg - k + lane;
+  int64_t t = 0;
+  if (draw && lane < k) {
+    const uint64_t rr = slot_mix64(key + static_cast<uint64_t>(lane));
+    t = static_cast<int64_t>(__umul64hi(rr, static_cast<uint64_t>(jl + 1)));
   }
-  if (lane < k) {
+  if (__any(draw)) {  // (wave-uniform)
+    int64_t pick = -1;
+    for (int c = 0; c < k; ++c) {
+      const int64_t tc = kPer == 1 ? bcast_uniform(t, c) : bcast_lane(t, sub * G + c);
+      const uint64_t hits = __ballot(lane < c && pick == tc);
+      const bool dup = kPer == 1 ? hits != 0
+                                 : ((hits >> (sub * G)) & ((G == 64 ? ~0ull : (1ull << G) - 1))) != 0;
+      if (lane == c) pick = dup ? jl : tc;
+    }
+    if (draw) mine = pick;
+  }
+  if (live && lane < k) {
     int64_t sg = -1;
     if (lane < cnt) {
       sg = static_cast<int64_t>(row[s + mine]);
@@ -117,7 +133,7 @@ __global__ void __launch_bounds__(kBlock)
     }
     src_g[begin + lane] = sg;
   }
-  if (lane == 0) {
+  if (live && lane == 0) {
     row_end[r] = static_cast<int32_t>(begin + cnt);
     inv_cnt[r] = 1.f / static_cast<float>(cnt > 0 ? cnt : 1);
   }
@@ -330,12 +346,18 @@ int pygamd_slots_sample(const void* colptr, const void* row, int idx_dtype, cons
   if (!colptr || !row || !node_g || !epoch_dev || !local_map || !src_g || !row_end || !inv_cnt)
     return PYGAMD_ERR_INVALID_ARG;
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
-    hipLaunchKernelGGL((slots_sample_kernel<IdxT>),
-                       dim3(static_cast<unsigned>(ceil_div(n_frontier, kWavesPerBlock))),
-                       dim3(kBlock), 0, as_stream(stream), static_cast<const IdxT*>(colptr),
-                       static_cast<const IdxT*>(row), node_g, frontier_base, n_frontier, fanout,
-                       slot_base, B, seed, hop, epoch_dev,
-                       reinterpret_cast<long long*>(local_map), src_g, row_end, inv_cnt);
+    auto launch = [&](auto kernel, int per_wave) {
+      hipLaunchKernelGGL(kernel,
+                         dim3(static_cast<unsigned>(
+                             ceil_div(n_frontier, static_cast<int64_t>(kWavesPerBlock) * per_wave))),
+                         dim3(kBlock), 0, as_stream(stream), static_cast<const IdxT*>(colptr),
+                         static_cast<const IdxT*>(row), node_g, frontier_base, n_frontier, fanout,
+                         slot_base, B, seed, hop, epoch_dev,
+                         reinterpret_cast<long long*>(local_map), src_g, row_end, inv_cnt);
+    };
+    if (fanout <= 16) launch(slots_sample_kernel<IdxT, 16>, 4);
+    else if (fanout <= 32) launch(slots_sample_kernel<IdxT, 32>, 2);
+    else launch(slots_sample_kernel<IdxT, 64>, 1);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
   });
