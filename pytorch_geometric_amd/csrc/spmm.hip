@@ -1665,7 +1665,17 @@ __global__ void __launch_bounds__(1024)
     bits_count_kernel(const uint32_t* __restrict__ bits, int64_t words, int64_t* __restrict__ n_set) {
   __shared__ unsigned long long part[16];
   unsigned long long c = 0;
-  for (int64_t i = threadIdx.x; i < words; i += 1024) c += __popc(bits[i]);
+  // (eight loads in flight: the plain loop waits for each word before it asks for the next —
+  // 75 serial trips to L2 for the 300 KiB bitmap of the products shape, 31 us)
+  int64_t i = threadIdx.x;
+  for (; i + 7 * 1024 < words; i += 8 * 1024) {
+    uint32_t w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = bits[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c += __popc(w[u]);
+  }
+  for (; i < words; i += 1024) c += __popc(bits[i]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
