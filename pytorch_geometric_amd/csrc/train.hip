@@ -20,12 +20,17 @@
 
 namespace pygamd {
 
-constexpr int kCeRowsPerBlock = kWavesPerBlock;  // one wave per row
+constexpr int kCeRpw = 4;                                   // rows per wave (<= 256 classes)
+constexpr int kCeRowsPerBlock = kWavesPerBlock * kCeRpw;
 
 // One wave per row: max, sum of exp, the row's loss, the row's gradient.  Labels:
 // y[label_idx[r]] (label_idx NULL: y[r]); a label outside [0, C) contributes no loss and a zero
 // gradient row and raises *err_flag (the reference's device assert), the mean still divides by B
 // (no ignore_index).
+// A wave takes kCeRpw consecutive rows and issues every row's loads TOGETHER — the row indices,
+// then the labels and the rows themselves: a row is a chain of dependent reads (index -> row,
+// index -> label) and the 196 k rows of a full-batch training split were bound by how many chains
+// the chip keeps in flight, not by their 74 MB.
 __global__ void __launch_bounds__(kBlock)
     cross_entropy_rows_kernel(const float* __restrict__ logits, int64_t ld, int64_t B, int C,
                               const int64_t* __restrict__ row_idx, int64_t n_logit_rows,
@@ -34,65 +39,90 @@ __global__ void __launch_bounds__(kBlock)
                               float* __restrict__ grad, int64_t ldg, float* __restrict__ row_loss,
                               int32_t* __restrict__ err_flag) {
   const int lane = lane_id();
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * kCeRowsPerBlock + wave_in_block();
-  if (r >= B) return;
+  const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kCeRpw;
+  if (r0 >= B) return;
+  const float inv_b = 1.f / static_cast<float>(B);
   // (row_idx: the loss of a ROW SUBSET of the logits — a full-batch model's training split,
   // `F.cross_entropy(out[train_idx], y[train_idx])` — without the gathered copy; an index outside
   // the logits is treated like a bad label)
-  int64_t src = row_idx ? row_idx[r] : r;
-  const bool src_ok = src >= 0 && src < n_logit_rows;
-  src = src_ok ? src : 0;
-  const float* __restrict__ row = logits + src * ld;
-  const int64_t lab = y[label_idx ? label_idx[r] : r];
-  const bool lab_ok = src_ok && lab >= 0 && lab < C;
-  const float inv_b = 1.f / static_cast<float>(B);
-  float* __restrict__ grow = grad + r * ldg;
+  int64_t src[kCeRpw], li[kCeRpw], lab[kCeRpw];
+  bool live[kCeRpw], src_ok[kCeRpw];
+#pragma unroll
+  for (int q = 0; q < kCeRpw; ++q) {
+    live[q] = r0 + q < B;
+    const int64_t r = live[q] ? r0 + q : B - 1;
+    src[q] = row_idx ? row_idx[r] : r;
+    li[q] = label_idx ? label_idx[r] : r;
+  }
+#pragma unroll
+  for (int q = 0; q < kCeRpw; ++q) {
+    src_ok[q] = src[q] >= 0 && src[q] < n_logit_rows;
+    src[q] = src_ok[q] ? src[q] : 0;
+    lab[q] = y[li[q]];
+  }
   if (C <= 4 * kWave) {
-    // up to 256 classes: the row is read ONCE (four loads issued together) and kept in registers —
-    // the three passes below each wait for memory behind the row index and the row address
-    float v[4];
+    // up to 256 classes: every row is read ONCE (all loads of the wave issued together) and kept
+    // in registers
+    float v[kCeRpw][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = lane + u * kWave < C ? row[lane + u * kWave] : -INFINITY;
-    float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    for (int q = 0; q < kCeRpw; ++q) {
+      const float* __restrict__ row = logits + src[q] * ld;
 #pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
-    float se = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (lane + u * kWave < C) se += expf(v[u] - mx);
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) se += __shfl_xor(se, o, kWave);
-    const float lse = mx + logf(se);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = lane + u * kWave;
-      if (c < C) {
-        const float p = expf(v[u] - lse);
-        grow[c] = lab_ok ? (p - (c == lab ? 1.f : 0.f)) * inv_b : 0.f;
-      }
+      for (int u = 0; u < 4; ++u)
+        v[q][u] = lane + u * kWave < C ? row[lane + u * kWave] : -INFINITY;
     }
-    if (lane == 0) {
-      row_loss[r] = lab_ok ? lse - row[lab_ok ? lab : 0] : 0.f;
-      if (!lab_ok && err_flag) atomicOr(err_flag, 1);
+#pragma unroll
+    for (int q = 0; q < kCeRpw; ++q) {
+      if (!live[q]) continue;  // (wave-uniform)
+      const bool lab_ok = src_ok[q] && lab[q] >= 0 && lab[q] < C;
+      float mx = fmaxf(fmaxf(v[q][0], v[q][1]), fmaxf(v[q][2], v[q][3]));
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
+      float se = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane + u * kWave < C) se += expf(v[q][u] - mx);
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) se += __shfl_xor(se, o, kWave);
+      const float lse = mx + logf(se);
+      float* __restrict__ grow = grad + (r0 + q) * ldg;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = lane + u * kWave;
+        if (c < C) {
+          const float p = expf(v[q][u] - lse);
+          grow[c] = lab_ok ? (p - (c == lab[q] ? 1.f : 0.f)) * inv_b : 0.f;
+        }
+      }
+      if (lane == 0) {
+        row_loss[r0 + q] = lab_ok ? lse - logits[src[q] * ld + (lab_ok ? lab[q] : 0)] : 0.f;
+        if (!lab_ok && err_flag) atomicOr(err_flag, 1);
+      }
     }
     return;
   }
-  float mx = -INFINITY;
-  for (int c = lane; c < C; c += kWave) mx = fmaxf(mx, row[c]);
+  for (int q = 0; q < kCeRpw; ++q) {
+    if (!live[q]) break;
+    const float* __restrict__ row = logits + src[q] * ld;
+    const bool lab_ok = src_ok[q] && lab[q] >= 0 && lab[q] < C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += kWave) mx = fmaxf(mx, row[c]);
 #pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
-  float se = 0.f;
-  for (int c = lane; c < C; c += kWave) se += expf(row[c] - mx);
+    for (int o = kWave / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
+    float se = 0.f;
+    for (int c = lane; c < C; c += kWave) se += expf(row[c] - mx);
 #pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) se += __shfl_xor(se, o, kWave);
-  const float lse = mx + logf(se);
-  for (int c = lane; c < C; c += kWave) {
-    const float p = expf(row[c] - lse);
-    grow[c] = lab_ok ? (p - (c == lab ? 1.f : 0.f)) * inv_b : 0.f;
-  }
-  if (lane == 0) {
-    row_loss[r] = lab_ok ? lse - row[lab_ok ? lab : 0] : 0.f;
-    if (!lab_ok && err_flag) atomicOr(err_flag, 1);
+    for (int o = kWave / 2; o > 0; o >>= 1) se += __shfl_xor(se, o, kWave);
+    const float lse = mx + logf(se);
+    float* __restrict__ grow = grad + (r0 + q) * ldg;
+    for (int c = lane; c < C; c += kWave) {
+      const float p = expf(row[c] - lse);
+      grow[c] = lab_ok ? (p - (c == lab[q] ? 1.f : 0.f)) * inv_b : 0.f;
+    }
+    if (lane == 0) {
+      row_loss[r0 + q] = lab_ok ? lse - row[lab_ok ? lab[q] : 0] : 0.f;
+      if (!lab_ok && err_flag) atomicOr(err_flag, 1);
+    }
   }
 }
 
