@@ -49,11 +49,70 @@ struct GatLoader {
   }
 };
 
+// kSegPer segments per wave, one after the other — but with every segment's pointer reads, then
+// every segment's first kSegKeep passes of values issued TOGETHER and kept in registers: a
+// segment is a chain of dependent reads (ptr -> col -> alpha_src[col] for the GAT loader) and a
+// graph of short rows (13 edges on average at the arxiv shape, 8 heads: two passes of a wave) is
+// bound by how many chains the chip has in flight.  Longer segments re-read their tail.
+constexpr int kSegPer = 4;
+constexpr int kSegKeep = 2;
+
 template <typename IdxT, typename Loader>
 __global__ void __launch_bounds__(kBlock)
     segment_softmax_fwd_kernel(Loader ld, const IdxT* __restrict__ ptr, int64_t n_seg, int64_t H,
                                float* __restrict__ out) {
   const int lane = lane_id();
+  if (H <= kWave && is_pow2(H)) {
+    const int64_t seg0 = (xcd_logical_block() * kWavesPerBlock + wave_in_block()) * kSegPer;
+    if (seg0 >= n_seg) return;
+    const int h = lane % static_cast<int>(H);
+    const int64_t kstep = kWave / H;
+    int64_t sb[kSegPer], se[kSegPer];
+#pragma unroll
+    for (int q = 0; q < kSegPer; ++q) {
+      const int64_t sg = seg0 + q < n_seg ? seg0 + q : n_seg - 1;
+      sb[q] = ptr[sg];
+      se[q] = seg0 + q < n_seg ? static_cast<int64_t>(ptr[sg + 1]) : sb[q];  // (past the end: empty)
+    }
+    float v[kSegPer][kSegKeep];
+#pragma unroll
+    for (int q = 0; q < kSegPer; ++q) {
+      Loader lq = ld;
+      lq.begin(seg0 + q < n_seg ? seg0 + q : n_seg - 1);
+#pragma unroll
+      for (int i = 0; i < kSegKeep; ++i) {
+        const int64_t k = sb[q] + lane / H + i * kstep;
+        v[q][i] = k < se[q] ? lq.at(k, h, H) : -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kSegPer; ++q) {
+      const int64_t s = sb[q], e = se[q];
+      if (e <= s) continue;  // (wave-uniform)
+      Loader lq = ld;
+      lq.begin(seg0 + q);
+      const int64_t k0 = s + lane / H;
+      const int64_t kt = k0 + kSegKeep * kstep;  // first k behind the kept passes
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < kSegKeep; ++i) m = fmaxf(m, v[q][i]);
+      for (int64_t k = kt; k < e; k += kstep) m = fmaxf(m, lq.at(k, h, H));
+      m = column_reduce<true>(m, static_cast<int>(H));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < kSegKeep; ++i)
+        if (k0 + i * kstep < e) sum += expf(v[q][i] - m);
+      for (int64_t k = kt; k < e; k += kstep) sum += expf(lq.at(k, h, H) - m);
+      sum = column_reduce<false>(sum, static_cast<int>(H)) + 1e-16f;
+#pragma unroll
+      for (int i = 0; i < kSegKeep; ++i) {
+        const int64_t k = k0 + i * kstep;
+        if (k < e) out[k * H + h] = expf(v[q][i] - m) / sum;
+      }
+      for (int64_t k = kt; k < e; k += kstep) out[k * H + h] = expf(lq.at(k, h, H) - m) / sum;
+    }
+    return;
+  }
   const int64_t seg = xcd_logical_block() * kWavesPerBlock + wave_in_block();
   if (seg >= n_seg) return;
   const int64_t s = ptr[seg];
@@ -133,6 +192,87 @@ __global__ void __launch_bounds__(kBlock)
                                float* __restrict__ grad_alpha_src,
                                float* __restrict__ grad_alpha_dst) {
   const int lane = lane_id();
+  if (H <= kWave && is_pow2(H)) {
+    // kSegPer segments per wave, their first kSegKeep passes loaded together (see the forward)
+    const int64_t seg0 = (xcd_logical_block() * kWavesPerBlock + wave_in_block()) * kSegPer;
+    if (seg0 >= n_seg) return;
+    const int h = lane % static_cast<int>(H);
+    const int64_t kstep = kWave / H;
+    int64_t sb[kSegPer], se[kSegPer];
+#pragma unroll
+    for (int q = 0; q < kSegPer; ++q) {
+      const int64_t sg = seg0 + q < n_seg ? seg0 + q : n_seg - 1;
+      sb[q] = ptr[sg];
+      se[q] = seg0 + q < n_seg ? static_cast<int64_t>(ptr[sg + 1]) : sb[q];
+    }
+    float vo[kSegPer][kSegKeep], vg[kSegPer][kSegKeep], vp[kSegPer][kSegKeep];
+    int64_t vc[kSegPer][kSegKeep];
+#pragma unroll
+    for (int q = 0; q < kSegPer; ++q) {
+#pragma unroll
+      for (int i = 0; i < kSegKeep; ++i) {
+        const int64_t k = sb[q] + lane / H + i * kstep;
+        const bool ok = k < se[q];
+        vo[q][i] = ok ? out[k * H + h] : 0.f;
+        vg[q][i] = ok ? g[k * H + h] : 0.f;
+        vc[q][i] = (GAT && ok) ? static_cast<int64_t>(gat.col[k]) : 0;
+      }
+    }
+    if (GAT) {
+#pragma unroll
+      for (int q = 0; q < kSegPer; ++q) {
+        const int64_t sg = seg0 + q < n_seg ? seg0 + q : n_seg - 1;
+        const float ad = gat.alpha_dst[sg * H + h];
+#pragma unroll
+        for (int i = 0; i < kSegKeep; ++i) vp[q][i] = gat.alpha_src[vc[q][i] * H + h] + ad;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kSegPer; ++q) {
+      const int64_t s = sb[q], e = se[q];
+      if (seg0 + q >= n_seg) break;  // (wave-uniform)
+      if (GAT) gat.begin(seg0 + q);
+      const int64_t k0 = s + lane / H;
+      const int64_t kt = k0 + kSegKeep * kstep;
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < kSegKeep; ++i)
+        if (k0 + i * kstep < e) dot = fmaf(vo[q][i], vg[q][i], dot);
+      for (int64_t k = kt; k < e; k += kstep) dot = fmaf(out[k * H + h], g[k * H + h], dot);
+      dot = column_reduce<false>(dot, static_cast<int>(H));
+      float dsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < kSegKeep; ++i) {
+        const int64_t k = k0 + i * kstep;
+        if (k < e) {
+          float gs = vo[q][i] * (vg[q][i] - dot);
+          if (GAT) {
+            gs = vp[q][i] > 0.f ? gs : gs * gat.slope;
+            dsum += gs;
+            atomicAdd(grad_alpha_src + vc[q][i] * H + h, gs);
+          } else {
+            grad_src[k * H + h] = gs;
+          }
+        }
+      }
+      for (int64_t k = kt; k < e; k += kstep) {
+        float gs = out[k * H + h] * (g[k * H + h] - dot);
+        if (GAT) {
+          const float p = gat.pre(k, h, H);
+          gs = p > 0.f ? gs : gs * gat.slope;
+          dsum += gs;
+          atomicAdd(grad_alpha_src + static_cast<int64_t>(gat.col[k]) * H + h, gs);
+        } else {
+          grad_src[k * H + h] = gs;
+        }
+      }
+      if (GAT) {
+        dsum = column_reduce<false>(dsum, static_cast<int>(H));
+        if (lane < H) grad_alpha_dst[(seg0 + q) * H + h] = dsum;
+      }
+    }
+    return;
+  }
   const int64_t seg = xcd_logical_block() * kWavesPerBlock + wave_in_block();
   if (seg >= n_seg) return;
   const int64_t s = ptr[seg];
@@ -366,6 +506,11 @@ __global__ void __launch_bounds__(kBlock)
 
 using namespace pygamd;
 
+// waves of segment_softmax_{fwd,bwd}_kernel: kSegPer segments each on the narrow power-of-two route
+static int64_t softmax_fwd_waves(int64_t n_seg, int64_t H) {
+  return (H > 0 && H <= kWave && (H & (H - 1)) == 0) ? ceil_div(n_seg, static_cast<int64_t>(kSegPer)) : n_seg;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 extern "C" {
@@ -378,7 +523,8 @@ int pygamd_segment_softmax_forward(const float* src, const void* ptr, int idx_dt
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     PlainLoader<IdxT> ld{src};
     hipLaunchKernelGGL((segment_softmax_fwd_kernel<IdxT, PlainLoader<IdxT>>),
-                       dim3(wave_grid(n_seg)), dim3(kBlock), 0, as_stream(stream), ld,
+                       dim3(wave_grid(softmax_fwd_waves(n_seg, H))), dim3(kBlock), 0,
+                       as_stream(stream), ld,
                        static_cast<const IdxT*>(ptr), n_seg, H, out);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
@@ -393,7 +539,8 @@ int pygamd_segment_softmax_backward(const float* out, const float* grad_out, con
   if (!out || !grad_out || !ptr || !grad_src) return PYGAMD_ERR_INVALID_ARG;
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     GatLoader<IdxT> none{nullptr, nullptr, nullptr, 0.f, 0};
-    hipLaunchKernelGGL((segment_softmax_bwd_kernel<IdxT, false>), dim3(wave_grid(n_seg)),
+    hipLaunchKernelGGL((segment_softmax_bwd_kernel<IdxT, false>),
+                       dim3(wave_grid(softmax_fwd_waves(n_seg, H))),
                        dim3(kBlock), 0, as_stream(stream), out, grad_out,
                        static_cast<const IdxT*>(ptr), n_seg, H, grad_src, none,
                        static_cast<float*>(nullptr), static_cast<float*>(nullptr));
@@ -552,7 +699,8 @@ int pygamd_gat_edge_softmax_forward(const void* rowptr, const void* col, int idx
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     GatLoader<IdxT> ld{static_cast<const IdxT*>(col), alpha_src, alpha_dst, slope, 0};
     hipLaunchKernelGGL((segment_softmax_fwd_kernel<IdxT, GatLoader<IdxT>>),
-                       dim3(wave_grid(n_rows)), dim3(kBlock), 0, as_stream(stream), ld,
+                       dim3(wave_grid(softmax_fwd_waves(n_rows, H))), dim3(kBlock), 0,
+                       as_stream(stream), ld,
                        static_cast<const IdxT*>(rowptr), n_rows, H, alpha_out);
     PYGAMD_LAUNCH_CHECK();
     return PYGAMD_OK;
@@ -572,7 +720,8 @@ int pygamd_gat_edge_softmax_backward(const void* rowptr, const void* col, int id
     return PYGAMD_ERR_INVALID_ARG;
   return PYGAMD_DISPATCH_IDX(idx_dtype, [&]() -> int {
     GatLoader<IdxT> ld{static_cast<const IdxT*>(col), alpha_src, alpha_dst, slope, 0};
-    hipLaunchKernelGGL((segment_softmax_bwd_kernel<IdxT, true>), dim3(wave_grid(n_rows)),
+    hipLaunchKernelGGL((segment_softmax_bwd_kernel<IdxT, true>),
+                       dim3(wave_grid(softmax_fwd_waves(n_rows, H))),
                        dim3(kBlock), 0, as_stream(stream), alpha_out, grad_alpha,
                        static_cast<const IdxT*>(rowptr), n_rows, H,
                        static_cast<float*>(nullptr), ld, grad_alpha_src, grad_alpha_dst);
