@@ -24,10 +24,13 @@
 
 namespace pygamd {
 
-// One destination row: epilogue operands, gather loop, epilogue.  PRE: see spmm_accumulate.
-template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, bool PRE>
-__device__ __forceinline__ void spmm_sum_row(const SpmmDev<IdxT>& a, int64_t row, IdxT start,
-                                             IdxT end, int lane, IdxT pre_c) {
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
+__global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
+  const int lane = lane_id();
+  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
+  if (row >= a.n_rows) return;
+  const IdxT start = a.rowptr[row];
+  const IdxT end = spmm_row_end(a, row);
   const IdxT deg = end - start;
   if (a.hub_threshold > 0 && deg > a.hub_threshold) return;  // owned by the hub path
   const bool has_old = a.accumulate && (a.accumulate_rows <= 0 || row < a.accumulate_rows);
@@ -64,8 +67,7 @@ __device__ __forceinline__ void spmm_sum_row(const SpmmDev<IdxT>& a, int64_t row
       }
     }
   }
-  spmm_accumulate<IdxT, VW, LPR, CH, WMODE, IDENT, 0, PRE>(a, start, end, lane, fo, fv, head, acc,
-                                                           pre_c);
+  spmm_accumulate<IdxT, VW, LPR, CH, WMODE, IDENT>(a, start, end, lane, fo, fv, head, acc);
   combine_subgroups<VW, LPR, CH>(acc);
   if (lane < LPR) {
     const float cntf = static_cast<float>(deg > 0 ? deg : 1);
@@ -81,43 +83,6 @@ __device__ __forceinline__ void spmm_sum_row(const SpmmDev<IdxT>& a, int64_t row
         }
       }
     }
-  }
-}
-
-template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT>
-__global__ void __launch_bounds__(kBlock) spmm_sum_rows(SpmmDev<IdxT> a) {
-  const int lane = lane_id();
-  const int64_t row = xcd_logical_block() * kWavesPerBlock + wave_in_block();
-  if (row >= a.n_rows) return;
-  const IdxT start = a.rowptr[row];
-  const IdxT end = spmm_row_end(a, row);
-  spmm_sum_row<IdxT, VW, LPR, CH, WMODE, IDENT, false>(a, row, start, end, lane, 0);
-}
-
-// R consecutive rows per wave, one after the other — with every row's pointer reads, then every
-// row's first chunk of slot indices issued TOGETHER: a row is a chain of dependent reads (rowptr ->
-// col -> x row) and a graph of very short rows — the (relation, destination) pairs of an RGCN
-// layer hold 1.4 edges on average — is bound by how many chains the chip keeps in flight, not by
-// bytes.  The sums themselves are spmm_sum_row's, slot by slot.
-template <typename IdxT, int VW, int LPR, int CH, int WMODE, int R>
-__global__ void __launch_bounds__(kBlock) spmm_sum_rows_multi(SpmmDev<IdxT> a) {
-  const int lane = lane_id();
-  const int64_t row0 = (xcd_logical_block() * kWavesPerBlock + wave_in_block()) * R;
-  if (row0 >= a.n_rows) return;
-  IdxT st[R], en[R], c0[R];
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    const int64_t r = row0 + q < a.n_rows ? row0 + q : a.n_rows - 1;
-    st[q] = a.rowptr[r];
-    en[q] = spmm_row_end(a, r);
-  }
-#pragma unroll
-  for (int q = 0; q < R; ++q)
-    c0[q] = st[q] + lane < en[q] ? __builtin_nontemporal_load(&a.col[st[q] + lane]) : 0;
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    if (row0 + q < a.n_rows)  // (wave-uniform)
-      spmm_sum_row<IdxT, VW, LPR, CH, WMODE, false, true>(a, row0 + q, st[q], en[q], lane, c0[q]);
   }
 }
 
@@ -1349,16 +1314,6 @@ static int launch_sum(const pygamd_spmm_args* p, const Shape& s, float* partial,
         dim3 grid(wave_grid(ceil_div(p->n_rows, static_cast<int64_t>(R))), s.tiles);
         hipLaunchKernelGGL((spmm_sum_rows_sparse<IdxT, VW, LPR, CH, R>), grid, dim3(kBlock), 0,
                            st, a);
-        done = true;
-      }
-    }
-    if constexpr (CH == 2 && (WMODE == 0 || WMODE == 1) && !IDENT) {
-      // rows wider than 256 floats (the 500-wide rows of the RGCN config): several rows per wave
-      if (!done) {
-        constexpr int R = 4;
-        dim3 grid(wave_grid(ceil_div(p->n_rows, static_cast<int64_t>(R))), s.tiles);
-        hipLaunchKernelGGL((spmm_sum_rows_multi<IdxT, VW, LPR, CH, WMODE, R>), grid, dim3(kBlock),
-                           0, st, a);
         done = true;
       }
     }

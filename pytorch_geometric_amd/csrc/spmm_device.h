@@ -214,15 +214,11 @@ __device__ __forceinline__ void spmm_batch_zrows(const SpmmDev<IdxT>& a, int j, 
 
 // UF > 0 overrides the number of row loads in flight per lane (a kernel with few resident waves
 // needs more memory-level parallelism per wave)
-// PRE: the caller already holds the first chunk's slot indices (`pre_c` = col[start + lane], 0
-// past the row's end) — a kernel that walks several rows per wave issues those loads for all of
-// its rows together (spmm_sum_rows_multi).
-template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, int UF = 0,
-          bool PRE = false>
+template <typename IdxT, int VW, int LPR, int CH, int WMODE, bool IDENT, int UF = 0>
 __device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT start, IdxT end,
                                                 int lane, const int (&fo)[CH],
                                                 const bool (&fv)[CH], const int (&head)[CH],
-                                                float (&acc)[CH][VW], IdxT pre_c = 0) {
+                                                float (&acc)[CH][VW]) {
   constexpr int EPI = kWave / LPR;
   constexpr int U = UF > 0 ? UF : spmm_unroll<LPR, CH>();
   constexpr int STEP = EPI * U;
@@ -240,8 +236,6 @@ __device__ __forceinline__ void spmm_accumulate(const SpmmDev<IdxT>& a, IdxT sta
       const IdxT k = base + lane;
       if constexpr (IDENT) {
         myc = k;
-      } else if constexpr (PRE) {
-        myc = base == start ? pre_c : __builtin_nontemporal_load(&a.col[k]);
       } else {
         myc = __builtin_nontemporal_load(&a.col[k]);  // streamed once: keep L2 for feature rows
       }
