@@ -18,7 +18,10 @@ from ._lib import REDUCE_IDS, PygAmdError, SpmmArgs, check
 
 # rows with more stored entries than this are split into chunks (see csrc/spmm.hip)
 HUB_THRESHOLD = 1024
-HUB_CHUNK = 1024
+# (256-slot chunks: a chunk is ONE wave's chain of gathers — at 1,024 slots the ~700 chunks of the
+# products shape were 700 waves on 1,024 SIMDs, 151 us per 256-wide launch; at 256: 71 us.  128
+# gains nothing more: profiles/r06_bench_kernel_stats.md)
+HUB_CHUNK = int(os.environ.get('PYGAMD_HUB_CHUNK', '256'))
 
 
 def _require_device(*tensors):

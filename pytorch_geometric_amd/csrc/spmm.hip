@@ -277,8 +277,18 @@ __global__ void __launch_bounds__(kBlock)
   const IdxT deg = rowptr[row + 1] - rowptr[row];
   const float cntf = static_cast<float>(deg > 0 ? deg : 1);
   for (int64_t f = lane; f < F; f += kWave) {
+    // (eight chunks' loads in flight, added in chunk order: one at a time a hub row of 16 k slots
+    // in 256-slot chunks was 64 serial trips to memory per 64 columns)
     float s = 0.f;
-    for (int64_t c = c0; c < c1; ++c) s += partial[c * F + f];
+    int64_t c = c0;
+    for (; c + 8 <= c1; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(c + u) * F + f];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < c1; ++c) s += partial[c * F + f];
     s = mean ? s / cntf : s;
     s = accumulate ? out[row * ldo + f] + s : s;
     if (relu_mask) s = relu_mask[row * ldm + f] > 0.f ? s : 0.f;
