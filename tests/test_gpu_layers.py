@@ -960,8 +960,9 @@ def test_gat_takes_half_precision_and_autocast_inputs(dev):
         gat_mod.GatAttendFunction = keep
 
 
+@pytest.mark.parametrize('C', [47, 130, 300])   # one / three register slots per lane; the > 256 loop
 @pytest.mark.parametrize('with_index', [True, False])
-def test_rows_cross_entropy_equals_torch(dev, with_index):
+def test_rows_cross_entropy_equals_torch(dev, with_index, C):
     """nn.functional.cross_entropy(out, y, index) — the train-split loss of a full-batch model as
     one pass over the selected rows — against F.cross_entropy(out[index], y[index]): value,
     gradient (an upstream factor, duplicate indices, strided logits), the out-of-range flag."""
@@ -970,7 +971,7 @@ def test_rows_cross_entropy_equals_torch(dev, with_index):
     import pytorch_geometric_amd as pga
     from pytorch_geometric_amd.nn.functional import cross_entropy
     g = gen(12)
-    N, C = 5000, 47
+    N = 5000
     wide = (torch.randn(N, C + 9, generator=g) * 2).to(dev)
     y = torch.randint(0, C, (N, ), generator=g).to(dev)
     idx = None
