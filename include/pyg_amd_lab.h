@@ -42,7 +42,9 @@ PYGAMD_API int pygamd_lab_sage_layer_fused(const pygamd_spmm_args* graph,
  *   32 (+ 8)   variant 0 with the residual subtractions as v_pk_add_f32 (what the compiler
  *              emits unforced; same results);
  *   16         variant 0 without gemm_tn_skinny_kernel (narrow g, one wide x, >= 32 k rows: the
- *              tiled kernel for that shape too — the A/B of scripts/wgrad_probe.py).           */
+ *              tiled kernel for that shape too — the A/B of scripts/wgrad_probe.py);
+ *   64 + bits  timing probes of gemm_tn_skinny_kernel<3> (g 65..96 columns wide), bits as for
+ *              2 .. 14 above: 66 = no products, 68 = no conversion, 72 = no loads, ...          */
 PYGAMD_API int pygamd_lab_set_wgrad_variant(int variant);
 
 /* Streaming device-to-device copy of n_bytes (a multiple of 16, both pointers 16-byte aligned):
